@@ -1,0 +1,97 @@
+"""ctypes binding of libfcaf3d_hip.so.
+
+The prototypes are parsed from include/fcaf3d_hip.h (single source of truth), so an argument-type
+mismatch between Python and the C ABI cannot creep in.  There is NO fallback: if the shared library
+is missing the product path raises.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfcaf3d_hip.so')
+HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'fcaf3d_hip.h')
+
+_SCALARS = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float,
+            'hipStream_t': ctypes.c_void_p}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [(argname, ctype)])}"""
+    txt = open(path).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r'\b(int64_t|int)\s+(fc_\w+)\s*\(([^)]*)\)\s*;', txt):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        argl = []
+        for a in args.split(','):
+            a = ' '.join(a.split())
+            if not a:
+                continue
+            if '*' in a:
+                argl.append((a.split('*')[-1].strip(), ctypes.c_void_p))
+            else:
+                ty, nm = a.rsplit(' ', 1)
+                argl.append((nm, _SCALARS[ty.replace('const ', '')]))
+        protos[name] = (_SCALARS[ret], argl)
+    return protos
+
+
+_lib = None
+_protos = None
+
+
+def lib():
+    global _lib, _protos
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `python -m fcaf3d_amd.build` '
+                '(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+        l = ctypes.CDLL(LIB_PATH)
+        _protos = parse_header()
+        for name, (ret, args) in _protos.items():
+            fn = getattr(l, name)            # AttributeError if the library lacks a declared symbol
+            fn.restype = ret
+            fn.argtypes = [t for _, t in args]
+        _lib = l
+    return _lib
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'C ABI takes contiguous buffers'
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an `int`-returning entry point; raises on a non-zero status."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        kind = 'invalid argument' if rc == -1 else 'workspace too small' if rc == -2 else f'hipError {rc}'
+        raise RuntimeError(f'{name} failed: {kind}')
+
+
+def query(name, *args):
+    """Invoke an `int64_t`-returning size query."""
+    return int(getattr(lib(), name)(*args))
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, stream) — the library never allocates."""
+    key = (device, stream())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

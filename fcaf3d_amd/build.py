@@ -1,0 +1,49 @@
+"""Builds libfcaf3d_hip.so (gfx950) in-tree with hipcc.  No GPU needed (cross-compiles)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libfcaf3d_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wno-unused-result']
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    objs, jobs = [], []
+    for s in _sources():
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, s[:-4] + '.o')
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)

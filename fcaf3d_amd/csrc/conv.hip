@@ -1,0 +1,383 @@
+// Sparse convolution on gfx950 as an OUTPUT-STATIONARY implicit GEMM over a dense neighbour
+// table nbr[k][o] (built by fc_kernel_map):
+//     out[o, :] = sum_k  in[nbr[k][o], :] @ W[k]            (rows with nbr < 0 contribute zero)
+// Each output row is written exactly once (no atomics, deterministic).  The same kernel computes
+// dgrad (gather over the transposed table with W[k]^T) and, with nbr == NULL (identity), the dense
+// GEMMs of the generative transposed convolution and the 1x1 head convolutions.
+//
+// fp32 in / fp32 accumulate on the matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
+// Workgroup = 256 threads = 4 wave64 in a 2x2 grid; gathered input rows and the W[k] slab are
+// staged through LDS with 16-byte coalesced loads.
+//
+// Replaces MinkowskiEngine's ConvolutionForward/Backward (and ConvolutionTranspose, 1x1 mm) called
+// from me_resnet.py:19-21,56-62, BasicBlock, fcaf3d_neck_with_head.py:52,60-69,83-85,257-263.
+#include "fc_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32            // reduction slab (input channels per stage / rows per stage for wgrad)
+#define LDA (BK + 4)     // A row stride in floats: 16B-aligned rows, conflict-free ds_read_b128 (9r mod 16)
+
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
+                                                   const int* __restrict__ nbr, float* __restrict__ out, int64_t n_out,
+                                                   int K, int Cin, int Cout) {
+  constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave
+  constexpr int AR = BM / 32;                    // float4 gathers per thread per stage
+  constexpr int BR = BN / 32;                    // float4 weight loads per thread per stage
+  __shared__ __attribute__((aligned(16))) float As[BM * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int a_c4 = tid & 7, a_r = tid >> 3;      // A staging: 8 float4 per row, 32 rows per pass
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  for (int k = 0; k < K; ++k) {
+    int idx[AR];
+    int any = 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      int64_t row = m0 + a_r + 32 * i;
+      int v = -1;
+      if (row < n_out) v = nbr ? nbr[(int64_t)k * n_out + row] : (int)row;
+      idx[i] = v;
+      any |= (v >= 0);
+    }
+    if (!__syncthreads_or(any)) continue;        // nobody in this tile has a neighbour at offset k
+    const float* Wk = W + (int64_t)k * Cin * Cout;
+    for (int c0 = 0; c0 < Cin; c0 += BK) {
+      float4 av[AR], bv[BR];
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx[i] >= 0) av[i] = *reinterpret_cast<const float4*>(in + (int64_t)idx[i] * Cin + c0 + a_c4 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        int lin = tid + 256 * i;
+        int kk = lin / (BN / 4), c4 = lin % (BN / 4);
+        bv[i] = *reinterpret_cast<const float4*>(Wk + (int64_t)(c0 + kk) * Cout + n0 + c4 * 4);
+      }
+      __syncthreads();                           // previous stage fully consumed
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        *reinterpret_cast<float4*>(&As[(a_r + 32 * i) * LDA + a_c4 * 4]) = av[i];
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        int lin = tid + 256 * i;
+        int kk = lin / (BN / 4), c4 = lin % (BN / 4);
+        *reinterpret_cast<float4*>(&Bs[kk * BN + c4 * 4]) = bv[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < BK / 8; ++q) {
+        float4 a[TM];
+        float b[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          a[i] = *reinterpret_cast<const float4*>(&As[(wr * (BM / 2) + i * 32 + r) * LDA + 8 * q + 4 * h]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[j][e] = Bs[(8 * q + 4 * h + e) * BN + wc * (BN / 2) + j * 32 + r];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            float ae = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, b[j][e], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int64_t row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        int col = n0 + wc * (BN / 2) + j * 32 + r;
+        if (row < n_out) out[row * Cout + col] = acc[i][j][e];
+      }
+}
+
+// generic fallback (any Cin/Cout): one thread per (row, cout).  Used for the Cin=3 stem and as the
+// cross-check path of the parity tests (flags & 1).
+__global__ void k_conv_fma(const float* __restrict__ in, const float* __restrict__ W, const int* __restrict__ nbr,
+                           float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out * Cout) return;
+  int64_t o = t / Cout;
+  int co = (int)(t % Cout);
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    int i = nbr ? nbr[(int64_t)k * n_out + o] : (int)o;
+    if (i < 0) continue;
+    const float* x = in + (int64_t)i * Cin;
+    const float* w = W + (int64_t)k * Cin * Cout + co;
+    for (int ci = 0; ci < Cin; ++ci) acc = fmaf(x[ci], w[(int64_t)ci * Cout], acc);
+  }
+  out[t] = acc;
+}
+
+extern "C" {
+
+// flags: bit0 = force the generic FMA kernel.
+int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int64_t n_in, int64_t n_out, int K, int Cin,
+                int Cout, int flags, hipStream_t stream) {
+  if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
+  if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
+  if (n_out == 0) return FC_OK;
+  bool mfma_ok = !(flags & 1) && (Cin % BK == 0) && (Cout % 64 == 0);
+  if (!mfma_ok) {
+    k_conv_fma<<<(unsigned)fc_cdiv(n_out * Cout, 256), 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
+    FC_CHECK_LAUNCH();
+    return FC_OK;
+  }
+  const bool wide = (Cout % 128 == 0);
+  const int bn = wide ? 128 : 64;
+  const int64_t wg128 = fc_cdiv(n_out, 128) * (Cout / bn);
+  const bool tall = wg128 >= 512;               // enough workgroups to fill 256 CUs twice over
+  const int bm = tall ? 128 : 64;
+  dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn);
+  if (tall && wide) k_conv_mfma<128, 128><<<grid, 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
+  else if (tall) k_conv_mfma<128, 64><<<grid, 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
+  else if (wide) k_conv_mfma<64, 128><<<grid, 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
+  else k_conv_mfma<64, 64><<<grid, 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// wgrad:  gW[k][ci][co] = sum_o in[nbr[k][o]][ci] * gout[o][co]
+// GEMM with M = Cin, N = Cout and the reduction over output rows, split over `S` row ranges whose
+// partial products are written to the workspace and summed by k_wgrad_reduce in a fixed order
+// (deterministic, no atomics).
+template <int BMc, int BNc>
+__global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ gout,
+                                                    const int* __restrict__ nbr, float* __restrict__ part, int64_t n_out,
+                                                    int K, int Cin, int Cout, int64_t rows_per_split) {
+  constexpr int TM = BMc / 64, TN = BNc / 64;
+  constexpr int AR = BMc / 32, GR = BNc / 32;    // float4 loads per thread per stage (32 rows)
+  __shared__ __attribute__((aligned(16))) float As[BK * BMc];
+  __shared__ __attribute__((aligned(16))) float Gs[BK * BNc];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles_n = Cout / BNc, tiles_m = Cin / BMc;
+  int y = blockIdx.y;
+  const int tn = y % tiles_n; y /= tiles_n;
+  const int tm = y % tiles_m; y /= tiles_m;
+  const int k = y;
+  const int ci0 = tm * BMc, co0 = tn * BNc;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_split;
+  int64_t r_end = r_begin + rows_per_split;
+  if (r_end > n_out) r_end = n_out;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  for (int64_t rb = r_begin; rb < r_end; rb += BK) {
+    // A: 32 rows x BMc channels -> BMc/4 float4 per row
+    float4 av[AR], gv[GR];
+    int any = 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      int lin = tid + 256 * i;
+      int rr = lin / (BMc / 4), c4 = lin % (BMc / 4);
+      int64_t row = rb + rr;
+      int src = -1;
+      if (row < r_end) src = nbr ? nbr[(int64_t)k * n_out + row] : (int)row;
+      av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (src >= 0) {
+        av[i] = *reinterpret_cast<const float4*>(in + (int64_t)src * Cin + ci0 + c4 * 4);
+        any = 1;
+      }
+    }
+    if (!__syncthreads_or(any)) continue;
+#pragma unroll
+    for (int i = 0; i < GR; ++i) {
+      int lin = tid + 256 * i;
+      int rr = lin / (BNc / 4), c4 = lin % (BNc / 4);
+      int64_t row = rb + rr;
+      gv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < r_end) gv[i] = *reinterpret_cast<const float4*>(gout + row * Cout + co0 + c4 * 4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      int lin = tid + 256 * i;
+      int rr = lin / (BMc / 4), c4 = lin % (BMc / 4);
+      *reinterpret_cast<float4*>(&As[rr * BMc + c4 * 4]) = av[i];
+    }
+#pragma unroll
+    for (int i = 0; i < GR; ++i) {
+      int lin = tid + 256 * i;
+      int rr = lin / (BNc / 4), c4 = lin % (BNc / 4);
+      *reinterpret_cast<float4*>(&Gs[rr * BNc + c4 * 4]) = gv[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      float a[TM][4], b[TN][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i][e] = As[(8 * q + 4 * h + e) * BMc + wr * (BMc / 2) + i * 32 + r];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j][e] = Gs[(8 * q + 4 * h + e) * BNc + wc * (BNc / 2) + j * 32 + r];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* dst = part + ((int64_t)blockIdx.x * K + k) * Cin * Cout;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int row = ci0 + wr * (BMc / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        int col = co0 + wc * (BNc / 2) + j * 32 + r;
+        dst[(int64_t)row * Cout + col] = acc[i][j][e];
+      }
+}
+
+// generic wgrad: block = (row range, k); each thread owns (ci,co) pairs strided by blockDim.
+__global__ void k_wgrad_fma(const float* __restrict__ in, const float* __restrict__ gout, const int* __restrict__ nbr,
+                            float* __restrict__ part, int64_t n_out, int K, int Cin, int Cout, int64_t rows_per_split) {
+  const int k = blockIdx.y;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_split;
+  int64_t r_end = r_begin + rows_per_split;
+  if (r_end > n_out) r_end = n_out;
+  float* dst = part + ((int64_t)blockIdx.x * K + k) * Cin * Cout;
+  for (int p = threadIdx.x; p < Cin * Cout; p += blockDim.x) {
+    int ci = p / Cout, co = p % Cout;
+    float acc = 0.f;
+    for (int64_t o = r_begin; o < r_end; ++o) {
+      int i = nbr ? nbr[(int64_t)k * n_out + o] : (int)o;
+      if (i >= 0) acc = fmaf(in[(int64_t)i * Cin + ci], gout[o * Cout + co], acc);
+    }
+    dst[p] = acc;
+  }
+}
+
+__global__ void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ gW, int64_t elems, int S) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= elems) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += part[(int64_t)s * elems + i];
+  gW[i] = acc;
+}
+
+// (K,Cin,Cout) -> (K,Cout,Cin)
+__global__ void k_transpose_w(const float* __restrict__ W, float* __restrict__ Wt, int K, int Cin, int Cout) {
+  __shared__ float tile[32][33];
+  int k = blockIdx.z;
+  int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    int ci = ci0 + j, co = co0 + tx;
+    tile[j][tx] = (ci < Cin && co < Cout) ? W[((int64_t)k * Cin + ci) * Cout + co] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int co = co0 + j, ci = ci0 + tx;
+    if (ci < Cin && co < Cout) Wt[((int64_t)k * Cout + co) * Cin + ci] = tile[tx][j];
+  }
+}
+
+extern "C" {
+
+static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, int* S, int64_t* rows_per_split) {
+  bool mfma_ok = !(flags & 1) && (Cin % 64 == 0) && (Cout % 64 == 0);
+  int64_t tiles = mfma_ok ? (int64_t)K * (Cin / (Cin % 128 == 0 ? 128 : 64)) * (Cout / (Cout % 128 == 0 ? 128 : 64))
+                          : (int64_t)K;
+  // aim for ~2048 workgroups, at least 512 rows per split, at most 256 splits
+  int64_t s = fc_cdiv(2048, tiles);
+  int64_t max_by_rows = fc_cdiv(n_out > 0 ? n_out : 1, mfma_ok ? 512 : 2048);
+  if (s > max_by_rows) s = max_by_rows;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  int64_t rps = fc_align(fc_cdiv(n_out > 0 ? n_out : 1, s), BK);
+  s = fc_cdiv(n_out > 0 ? n_out : 1, rps);
+  *S = (int)s;
+  *rows_per_split = rps;
+}
+
+int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags) {
+  int S; int64_t rps;
+  wgrad_plan(n_out, K, Cin, Cout, flags, &S, &rps);
+  return (int64_t)S * K * Cin * Cout * (int64_t)sizeof(float);
+}
+
+int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, float* gW, int64_t n_in, int64_t n_out, int K,
+                  int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
+  if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
+  const int64_t elems = (int64_t)K * Cin * Cout;
+  if (n_out == 0) {
+    FC_HIP(hipMemsetAsync(gW, 0, elems * sizeof(float), stream));
+    return FC_OK;
+  }
+  int S; int64_t rps;
+  wgrad_plan(n_out, K, Cin, Cout, flags, &S, &rps);
+  if (ws_bytes < (int64_t)S * elems * (int64_t)sizeof(float)) return FC_EWS;
+  float* part = (S == 1) ? gW : (float*)ws;
+  bool mfma_ok = !(flags & 1) && (Cin % 64 == 0) && (Cout % 64 == 0);
+  if (mfma_ok) {
+    const int bm = (Cin % 128 == 0) ? 128 : 64, bn = (Cout % 128 == 0) ? 128 : 64;
+    dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
+    if (bm == 128 && bn == 128) k_wgrad_mfma<128, 128><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
+    else if (bm == 128) k_wgrad_mfma<128, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
+    else if (bn == 128) k_wgrad_mfma<64, 128><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
+    else k_wgrad_mfma<64, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
+  } else {
+    dim3 grid((unsigned)S, (unsigned)K);
+    k_wgrad_fma<<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
+  }
+  FC_CHECK_LAUNCH();
+  if (S > 1) {
+    k_wgrad_reduce<<<(unsigned)fc_cdiv(elems, 256), 256, 0, stream>>>(part, gW, elems, S);
+    FC_CHECK_LAUNCH();
+  }
+  return FC_OK;
+}
+
+int fc_transpose_weight(const float* W, float* Wt, int K, int Cin, int Cout, hipStream_t stream) {
+  if (K < 1 || Cin < 1 || Cout < 1 || K > 65535) return FC_EINVAL;
+  dim3 grid((unsigned)fc_cdiv(Cout, 32), (unsigned)fc_cdiv(Cin, 32), (unsigned)K);
+  k_transpose_w<<<grid, 256, 0, stream>>>(W, Wt, K, Cin, Cout);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// Shared helpers for the gfx950 kernels of libfcaf3d_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FC_OK 0
+#define FC_EINVAL (-1)
+#define FC_EWS (-2)   // workspace too small
+
+#define FC_CHECK_LAUNCH()                      \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return (int)e__;    \
+  } while (0)
+
+#define FC_HIP(x)                              \
+  do {                                         \
+    hipError_t e__ = (x);                      \
+    if (e__ != hipSuccess) return (int)e__;    \
+  } while (0)
+
+static inline int64_t fc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t fc_align(int64_t a, int64_t b) { return fc_cdiv(a, b) * b; }
+
+#define FC_EMPTY_KEY ((unsigned long long)0xFFFFFFFFFFFFFFFFull)
+
+// (b,x,y,z) -> 64-bit key, lexicographic; 16 bits per spatial axis with a 2^15 bias.
+__host__ __device__ static inline unsigned long long fc_pack(int b, int x, int y, int z) {
+  return ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)(unsigned)(x + 32768) << 32) |
+         ((unsigned long long)(unsigned)(y + 32768) << 16) | (unsigned long long)(unsigned)(z + 32768);
+}
+
+__device__ static inline unsigned long long fc_mix(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return k;
+}
+
+// probe an open-addressing table; returns value or -1
+__device__ static inline int fc_lookup(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
+                                       unsigned long long mask, unsigned long long key) {
+  unsigned long long h = fc_mix(key) & mask;
+  while (true) {
+    unsigned long long k = keys[h];
+    if (k == key) return vals[h];
+    if (k == FC_EMPTY_KEY) return -1;
+    h = (h + 1) & mask;
+  }
+}
+
+__device__ static inline int fc_floor_div(int a, int b) {
+  int q = a / b, r = a % b;
+  return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q;
+}

@@ -1,0 +1,412 @@
+// Bandwidth-bound feature-matrix ops on gfx950: segmented column statistics (BatchNorm over all
+// voxels / InstanceNorm per scene), fused normalise + affine + residual + ReLU/ELU forward and
+// backward, max pooling over the k2s2 kernel map, row gather / scatter.
+// All reductions are two-level with a fixed summation order (deterministic, no float atomics).
+//
+// Replaces MinkowskiBatchNorm / MinkowskiInstanceNorm / MinkowskiReLU / MinkowskiELU /
+// MinkowskiMaxPooling / MinkowskiPruning feature paths used at me_resnet.py:22-24,63,
+// BasicBlock (MinkowskiEngine.modules.resnet_block), fcaf3d_neck_with_head.py:53-54,67-71,76,125.
+#include "fc_common.h"
+
+#define ROWS_PER_BLOCK 256   // rows reduced by one block in the partial pass
+#define MAXSEG 64
+
+__device__ static inline int seg_of(const int* seg, int seg_stride, int64_t row) {
+  return seg ? seg[row * seg_stride] : 0;
+}
+
+// ---- pass 1: partial sums of f(x) per (block, segment, channel) --------------------------------
+// mode 0: sum x ; mode 1: sum (x-mean[seg])^2
+// block = 256 threads laid out as (C/4 lanes of float4) x (256/(C/4) row lanes); C % 4 == 0, C <= 1024
+__global__ void k_stats_partial(const float* __restrict__ x, const int* __restrict__ seg, int seg_stride, int64_t n, int C,
+                                int nseg, const float* __restrict__ mean, int mode, float* __restrict__ part,
+                                float* __restrict__ part_cnt) {
+  extern __shared__ float sm[];               // [rl][C] staging for the cross-row-lane reduction
+  const int c4n = C / 4;
+  const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+  const int nrl = blockDim.x / c4n;
+  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  int64_t r1 = r0 + ROWS_PER_BLOCK;
+  if (r1 > n) r1 = n;
+  // segments are (nearly) contiguous in row order: handle the block's segment range one at a time
+  int s_lo = seg_of(seg, seg_stride, r0), s_hi = s_lo;
+  if (seg) {
+    // rows inside a block may interleave segments in general -> scan min/max cheaply
+    for (int64_t r = r0; r < r1; ++r) {
+      int s = seg[r * seg_stride];
+      s_lo = s < s_lo ? s : s_lo;
+      s_hi = s > s_hi ? s : s_hi;
+    }
+  }
+  for (int s = 0; s < nseg; ++s) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cnt = 0.f;
+    if (s >= s_lo && s <= s_hi && rl < nrl) {
+      float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mode == 1) mu = *reinterpret_cast<const float4*>(mean + (int64_t)s * C + cl * 4);
+      for (int64_t r = r0 + rl; r < r1; r += nrl) {
+        if (seg_of(seg, seg_stride, r) != s) continue;
+        float4 v = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
+        if (mode == 1) {
+          v.x -= mu.x; v.y -= mu.y; v.z -= mu.z; v.w -= mu.w;
+          v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w;
+        }
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        cnt += 1.f;
+      }
+    }
+    __syncthreads();
+    if (rl < nrl) *reinterpret_cast<float4*>(&sm[(rl * c4n + cl) * 4]) = acc;
+    // counts: reuse tail of shared memory
+    float* smc = sm + nrl * C;
+    if (cl == 0 && rl < nrl) smc[rl] = cnt;
+    __syncthreads();
+    if (rl == 0) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < nrl; ++j) {
+        float4 u = *reinterpret_cast<const float4*>(&sm[(j * c4n + cl) * 4]);
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.x * nseg + s) * C + cl * 4) = t;
+      if (cl == 0 && part_cnt) {
+        float c = 0.f;
+        for (int j = 0; j < nrl; ++j) c += smc[j];
+        part_cnt[(int64_t)blockIdx.x * nseg + s] = c;
+      }
+    }
+  }
+}
+
+// ---- pass 2: sum partials over blocks in order; thread per (seg, channel) ------------------------
+// mode 0: out = sum / cnt (mean), also writes cnt[seg];  mode 1: out = sum / cnt (biased variance)
+// mode 2: out = sum (plain)
+__global__ void k_stats_final(const float* __restrict__ part, const float* __restrict__ part_cnt, int64_t nblocks, int nseg,
+                              int C, int mode, float* __restrict__ out, float* __restrict__ cnt_io) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nseg * C) return;
+  int s = t / C;
+  float acc = 0.f;
+  for (int64_t b = 0; b < nblocks; ++b) acc += part[(b * nseg) * C + t];
+  float cnt = 1.f;
+  if (mode == 0) {
+    float c = 0.f;
+    for (int64_t b = 0; b < nblocks; ++b) c += part_cnt[b * nseg + s];
+    if (t % C == 0) cnt_io[s] = c;
+    cnt = c;
+  } else if (mode == 1) {
+    cnt = cnt_io[s];
+  }
+  out[t] = (mode == 2) ? acc : (cnt > 0.f ? acc / cnt : 0.f);
+}
+
+__device__ static inline float act_fwd(float v, int act) {
+  if (act == 1) return v > 0.f ? v : 0.f;
+  if (act == 2) return v > 0.f ? v : expm1f(v);
+  return v;
+}
+// derivative expressed through the OUTPUT y (ReLU: y>0 ; ELU(alpha=1): y>0 ? 1 : y+1)
+__device__ static inline float act_bwd_from_y(float y, int act) {
+  if (act == 1) return y > 0.f ? 1.f : 0.f;
+  if (act == 2) return y > 0.f ? 1.f : y + 1.f;
+  return 1.f;
+}
+
+// y = act( (x-mean[seg])*invstd[seg]*gamma + beta (+ residual) ) ; invstd = 1/sqrt(var+eps)
+__global__ void k_norm_act_fwd(const float* __restrict__ x, const int* __restrict__ seg, int seg_stride, int64_t n, int C,
+                               const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ residual, int act, float* __restrict__ y) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4n = C / 4;
+  if (t >= n * c4n) return;
+  int64_t r = t / c4n;
+  int c = (int)(t % c4n) * 4;
+  int s = seg_of(seg, seg_stride, r);
+  float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
+  float4 mu = *reinterpret_cast<const float4*>(mean + (int64_t)s * C + c);
+  float4 va = *reinterpret_cast<const float4*>(var + (int64_t)s * C + c);
+  float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+  float4 b = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 o;
+  o.x = (v.x - mu.x) * (1.f / sqrtf(va.x + eps)) * g.x + b.x;
+  o.y = (v.y - mu.y) * (1.f / sqrtf(va.y + eps)) * g.y + b.y;
+  o.z = (v.z - mu.z) * (1.f / sqrtf(va.z + eps)) * g.z + b.z;
+  o.w = (v.w - mu.w) * (1.f / sqrtf(va.w + eps)) * g.w + b.w;
+  if (residual) {
+    float4 rs = *reinterpret_cast<const float4*>(residual + r * C + c);
+    o.x += rs.x; o.y += rs.y; o.z += rs.z; o.w += rs.w;
+  }
+  o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
+  *reinterpret_cast<float4*>(y + r * C + c) = o;
+}
+
+// backward pass 1: per (block, seg, channel) partial sums of g' and g'*xhat, g' = gy * act'(y)
+// part layout: [block][seg][2][C]
+__global__ void k_norm_bwd_partial(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
+                                   const int* __restrict__ seg, int seg_stride, int64_t n, int C, int nseg,
+                                   const float* __restrict__ mean, const float* __restrict__ var, float eps, int act,
+                                   float* __restrict__ part) {
+  extern __shared__ float sm[];               // [rl][2][C]
+  const int c4n = C / 4;
+  const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+  const int nrl = blockDim.x / c4n;
+  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+  int64_t r1 = r0 + ROWS_PER_BLOCK;
+  if (r1 > n) r1 = n;
+  int s_lo = seg_of(seg, seg_stride, r0), s_hi = s_lo;
+  if (seg) {
+    for (int64_t r = r0; r < r1; ++r) {
+      int s = seg[r * seg_stride];
+      s_lo = s < s_lo ? s : s_lo;
+      s_hi = s > s_hi ? s : s_hi;
+    }
+  }
+  for (int s = 0; s < nseg; ++s) {
+    float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+    if (s >= s_lo && s <= s_hi && rl < nrl) {
+      float4 mu = *reinterpret_cast<const float4*>(mean + (int64_t)s * C + cl * 4);
+      float4 va = *reinterpret_cast<const float4*>(var + (int64_t)s * C + cl * 4);
+      float4 is = make_float4(1.f / sqrtf(va.x + eps), 1.f / sqrtf(va.y + eps), 1.f / sqrtf(va.z + eps),
+                              1.f / sqrtf(va.w + eps));
+      for (int64_t r = r0 + rl; r < r1; r += nrl) {
+        if (seg_of(seg, seg_stride, r) != s) continue;
+        float4 xv = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
+        float4 g = *reinterpret_cast<const float4*>(gy + r * C + cl * 4);
+        if (act) {
+          float4 yv = *reinterpret_cast<const float4*>(y + r * C + cl * 4);
+          g.x *= act_bwd_from_y(yv.x, act); g.y *= act_bwd_from_y(yv.y, act);
+          g.z *= act_bwd_from_y(yv.z, act); g.w *= act_bwd_from_y(yv.w, act);
+        }
+        a1.x += g.x; a1.y += g.y; a1.z += g.z; a1.w += g.w;
+        a2.x += g.x * (xv.x - mu.x) * is.x; a2.y += g.y * (xv.y - mu.y) * is.y;
+        a2.z += g.z * (xv.z - mu.z) * is.z; a2.w += g.w * (xv.w - mu.w) * is.w;
+      }
+    }
+    __syncthreads();
+    if (rl < nrl) {
+      *reinterpret_cast<float4*>(&sm[(rl * 2 + 0) * C + cl * 4]) = a1;
+      *reinterpret_cast<float4*>(&sm[(rl * 2 + 1) * C + cl * 4]) = a2;
+    }
+    __syncthreads();
+    if (rl == 0) {
+      float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+      for (int j = 0; j < nrl; ++j) {
+        float4 u = *reinterpret_cast<const float4*>(&sm[(j * 2 + 0) * C + cl * 4]);
+        float4 w = *reinterpret_cast<const float4*>(&sm[(j * 2 + 1) * C + cl * 4]);
+        t1.x += u.x; t1.y += u.y; t1.z += u.z; t1.w += u.w;
+        t2.x += w.x; t2.y += w.y; t2.z += w.z; t2.w += w.w;
+      }
+      float* dst = part + (((int64_t)blockIdx.x * nseg + s) * 2) * C;
+      *reinterpret_cast<float4*>(dst + cl * 4) = t1;
+      *reinterpret_cast<float4*>(dst + C + cl * 4) = t2;
+    }
+  }
+}
+
+// backward pass 3:  gx = gamma*invstd*( g' - sum_g/cnt - xhat * sum_gx/cnt ) ; gres = g'
+__global__ void k_norm_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
+                                 const int* __restrict__ seg, int seg_stride, int64_t n, int C,
+                                 const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                 const float* __restrict__ gamma, const float* __restrict__ sums /*[seg][2][C]*/,
+                                 const float* __restrict__ cnt, int act, float* __restrict__ gx, float* __restrict__ gres) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4n = C / 4;
+  if (t >= n * c4n) return;
+  int64_t r = t / c4n;
+  int c = (int)(t % c4n) * 4;
+  int s = seg_of(seg, seg_stride, r);
+  float inv_n = 1.f / cnt[s];
+  float xv[4], gv[4], muv[4], vav[4], gam[4], s1[4], s2[4], yv[4], o[4], gr[4];
+  *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + r * C + c);
+  *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(gy + r * C + c);
+  *reinterpret_cast<float4*>(muv) = *reinterpret_cast<const float4*>(mean + (int64_t)s * C + c);
+  *reinterpret_cast<float4*>(vav) = *reinterpret_cast<const float4*>(var + (int64_t)s * C + c);
+  *reinterpret_cast<float4*>(s1) = *reinterpret_cast<const float4*>(sums + ((int64_t)s * 2) * C + c);
+  *reinterpret_cast<float4*>(s2) = *reinterpret_cast<const float4*>(sums + ((int64_t)s * 2 + 1) * C + c);
+  if (gamma) *reinterpret_cast<float4*>(gam) = *reinterpret_cast<const float4*>(gamma + c);
+  else gam[0] = gam[1] = gam[2] = gam[3] = 1.f;
+  if (act) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y + r * C + c);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float g = gv[j];
+    if (act) g *= act_bwd_from_y(yv[j], act);
+    float is = 1.f / sqrtf(vav[j] + eps);
+    float xh = (xv[j] - muv[j]) * is;
+    gr[j] = g;
+    o[j] = gam[j] * is * (g - s1[j] * inv_n - xh * s2[j] * inv_n);
+  }
+  *reinterpret_cast<float4*>(gx + r * C + c) = *reinterpret_cast<float4*>(o);
+  if (gres) *reinterpret_cast<float4*>(gres + r * C + c) = *reinterpret_cast<float4*>(gr);
+}
+
+// ---- max pooling over a (K, n_out) neighbour table ---------------------------------------------
+__global__ void k_maxpool_fwd(const float* __restrict__ in, const int* __restrict__ nbr, int64_t n_out, int K, int C,
+                              float* __restrict__ out, int* __restrict__ argrow) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out * C) return;
+  int64_t o = t / C;
+  int c = (int)(t % C);
+  float best = -INFINITY;
+  int arg = -1;
+  for (int k = 0; k < K; ++k) {
+    int i = nbr[(int64_t)k * n_out + o];
+    if (i < 0) continue;
+    float v = in[(int64_t)i * C + c];
+    if (arg < 0 || v > best) { best = v; arg = i; }   // first max in offset order wins ties (A.5)
+  }
+  out[t] = arg < 0 ? 0.f : best;
+  argrow[t] = arg;
+}
+
+__global__ void k_maxpool_bwd(const float* __restrict__ gout, const int* __restrict__ argrow, int64_t n_out, int C,
+                              float* __restrict__ gin) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out * C) return;
+  int i = argrow[t];
+  // k2s2 children are disjoint between output cells -> each (row, channel) receives at most one write
+  if (i >= 0) gin[(int64_t)i * C + (t % C)] = gout[t];
+}
+
+// ---- row gather / scatter ----------------------------------------------------------------------
+__global__ void k_gather_rows(const float* __restrict__ src, const int* __restrict__ idx, int64_t n, int C,
+                              float* __restrict__ dst) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * C) return;
+  int64_t r = t / C;
+  int i = idx[r];
+  dst[t] = i >= 0 ? src[(int64_t)i * C + (t % C)] : 0.f;
+}
+
+// dst[idx[r]] += src[r]   (idx unique -> race free)
+__global__ void k_scatter_rows_add(const float* __restrict__ src, const int* __restrict__ idx, int64_t n, int C,
+                                   float* __restrict__ dst) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * C) return;
+  int64_t r = t / C;
+  int i = idx[r];
+  if (i >= 0) dst[(int64_t)i * C + (t % C)] += src[t];
+}
+
+extern "C" {
+
+static int stats_geometry(int C, int* threads, size_t* smem_fwd, size_t* smem_bwd) {
+  if (C < 4 || C % 4 || C > 1024) return FC_EINVAL;
+  int c4n = C / 4;
+  int nrl = 256 / c4n;
+  if (nrl < 1) nrl = 1;
+  if (nrl > 16) nrl = 16;
+  *threads = nrl * c4n;
+  *smem_fwd = (size_t)(nrl * C + nrl) * sizeof(float);
+  *smem_bwd = (size_t)(nrl * 2 * C) * sizeof(float);
+  return FC_OK;
+}
+
+int64_t fc_col_stats_ws_bytes(int64_t n, int C, int nseg) {
+  int64_t nb = fc_cdiv(n > 0 ? n : 1, ROWS_PER_BLOCK);
+  return nb * nseg * ((int64_t)C + 1) * (int64_t)sizeof(float);
+}
+
+// mean (nseg,C), var (nseg,C) biased, cnt (nseg) ; seg = per-row segment id pointer (NULL -> one segment)
+int fc_col_stats(const float* x, const int* seg, int seg_stride, int64_t n, int C, int nseg, float* mean, float* var,
+                 float* cnt, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (n < 0 || nseg < 1 || nseg > MAXSEG) return FC_EINVAL;
+  int threads; size_t sf, sb;
+  if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
+  if (ws_bytes < fc_col_stats_ws_bytes(n, C, nseg)) return FC_EWS;
+  int64_t nb = fc_cdiv(n > 0 ? n : 1, ROWS_PER_BLOCK);
+  float* part = (float*)ws;
+  float* part_cnt = part + nb * nseg * C;
+  if (n == 0) {
+    FC_HIP(hipMemsetAsync(mean, 0, sizeof(float) * nseg * C, stream));
+    FC_HIP(hipMemsetAsync(var, 0, sizeof(float) * nseg * C, stream));
+    FC_HIP(hipMemsetAsync(cnt, 0, sizeof(float) * nseg, stream));
+    return FC_OK;
+  }
+  unsigned gfin = (unsigned)fc_cdiv((int64_t)nseg * C, 256);
+  k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, nullptr, 0, part, part_cnt);
+  FC_CHECK_LAUNCH();
+  k_stats_final<<<gfin, 256, 0, stream>>>(part, part_cnt, nb, nseg, C, 0, mean, cnt);
+  FC_CHECK_LAUNCH();
+  k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, mean, 1, part, nullptr);
+  FC_CHECK_LAUNCH();
+  k_stats_final<<<gfin, 256, 0, stream>>>(part, nullptr, nb, nseg, C, 1, var, cnt);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+int fc_norm_act_fwd(const float* x, const int* seg, int seg_stride, int64_t n, int C, const float* mean, const float* var,
+                    float eps, const float* gamma, const float* beta, const float* residual, int act, float* y,
+                    hipStream_t stream) {
+  if (n < 0 || C < 4 || C % 4 || act < 0 || act > 2) return FC_EINVAL;
+  if (n == 0) return FC_OK;
+  k_norm_act_fwd<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, seg, seg_stride, n, C, mean, var, eps, gamma,
+                                                                         beta, residual, act, y);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+int64_t fc_norm_act_bwd_ws_bytes(int64_t n, int C, int nseg) {
+  int64_t nb = fc_cdiv(n > 0 ? n : 1, ROWS_PER_BLOCK);
+  return nb * nseg * 2 * (int64_t)C * (int64_t)sizeof(float);
+}
+
+// sums (nseg,2,C): [.,0,.] = sum g' (= d beta per segment), [.,1,.] = sum g'*xhat (= d gamma per segment)
+int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* seg, int seg_stride, int64_t n, int C,
+                    int nseg, const float* mean, const float* var, const float* cnt, float eps, const float* gamma,
+                    int act, float* gx, float* gres, float* sums, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (n < 0 || nseg < 1 || nseg > MAXSEG || act < 0 || act > 2) return FC_EINVAL;
+  int threads; size_t sf, sb;
+  if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
+  if (ws_bytes < fc_norm_act_bwd_ws_bytes(n, C, nseg)) return FC_EWS;
+  if (n == 0) {
+    FC_HIP(hipMemsetAsync(sums, 0, sizeof(float) * nseg * 2 * C, stream));
+    return FC_OK;
+  }
+  int64_t nb = fc_cdiv(n, ROWS_PER_BLOCK);
+  float* part = (float*)ws;
+  k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, seg, seg_stride, n, C, nseg, mean, var, eps, act, part);
+  FC_CHECK_LAUNCH();
+  k_stats_final<<<(unsigned)fc_cdiv((int64_t)nseg * 2 * C, 256), 256, 0, stream>>>(part, nullptr, nb, nseg, 2 * C, 2, sums,
+                                                                                  nullptr);
+  FC_CHECK_LAUNCH();
+  k_norm_bwd_apply<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, y, gy, seg, seg_stride, n, C, mean, var, eps,
+                                                                           gamma, sums, cnt, act, gx, gres);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+int fc_maxpool_fwd(const float* in, const int* nbr, int64_t n_out, int K, int C, float* out, int* argrow,
+                   hipStream_t stream) {
+  if (n_out < 0 || K < 1 || C < 1) return FC_EINVAL;
+  if (n_out == 0) return FC_OK;
+  k_maxpool_fwd<<<(unsigned)fc_cdiv(n_out * C, 256), 256, 0, stream>>>(in, nbr, n_out, K, C, out, argrow);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+// gin must be zero-filled by the caller (n_in rows)
+int fc_maxpool_bwd(const float* gout, const int* argrow, int64_t n_out, int C, float* gin, hipStream_t stream) {
+  if (n_out < 0 || C < 1) return FC_EINVAL;
+  if (n_out == 0) return FC_OK;
+  k_maxpool_bwd<<<(unsigned)fc_cdiv(n_out * C, 256), 256, 0, stream>>>(gout, argrow, n_out, C, gin);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+int fc_gather_rows(const float* src, const int* idx, int64_t n, int C, float* dst, hipStream_t stream) {
+  if (n < 0 || C < 1) return FC_EINVAL;
+  if (n == 0) return FC_OK;
+  k_gather_rows<<<(unsigned)fc_cdiv(n * C, 256), 256, 0, stream>>>(src, idx, n, C, dst);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+int fc_scatter_rows_add(const float* src, const int* idx, int64_t n, int C, float* dst, hipStream_t stream) {
+  if (n < 0 || C < 1) return FC_EINVAL;
+  if (n == 0) return FC_OK;
+  k_scatter_rows_add<<<(unsigned)fc_cdiv(n * C, 256), 256, 0, stream>>>(src, idx, n, C, dst);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+}  // extern "C"

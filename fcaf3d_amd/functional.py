@@ -1,0 +1,221 @@
+"""torch.autograd wrappers over the C ABI (libfcaf3d_hip.so).  fp32 only; every forward/backward is
+HIP — there is no eager/CPU fallback (tensors on the CPU raise)."""
+import torch
+
+from . import _lib as L
+
+FLAGS = 0   # bit0: force the generic FMA conv kernels (parity cross-check)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('fcaf3d_amd ops run on the GPU only (HIP); got a CPU tensor')
+
+
+# ---- rows ------------------------------------------------------------------------------------------
+def _gather(src, idx, n_out=None):
+    n = idx.numel()
+    out = torch.empty((n, src.shape[1]), dtype=src.dtype, device=src.device)
+    L.call('fc_gather_rows', L.ptr(src), L.ptr(idx), n, src.shape[1], L.ptr(out), L.stream())
+    return out
+
+
+def _scatter_add(dst, idx, src):
+    L.call('fc_scatter_rows_add', L.ptr(src), L.ptr(idx), idx.numel(), src.shape[1], L.ptr(dst), L.stream())
+
+
+class _GatherRows(torch.autograd.Function):
+    """dst[i] = src[idx[i]] with unique idx (pruning / per-scene split / first-occurrence pick)."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        _chk(src, idx)
+        ctx.save_for_backward(idx)
+        ctx.n_src = src.shape[0]
+        return _gather(src.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.zeros((ctx.n_src, g.shape[1]), dtype=g.dtype, device=g.device)
+        _scatter_add(out, idx, g)
+        return out, None
+
+
+def gather_rows(src, idx):
+    return _GatherRows.apply(src, idx.to(torch.int32).contiguous())
+
+
+# ---- convolution -----------------------------------------------------------------------------------
+class _SparseConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, weight, kmap, n_out):
+        """feats (n_in,Cin), weight (K,Cin,Cout), kmap KernelMap or None (identity, K==1)."""
+        _chk(feats, weight)
+        feats = feats.contiguous()
+        weight = weight.contiguous()
+        K, Cin, Cout = weight.shape
+        n_in = feats.shape[0]
+        out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
+        nbr = kmap.nbr if kmap is not None else None
+        L.call('fc_conv_fwd', L.ptr(feats), L.ptr(weight), L.ptr(nbr), L.ptr(out), n_in, n_out, K, Cin, Cout, FLAGS,
+               L.stream())
+        ctx.save_for_backward(feats, weight)
+        ctx.kmap = kmap
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        feats, weight = ctx.saved_tensors
+        kmap = ctx.kmap
+        gout = gout.contiguous()
+        K, Cin, Cout = weight.shape
+        n_in, n_out = feats.shape[0], gout.shape[0]
+        dev = feats.device
+        gin = gw = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty((K, Cout, Cin), dtype=torch.float32, device=dev)
+            L.call('fc_transpose_weight', L.ptr(weight), L.ptr(wt), K, Cin, Cout, L.stream())
+            gin = torch.empty((n_in, Cin), dtype=torch.float32, device=dev)
+            nbr_t = kmap.nbr_t if kmap is not None else None
+            L.call('fc_conv_fwd', L.ptr(gout), L.ptr(wt), L.ptr(nbr_t), L.ptr(gin), n_out, n_in, K, Cout, Cin, FLAGS,
+                   L.stream())
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(weight)
+            nbr = kmap.nbr if kmap is not None else None
+            wsb = L.query('fc_conv_wgrad_ws_bytes', n_out, K, Cin, Cout, FLAGS)
+            ws = L.workspace(wsb, dev)
+            L.call('fc_conv_wgrad', L.ptr(feats), L.ptr(gout), L.ptr(nbr), L.ptr(gw), n_in, n_out, K, Cin, Cout, FLAGS,
+                   L.ptr(ws), ws.numel(), L.stream())
+        return gin, gw, None, None
+
+
+def sparse_conv(feats, weight, kmap, n_out):
+    return _SparseConv.apply(feats, weight, kmap, n_out)
+
+
+# ---- normalisation + activation ---------------------------------------------------------------------
+ACT = {None: 0, 'none': 0, 'relu': 1, 'elu': 2}
+
+
+def col_stats(x, seg, nseg):
+    """mean, biased var (nseg,C), count (nseg)."""
+    n, C = x.shape
+    dev = x.device
+    mean = torch.empty((nseg, C), dtype=torch.float32, device=dev)
+    var = torch.empty((nseg, C), dtype=torch.float32, device=dev)
+    cnt = torch.empty(nseg, dtype=torch.float32, device=dev)
+    ws = L.workspace(L.query('fc_col_stats_ws_bytes', n, C, nseg), dev)
+    L.call('fc_col_stats', L.ptr(x), L.ptr(seg), 4 if seg is not None else 0, n, C, nseg, L.ptr(mean), L.ptr(var),
+           L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+    return mean, var, cnt
+
+
+class _NormAct(torch.autograd.Function):
+    """y = act(norm(x)*gamma + beta (+ residual)); statistics over segments (1 = batch norm, B = instance norm).
+    In eval mode the caller passes fixed mean/var (stats_const=True) and the backward treats them as constants."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, seg, nseg, eps, act, mean, var, cnt, stats_const):
+        _chk(x, gamma, beta, residual)
+        x = x.contiguous()
+        n, C = x.shape
+        y = torch.empty_like(x)
+        res = residual.contiguous() if residual is not None else None
+        g = gamma.reshape(-1).contiguous() if gamma is not None else None
+        b = beta.reshape(-1).contiguous() if beta is not None else None
+        L.call('fc_norm_act_fwd', L.ptr(x), L.ptr(seg), 4 if seg is not None else 0, n, C, L.ptr(mean), L.ptr(var),
+               float(eps), L.ptr(g), L.ptr(b), L.ptr(res), act, L.ptr(y), L.stream())
+        ctx.save_for_backward(x, y, g, mean, var, cnt, seg)
+        ctx.cfg = (nseg, float(eps), act, residual is not None, stats_const,
+                   gamma.shape if gamma is not None else None, beta.shape if beta is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, g, mean, var, cnt, seg = ctx.saved_tensors
+        nseg, eps, act, has_res, stats_const, gshape, bshape = ctx.cfg
+        gy = gy.contiguous()
+        n, C = x.shape
+        dev = x.device
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if has_res else None
+        sums = torch.empty((nseg, 2, C), dtype=torch.float32, device=dev)
+        ws = L.workspace(L.query('fc_norm_act_bwd_ws_bytes', n, C, nseg), dev)
+        L.call('fc_norm_act_bwd', L.ptr(x), L.ptr(y), L.ptr(gy), L.ptr(seg), 4 if seg is not None else 0, n, C, nseg,
+               L.ptr(mean), L.ptr(var), L.ptr(cnt), eps, L.ptr(g), act, L.ptr(gx), L.ptr(gres), L.ptr(sums),
+               L.ptr(ws), ws.numel(), L.stream())
+        if stats_const:
+            raise RuntimeError('backward through eval-mode normalisation is not supported')
+        ggamma = sums[:, 1].sum(0).reshape(gshape) if gshape is not None else None
+        gbeta = sums[:, 0].sum(0).reshape(bshape) if bshape is not None else None
+        return gx, ggamma, gbeta, gres, None, None, None, None, None, None, None, None
+
+
+def norm_act(x, gamma, beta, residual=None, seg=None, nseg=1, eps=1e-5, act=None, stats=None):
+    """stats=None: batch statistics (training); stats=(mean,var,cnt): fixed statistics."""
+    const = stats is not None
+    if stats is None:
+        stats = col_stats(x.detach().contiguous(), seg, nseg)
+    mean, var, cnt = stats
+    y = _NormAct.apply(x, gamma, beta, residual, seg, nseg, eps, ACT[act], mean, var, cnt, const)
+    return y, stats
+
+
+# ---- pooling ---------------------------------------------------------------------------------------
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, kmap):
+        _chk(feats)
+        feats = feats.contiguous()
+        C = feats.shape[1]
+        out = torch.empty((kmap.n_out, C), dtype=torch.float32, device=feats.device)
+        arg = torch.empty((kmap.n_out, C), dtype=torch.int32, device=feats.device)
+        L.call('fc_maxpool_fwd', L.ptr(feats), L.ptr(kmap.nbr), kmap.n_out, kmap.K, C, L.ptr(out), L.ptr(arg), L.stream())
+        ctx.save_for_backward(arg)
+        ctx.n_in = feats.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, = ctx.saved_tensors
+        g = g.contiguous()
+        gin = torch.zeros((ctx.n_in, g.shape[1]), dtype=torch.float32, device=g.device)
+        L.call('fc_maxpool_bwd', L.ptr(g), L.ptr(arg), g.shape[0], g.shape[1], L.ptr(gin), L.stream())
+        return gin, None
+
+
+def max_pool(feats, kmap):
+    return _MaxPool.apply(feats, kmap)
+
+
+# ---- union add -------------------------------------------------------------------------------------
+class _UnionAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fa, fb, row_b, n_union):
+        _chk(fa, fb)
+        fa = fa.contiguous()
+        fb = fb.contiguous()
+        out = torch.zeros((n_union, fa.shape[1]), dtype=torch.float32, device=fa.device)
+        out[:fa.shape[0]] = fa
+        _scatter_add(out, row_b, fb)
+        ctx.save_for_backward(row_b)
+        ctx.n_a = fa.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        row_b, = ctx.saved_tensors
+        g = g.contiguous()
+        return g[:ctx.n_a], _gather(g, row_b), None, None
+
+
+def union_add(a, b):
+    """SparseTensor a + b (fcaf3d_neck_with_head.py:101)."""
+    from .sparse import SparseTensor
+    if a.cmap is b.cmap:
+        return SparseTensor(a.F + b.F, coordinate_map_key=a.cmap)
+    cm, row_b = a.cmap.union(b.cmap)
+    return SparseTensor(_UnionAdd.apply(a.F, b.F, row_b, cm.n), coordinate_map_key=cm)

@@ -1,0 +1,241 @@
+"""Sparse tensor + coordinate maps on the GPU (host-side mirror of ME.SparseTensor /
+ME.CoordinateManager as FCAF3D uses them: single_stage_sparse.py:34-37, me_resnet.py,
+fcaf3d_neck_with_head.py).  All coordinate work runs in libfcaf3d_hip.so (csrc/coords.hip).
+
+Row-order rule: every coordinate set keeps its rows in order of first occurrence in the sequence
+that produced it (ME's CPU rule) — deterministic, and identical to the
+oracle's, so parity is checked row for row.
+"""
+import itertools
+
+import torch
+
+from . import _lib as L
+
+
+def _next_pow2(n):
+    p = 2
+    while p < n:
+        p *= 2
+    return p
+
+
+def kernel_offsets(kernel_size, tensor_stride, device):
+    """(K,3) int32, x fastest; centred for odd kernels, {0..k-1} for even (Appendix A.3)."""
+    if kernel_size % 2 == 1:
+        r = [i - kernel_size // 2 for i in range(kernel_size)]
+    else:
+        r = list(range(kernel_size))
+    offs = [(dx * tensor_stride, dy * tensor_stride, dz * tensor_stride)
+            for dz, dy, dx in itertools.product(r, r, r)]
+    return torch.tensor(offs, dtype=torch.int32, device=device)
+
+
+class KernelMap:
+    """nbr (K, n_out) int32 plus, lazily, its transpose for the backward-data pass."""
+
+    def __init__(self, nbr, n_in, n_out):
+        self.nbr = nbr
+        self.n_in = n_in
+        self.n_out = n_out
+        self.K = nbr.shape[0]
+        self._nbr_t = None
+
+    @property
+    def nbr_t(self):
+        if self._nbr_t is None:
+            t = torch.empty((self.K, self.n_in), dtype=torch.int32, device=self.nbr.device)
+            L.call('fc_kernel_map_transpose', L.ptr(self.nbr), self.n_out, self.n_in, self.K, L.ptr(t), L.stream())
+            self._nbr_t = t
+        return self._nbr_t
+
+    def n_pairs(self):
+        return int((self.nbr >= 0).sum().item())
+
+
+class CoordMap:
+    """One coordinate set: coords (N,4) int32 [b,x,y,z], tensor stride, voxel hash, cached maps."""
+
+    def __init__(self, coords, stride, keys, vals, batch_size):
+        self.coords = coords
+        self.stride = stride
+        self.keys = keys
+        self.vals = vals
+        self.cap = keys.numel()
+        self.batch_size = batch_size
+        self.n = coords.shape[0]
+        self._kmaps = {}
+        self._strided = {}
+        self._perm = None
+
+    # ---- construction -------------------------------------------------------------------------
+    @staticmethod
+    def from_coords(coords, stride, batch_size, q=1, want_first=False, want_inverse=False):
+        """Unique rows of floor(coords/q)*q in order of first occurrence + hash of the result."""
+        assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+        coords = coords.contiguous()
+        dev = coords.device
+        n = coords.shape[0]
+        cap = _next_pow2(max(2 * n, 2))
+        keys = torch.empty(cap, dtype=torch.int64, device=dev)
+        vals = torch.empty(cap, dtype=torch.int32, device=dev)
+        out = torch.empty((n, 4), dtype=torch.int32, device=dev)
+        first = torch.empty(n, dtype=torch.int32, device=dev) if want_first else None
+        inv = torch.empty(n, dtype=torch.int32, device=dev) if want_inverse else None
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        wsb = L.query('fc_hash_unique_ws_bytes', n)
+        ws = L.workspace(wsb, dev)
+        L.call('fc_hash_unique', L.ptr(coords), n, q, L.ptr(keys), L.ptr(vals), cap, L.ptr(out), L.ptr(first),
+               L.ptr(inv), L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+        m = int(cnt.item())                      # the one host read-back of this op
+        cm = CoordMap(out[:m].contiguous() if m != n else out, stride, keys, vals, batch_size)
+        return cm, (first[:m] if want_first else None), inv
+
+    def strided(self, s):
+        """Output map of a stride-s conv / pooling (cached: k3s2 conv and k1s2 downsample share it)."""
+        if s == 1:
+            return self
+        if s not in self._strided:
+            cm, _, _ = CoordMap.from_coords(self.coords, self.stride * s, self.batch_size, q=self.stride * s)
+            self._strided[s] = cm
+        return self._strided[s]
+
+    def generate(self):
+        """Children set of MinkowskiGenerativeConvolutionTranspose(k2,s2): row 8i+k."""
+        assert self.stride % 2 == 0
+        half = self.stride // 2
+        out = torch.empty((self.n * 8, 4), dtype=torch.int32, device=self.coords.device)
+        L.call('fc_gen_coords', L.ptr(self.coords), self.n, half, L.ptr(out), L.stream())
+        cm, _, _ = CoordMap.from_coords(out, half, self.batch_size)
+        assert cm.n == 8 * self.n, 'children of a unique stride-T set are unique'
+        return cm
+
+    def kernel_map(self, out_map, kernel_size):
+        """KernelMap from this (input) set to `out_map`, offsets in units of this set's stride."""
+        key = (id(out_map), kernel_size)
+        km = self._kmaps.get(key)
+        if km is None:
+            offs = kernel_offsets(kernel_size, self.stride, self.coords.device)
+            K = offs.shape[0]
+            nbr = torch.empty((K, out_map.n), dtype=torch.int32, device=self.coords.device)
+            L.call('fc_kernel_map', L.ptr(out_map.coords), out_map.n, L.ptr(self.keys), L.ptr(self.vals), self.cap,
+                   L.ptr(offs), K, L.ptr(nbr), L.stream())
+            km = KernelMap(nbr, self.n, out_map.n)
+            km._out_map = out_map            # keep alive so id() stays unique
+            self._kmaps[key] = km
+        return km
+
+    def union(self, other):
+        """Union map for `self + other` (rows of self first). Returns (map, row_of_other_rows)."""
+        assert self.stride == other.stride
+        dev = self.coords.device
+        row_b = torch.empty(other.n, dtype=torch.int32, device=dev)
+        newc = torch.empty((other.n, 4), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = L.workspace(L.query('fc_union_map_ws_bytes', other.n), dev)
+        L.call('fc_union_map', L.ptr(other.coords), other.n, L.ptr(self.keys), L.ptr(self.vals), self.cap, self.n,
+               L.ptr(row_b), L.ptr(newc), L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+        n_new = int(cnt.item())
+        if n_new == 0:
+            return self, row_b
+        coords = torch.cat([self.coords, newc[:n_new]])
+        cm, _, _ = CoordMap.from_coords(coords, self.stride, self.batch_size)
+        assert cm.n == coords.shape[0]
+        return cm, row_b
+
+    def pruned(self, kept):
+        """Map of the kept rows (int32 ascending row indices), order preserved."""
+        out = torch.empty((kept.numel(), 4), dtype=torch.int32, device=self.coords.device)
+        L.call('fc_gather_coords', L.ptr(self.coords), L.ptr(kept), kept.numel(), L.ptr(out), L.stream())
+        cm, _, _ = CoordMap.from_coords(out, self.stride, self.batch_size)
+        return cm
+
+    # ---- per-scene decomposition --------------------------------------------------------------
+    @property
+    def decomposition_permutations(self):
+        if self._perm is None:
+            b = self.coords[:, 0]
+            self._perm = [torch.nonzero(b == i).squeeze(1) for i in range(self.batch_size)]
+        return self._perm
+
+
+def compact_mask(mask):
+    """bool/uint8 mask (n,) -> int32 indices of set rows, ascending (ballot + prefix-sum kernel)."""
+    flags = mask.to(torch.uint8).contiguous()
+    n = flags.numel()
+    dev = flags.device
+    pos = torch.empty(n, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = L.workspace(4 * (n // 1024 + 1), dev)
+    L.call('fc_scan_flags', L.ptr(flags), n, L.ptr(pos), L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+    m = int(cnt.item())
+    kept = torch.empty(m, dtype=torch.int32, device=dev)
+    L.call('fc_compact_rows', L.ptr(flags), L.ptr(pos), n, L.ptr(kept), L.stream())
+    return kept
+
+
+class SparseTensor:
+    """features (N,C) fp32 on a CoordMap.  Attribute surface follows ME.SparseTensor as used by the
+    reference: .F/.features, .C/.coordinates, .tensor_stride, .coordinate_map_key (= the CoordMap),
+    .decomposition_permutations, .decomposed_coordinates, .features_at_coordinates()."""
+
+    def __init__(self, features, coordinates=None, coordinate_map_key=None, coordinate_manager=None,
+                 batch_size=None):
+        if coordinate_map_key is not None:
+            self.cmap = coordinate_map_key
+            self.F = features
+        else:
+            assert coordinates is not None
+            if batch_size is None:
+                batch_size = int(coordinates[:, 0].max().item()) + 1 if coordinates.numel() else 0
+            cm, first, _ = CoordMap.from_coords(coordinates.to(torch.int32), 1, batch_size, want_first=True)
+            from .functional import gather_rows
+            self.cmap = cm
+            self.F = gather_rows(features.contiguous(), first)   # first occurrence wins (A.2)
+        assert self.F.shape[0] == self.cmap.n
+
+    @property
+    def features(self):
+        return self.F
+
+    @property
+    def C(self):
+        return self.cmap.coords
+
+    coordinates = C
+
+    @property
+    def coordinate_map_key(self):
+        return self.cmap
+
+    @property
+    def coordinate_manager(self):
+        return None
+
+    @property
+    def tensor_stride(self):
+        return self.cmap.stride
+
+    @property
+    def decomposition_permutations(self):
+        return self.cmap.decomposition_permutations
+
+    @property
+    def decomposed_coordinates(self):
+        return [self.cmap.coords[p, 1:] for p in self.decomposition_permutations]
+
+    def features_at_coordinates(self, query):
+        """Trilinear interpolation at integer-valued query coordinates (M,4) [b,x,y,z]."""
+        q = query.to(torch.int32).contiguous()
+        out = torch.empty((q.shape[0], self.F.shape[1]), dtype=torch.float32, device=q.device)
+        F = self.F.detach().contiguous()
+        L.call('fc_interp', L.ptr(q), q.shape[0], L.ptr(self.cmap.keys), L.ptr(self.cmap.vals), self.cmap.cap,
+               L.ptr(F), F.shape[1], self.cmap.stride, L.ptr(out), L.stream())
+        return out
+
+    def __add__(self, other):
+        from .functional import union_add
+        return union_add(self, other)
+
+    def __len__(self):
+        return self.cmap.n

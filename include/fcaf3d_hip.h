@@ -1,0 +1,125 @@
+/* libfcaf3d_hip.so — C ABI of the MI355X-native FCAF3D sparse-voxel hot path.
+ *
+ * Every entry point takes raw DEVICE pointers, explicit sizes and a hipStream_t, enqueues its
+ * kernels on that stream and returns immediately:
+ *     0  = ok,  <0 = invalid argument (-1) / workspace too small (-2),  >0 = hipError_t.
+ * The library is stateless and never allocates: data-dependent output sizes come back through a
+ * device counter (`*_dev`), and scratch space is passed in (`ws`, size from the matching
+ * `*_ws_bytes`).  It never calls exit() (contrast mmdet3d/ops/pcdet_nms/src/iou3d_nms.cpp:14-38).
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the reference
+ * repository; "ME" = MinkowskiEngine v0.5.4, the un-vendored dependency pinned at
+ * docker/Dockerfile:27-32, named by its Python call site).
+ *
+ * Layouts: coords int32 (N,4) = [batch, x, y, z] in voxel units (multiples of the tensor stride);
+ * features fp32 (N,C) row-major; conv kernels fp32 (K,Cin,Cout) with offsets x-fastest;
+ * neighbour tables int32 (K,N_out), -1 = absent; voxel hash = open addressing over 64-bit packed
+ * keys (`cap` a power of two >= 2N) with int32 values = row index.
+ */
+#ifndef FCAF3D_HIP_H
+#define FCAF3D_HIP_H
+#include <stdint.h>
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- coordinates -------------------------------------------------------------------------- */
+
+/* ME.utils.batch_sparse_collate quantisation of one scene — single_stage_sparse.py:34-36.
+ * coords[i] = [batch_idx, floor(xyz/voxel_size)], feats[i] = points[i,3:3+nfeat] / feat_div. */
+int fc_voxelize(const float* points, int64_t n, int pt_stride, int batch_idx, float voxel_size, float feat_div,
+                int nfeat, int* coords, float* feats, hipStream_t stream);
+
+/* Order-preserving compaction primitive (wave ballot + prefix sum): pos[i] = #set flags before i. */
+int fc_scan_flags(const unsigned char* flags, int64_t n, int* pos, int* total_dev, void* ws, int64_t ws_bytes,
+                  hipStream_t stream);
+int fc_compact_rows(const unsigned char* flags, const int* pos, int64_t n, int* kept, hipStream_t stream);
+
+/* ME.SparseTensor(coordinates, features) de-duplication (single_stage_sparse.py:37) and the strided
+ * output coordinate set of MinkowskiConvolution/MaxPooling(stride=2) (me_resnet.py:19-24,56-62):
+ * unique rows of floor(coords/q)*q in order of first occurrence; builds the voxel hash of the
+ * result (key -> row).  first_idx / inverse may be NULL. */
+int64_t fc_hash_unique_ws_bytes(int64_t n);
+int fc_hash_unique(const int* coords, int64_t n, int q, unsigned long long* table_keys, int* table_vals, int64_t cap,
+                   int* out_coords, int* first_idx, int* inverse, int* n_out_dev, void* ws, int64_t ws_bytes,
+                   hipStream_t stream);
+
+/* ME CoordinateManager kernel map for one (in set, out set, kernel) triple: nbr[k][o] = input row at
+ * out_coords[o] + offsets[k] (every ME.MinkowskiConvolution / MinkowskiMaxPooling call). */
+int fc_kernel_map(const int* out_coords, int64_t n_out, const unsigned long long* table_keys, const int* table_vals,
+                  int64_t cap, const int* offsets, int K, int* nbr, hipStream_t stream);
+/* nbr_t[k][i] = o  iff  nbr[k][o] == i  (the gather table of the backward-data pass). */
+int fc_kernel_map_transpose(const int* nbr, int64_t n_out, int64_t n_in, int K, int* nbr_t, hipStream_t stream);
+
+/* ME.MinkowskiGenerativeConvolutionTranspose(k=2,s=2) output coordinates — fcaf3d_neck_with_head.py:60-66:
+ * out[8i+k] = coords[i] + {0,half_stride}^3 (x fastest). */
+int fc_gen_coords(const int* coords, int64_t n, int half_stride, int* out_coords, hipStream_t stream);
+
+/* SparseTensor `a + b` on different coordinate maps — fcaf3d_neck_with_head.py:101: row of every b
+ * voxel in the union (a's rows first, then b's new voxels in order); new_coords gets b's new rows. */
+int64_t fc_union_map_ws_bytes(int64_t n_b);
+int fc_union_map(const int* coords_b, int64_t n_b, const unsigned long long* table_keys_a, const int* table_vals_a,
+                 int64_t cap_a, int64_t n_a, int* row_b, int* new_coords, int* n_new_dev, void* ws, int64_t ws_bytes,
+                 hipStream_t stream);
+
+/* SparseTensor.features_at_coordinates (MinkowskiInterpolation) — fcaf3d_neck_with_head.py:115-116. */
+int fc_interp(const int* query_coords, int64_t n, const unsigned long long* table_keys, const int* table_vals, int64_t cap,
+              const float* feats, int C, int tensor_stride, float* out, hipStream_t stream);
+
+/* coordinate rows of a pruned set (MinkowskiPruning, fcaf3d_neck_with_head.py:125). */
+int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStream_t stream);
+
+/* ---- sparse convolution ------------------------------------------------------------------- */
+
+/* ME.MinkowskiConvolution forward (me_resnet.py:19-21,56-62; BasicBlock; fcaf3d_neck_with_head.py:52,69),
+ * its backward-data pass (call with the transposed table and fc_transpose_weight'ed kernel), and with
+ * nbr == NULL (K = 1, identity) the dense GEMMs of MinkowskiGenerativeConvolutionTranspose (:60-66)
+ * and of the 1x1 head convolutions (:83-85, :257-263).  out[o] = sum_k in[nbr[k][o]] @ W[k].
+ * flags bit0: force the generic FMA kernel instead of the MFMA kernel. */
+int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int64_t n_in, int64_t n_out, int K, int Cin,
+                int Cout, int flags, hipStream_t stream);
+
+/* backward-weights: gW[k] = sum_o in[nbr[k][o]]^T (x) gout[o]; deterministic two-level reduction. */
+int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);
+int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, float* gW, int64_t n_in, int64_t n_out, int K,
+                  int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);
+
+/* (K,Cin,Cout) -> (K,Cout,Cin) */
+int fc_transpose_weight(const float* W, float* Wt, int K, int Cin, int Cout, hipStream_t stream);
+
+/* ---- normalisation / pooling / rows ------------------------------------------------------- */
+
+/* column statistics per segment: MinkowskiBatchNorm (seg == NULL, one segment: all voxels on this GPU)
+ * and MinkowskiInstanceNorm (seg = &coords[0], seg_stride = 4: per scene) — me_resnet.py:22,63. */
+int64_t fc_col_stats_ws_bytes(int64_t n, int C, int nseg);
+int fc_col_stats(const float* x, const int* seg, int seg_stride, int64_t n, int C, int nseg, float* mean, float* var,
+                 float* cnt, void* ws, int64_t ws_bytes, hipStream_t stream);
+
+/* y = act((x-mean)/sqrt(var+eps)*gamma + beta (+ residual)); act 0 none, 1 ReLU, 2 ELU —
+ * MinkowskiBatchNorm/InstanceNorm + MinkowskiReLU/ELU (+ BasicBlock's `out += residual`). */
+int fc_norm_act_fwd(const float* x, const int* seg, int seg_stride, int64_t n, int C, const float* mean, const float* var,
+                    float eps, const float* gamma, const float* beta, const float* residual, int act, float* y,
+                    hipStream_t stream);
+int64_t fc_norm_act_bwd_ws_bytes(int64_t n, int C, int nseg);
+int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* seg, int seg_stride, int64_t n, int C,
+                    int nseg, const float* mean, const float* var, const float* cnt, float eps, const float* gamma,
+                    int act, float* gx, float* gres, float* sums, void* ws, int64_t ws_bytes, hipStream_t stream);
+
+/* ME.MinkowskiMaxPooling(k=2,s=2) — me_resnet.py:24. */
+int fc_maxpool_fwd(const float* in, const int* nbr, int64_t n_out, int K, int C, float* out, int* argrow,
+                   hipStream_t stream);
+int fc_maxpool_bwd(const float* gout, const int* argrow, int64_t n_out, int C, float* gin, hipStream_t stream);
+
+/* feature rows of MinkowskiPruning / union-add / per-scene decomposition. */
+int fc_gather_rows(const float* src, const int* idx, int64_t n, int C, float* dst, hipStream_t stream);
+int fc_scatter_rows_add(const float* src, const int* idx, int64_t n, int C, float* dst, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCAF3D_HIP_H */

@@ -1,0 +1,271 @@
+"""-m gpu: HIP operators (through the C ABI) against the CPU oracle on identical inputs.
+Integer results (coordinates, hash order, kernel maps, argmax) must be bit-exact; fp32 features
+within 1e-4 relative to the tensor scale (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import me_oracle as mo
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def _close(a, b, tol=TOL, what=''):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(b.abs().max())) if b.numel() else 1.0
+    err = float((a - b).abs().max()) if b.numel() else 0.0
+    assert err <= tol * scale, f'{what}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+def _scene_coords(seed, n_points=20000, B=2, vs=0.02):
+    from fcaf3d_amd.synthetic import make_scene
+    pts = [make_scene(seed + b, n_points=n_points)[0] for b in range(B)]
+    c, f = mo.batch_sparse_collate([p[:, :3] / np.float32(vs) for p in pts], [p[:, 3:] / np.float32(255.) for p in pts])
+    return pts, c, f
+
+
+def test_voxelize_and_unique():
+    from fcaf3d_amd import _lib as L
+    from fcaf3d_amd.sparse import CoordMap
+    dev = _dev()
+    pts, c_ref, f_ref = _scene_coords(0)
+    coords = torch.empty((len(c_ref), 4), dtype=torch.int32, device=dev)
+    feats = torch.empty((len(c_ref), 3), dtype=torch.float32, device=dev)
+    off = 0
+    for b, p in enumerate(pts):
+        t = torch.from_numpy(p).to(dev)
+        L.call('fc_voxelize', L.ptr(t), len(p), 6, b, 0.02, 255.0, 3, L.ptr(coords[off:]), L.ptr(feats[off:]), L.stream())
+        off += len(p)
+    assert np.array_equal(coords.cpu().numpy(), c_ref)
+    assert np.array_equal(feats.cpu().numpy(), f_ref)
+    for q in (1, 2, 4):
+        cq = c_ref.copy(); cq[:, 1:] = np.floor_divide(cq[:, 1:], q) * q
+        uc, first, inv = mo.unique_first(cq)
+        cm, gfirst, ginv = CoordMap.from_coords(coords, q, 2, q=q, want_first=True, want_inverse=True)
+        assert cm.n == len(uc)
+        assert np.array_equal(cm.coords.cpu().numpy(), uc)
+        assert np.array_equal(gfirst.cpu().numpy(), first)
+        assert np.array_equal(ginv.cpu().numpy(), inv)
+
+
+def test_unique_edge_cases():
+    from fcaf3d_amd.sparse import CoordMap
+    dev = _dev()
+    cm, _, _ = CoordMap.from_coords(torch.zeros((0, 4), dtype=torch.int32, device=dev), 1, 1)
+    assert cm.n == 0
+    c = torch.tensor([[0, -1, -3, 5]] * 7 + [[1, -1, -3, 5]], dtype=torch.int32, device=dev)
+    cm, first, inv = CoordMap.from_coords(c, 1, 2, want_first=True, want_inverse=True)
+    assert cm.coords.cpu().tolist() == [[0, -1, -3, 5], [1, -1, -3, 5]]
+    assert first.cpu().tolist() == [0, 7] and inv.cpu().tolist() == [0] * 7 + [1]
+    cm2, _, _ = CoordMap.from_coords(c, 2, 2, q=2)
+    assert cm2.coords.cpu().tolist() == [[0, -2, -4, 4], [1, -2, -4, 4]]
+
+
+@pytest.mark.parametrize('ks,s', [(3, 1), (3, 2), (2, 2), (1, 2)])
+def test_kernel_maps_exact(ks, s):
+    from fcaf3d_amd.sparse import CoordMap
+    dev = _dev()
+    _, c_ref, _ = _scene_coords(3)
+    uc, _, _ = mo.unique_first(c_ref)
+    cm, _, _ = CoordMap.from_coords(torch.from_numpy(c_ref).to(dev), 1, 2)
+    out_ref = mo.stride_coords(uc, 1, s) if s > 1 else uc
+    om = cm.strided(s)
+    assert np.array_equal(om.coords.cpu().numpy(), out_ref)
+    nbr_ref = mo.kernel_map(uc, out_ref, mo.kernel_offsets(ks, 1))
+    km = cm.kernel_map(om, ks)
+    assert np.array_equal(km.nbr.cpu().numpy(), nbr_ref)
+    # transpose property: nbr_t[k][i] == o  <=>  nbr[k][o] == i
+    nt = km.nbr_t.cpu().numpy()
+    K = nbr_ref.shape[0]
+    ref_t = np.full((K, len(uc)), -1, np.int32)
+    for k in range(K):
+        o = np.nonzero(nbr_ref[k] >= 0)[0]
+        ref_t[k, nbr_ref[k, o]] = o
+    assert np.array_equal(nt, ref_t)
+
+
+def _conv_case(dev, n_points, Cin, Cout, ks, s, flags, seed=5, B=2, level_q=1):
+    import fcaf3d_amd.functional as Fn
+    from fcaf3d_amd.sparse import CoordMap
+    _, c_ref, _ = _scene_coords(seed, n_points=n_points, B=B)
+    if level_q > 1:
+        c_ref = c_ref.copy(); c_ref[:, 1:] = np.floor_divide(c_ref[:, 1:], level_q) * level_q
+    uc, _, _ = mo.unique_first(c_ref)
+    T = level_q
+    cm, _, _ = CoordMap.from_coords(torch.from_numpy(uc).to(dev), T, B)
+    om = cm.strided(s)
+    out_ref_c = mo.stride_coords(uc, T, s) if s > 1 else uc
+    nbr = mo.kernel_map(uc, out_ref_c, mo.kernel_offsets(ks, T))
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(len(uc), Cin, generator=g)
+    w = torch.randn(ks ** 3, Cin, Cout, generator=g) / np.sqrt(Cin * ks ** 3)
+    go = torch.randn(len(out_ref_c), Cout, generator=g)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    out_r = mo.conv(xr, wr, nbr)
+    gx_r, gw_r = torch.autograd.grad(out_r, [xr, wr], go)
+    xg = x.to(dev).requires_grad_(True); wg = w.to(dev).requires_grad_(True)
+    Fn.FLAGS = flags
+    try:
+        km = cm.kernel_map(om, ks)
+        out_g = Fn.sparse_conv(xg, wg, km, om.n)
+        gx_g, gw_g = torch.autograd.grad(out_g, [xg, wg], go.to(dev))
+    finally:
+        Fn.FLAGS = 0
+    tag = f'conv n={len(uc)} {Cin}->{Cout} k{ks}s{s} flags={flags}'
+    _close(out_g, out_r, what=tag + ' fwd')
+    _close(gx_g, gx_r, what=tag + ' dgrad')
+    _close(gw_g, gw_r, what=tag + ' wgrad')
+
+
+@pytest.mark.parametrize('Cin,Cout', [(64, 64), (64, 128), (128, 128), (128, 64), (32, 64), (256, 256)])
+def test_conv_mfma_small_tiles(Cin, Cout):
+    _conv_case(_dev(), 6000, Cin, Cout, 3, 1, 0, level_q=4)
+
+
+def test_conv_mfma_k3s2_and_k1s2():
+    _conv_case(_dev(), 8000, 64, 128, 3, 2, 0, level_q=2)
+    _conv_case(_dev(), 8000, 64, 64, 1, 2, 0, level_q=2)
+
+
+@pytest.mark.parametrize('Cin,Cout', [(64, 64), (64, 128)])
+def test_conv_mfma_large_tiles(Cin, Cout):
+    # > 65k output rows -> the 128-row tile variants
+    _conv_case(_dev(), 100000, Cin, Cout, 3, 1, 0, B=1)
+
+
+@pytest.mark.parametrize('Cin,Cout,ks,s', [(3, 64, 3, 2), (64, 64, 3, 1), (16, 24, 3, 1)])
+def test_conv_generic_fma(Cin, Cout, ks, s):
+    _conv_case(_dev(), 4000, Cin, Cout, ks, s, 1, level_q=2)
+
+
+def test_conv_identity_dense_gemm():
+    import fcaf3d_amd.functional as Fn
+    dev = _dev()
+    g = torch.Generator().manual_seed(1)
+    for n, Cin, Cout in ((1000, 128, 512), (70000, 128, 64), (333, 64, 64), (5, 512, 2048)):
+        x = torch.randn(n, Cin, generator=g); w = torch.randn(1, Cin, Cout, generator=g) / 10
+        go = torch.randn(n, Cout, generator=g)
+        xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+        out_r = xr @ wr[0]
+        gx_r, gw_r = torch.autograd.grad(out_r, [xr, wr], go)
+        xg = x.to(dev).requires_grad_(True); wg = w.to(dev).requires_grad_(True)
+        out_g = Fn.sparse_conv(xg, wg, None, n)
+        gx_g, gw_g = torch.autograd.grad(out_g, [xg, wg], go.to(dev))
+        _close(out_g, out_r, what=f'gemm {n}x{Cin}x{Cout} fwd')
+        _close(gx_g, gx_r, what='gemm dgrad'); _close(gw_g, gw_r, what='gemm wgrad')
+
+
+@pytest.mark.parametrize('C,nseg,act,res', [(64, 1, 'relu', False), (64, 1, 'relu', True), (128, 1, 'elu', False),
+                                            (512, 1, None, False), (64, 3, 'relu', False), (256, 1, 'elu', True)])
+def test_norm_act(C, nseg, act, res):
+    import fcaf3d_amd.functional as Fn
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    n = 5003
+    x = torch.randn(n, C, generator=g) * 2 + 0.5
+    gamma = torch.rand(C, generator=g) + 0.5; beta = torch.randn(C, generator=g)
+    r = torch.randn(n, C, generator=g) if res else None
+    go = torch.randn(n, C, generator=g)
+    b = np.sort(np.random.default_rng(0).integers(0, nseg, n)).astype(np.int32)
+    coords = np.zeros((n, 4), np.int32); coords[:, 0] = b
+    eps = 1e-8 if nseg > 1 else 1e-5
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    if nseg > 1:
+        y = mo.instance_norm(xr, b, gr[None], br[None], eps)
+    else:
+        y = mo.batch_norm(xr, gr, br, eps)
+    if res:
+        y = y + rr
+    y = {'relu': torch.relu, 'elu': torch.nn.functional.elu, None: lambda t: t}[act](y)
+    grads_r = torch.autograd.grad(y, [xr, gr, br] + ([rr] if res else []), go)
+    xg = x.to(dev).requires_grad_(True); gg = gamma.to(dev).requires_grad_(True); bg = beta.to(dev).requires_grad_(True)
+    rg = r.to(dev).requires_grad_(True) if res else None
+    seg = torch.from_numpy(coords).to(dev) if nseg > 1 else None
+    yg, stats = Fn.norm_act(xg, gg, bg, residual=rg, seg=seg, nseg=nseg, eps=eps, act=act)
+    grads_g = torch.autograd.grad(yg, [xg, gg, bg] + ([rg] if res else []), go.to(dev))
+    _close(yg, y, what='norm fwd')
+    for a, bb, nm in zip(grads_g, grads_r, ['gx', 'ggamma', 'gbeta', 'gres']):
+        _close(a, bb, tol=2e-4, what=f'norm {nm} C={C} nseg={nseg}')
+    _close(stats[0], torch.stack([x[torch.from_numpy(b.astype(np.int64)) == s].mean(0) for s in range(nseg)]), what='mean')
+
+
+def test_maxpool():
+    import fcaf3d_amd.functional as Fn
+    from fcaf3d_amd.sparse import CoordMap
+    dev = _dev()
+    _, c_ref, _ = _scene_coords(7, n_points=8000)
+    uc, _, _ = mo.unique_first(c_ref)
+    out_c = mo.stride_coords(uc, 1, 2)
+    nbr = mo.kernel_map(uc, out_c, mo.kernel_offsets(2, 1))
+    x = torch.randn(len(uc), 64)
+    xr = x.clone().requires_grad_(True)
+    y = mo.max_pool(xr, nbr)
+    go = torch.randn_like(y)
+    gx_r, = torch.autograd.grad(y, xr, go)
+    cm, _, _ = CoordMap.from_coords(torch.from_numpy(uc).to(dev), 1, 2)
+    km = cm.kernel_map(cm.strided(2), 2)
+    xg = x.to(dev).requires_grad_(True)
+    yg = Fn.max_pool(xg, km)
+    gx_g, = torch.autograd.grad(yg, xg, go.to(dev))
+    assert torch.equal(yg.cpu(), y.detach())
+    assert torch.equal(gx_g.cpu(), gx_r)
+
+
+def test_generate_union_interp_prune():
+    import fcaf3d_amd.functional as Fn
+    from fcaf3d_amd.sparse import CoordMap, SparseTensor, compact_mask
+    dev = _dev()
+    _, c_ref, _ = _scene_coords(9, n_points=6000)
+    c4 = c_ref.copy(); c4[:, 1:] = np.floor_divide(c4[:, 1:], 4) * 4
+    fine, _, _ = mo.unique_first(c4)                       # stride 4 (backbone level)
+    coarse = mo.stride_coords(fine, 4, 2)                  # stride 8
+    # drop some coarse voxels so that the union really adds rows
+    keep = np.random.default_rng(1).random(len(coarse)) < 0.7
+    coarse_p = coarse[keep]
+    gen_ref = mo.gen_conv_transpose_coords(coarse_p, 8)
+    cmc, _, _ = CoordMap.from_coords(torch.from_numpy(coarse_p).to(dev), 8, 2)
+    gen = cmc.generate()
+    assert gen.stride == 4 and np.array_equal(gen.coords.cpu().numpy(), gen_ref)
+    fa = torch.randn(len(fine), 8); fb = torch.randn(len(gen_ref), 8)
+    far = fa.clone().requires_grad_(True); fbr = fb.clone().requires_grad_(True)
+    uc_ref, uf_ref = mo.union_add(fine, far, gen_ref, fbr)
+    go = torch.randn_like(uf_ref)
+    ga_r, gb_r = torch.autograd.grad(uf_ref, [far, fbr], go)
+    cmf, _, _ = CoordMap.from_coords(torch.from_numpy(fine).to(dev), 4, 2)
+    fag = fa.to(dev).requires_grad_(True); fbg = fb.to(dev).requires_grad_(True)
+    u = SparseTensor(fag, coordinate_map_key=cmf) + SparseTensor(fbg, coordinate_map_key=gen)
+    assert len(uc_ref) > len(fine)
+    assert np.array_equal(u.C.cpu().numpy(), uc_ref)
+    ga_g, gb_g = torch.autograd.grad(u.F, [fag, fbg], go.to(dev))
+    assert torch.equal(u.F.detach().cpu(), uf_ref.detach())
+    assert torch.equal(ga_g.cpu(), ga_r) and torch.equal(gb_g.cpu(), gb_r)
+    # interpolation of a 1-channel coarse tensor at the union coordinates
+    sc = torch.randn(len(coarse_p), 1)
+    ref = mo.features_at_coordinates(coarse_p, sc, 8, uc_ref.astype(np.float32))
+    got = SparseTensor(sc.to(dev), coordinate_map_key=cmc).features_at_coordinates(u.C.float())
+    _close(got, ref, tol=1e-6, what='interp')
+    # prune
+    mask = np.random.default_rng(2).random(len(uc_ref)) < 0.4
+    pc_ref, pf_ref = mo.prune(uc_ref, uf_ref.detach(), mask)
+    kept = compact_mask(torch.from_numpy(mask).to(dev))
+    assert np.array_equal(kept.cpu().numpy(), np.nonzero(mask)[0])
+    pm = u.cmap.pruned(kept)
+    assert np.array_equal(pm.coords.cpu().numpy(), pc_ref)
+    pf = Fn.gather_rows(u.F, kept)
+    assert torch.equal(pf.detach().cpu(), pf_ref)
+    perms = pm.decomposition_permutations
+    assert sum(len(p) for p in perms) == pm.n
+
+
+def test_no_cpu_fallback():
+    import fcaf3d_amd.functional as Fn
+    with pytest.raises(RuntimeError):
+        Fn.sparse_conv(torch.zeros(4, 64), torch.zeros(1, 64, 64), None, 4)
