@@ -1,0 +1,292 @@
+// Loss kernels of the FCAF3D head on gfx950 (elementwise / per-box, latency- and HBM-bound).
+//   * sigmoid focal loss  — mmcv `sigmoid_focal_loss` CUDA op reached through mmdet FocalLoss
+//     (fcaf3d_neck_with_head.py:29-34, :180); label -1 (background) => every class is a negative.
+//   * axis-aligned 3D IoU + its gradient — iou3d_loss.py:21-35 (axis_aligned_iou_loss) over
+//     iou3d_calculator.py:201-330 (axis_aligned_bbox_overlaps_3d, is_aligned=True, eps=1e-6).
+//   * rotated 3D IoU + its gradient — rotated_iou/oriented_iou_loss.py:86-109 (cal_iou_3d) with
+//     box_intersection_2d.py:13-184 and the un-vendored `sort_v`, as ONE
+//     fused kernel: the gradient is propagated in forward mode (7 dual parts per value) through the
+//     same arithmetic graph torch autograd differentiates in the reference.
+#include "fc_common.h"
+#include <float.h>
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_focal_fwd(const float* __restrict__ x, const long long* __restrict__ label, int64_t n, int C,
+                            float gamma, float alpha, float* __restrict__ loss) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * C) return;
+  int64_t r = t / C;
+  int c = (int)(t % C);
+  long long y = label[r];
+  float p = 1.f / (1.f + expf(-x[t]));
+  float v;
+  if (y == c) v = -alpha * powf(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
+  else v = -(1.f - alpha) * powf(p, gamma) * logf(fmaxf(1.f - p, FLT_MIN));
+  loss[t] = v;
+}
+
+__global__ void k_focal_bwd(const float* __restrict__ x, const long long* __restrict__ label, int64_t n, int C,
+                            float gamma, float alpha, const float* __restrict__ gscale, float* __restrict__ gx) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * C) return;
+  int64_t r = t / C;
+  int c = (int)(t % C);
+  long long y = label[r];
+  float p = 1.f / (1.f + expf(-x[t]));
+  float g;
+  if (y == c) g = -alpha * powf(1.f - p, gamma) * (1.f - p - gamma * p * logf(fmaxf(p, FLT_MIN)));
+  else g = -(1.f - alpha) * powf(p, gamma) * (gamma * (1.f - p) * logf(fmaxf(1.f - p, FLT_MIN)) - p);
+  gx[t] = g * gscale[0];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// torch.max / torch.min split the gradient evenly on ties; clamp(min=0) passes it at x >= 0.
+__device__ static inline void tie_max(float a, float b, float* v, float* wa) {
+  *v = a > b ? a : b;
+  *wa = a > b ? 1.f : (a == b ? 0.5f : 0.f);
+}
+__device__ static inline void tie_min(float a, float b, float* v, float* wa) {
+  *v = a < b ? a : b;
+  *wa = a < b ? 1.f : (a == b ? 0.5f : 0.f);
+}
+
+// pred (n,6) [cx,cy,cz,w,l,h]; target rows of `tstride` floats whose first 6 are [cx,cy,cz,w,l,h]
+__global__ void k_aiou3d(const float* __restrict__ pred, const float* __restrict__ target, int tstride, int64_t n,
+                         float eps, float* __restrict__ iou, float* __restrict__ dpred) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = pred + i * 6;
+  const float* t = target + i * tstride;
+  float wh[3], dwh_dc[3], dwh_ds[3], sp[3];
+  float a1 = 1.f, a2 = 1.f, ov = 1.f;
+  for (int a = 0; a < 3; ++a) {
+    float p1 = p[a] - p[3 + a] / 2, p2 = p[a] + p[3 + a] / 2;
+    float t1 = t[a] - t[3 + a] / 2, t2 = t[a] + t[3 + a] / 2;
+    float lt, rb, wl, wr;
+    tie_max(p1, t1, &lt, &wl);       // d lt / d p1
+    tie_min(p2, t2, &rb, &wr);       // d rb / d p2
+    float d = rb - lt;
+    float pass = d >= 0.f ? 1.f : 0.f;
+    wh[a] = d > 0.f ? d : 0.f;
+    // wh = clamp(rb - lt): d/dc = wr - wl ; d/ds = wr/2 + wl/2
+    dwh_dc[a] = pass * (wr - wl);
+    dwh_ds[a] = pass * 0.5f * (wr + wl);
+    sp[a] = p2 - p1;
+    a1 *= sp[a];
+    a2 *= (t2 - t1);
+    ov *= wh[a];
+  }
+  float un = a1 + a2 - ov;
+  float upass = un > eps ? 1.f : 0.f;     // torch.max(union, eps)
+  float U = un > eps ? un : eps;
+  iou[i] = ov / U;
+  if (!dpred) return;
+  for (int a = 0; a < 3; ++a) {
+    int b = (a + 1) % 3, c = (a + 2) % 3;
+    float dov_dwh = wh[b] * wh[c];
+    float dov_dc = dov_dwh * dwh_dc[a];
+    float dov_ds = dov_dwh * dwh_ds[a];
+    float da1_ds = sp[b] * sp[c];          // area1 = prod (p2-p1): d/ds_a = prod of the others
+    float dU_dc = upass * (-dov_dc);
+    float dU_ds = upass * (da1_ds - dov_ds);
+    dpred[i * 6 + a] = (dov_dc * U - ov * dU_dc) / (U * U);
+    dpred[i * 6 + 3 + a] = (dov_ds * U - ov * dU_ds) / (U * U);
+  }
+}
+
+extern "C" {
+
+int fc_focal_loss_fwd(const float* logits, const long long* labels, int64_t n, int C, float gamma, float alpha,
+                      float* loss, hipStream_t stream) {
+  if (n < 0 || C < 1) return FC_EINVAL;
+  if (n == 0) return FC_OK;
+  k_focal_fwd<<<(unsigned)fc_cdiv(n * C, 256), 256, 0, stream>>>(logits, labels, n, C, gamma, alpha, loss);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+int fc_focal_loss_bwd(const float* logits, const long long* labels, int64_t n, int C, float gamma, float alpha,
+                      const float* gscale_dev, float* glogits, hipStream_t stream) {
+  if (n < 0 || C < 1) return FC_EINVAL;
+  if (n == 0) return FC_OK;
+  k_focal_bwd<<<(unsigned)fc_cdiv(n * C, 256), 256, 0, stream>>>(logits, labels, n, C, gamma, alpha, gscale_dev, glogits);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+int fc_aiou3d_fwd_bwd(const float* pred, const float* target, int target_stride, int64_t n, float eps, float* iou,
+                      float* dpred, hipStream_t stream) {
+  if (n < 0 || target_stride < 6) return FC_EINVAL;
+  if (n == 0) return FC_OK;
+  k_aiou3d<<<(unsigned)fc_cdiv(n, 128), 128, 0, stream>>>(pred, target, target_stride, n, eps, iou, dpred);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// rotated 3D IoU with forward-mode derivatives w.r.t. the 7 parameters of `pred`
+struct D7 {
+  float v;
+  float d[7];
+};
+__device__ static inline D7 dconst(float c) { D7 r; r.v = c; for (int i = 0; i < 7; ++i) r.d[i] = 0.f; return r; }
+__device__ static inline D7 dvar(float c, int i) { D7 r = dconst(c); r.d[i] = 1.f; return r; }
+__device__ static inline D7 operator+(const D7& a, const D7& b) { D7 r; r.v = a.v + b.v; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ static inline D7 operator-(const D7& a, const D7& b) { D7 r; r.v = a.v - b.v; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ static inline D7 operator*(const D7& a, const D7& b) { D7 r; r.v = a.v * b.v; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ static inline D7 operator/(const D7& a, const D7& b) {
+  D7 r; r.v = a.v / b.v; float inv = 1.f / b.v;
+  for (int i = 0; i < 7; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+  return r;
+}
+__device__ static inline D7 dscale(const D7& a, float s) { D7 r; r.v = a.v * s; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * s; return r; }
+__device__ static inline D7 dmin_tie(const D7& a, const D7& b) {     // torch.min(a,b): ties split the gradient
+  if (a.v < b.v) return a;
+  if (b.v < a.v) return b;
+  return dscale(a + b, 0.5f);
+}
+__device__ static inline D7 dmax_tie(const D7& a, const D7& b) {
+  if (a.v > b.v) return a;
+  if (b.v > a.v) return b;
+  return dscale(a + b, 0.5f);
+}
+
+struct V2 { D7 x, y; };
+
+__device__ static void corners_of(const D7& cx, const D7& cy, const D7& w, const D7& h, const D7& alpha, V2* out) {
+  const float sx[4] = {0.5f, -0.5f, -0.5f, 0.5f}, sy[4] = {0.5f, 0.5f, -0.5f, -0.5f};
+  D7 cs, sn;
+  cs.v = cosf(alpha.v); sn.v = sinf(alpha.v);
+  for (int i = 0; i < 7; ++i) { cs.d[i] = -sn.v * alpha.d[i]; sn.d[i] = cs.v * alpha.d[i]; }
+  for (int k = 0; k < 4; ++k) {
+    D7 x4 = dscale(w, sx[k]), y4 = dscale(h, sy[k]);
+    out[k].x = x4 * cs - y4 * sn + cx;
+    out[k].y = x4 * sn + y4 * cs + cy;
+  }
+}
+
+// value-only: corner m lies inside the rectangle with corners q[0..3] (box_intersection_2d.py:57-82)
+__device__ static inline bool corner_in_rect(const V2& m, const V2* q) {
+  float abx = q[1].x.v - q[0].x.v, aby = q[1].y.v - q[0].y.v;
+  float adx = q[3].x.v - q[0].x.v, ady = q[3].y.v - q[0].y.v;
+  float amx = m.x.v - q[0].x.v, amy = m.y.v - q[0].y.v;
+  float pab = (abx * amx + aby * amy) / (abx * abx + aby * aby);
+  float pad = (adx * amx + ady * amy) / (adx * adx + ady * ady);
+  return pab > -1e-6f && pab < 1.f + 1e-6f && pad > -1e-6f && pad < 1.f + 1e-6f;
+}
+
+__global__ void k_riou3d(const float* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ weight,
+                         int64_t n, float* __restrict__ iou_out, float* __restrict__ dpred) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (weight && !(weight[i] > 0.f)) {
+    iou_out[i] = 0.f;
+    for (int e = 0; e < 7; ++e) dpred[i * 7 + e] = 0.f;
+    return;
+  }
+  const float* p = pred + i * 7;
+  const float* t = target + i * 7;
+  D7 P[7];
+  for (int e = 0; e < 7; ++e) P[e] = dvar(p[e], e);
+  V2 vert[24];
+  bool valid[24];
+  corners_of(P[0], P[1], P[3], P[4], P[6], vert);                                     // 0..3  box1
+  corners_of(dconst(t[0]), dconst(t[1]), dconst(t[3]), dconst(t[4]), dconst(t[6]), vert + 4);   // 4..7 box2
+  // 16 edge-edge intersections (box_intersection_2d.py:13-54)
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) {
+      const V2& p1 = vert[a]; const V2& p2 = vert[(a + 1) & 3];
+      const V2& p3 = vert[4 + b]; const V2& p4 = vert[4 + ((b + 1) & 3)];
+      D7 num = (p1.x - p2.x) * (p3.y - p4.y) - (p1.y - p2.y) * (p3.x - p4.x);
+      D7 den_t = (p1.x - p3.x) * (p3.y - p4.y) - (p1.y - p3.y) * (p3.x - p4.x);
+      float den_u = (p1.x.v - p2.x.v) * (p1.y.v - p3.y.v) - (p1.y.v - p2.y.v) * (p1.x.v - p3.x.v);
+      float tt = num.v == 0.f ? -1.f : den_t.v / num.v;
+      float uu = num.v == 0.f ? -1.f : -den_u / num.v;
+      bool m = tt > 0.f && tt < 1.f && uu > 0.f && uu < 1.f;
+      int k = 8 + a * 4 + b;
+      valid[k] = m;
+      if (m) {
+        D7 ts = den_t / (num + dconst(1e-8f));
+        vert[k].x = p1.x + ts * (p2.x - p1.x);
+        vert[k].y = p1.y + ts * (p2.y - p1.y);
+      } else {
+        vert[k].x = dconst(0.f);
+        vert[k].y = dconst(0.f);
+      }
+    }
+  for (int k = 0; k < 4; ++k) {
+    valid[k] = corner_in_rect(vert[k], vert + 4);
+    valid[4 + k] = corner_in_rect(vert[4 + k], vert);
+  }
+  // order the valid vertices by polar angle about their mean (sort_v)
+  int nv = 0;
+  float mx = 0.f, my = 0.f;
+  for (int k = 0; k < 24; ++k)
+    if (valid[k]) { mx += vert[k].x.v; my += vert[k].y.v; ++nv; }
+  int order[24];
+  int cnt = 0;
+  if (nv >= 3) {
+    mx /= nv; my /= nv;
+    float ang[24];
+    for (int k = 0; k < 24; ++k) {
+      if (!valid[k]) continue;
+      float g = atan2f(vert[k].y.v - my, vert[k].x.v - mx);
+      int m = cnt - 1;
+      while (m >= 0 && ang[m] > g) { ang[m + 1] = ang[m]; order[m + 1] = order[m]; --m; }   // stable insertion
+      ang[m + 1] = g; order[m + 1] = k;
+      ++cnt;
+    }
+    // drop coincident neighbours (identical boxes list every corner twice)
+    int kept = 0;
+    for (int k = 0; k < cnt; ++k) {
+      if (kept > 0) {
+        int q = order[kept - 1];
+        if (fmaxf(fabsf(vert[order[k]].x.v - vert[q].x.v), fabsf(vert[order[k]].y.v - vert[q].y.v)) <= 1e-6f) continue;
+      }
+      order[kept++] = order[k];
+    }
+    if (kept > 1) {
+      int a0 = order[0], q = order[kept - 1];
+      if (fmaxf(fabsf(vert[a0].x.v - vert[q].x.v), fabsf(vert[a0].y.v - vert[q].y.v)) <= 1e-6f) --kept;
+    }
+    cnt = kept > 8 ? 8 : kept;
+  }
+  D7 total = dconst(0.f);
+  if (cnt >= 3) {
+    for (int k = 0; k < cnt; ++k) {
+      const V2& a = vert[order[k]];
+      const V2& b = vert[order[(k + 1) % cnt]];
+      total = total + (a.x * b.y - a.y * b.x);
+    }
+  }
+  D7 inter = dscale(total, total.v > 0.f ? 0.5f : (total.v < 0.f ? -0.5f : 0.f));
+  D7 area1 = P[3] * P[4];
+  D7 u2d = area1 + dconst(t[3] * t[4]) - inter;
+  D7 iou2d = inter / u2d;
+  D7 zmax1 = P[2] + dscale(P[5], 0.5f), zmin1 = P[2] - dscale(P[5], 0.5f);
+  D7 zmax2 = dconst(t[2] + t[5] * 0.5f), zmin2 = dconst(t[2] - t[5] * 0.5f);
+  D7 zo = dmin_tie(zmax1, zmax2) - dmax_tie(zmin1, zmin2);
+  if (!(zo.v >= 0.f)) zo = dconst(0.f);                       // clamp_min(0): gradient passes at x >= 0
+  else if (zo.v == 0.f) zo.v = 0.f;
+  D7 inter3d = iou2d * u2d * zo;
+  D7 v1 = P[3] * P[4] * P[5];
+  D7 u3d = v1 + dconst(t[3] * t[4] * t[5]) - inter3d;
+  D7 r = inter3d / u3d;
+  iou_out[i] = r.v;
+  for (int e = 0; e < 7; ++e) dpred[i * 7 + e] = r.d[e];
+}
+
+extern "C" {
+
+int fc_riou3d_fwd_bwd(const float* pred, const float* target, const float* weight, int64_t n, float* iou, float* dpred,
+                      hipStream_t stream) {
+  if (n < 0) return FC_EINVAL;
+  if (n == 0) return FC_OK;
+  k_riou3d<<<(unsigned)fc_cdiv(n, 64), 64, 0, stream>>>(pred, target, weight, n, iou, dpred);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,348 @@
+"""FCAF3D neck + anchor-free head, loss, target assignment and box decoding/NMS driver.
+
+Host-side mirror of mmdet3d/models/dense_heads/fcaf3d_neck_with_head.py (class names, constructor
+kwargs, method names, return structures and parameter names are the reference's; the body runs on
+the HIP operators of this package).  Differences that do not change results:
+  * norm+activation pairs and the three 1x1 head convolutions are fused into single kernel passes;
+  * the loss is evaluated with positive-MASKS instead of `nonzero` index lists (no host syncs), and
+    the two per-scene `reduce_mean` scalars (reference :179, :187) of ALL scenes of the batch travel in
+    ONE all-reduce — numerically identical.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import functional as Fn
+from . import nn as MEnn
+from .dist import reduce_mean
+from .nms import nms_bev
+from .registry import BBOX_ASSIGNERS, HEADS, build_assigner, build_loss
+from .sparse import SparseTensor
+
+
+class Scale(nn.Module):
+    """mmcv.cnn.Scale"""
+
+    def __init__(self, scale=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+def bias_init_with_prob(prior_prob):
+    return float(-math.log((1 - prior_prob) / prior_prob))
+
+
+@HEADS.register_module()
+class Fcaf3DNeckWithHead(nn.Module):
+    def __init__(self,
+                 n_classes,
+                 in_channels,
+                 out_channels,
+                 n_reg_outs,
+                 voxel_size,
+                 pts_threshold,
+                 assigner,
+                 yaw_parametrization='fcaf3d',
+                 loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 loss_bbox=dict(type='IoU3DLoss', loss_weight=1.0),
+                 loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 train_cfg=None,
+                 test_cfg=None):
+        super().__init__()
+        self.voxel_size = voxel_size
+        self.yaw_parametrization = yaw_parametrization
+        self.assigner = build_assigner(assigner)
+        self.loss_centerness = build_loss(loss_centerness)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.loss_cls = build_loss(loss_cls)
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        self.pts_threshold = pts_threshold
+        self.n_classes, self.n_reg_outs = n_classes, n_reg_outs
+        self._init_layers(in_channels, out_channels, n_reg_outs, n_classes)
+
+    # ---- module graph (reference :49-86; parameter names per SURVEY.md Appendix B) -----------------
+    @staticmethod
+    def _make_block(in_channels, out_channels):
+        return nn.Sequential(
+            MEnn.MinkowskiConvolution(in_channels, out_channels, kernel_size=3, dimension=3),
+            MEnn.MinkowskiBatchNorm(out_channels),
+            MEnn.MinkowskiELU())
+
+    @staticmethod
+    def _make_up_block(in_channels, out_channels):
+        return nn.Sequential(
+            MEnn.MinkowskiGenerativeConvolutionTranspose(in_channels, out_channels, kernel_size=2, stride=2, dimension=3),
+            MEnn.MinkowskiBatchNorm(out_channels),
+            MEnn.MinkowskiELU(),
+            MEnn.MinkowskiConvolution(out_channels, out_channels, kernel_size=3, dimension=3),
+            MEnn.MinkowskiBatchNorm(out_channels),
+            MEnn.MinkowskiELU())
+
+    def _init_layers(self, in_channels, out_channels, n_reg_outs, n_classes):
+        self.pruning = MEnn.MinkowskiPruning()
+        for i in range(len(in_channels)):
+            if i > 0:
+                self.__setattr__(f'up_block_{i}', self._make_up_block(in_channels[i], in_channels[i - 1]))
+            self.__setattr__(f'out_block_{i}', self._make_block(in_channels[i], out_channels))
+        self.centerness_conv = MEnn.MinkowskiConvolution(out_channels, 1, kernel_size=1, dimension=3)
+        self.reg_conv = MEnn.MinkowskiConvolution(out_channels, n_reg_outs, kernel_size=1, dimension=3)
+        self.cls_conv = MEnn.MinkowskiConvolution(out_channels, n_classes, kernel_size=1, bias=True, dimension=3)
+        self.scales = nn.ModuleList([Scale(1.) for _ in range(len(in_channels))])
+
+    def init_weights(self):
+        nn.init.normal_(self.centerness_conv.kernel, std=.01)
+        nn.init.normal_(self.reg_conv.kernel, std=.01)
+        nn.init.normal_(self.cls_conv.kernel, std=.01)
+        nn.init.constant_(self.cls_conv.bias, bias_init_with_prob(.01))
+
+    # ---- forward (reference :94-108) ---------------------------------------------------------------
+    def forward(self, x):
+        outs = []
+        inputs = x
+        x = inputs[-1]
+        scores = None
+        for i in range(len(inputs) - 1, -1, -1):
+            if i < len(inputs) - 1:
+                x = MEnn.run_sequential(getattr(self, f'up_block_{i + 1}'), x)
+                x = inputs[i] + x
+                x = self._prune(x, scores)
+            out = MEnn.run_sequential(getattr(self, f'out_block_{i}'), x)
+            out = self.forward_single(out, self.scales[i])
+            scores = out[-1]
+            outs.append(out[:-1])
+        return zip(*outs[::-1])
+
+    def _prune(self, x, scores):
+        """Keep, per scene, the pts_threshold voxels with the largest interpolated parent score (:110-126)."""
+        if self.pts_threshold < 0:
+            return x
+        perms = x.decomposition_permutations
+        if all(len(p) <= self.pts_threshold for p in perms):
+            return x                        # top-k of everything keeps everything
+        with torch.no_grad():
+            interpolated = scores.features_at_coordinates(x.C).squeeze(1)
+            mask = torch.zeros(len(interpolated), dtype=torch.bool, device=interpolated.device)
+            for perm in perms:
+                k = min(len(perm), self.pts_threshold)
+                ids = torch.topk(interpolated[perm], k, sorted=False).indices
+                mask[perm[ids]] = True
+        return self.pruning(x, mask)
+
+    def forward_single(self, x, scale):
+        """Three 1x1 convs as ONE 128 -> (1 + n_reg + n_cls) GEMM, padded to a multiple of 64 columns for
+        the MFMA tile (reference :256-279)."""
+        n_c, n_r = self.n_classes, self.n_reg_outs
+        w = torch.cat((self.centerness_conv.kernel, self.reg_conv.kernel, self.cls_conv.kernel), dim=1)
+        used = w.shape[1]
+        pad = (-used) % 64
+        if pad:
+            w = torch.cat((w, w.new_zeros(w.shape[0], pad)), dim=1)
+        y = Fn.sparse_conv(x.F, w.unsqueeze(0), None, x.F.shape[0])
+        centerness = y[:, :1]
+        reg_final = y[:, 1:1 + n_r]
+        cls_score = y[:, 1 + n_r:used] + self.cls_conv.bias
+        prune_scores = SparseTensor(cls_score.detach().max(dim=1, keepdim=True).values, coordinate_map_key=x.cmap)
+        reg_distance = torch.exp(scale(reg_final[:, :6]))
+        bbox_pred = torch.cat((reg_distance, reg_final[:, 6:]), dim=1)
+
+        centernesses, bbox_preds, cls_scores, points = [], [], [], []
+        for perm in x.decomposition_permutations:
+            centernesses.append(centerness[perm])
+            bbox_preds.append(bbox_pred[perm])
+            cls_scores.append(cls_score[perm])
+            points.append(x.C[perm, 1:].float() * self.voxel_size)
+        return centernesses, bbox_preds, cls_scores, points, prune_scores
+
+    # ---- loss (reference :128-203) -----------------------------------------------------------------
+    def loss(self, centernesses, bbox_preds, cls_scores, points, gt_bboxes, gt_labels, img_metas):
+        assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) \
+            == len(points[0]) == len(img_metas) == len(gt_bboxes) == len(gt_labels)
+        n_img = len(img_metas)
+        per_img = []
+        for i in range(n_img):
+            pts = [x[i] for x in points]
+            with torch.no_grad():
+                centerness_targets, bbox_targets, labels = self.assigner.assign(pts, gt_bboxes[i], gt_labels[i])
+                pos = labels >= 0
+                centerness_targets = torch.where(pos, centerness_targets, torch.zeros_like(centerness_targets))
+            per_img.append(dict(
+                centerness=torch.cat([x[i] for x in centernesses]),
+                bbox_preds=torch.cat([x[i] for x in bbox_preds]),
+                cls_scores=torch.cat([x[i] for x in cls_scores]),
+                points=torch.cat(pts), pos=pos, labels=labels,
+                centerness_targets=centerness_targets, bbox_targets=bbox_targets))
+        # one all-reduce for the 2*n_img normalisers instead of 2 per scene
+        with torch.no_grad():
+            norms = torch.stack([torch.stack((d['pos'].sum().float(), d['centerness_targets'].sum()))
+                                 for d in per_img])
+            norms = reduce_mean(norms)
+        loss_centerness, loss_bbox, loss_cls = [], [], []
+        for i, d in enumerate(per_img):
+            lc, lb, ls = self._loss_single(d, norms[i, 0].clamp(min=1.), norms[i, 1].clamp(min=1e-6))
+            loss_centerness.append(lc)
+            loss_bbox.append(lb)
+            loss_cls.append(ls)
+        return dict(
+            loss_centerness=torch.mean(torch.stack(loss_centerness)),
+            loss_bbox=torch.mean(torch.stack(loss_bbox)),
+            loss_cls=torch.mean(torch.stack(loss_cls)))
+
+    def _loss_single(self, d, n_pos, centerness_denorm):
+        posf = d['pos'].float()
+        loss_cls = self.loss_cls(d['cls_scores'], d['labels'], avg_factor=n_pos)
+        loss_centerness = self.loss_centerness(d['centerness'], d['centerness_targets'].unsqueeze(1),
+                                               weight=posf.unsqueeze(1), avg_factor=n_pos)
+        loss_bbox = self.loss_bbox(self._bbox_pred_to_bbox(d['points'], d['bbox_preds']), d['bbox_targets'],
+                                   weight=d['centerness_targets'], avg_factor=centerness_denorm)
+        return loss_centerness, loss_bbox, loss_cls
+
+    # ---- inference (reference :205-253, :332-374) --------------------------------------------------
+    def get_bboxes(self, centernesses, bbox_preds, cls_scores, points, img_metas, rescale=False):
+        assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) == len(points[0]) == len(img_metas)
+        results = []
+        for i in range(len(img_metas)):
+            results.append(self._get_bboxes_single(
+                centernesses=[x[i] for x in centernesses], bbox_preds=[x[i] for x in bbox_preds],
+                cls_scores=[x[i] for x in cls_scores], points=[x[i] for x in points], img_meta=img_metas[i]))
+        return results
+
+    def _get_bboxes_single(self, centernesses, bbox_preds, cls_scores, points, img_meta):
+        mlvl_bboxes, mlvl_scores = [], []
+        for centerness, bbox_pred, cls_score, point in zip(centernesses, bbox_preds, cls_scores, points):
+            scores = cls_score.sigmoid() * centerness.sigmoid()
+            max_scores, _ = scores.max(dim=1)
+            if len(scores) > self.test_cfg.nms_pre > 0:
+                _, ids = max_scores.topk(self.test_cfg.nms_pre)
+                bbox_pred, scores, point = bbox_pred[ids], scores[ids], point[ids]
+            mlvl_bboxes.append(self._bbox_pred_to_bbox(point, bbox_pred))
+            mlvl_scores.append(scores)
+        return self._nms(torch.cat(mlvl_bboxes), torch.cat(mlvl_scores), img_meta)
+
+    def _bbox_pred_to_bbox(self, points, bbox_pred):
+        """(dx_min,dx_max,dy_min,dy_max,dz_min,dz_max[,r6,r7]) at `points` -> (cx,cy,cz,w,l,h[,yaw]) (:281-330)."""
+        if bbox_pred.shape[0] == 0:
+            return bbox_pred
+        d = bbox_pred
+        centre = points + torch.stack((d[:, 1] - d[:, 0], d[:, 3] - d[:, 2], d[:, 5] - d[:, 4]), -1) / 2
+        if d.shape[1] == 6:
+            return torch.cat((centre, torch.stack((d[:, 0] + d[:, 1], d[:, 2] + d[:, 3], d[:, 4] + d[:, 5]), -1)), -1)
+        if self.yaw_parametrization == 'naive':
+            size = torch.stack((d[:, 0] + d[:, 1], d[:, 2] + d[:, 3], d[:, 4] + d[:, 5]), -1)
+            return torch.cat((centre, size, d[:, 6:7]), -1)
+        if self.yaw_parametrization == 'sin-cos':
+            size = torch.stack((d[:, 0] + d[:, 1], d[:, 2] + d[:, 3], d[:, 4] + d[:, 5]), -1)
+            norm = torch.pow(torch.pow(d[:, 6:7], 2) + torch.pow(d[:, 7:8], 2), 0.5)
+            return torch.cat((centre, size, torch.atan2(d[:, 6:7] / norm, d[:, 7:8] / norm)), -1)
+        # 'fcaf3d': (r6, r7) = ln(q)·(sin 2a, cos 2a), q = l / w
+        scale = d[:, 0] + d[:, 1] + d[:, 2] + d[:, 3]
+        q = torch.exp(torch.sqrt(torch.pow(d[:, 6], 2) + torch.pow(d[:, 7], 2)))
+        alpha = 0.5 * torch.atan2(d[:, 6], d[:, 7])
+        w = scale / (1 + q)
+        return torch.cat((centre, torch.stack((w, w * q, d[:, 5] + d[:, 4], alpha), dim=-1)), -1)
+
+    def _nms(self, bboxes, scores, img_meta):
+        n_classes = scores.shape[1]
+        yaw_flag = bboxes.shape[1] == 7
+        nms_bboxes, nms_scores, nms_labels = [], [], []
+        boxes7 = bboxes if yaw_flag else torch.cat((bboxes, torch.zeros_like(bboxes[:, :1])), dim=1)
+        for i in range(n_classes):
+            ids = scores[:, i] > self.test_cfg.score_thr
+            if not ids.any():
+                continue
+            class_scores = scores[ids, i]
+            class_bboxes = boxes7[ids]
+            nms_ids = nms_bev(class_bboxes, class_scores, self.test_cfg.iou_thr, rotated=yaw_flag)
+            nms_bboxes.append(class_bboxes[nms_ids])
+            nms_scores.append(class_scores[nms_ids])
+            nms_labels.append(bboxes.new_full(class_scores[nms_ids].shape, i, dtype=torch.long))
+        if len(nms_bboxes):
+            nms_bboxes = torch.cat(nms_bboxes, dim=0)
+            nms_scores = torch.cat(nms_scores, dim=0)
+            nms_labels = torch.cat(nms_labels, dim=0)
+        else:
+            nms_bboxes = bboxes.new_zeros((0, 7))
+            nms_scores = bboxes.new_zeros((0,))
+            nms_labels = bboxes.new_zeros((0,))
+        if yaw_flag:
+            box_dim, with_yaw = 7, True
+        else:
+            box_dim, with_yaw = 6, False
+            nms_bboxes = nms_bboxes[:, :6]
+        nms_bboxes = img_meta['box_type_3d'](nms_bboxes, box_dim=box_dim, with_yaw=with_yaw, origin=(.5, .5, .5))
+        return nms_bboxes, nms_scores, nms_labels
+
+
+def compute_centerness(bbox_targets):
+    """sqrt( Π_axis min(d-,d+)/max(d-,d+) ) over the 6 face distances (:377-384)."""
+    d = bbox_targets[..., :6].reshape(bbox_targets.shape[:-1] + (3, 2))
+    lo = d.min(dim=-1).values
+    hi = d.max(dim=-1).values
+    return torch.sqrt(lo[..., 0] / hi[..., 0] * lo[..., 1] / hi[..., 1] * lo[..., 2] / hi[..., 2])
+
+
+@BBOX_ASSIGNERS.register_module()
+class Fcaf3DAssigner:
+    """Target assignment of FCAF3D (:387-466): a location is positive for a GT box when it lies inside
+    the (rotated) box, on the box's best pyramid level (the last level that still holds >= `limit`
+    inside locations), and among the `topk` most central such locations; ties between boxes go to the
+    smallest volume."""
+
+    def __init__(self, limit, topk, n_scales):
+        self.limit = limit
+        self.topk = topk
+        self.n_scales = n_scales
+
+    @torch.no_grad()
+    def assign(self, points, gt_bboxes, gt_labels):
+        float_max = 1e8
+        dev = points[0].device
+        level = torch.cat([points[i].new_full((len(points[i]),), i) for i in range(len(points))])
+        pts = torch.cat(points, dim=0)
+        n_points, n_boxes = len(pts), len(gt_bboxes)
+        boxes = torch.cat((gt_bboxes.gravity_center, gt_bboxes.tensor[:, 3:]), dim=1).to(dev)   # (m,7)
+        volumes = gt_bboxes.volume.to(dev)
+        if n_boxes == 0:
+            return (pts.new_zeros(n_points), pts.new_zeros((n_points, 7)),
+                    gt_labels.new_full((n_points,), -1))
+        # offsets of every location from every box centre, rotated into the box frame (angle -yaw about z,
+        # the reference's rotation_3d_in_axis convention: x' = x cos a + y sin a, y' = -x sin a + y cos a)
+        shift = pts[:, None, :] - boxes[None, :, :3]                          # (n,m,3)
+        ang = -boxes[:, 6]
+        ca, sa = torch.cos(ang)[None], torch.sin(ang)[None]
+        rx = shift[..., 0] * ca + shift[..., 1] * sa
+        ry = -shift[..., 0] * sa + shift[..., 1] * ca
+        centre = boxes[None, :, :3] + torch.stack((rx, ry, shift[..., 2]), dim=-1)
+        half = boxes[None, :, 3:6] / 2
+        lo = centre - boxes[None, :, :3] + half                               # distance to the "min" faces
+        hi = boxes[None, :, :3] + half - centre                               # distance to the "max" faces
+        targets = torch.stack((lo[..., 0], hi[..., 0], lo[..., 1], hi[..., 1], lo[..., 2], hi[..., 2],
+                               boxes[None, :, 6].expand(n_points, n_boxes)), dim=-1)   # (n,m,7)
+        inside = targets[..., :6].min(-1).values > 0                          # (n,m)
+
+        # best level per box
+        per_level = torch.stack([inside[level == i].sum(dim=0) for i in range(self.n_scales)])   # (L,m)
+        starved = per_level < self.limit
+        first_starved = torch.argmax(starved.int(), dim=0) - 1
+        first_starved = first_starved.clamp(min=0)
+        best = torch.where(~starved.any(dim=0), torch.full_like(first_starved, self.n_scales - 1), first_starved)
+        on_best = level[:, None] == best[None, :].to(level.dtype)
+
+        # top-k most central candidates per box
+        centerness = compute_centerness(targets)
+        neg = torch.full_like(centerness, -1.0)
+        centerness = torch.where(inside & on_best, centerness, neg)
+        kth = torch.topk(centerness, min(self.topk + 1, n_points), dim=0).values[-1]
+        central = centerness > kth[None]
+
+        vol = torch.where(inside & on_best & central, volumes[None].expand(n_points, n_boxes),
+                          volumes.new_full((1,), float_max))
+        min_vol, owner = vol.min(dim=1)
+        labels = torch.where(min_vol == float_max, gt_labels.new_full((1,), -1), gt_labels.to(dev)[owner])
+        rows = torch.arange(n_points, device=dev)
+        centerness_targets = compute_centerness(targets[rows, owner])
+        return centerness_targets, boxes[owner], labels

@@ -1,0 +1,167 @@
+"""Loss modules of the FCAF3D head with the reference's registry names and call signatures:
+  * IoU3DLoss(with_yaw, reduction, loss_weight)              — mmdet3d/models/losses/iou3d_loss.py:38-75
+  * FocalLoss(use_sigmoid, gamma, alpha, reduction, loss_weight)   — mmdet FocalLoss over mmcv's
+    sigmoid_focal_loss op (defaults at fcaf3d_neck_with_head.py:29-34)
+  * CrossEntropyLoss(use_sigmoid=True, ...)                   — mmdet (fcaf3d_neck_with_head.py:24-27)
+The per-element math runs in csrc/loss.hip; reductions follow mmdet's `weight_reduce_loss`
+(`sum / avg_factor` when an avg_factor is given with reduction='mean')."""
+import torch
+from torch import nn
+
+from . import _lib as L
+from .registry import LOSSES
+
+
+def _reduce(loss, weight, reduction, avg_factor):
+    if weight is not None:
+        loss = loss * weight
+    if avg_factor is None:
+        if reduction == 'mean':
+            return loss.mean()
+        if reduction == 'sum':
+            return loss.sum()
+        return loss
+    if reduction == 'mean':
+        return loss.sum() / avg_factor
+    if reduction == 'none':
+        return loss
+    raise ValueError('avg_factor can not be used with reduction="sum"')
+
+
+class _FocalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, gamma, alpha):
+        if not logits.is_cuda:
+            raise RuntimeError('sigmoid focal loss runs on the GPU only (HIP)')
+        logits = logits.contiguous()
+        labels = labels.to(torch.int64).contiguous()
+        n, C = logits.shape
+        loss = torch.empty_like(logits)
+        L.call('fc_focal_loss_fwd', L.ptr(logits), L.ptr(labels), n, C, float(gamma), float(alpha), L.ptr(loss), L.stream())
+        ctx.save_for_backward(logits, labels)
+        ctx.cfg = (float(gamma), float(alpha))
+        return loss.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels = ctx.saved_tensors
+        gamma, alpha = ctx.cfg
+        n, C = logits.shape
+        gx = torch.empty_like(logits)
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        L.call('fc_focal_loss_bwd', L.ptr(logits), L.ptr(labels), n, C, gamma, alpha, L.ptr(gs), L.ptr(gx), L.stream())
+        return gx, None, None, None
+
+
+def sigmoid_focal_loss_sum(logits, labels, gamma=2.0, alpha=0.25):
+    """Σ over (N,C) of the sigmoid focal loss; labels (N,) in {-1, 0..C-1}, -1 = background."""
+    return _FocalFn.apply(logits, labels, gamma, alpha)
+
+
+@LOSSES.register_module()
+class FocalLoss(nn.Module):
+    def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        assert use_sigmoid is True, 'Only sigmoid focal loss supported now.'
+        self.gamma, self.alpha, self.reduction, self.loss_weight = gamma, alpha, reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        assert reduction_override in (None, 'mean', 'sum')
+        assert weight is None, 'per-sample weights are not used by the FCAF3D head'
+        reduction = reduction_override or self.reduction
+        total = sigmoid_focal_loss_sum(pred, target, self.gamma, self.alpha)
+        if reduction == 'mean':
+            total = total / (avg_factor if avg_factor is not None else pred.numel())
+        return self.loss_weight * total
+
+
+@LOSSES.register_module()
+class CrossEntropyLoss(nn.Module):
+    def __init__(self, use_sigmoid=False, use_mask=False, reduction='mean', class_weight=None, loss_weight=1.0):
+        super().__init__()
+        assert use_sigmoid and not use_mask and class_weight is None, 'the FCAF3D head uses the sigmoid (BCE) form only'
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None):
+        reduction = reduction_override or self.reduction
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(cls_score, label.float(), reduction='none')
+        return self.loss_weight * _reduce(loss, weight, reduction, avg_factor)
+
+
+class _AlignedIoUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        if not pred.is_cuda:
+            raise RuntimeError('3D IoU runs on the GPU only (HIP)')
+        pred = pred.contiguous()
+        target = target.contiguous()
+        n = pred.shape[0]
+        iou = torch.empty(n, dtype=torch.float32, device=pred.device)
+        dpred = torch.empty((n, 6), dtype=torch.float32, device=pred.device)
+        L.call('fc_aiou3d_fwd_bwd', L.ptr(pred), L.ptr(target), target.shape[1], n, 1e-6, L.ptr(iou), L.ptr(dpred),
+               L.stream())
+        ctx.save_for_backward(dpred)
+        return iou
+
+    @staticmethod
+    def backward(ctx, g):
+        dpred, = ctx.saved_tensors
+        return g[:, None] * dpred, None
+
+
+def axis_aligned_iou_3d(pred, target):
+    """IoU of (n,6) boxes [cx,cy,cz,w,l,h] with targets (n,>=6) — iou3d_loss.py:21-35."""
+    assert pred.shape[1] == 6 and target.shape[1] >= 6
+    return _AlignedIoUFn.apply(pred, target)
+
+
+class _RotatedIoUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, weight):
+        if not pred.is_cuda:
+            raise RuntimeError('3D IoU runs on the GPU only (HIP)')
+        pred = pred.contiguous()
+        target = target.contiguous()
+        weight = weight.contiguous() if weight is not None else None
+        n = pred.shape[0]
+        iou = torch.empty(n, dtype=torch.float32, device=pred.device)
+        dpred = torch.empty((n, 7), dtype=torch.float32, device=pred.device)
+        L.call('fc_riou3d_fwd_bwd', L.ptr(pred), L.ptr(target), L.ptr(weight), n, L.ptr(iou), L.ptr(dpred), L.stream())
+        ctx.save_for_backward(dpred)
+        return iou
+
+    @staticmethod
+    def backward(ctx, g):
+        dpred, = ctx.saved_tensors
+        return g[:, None] * dpred, None, None
+
+
+def rotated_iou_3d(pred, target, weight=None):
+    """cal_iou_3d of (n,7) boxes [cx,cy,cz,w,l,h,yaw] — rotated_iou/oriented_iou_loss.py:86-109.
+    Rows whose `weight` is <= 0 are skipped by the kernel (they cannot contribute to the loss)."""
+    assert pred.shape[1] == 7 and target.shape[1] == 7
+    return _RotatedIoUFn.apply(pred, target, weight)
+
+
+@LOSSES.register_module()
+class IoU3DLoss(nn.Module):
+    """loss_weight * Σ w·(1 − IoU3D) / avg_factor  (iou3d_loss.py:38-75)."""
+
+    def __init__(self, with_yaw=True, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        self.with_yaw, self.reduction, self.loss_weight = with_yaw, reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        reduction = reduction_override or self.reduction
+        if weight is not None and weight.dim() > 1:
+            weight = weight.mean(-1)
+        if pred.shape[0] == 0:
+            return pred.sum() * 0.0
+        iou = rotated_iou_3d(pred, target, weight) if self.with_yaw else axis_aligned_iou_3d(pred, target)
+        loss = 1 - iou
+        if weight is not None:
+            # rows with zero weight contribute exactly zero (value and gradient), which also covers the
+            # reference's early-out `if not torch.any(weight > 0): return pred.sum() * weight.sum()`
+            loss = torch.where(weight > 0, loss, torch.zeros_like(loss))
+        return self.loss_weight * _reduce(loss, weight, reduction, avg_factor)

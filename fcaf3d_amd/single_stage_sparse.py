@@ -1,0 +1,76 @@
+"""Detector shell — host-side mirror of mmdet3d/models/detectors/single_stage_sparse.py:9-62 and the
+`forward(return_loss=...)` dispatch of detectors/base.py:45-60."""
+import torch
+from torch import nn
+
+from . import _lib as L
+from .boxes import bbox3d2result
+from .registry import DETECTORS, build_backbone, build_head
+from .sparse import SparseTensor
+
+
+@DETECTORS.register_module()
+class SingleStageSparse3DDetector(nn.Module):
+    def __init__(self, backbone, neck_with_head, voxel_size, pretrained=False, train_cfg=None, test_cfg=None):
+        super().__init__()
+        self.backbone = build_backbone(backbone)
+        neck_with_head = dict(neck_with_head)
+        neck_with_head.update(train_cfg=train_cfg)
+        neck_with_head.update(test_cfg=test_cfg)
+        self.neck_with_head = build_head(neck_with_head)
+        self.voxel_size = voxel_size
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        self.init_weights()
+
+    def init_weights(self, pretrained=None):
+        self.backbone.init_weights()
+        self.neck_with_head.init_weights()
+
+    def voxelize(self, points):
+        """ME.utils.batch_sparse_collate of [(xyz / voxel_size, rgb / 255)] (reference :34-36), one fused
+        kernel per scene: coords int32 (ΣN,4), feats (ΣN,3)."""
+        dev = points[0].device
+        total = sum(p.shape[0] for p in points)
+        nfeat = points[0].shape[1] - 3
+        coords = torch.empty((total, 4), dtype=torch.int32, device=dev)
+        feats = torch.empty((total, nfeat), dtype=torch.float32, device=dev)
+        off = 0
+        for b, p in enumerate(points):
+            p = p.contiguous()
+            n = p.shape[0]
+            L.call('fc_voxelize', L.ptr(p), n, p.shape[1], b, float(self.voxel_size), 255.0, nfeat,
+                   L.ptr(coords[off:]), L.ptr(feats[off:]), L.stream())
+            off += n
+        return coords, feats
+
+    def extract_feat(self, points, img_metas):
+        coordinates, features = self.voxelize(points)
+        x = SparseTensor(features, coordinates=coordinates, batch_size=len(points))
+        x = self.backbone(x)
+        x = self.neck_with_head(x)
+        return x
+
+    def forward_train(self, points, gt_bboxes_3d, gt_labels_3d, img_metas):
+        x = self.extract_feat(points, img_metas)
+        return self.neck_with_head.loss(*x, gt_bboxes_3d, gt_labels_3d, img_metas)
+
+    def simple_test(self, points, img_metas, imgs=None, rescale=False):
+        x = self.extract_feat(points, img_metas)
+        bbox_list = self.neck_with_head.get_bboxes(*x, img_metas, rescale=rescale)
+        return [bbox3d2result(bboxes, scores, labels) for bboxes, scores, labels in bbox_list]
+
+    def aug_test(self, points, img_metas, imgs=None, rescale=False):
+        pass
+
+    def forward_test(self, points, img_metas, img=None, **kwargs):
+        # base.py:14-43: one (non-augmented) sample per list entry
+        if isinstance(points[0], (list, tuple)):
+            assert len(points) == 1, 'test-time augmentation is a stub in the reference (aug_test: pass)'
+            return self.simple_test(points[0], img_metas[0], **kwargs)
+        return self.simple_test(points, img_metas, **kwargs)
+
+    def forward(self, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(**kwargs)
+        return self.forward_test(**kwargs)

@@ -119,6 +119,40 @@ int fc_maxpool_bwd(const float* gout, const int* argrow, int64_t n_out, int C, f
 int fc_gather_rows(const float* src, const int* idx, int64_t n, int C, float* dst, hipStream_t stream);
 int fc_scatter_rows_add(const float* src, const int* idx, int64_t n, int C, float* dst, hipStream_t stream);
 
+/* ---- losses ------------------------------------------------------------------------------- */
+
+/* mmcv sigmoid_focal_loss forward/backward (through mmdet FocalLoss, fcaf3d_neck_with_head.py:29-34,:180):
+ * loss[n,c] elementwise; labels int64 in {-1,0..C-1}, -1 = background (all classes negative).
+ * backward: glogits = dloss/dlogits * gscale_dev[0]. */
+int fc_focal_loss_fwd(const float* logits, const long long* labels, int64_t n, int C, float gamma, float alpha,
+                      float* loss, hipStream_t stream);
+int fc_focal_loss_bwd(const float* logits, const long long* labels, int64_t n, int C, float gamma, float alpha,
+                      const float* gscale_dev, float* glogits, hipStream_t stream);
+
+/* axis-aligned 3D IoU of (n,6) [cx,cy,cz,w,l,h] boxes and its gradient w.r.t. pred —
+ * iou3d_loss.py:21-35 over iou3d_calculator.py:201-330 (is_aligned=True). dpred may be NULL. */
+int fc_aiou3d_fwd_bwd(const float* pred, const float* target, int target_stride, int64_t n, float eps, float* iou,
+                      float* dpred, hipStream_t stream);
+
+/* rotated 3D IoU of (n,7) [cx,cy,cz,w,l,h,yaw] boxes and its gradient w.r.t. pred — cal_iou_3d,
+ * rotated_iou/oriented_iou_loss.py:86-109 + box_intersection_2d.py:13-184 + cuda_op sort_v.
+ * weight (nullable): rows with weight <= 0 are skipped (iou = 0, dpred = 0). */
+int fc_riou3d_fwd_bwd(const float* pred, const float* target, const float* weight, int64_t n, float* iou, float* dpred,
+                      hipStream_t stream);
+
+/* ---- NMS ---------------------------------------------------------------------------------- */
+
+/* pcdet_nms nms_gpu (rotated=1) / nms_normal_gpu (rotated=0) — iou3d_nms.cpp:90-186, kernels
+ * iou3d_nms_kernel.cu:267-372 — for `nseg` classes at once: boxes (nseg,stride,7) sorted by descending
+ * score inside each segment, counts_dev (nseg) valid boxes per segment; keep (nseg,stride) receives the
+ * ascending positions of the survivors, keep_count (nseg) their number.  Greedy scan runs on the device. */
+int64_t fc_nms_bev_ws_bytes(int nseg, int stride);
+int fc_nms_bev(const float* boxes, const int* counts_dev, int nseg, int stride, float thresh, int rotated,
+               unsigned long long* mask_ws, int64_t ws_bytes, int* keep, int* keep_count, hipStream_t stream);
+/* pcdet_nms boxes_iou_bev_gpu (iou3d_nms_kernel.cu:251-265): (n,m) BEV IoU matrix. */
+int fc_boxes_iou_bev(const float* boxes_a, int n, const float* boxes_b, int m, int rotated, float* out,
+                     hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""CPU: host-side logic of the product (registry/config shim, module graph & parameter names, target
+assignment, box decoding, centerness) against the golden vectors generated from the reference's own
+pure-torch code (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import torch
+
+import fcaf3d_amd as fa
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _gt(boxes):
+    return fa.DepthInstance3DBoxes(torch.from_numpy(boxes), origin=(.5, .5, .5))
+
+
+def test_assigner_matches_reference_goldens():
+    d = np.load(os.path.join(G, 'assigner.npz'))
+    for ci in range(int(d['n_cases'])):
+        L = int(d[f'c{ci}_n_scales'])
+        pts = [torch.from_numpy(d[f'c{ci}_points{l}']) for l in range(L)]
+        a = fa.Fcaf3DAssigner(limit=27, topk=18, n_scales=L)
+        ct, bt, lb = a.assign(pts, _gt(d[f'c{ci}_gt']), torch.from_numpy(d[f'c{ci}_labels']))
+        ref_lb = d[f'c{ci}_assigned']
+        assert np.array_equal(lb.numpy(), ref_lb), f'case {ci}'
+        pos = ref_lb >= 0
+        assert pos.sum() > 50
+        assert np.allclose(ct.numpy()[pos], d[f'c{ci}_centerness'][pos], atol=1e-6)
+        assert np.allclose(bt.numpy()[pos], d[f'c{ci}_bbox_targets'][pos], atol=1e-6)
+
+
+def test_assigner_no_boxes():
+    a = fa.Fcaf3DAssigner(limit=27, topk=18, n_scales=2)
+    ct, bt, lb = a.assign([torch.rand(10, 3), torch.rand(4, 3)], _gt(np.zeros((0, 7), np.float32)),
+                          torch.zeros(0, dtype=torch.long))
+    assert (lb == -1).all() and len(lb) == 14 and bt.shape == (14, 7)
+
+
+def test_decode_and_centerness_goldens():
+    d = np.load(os.path.join(G, 'decode.npz'))
+    head = fa.Fcaf3DNeckWithHead.__new__(fa.Fcaf3DNeckWithHead)
+    pts = torch.from_numpy(d['points'])
+    head.yaw_parametrization = 'fcaf3d'
+    assert np.allclose(head._bbox_pred_to_bbox(pts, torch.from_numpy(d['pred6'])).numpy(), d['out6'], atol=1e-6)
+    assert np.allclose(head._bbox_pred_to_bbox(pts, torch.from_numpy(d['pred8'])).numpy(), d['out8_fcaf3d'], atol=1e-6)
+    head.yaw_parametrization = 'sin-cos'
+    assert np.allclose(head._bbox_pred_to_bbox(pts, torch.from_numpy(d['pred8'])).numpy(), d['out8_sin-cos'], atol=1e-6)
+    head.yaw_parametrization = 'naive'
+    assert np.allclose(head._bbox_pred_to_bbox(pts, torch.from_numpy(d['pred8'][:, :7])).numpy(), d['out7_naive'], atol=1e-6)
+    assert np.allclose(fa.compute_centerness(torch.from_numpy(d['cent_in'])).numpy(), d['cent_out'], atol=1e-6)
+    assert head._bbox_pred_to_bbox(pts[:0], torch.zeros(0, 6)).shape == (0, 6)
+
+
+def test_configs_build_with_reference_names_and_shapes():
+    cfg = fa.get_config('fcaf3d_scannet-3d-18class')
+    assert cfg.model.voxel_size == 0.01 and cfg.model.neck_with_head.loss_bbox.with_yaw is False
+    assert cfg.model.neck_with_head.assigner.n_scales == 4 and cfg.optimizer.type == 'AdamW'
+    model = fa.build_detector(cfg.model, train_cfg=cfg.model.get('train_cfg'), test_cfg=cfg.model.get('test_cfg'))
+    sd = model.state_dict()
+    shapes = {
+        'backbone.conv1.0.kernel': (27, 3, 64), 'backbone.conv1.1.weight': (1, 64),
+        'backbone.layer1.0.conv1.kernel': (27, 64, 64), 'backbone.layer1.0.downsample.0.kernel': (1, 64, 64),
+        'backbone.layer1.0.downsample.1.bn.running_var': (64,), 'backbone.layer2.0.conv1.kernel': (27, 64, 128),
+        'backbone.layer3.5.conv2.kernel': (27, 256, 256), 'backbone.layer4.2.norm2.bn.weight': (512,),
+        'neck_with_head.up_block_1.0.kernel': (8, 128, 64), 'neck_with_head.up_block_3.3.kernel': (27, 256, 256),
+        'neck_with_head.out_block_0.0.kernel': (27, 64, 128), 'neck_with_head.out_block_3.1.bn.bias': (128,),
+        'neck_with_head.centerness_conv.kernel': (128, 1), 'neck_with_head.reg_conv.kernel': (128, 6),
+        'neck_with_head.cls_conv.kernel': (128, 18), 'neck_with_head.cls_conv.bias': (1, 18),
+        'neck_with_head.scales.3.scale': (),
+    }
+    for k, s in shapes.items():
+        assert tuple(sd[k].shape) == s, (k, sd[k].shape)
+    n_params = sum(p.numel() for p in model.parameters())
+    assert 69e6 < n_params < 72e6, n_params          # ~70.4 M
+    assert abs(float(sd['neck_with_head.cls_conv.bias'][0, 0]) + np.log(99)) < 1e-5
+    for name in ('fcaf3d_sunrgbd-3d-10class', 'fcaf3d_s3dis-3d-5class', 'fcaf3d_2scales_scannet-3d-18class',
+                 'fcaf3d_3scales_scannet-3d-18class'):
+        c = fa.get_config(name)
+        fa.build_detector(c.model, train_cfg=c.model.get('train_cfg'), test_cfg=c.model.get('test_cfg'))
+    c2 = fa.get_config('fcaf3d_2scales_scannet-3d-18class')
+    assert c2.model.voxel_size == 0.02 and c2.model.backbone.n_outs == 2 and c2.model.neck_with_head.n_classes == 18
+    c3 = fa.get_config('fcaf3d_scannet-3d-18class', voxel_size=0.02)
+    assert c3.model.neck_with_head.voxel_size == 0.02
+
+
+def test_registry_errors():
+    import pytest
+    with pytest.raises(KeyError):
+        fa.build_backbone(dict(type='NoSuchBackbone'))
+    with pytest.raises(ValueError):
+        fa.build_backbone(dict(type='MEResNet3D', in_channels=3, depth=7))
+    with pytest.raises(TypeError):
+        fa.build_loss('IoU3DLoss')
+
+
+def test_boxes_container():
+    b = fa.DepthInstance3DBoxes(torch.tensor([[1., 2., 3., 2., 4., 6., 0.5]]), origin=(.5, .5, .5))
+    assert torch.allclose(b.tensor[0, :3], torch.tensor([1., 2., 0.]))
+    assert torch.allclose(b.gravity_center[0], torch.tensor([1., 2., 3.]))
+    assert float(b.volume[0]) == 48.0 and len(b) == 1
+    b6 = fa.DepthInstance3DBoxes(torch.zeros(0, 6), box_dim=6, with_yaw=False, origin=(.5, .5, .5))
+    assert b6.tensor.shape == (0, 7) and b6.with_yaw is False
