@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""scenes/sec forward+backward of the FCAF3D sparse-voxel hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One step = forward_train + loss.backward() + gradient all-reduce (N>1) + grad-clip + AdamW step over one
+batch of `--batch` synthetic ScanNet-shaped scenes per GPU (100 000 points, 2 cm voxels, 18 classes,
+fcaf3d_scannet-3d-18class topology: MEResNet3D-34, 4 levels).  Scenes are resident in HBM before the
+timed region.  Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     — the dominant kernel (MFMA gather-GEMM sparse conv), algorithmic FLOPs / HIP-event time
+  cpu_baseline — the CPU oracle (ME-CPU-algorithm restatement, oracle/model_oracle.py) on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step (reference samples_per_gpu=8)')
+    ap.add_argument('--workload', default='scannet-100k', choices=['plumbing-20k', 'scannet-100k', 'sunrgbd-100k', 's3dis-500k'])
+    ap.add_argument('--voxel-size', type=float, default=0.02)
+    ap.add_argument('--levels', type=int, default=4)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-points', type=int, default=0, help='points of the cpu_baseline sample scene (0 = same as workload)')
+    ap.add_argument('--no-instrument', action='store_true', help='skip per-kernel HIP events (roofline = null)')
+    return ap.parse_args()
+
+
+CONFIG_OF = {'plumbing-20k': 'fcaf3d_scannet-3d-18class', 'scannet-100k': 'fcaf3d_scannet-3d-18class',
+             'sunrgbd-100k': 'fcaf3d_sunrgbd-3d-10class', 's3dis-500k': 'fcaf3d_s3dis-3d-5class'}
+
+
+def build_model(args):
+    import fcaf3d_amd as fa
+    cfg = fa.get_config(CONFIG_OF[args.workload], voxel_size=args.voxel_size)
+    m = cfg.model
+    if args.levels != 4:
+        m.backbone['n_outs'] = args.levels
+        m.neck_with_head['in_channels'] = (64, 128, 256, 512)[:args.levels]
+        m.neck_with_head.assigner['n_scales'] = args.levels
+    torch.manual_seed(0)
+    model = fa.build_detector(m, train_cfg=m.get('train_cfg'), test_cfg=m.get('test_cfg'))
+    return model, cfg
+
+
+def make_batches(args, rank, dev, n_batches=2):
+    import fcaf3d_amd as fa
+    from fcaf3d_amd.synthetic import WORKLOADS, make_scene
+    kw = WORKLOADS[args.workload]['scene']
+    batches = []
+    for j in range(n_batches):
+        pts, gts, labs = [], [], []
+        for i in range(args.batch):
+            p, g, l = make_scene(1000 * rank + j * args.batch + i, **kw)
+            pts.append(torch.from_numpy(p).to(dev))
+            gts.append(fa.DepthInstance3DBoxes(torch.from_numpy(g), origin=(.5, .5, .5)).to(dev))
+            labs.append(torch.from_numpy(l).to(dev))
+        batches.append(dict(points=pts, gt_bboxes_3d=gts, gt_labels_3d=labs,
+                            img_metas=[dict(box_type_3d=fa.DepthInstance3DBoxes)] * args.batch))
+    return batches
+
+
+class ConvProbe:
+    """HIP-event bracket around every MFMA sparse-conv launch (forward + backward-data), with the
+    launch's algorithmic FLOPs (2 * valid pairs * Cin * Cout) counted on the device."""
+
+    def __init__(self):
+        self.records = []
+
+    def install(self):
+        import fcaf3d_amd._lib as L
+        probe = self
+        orig = L.call
+
+        def call(name, *a):
+            if name != 'fc_conv_fwd':
+                return orig(name, *a)
+            # (in, W, nbr, out, n_in, n_out, K, Cin, Cout, flags, stream)
+            n_out, K, Cin, Cout = a[5], a[6], a[7], a[8]
+            if Cin % 32 or Cout % 64:
+                return orig(name, *a)          # generic FMA path (stem): not the kernel under the probe
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            orig(name, *a)
+            e.record()
+            probe.records.append((s, e, probe._pairs, 2.0 * Cin * Cout, n_out))
+        L.call = call
+        self._orig = orig
+        self._pairs = None
+        # make the conv wrapper tell us which map it is about to use
+        import fcaf3d_amd.functional as Fn
+        fwd0, bwd0 = Fn._SparseConv.forward, Fn._SparseConv.backward
+
+        def pairs_of(kmap):
+            if kmap is None:
+                return None
+            if getattr(kmap, '_pairs_dev', None) is None:
+                kmap._pairs_dev = (kmap.nbr >= 0).sum()
+            return kmap._pairs_dev
+
+        def fwd(ctx, feats, weight, kmap, n_out):
+            probe._pairs = pairs_of(kmap)
+            return fwd0(ctx, feats, weight, kmap, n_out)
+
+        def bwd(ctx, gout):
+            probe._pairs = pairs_of(ctx.kmap)
+            return bwd0(ctx, gout)
+        Fn._SparseConv.forward = staticmethod(fwd)
+        Fn._SparseConv.backward = staticmethod(bwd)
+
+    def summary(self):
+        if not self.records:
+            return None
+        torch.cuda.synchronize()
+        flops = 0.0
+        ms = 0.0
+        for s, e, pairs, per_pair, n_out in self.records:
+            p = float(pairs.item()) if pairs is not None else float(n_out)
+            flops += p * per_pair
+            ms += s.elapsed_time(e)
+        n = len(self.records)
+        achieved = flops / (ms * 1e-3) / 1e12
+        return dict(bound='mfma', kernel='k_conv_mfma (sparse conv fwd + dgrad, dense GEMMs of convT/heads)',
+                    achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, launches=n,
+                    avg_launch_us=round(ms * 1e3 / n, 2), flops_per_launch=round(flops / n / 1e9, 4),
+                    time_share_ms_per_step=None)
+
+
+def cpu_baseline(args, model, cfg):
+    """The oracle (ME-CPU-algorithm restatement) forward+backward on ONE scene of the same workload."""
+    from fcaf3d_amd.synthetic import WORKLOADS, make_scene
+    from oracle import model_oracle as MO
+    kw = dict(WORKLOADS[args.workload]['scene'])
+    if args.cpu_points:
+        kw['n_points'] = args.cpu_points
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    P = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    p, g, l = make_scene(999, **kw)
+    t0 = time.time()
+    losses = MO.forward_train(P, cfg.model, [p], [g], [l])
+    sum(losses.values()).backward()
+    dt = time.time() - t0
+    return dict(value=round(1.0 / dt, 5), unit='scenes/s', cores=cores, kind='port',
+                sample=f'1 scene of {kw["n_points"]} pts, fwd+bwd once ({dt:.1f} s), oracle/model_oracle.py '
+                       f'(ME-CPU-algorithm restatement: hash kernel maps + per-offset gather-GEMM-scatter, torch CPU fp32)')
+
+
+def main():
+    args = parse()
+    from fcaf3d_amd import dist as D
+    D.init_dist()
+    rank = int(os.environ.get('RANK', '0'))
+    world = D.world_size()
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X (there is no CPU fallback for the product path)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    model, cfg = build_model(args)
+    model = model.to(dev).train()
+    if world > 1:
+        for p in model.parameters():
+            torch.distributed.broadcast(p.data, 0)
+    averager = D.GradientAverager(model.parameters())
+    opt = torch.optim.AdamW(model.parameters(), lr=cfg.optimizer.lr, weight_decay=cfg.optimizer.weight_decay, fused=True)
+    max_norm = cfg.optimizer_config.grad_clip.max_norm
+    batches = make_batches(args, rank, dev)
+
+    probe = None
+    if not args.no_instrument and rank == 0:
+        probe = ConvProbe()
+        probe.install()
+
+    def step(i):
+        batch = batches[i % len(batches)]
+        opt.zero_grad(set_to_none=True)
+        losses = model(return_loss=True, **batch)
+        loss = losses['loss_centerness'] + losses['loss_bbox'] + losses['loss_cls']
+        loss.backward()
+        averager.finish()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    if probe:
+        torch.cuda.synchronize()
+        probe.records.clear()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+    assert np.isfinite(final_loss), 'loss diverged'
+
+    if rank == 0:
+        scenes = args.batch * world * args.steps
+        out = {
+            'metric': 'scenes/sec fwd+bwd, ScanNet 100k-pt 2cm voxels, 1/2/4/8 MI355X',
+            'value': round(scenes / dt, 3), 'unit': 'scenes/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.workload} synthetic, {CONFIG_OF[args.workload]}.py topology '
+                                   f'(MEResNet3D-34, {args.levels} levels), voxel {args.voxel_size} m',
+                       'scenes_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
+                       'step': 'forward_train + backward + grad all-reduce + grad-clip + AdamW',
+                       'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4)},
+        }
+        rl = probe.summary() if probe else None
+        if rl:
+            conv_ms = rl['avg_launch_us'] * rl['launches'] / 1e3 / args.steps
+            rl['time_share_ms_per_step'] = round(conv_ms, 3)
+        out['roofline'] = rl
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, model, cfg)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,205 @@
+"""-m gpu: the detector end to end (HIP path through the reference's plugin API) against the CPU oracle
+on identical synthetic scenes and identical weights; loss kernels and NMS against the reference goldens.
+Tolerances: integer outputs exact; fp32 1e-4 relative to tensor scale (gradients after ~40 layers: 1e-3)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fcaf3d_amd as fa
+from fcaf3d_amd.synthetic import make_scene
+from oracle import bev, loss_oracle as lo, model_oracle as MO
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _rel(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.numel() == 0:
+        return 0.0
+    return float((a - b).abs().max()) / max(1e-3, float(b.abs().max()))
+
+
+def _build(name, voxel_size, n_levels, seed=0, **head_over):
+    torch.manual_seed(seed)
+    cfg = fa.get_config(name, voxel_size=voxel_size)
+    m = cfg.model
+    m.backbone['n_outs'] = n_levels
+    m.neck_with_head['in_channels'] = (64, 128, 256, 512)[:n_levels]
+    m.neck_with_head.assigner['n_scales'] = n_levels
+    for k, v in head_over.items():
+        m.neck_with_head[k] = v
+    model = fa.build_detector(m, train_cfg=m.get('train_cfg'), test_cfg=m.get('test_cfg'))
+    return model, m
+
+
+def _scenes(seeds, **kw):
+    out = [make_scene(s, **kw) for s in seeds]
+    return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
+
+
+def _to_gpu_batch(pts, gts, labs, dev):
+    return dict(points=[torch.from_numpy(p).to(dev) for p in pts],
+                gt_bboxes_3d=[fa.DepthInstance3DBoxes(torch.from_numpy(g), origin=(.5, .5, .5)) for g in gts],
+                gt_labels_3d=[torch.from_numpy(l).to(dev) for l in labs],
+                img_metas=[dict(box_type_3d=fa.DepthInstance3DBoxes) for _ in pts])
+
+
+def _oracle_params(model):
+    return {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point)
+            for k, v in model.state_dict().items()}
+
+
+@pytest.mark.parametrize('name,levels,B,n_points,kw', [
+    ('fcaf3d_scannet-3d-18class', 1, 1, 20000, {}),                       # BASELINE config 1 (plumbing)
+    ('fcaf3d_scannet-3d-18class', 4, 2, 30000, {}),                       # 4 levels, 2 scenes
+    ('fcaf3d_sunrgbd-3d-10class', 2, 1, 20000, dict(rotated=True, n_boxes=6, n_classes=10)),   # rotated IoU loss
+])
+def test_forward_train_parity(name, levels, B, n_points, kw):
+    dev = _dev()
+    model, m = _build(name, 0.02, levels)
+    P = _oracle_params(model)
+    model = model.to(dev).train()
+    pts, gts, labs = _scenes(range(10, 10 + B), n_points=n_points, **kw)
+    # forward outputs
+    out_o = MO.extract_feat(P, m, pts)
+    out_g = [list(x) for x in model.extract_feat([torch.from_numpy(p).to(dev) for p in pts], None)]
+    for kind in range(4):
+        for l in range(levels):
+            for b in range(B):
+                if kind == 3:
+                    assert torch.equal(out_g[kind][l][b].cpu(), out_o[kind][l][b]), 'points (voxel corners) must be exact'
+                else:
+                    assert _rel(out_g[kind][l][b], out_o[kind][l][b]) < 1e-4, (kind, l, b)
+    # losses + gradients (fresh forward so that BN running stats are touched once per path)
+    model.zero_grad()
+    losses_g = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
+    losses_o = MO.forward_train(P, m, pts, gts, labs)
+    for k in ('loss_centerness', 'loss_bbox', 'loss_cls'):
+        assert _rel(losses_g[k], losses_o[k]) < 1e-4, (k, float(losses_g[k]), float(losses_o[k]))
+    sum(losses_g.values()).backward()
+    sum(losses_o.values()).backward()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        r = _rel(p.grad, P[k].grad)
+        worst = max(worst, r)
+        assert r < 2e-3, (k, r)
+    print(f'{name} L={levels} B={B}: worst grad rel err {worst:.2e}')
+
+
+def test_simple_test_parity():
+    dev = _dev()
+    model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 3)
+    with torch.no_grad():
+        model.neck_with_head.cls_conv.bias.fill_(0.0)         # random init would score below score_thr
+        model.neck_with_head.cls_conv.kernel.normal_(0, 0.3)
+    P = _oracle_params(model)
+    model = model.to(dev).train()                             # batch-stat BN, as the oracle
+    pts, _, _ = _scenes([21, 22], n_points=20000)
+    res_o = MO.simple_test(P, m, pts)
+    res_g = model(return_loss=False, points=[torch.from_numpy(p).to(dev) for p in pts],
+                  img_metas=[dict(box_type_3d=fa.DepthInstance3DBoxes)] * 2)
+    for (bo, so, lo_), rg in zip(res_o, res_g):
+        assert len(so) > 10
+        assert len(rg['scores_3d']) == len(so)
+        assert torch.equal(rg['labels_3d'], lo_)
+        assert _rel(rg['scores_3d'], so) < 1e-4
+        got = torch.cat((rg['boxes_3d'].gravity_center, rg['boxes_3d'].tensor[:, 3:6]), 1)
+        assert _rel(got, bo[:, :6]) < 1e-4
+
+
+def test_iou_losses_vs_reference_goldens():
+    from fcaf3d_amd.losses import IoU3DLoss, axis_aligned_iou_3d, rotated_iou_3d
+    dev = _dev()
+    d = np.load(os.path.join(G, 'iou3d.npz'))
+    for key, fn in (('al', axis_aligned_iou_3d), ('ro', rotated_iou_3d)):
+        pred = torch.from_numpy(d[f'{key}_pred']).to(dev).requires_grad_(True)
+        tgt = torch.from_numpy(d[f'{key}_target']).to(dev)
+        w = torch.from_numpy(d[f'{key}_w']).to(dev)
+        iou = fn(pred, tgt)
+        ((1 - iou) * w).sum().backward()
+        assert np.allclose(iou.detach().cpu().numpy(), d[f'{key}_iou'], atol=1e-5), key
+        assert np.allclose(pred.grad.cpu().numpy(), d[f'{key}_grad'], atol=2e-4, rtol=1e-3), key
+    # module API incl. the zero-weight early-out (iou3d_loss.py:53-54)
+    loss = IoU3DLoss(with_yaw=True)
+    p = torch.from_numpy(d['ro_pred']).to(dev).requires_grad_(True)
+    z = loss(p, torch.from_numpy(d['ro_target']).to(dev), weight=torch.zeros(len(p), device=dev), avg_factor=3.0)
+    z.backward()
+    assert float(z) == 0.0 and float(p.grad.abs().sum()) == 0.0
+
+
+def test_focal_loss_vs_oracle():
+    from fcaf3d_amd.losses import FocalLoss
+    dev = _dev()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5000, 18, generator=g) * 3
+    lab = torch.randint(-1, 18, (5000,), generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = lo.sigmoid_focal_loss_sum(xr, lab) / 37.0
+    ref.backward()
+    xg = x.to(dev).requires_grad_(True)
+    out = FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25)(xg, lab.to(dev), avg_factor=37.0)
+    out.backward()
+    assert _rel(out, ref) < 1e-5 and _rel(xg.grad, xr.grad) < 1e-5
+
+
+def test_bev_iou_and_nms_vs_reference():
+    from fcaf3d_amd import _lib as L
+    from fcaf3d_amd.nms import nms_bev, nms_bev_multiclass
+    dev = _dev()
+    d = np.load(os.path.join(G, 'bev_iou.npz'))
+    for n in ('1', '63', '64', '65', '300', '_hand'):
+        b = torch.from_numpy(d[f'boxes{n}']).to(dev)
+        out = torch.empty((len(b), len(b)), device=dev)
+        L.call('fc_boxes_iou_bev', L.ptr(b), len(b), L.ptr(b), len(b), 1, L.ptr(out), L.stream())
+        assert np.allclose(out.cpu().numpy(), d[f'iou{n}'], atol=2e-5), n
+    rng = np.random.default_rng(0)
+    for n in (1, 63, 64, 65, 1000, 4000):
+        for rotated in (True, False):
+            c = rng.uniform(0, 12, (n, 3)); s = rng.uniform(0.3, 2.0, (n, 3))
+            yaw = rng.uniform(-3.14, 3.14, (n, 1)) if rotated else np.zeros((n, 1))
+            boxes = np.concatenate([c, s, yaw], 1).astype(np.float32)
+            scores = rng.permutation(n).astype(np.float32) / n
+            ref = bev.nms(boxes, scores, 0.5, rotated)
+            got = nms_bev(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), 0.5, rotated)
+            assert np.array_equal(got.cpu().numpy(), ref), (n, rotated, len(ref))
+    # all classes in one launch == the per-class loop of fcaf3d_neck_with_head.py:336-353
+    n, C = 700, 5
+    boxes = np.concatenate([rng.uniform(0, 6, (n, 3)), rng.uniform(0.3, 2.0, (n, 3)), rng.uniform(-3, 3, (n, 1))], 1).astype(np.float32)
+    sc = rng.random((n, C)).astype(np.float32); sc[rng.random((n, C)) < 0.5] = 0.0
+    idx, cls = nms_bev_multiclass(torch.from_numpy(boxes).to(dev), torch.from_numpy(sc).to(dev), 0.01, 0.5, True)
+    exp_i, exp_c = [], []
+    for c_ in range(C):
+        ids = np.nonzero(sc[:, c_] > 0.01)[0]
+        k = bev.nms(boxes[ids], sc[ids, c_], 0.5, True)
+        exp_i.append(ids[k]); exp_c.append(np.full(len(k), c_))
+    assert np.array_equal(idx.cpu().numpy(), np.concatenate(exp_i)) and np.array_equal(cls.cpu().numpy(), np.concatenate(exp_c))
+
+
+def test_pruning_path_bites():
+    """pts_threshold smaller than the level sizes -> interpolation + top-k + MinkowskiPruning run."""
+    dev = _dev()
+    model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 3, pts_threshold=1500)
+    P = _oracle_params(model)
+    model = model.to(dev).train()
+    pts, gts, labs = _scenes([31, 32], n_points=20000)
+    out_o = MO.extract_feat(P, m, pts)
+    out_g = [list(x) for x in model.extract_feat([torch.from_numpy(p).to(dev) for p in pts], None)]
+    assert len(out_o[3][0][0]) == 1500                       # finest level was pruned to the threshold
+    for l in range(3):
+        for b in range(2):
+            # top-k ties aside, the kept coordinate SETS agree; compare in (x,y,z)-canonical order
+            po, pg = out_o[3][l][b].numpy(), out_g[3][l][b].cpu().numpy()
+            assert len(po) == len(pg)
+            so, sg = np.lexsort(po.T[::-1]), np.lexsort(pg.T[::-1])
+            assert np.array_equal(po[so], pg[sg])
+            assert _rel(out_g[2][l][b][torch.from_numpy(sg).to(dev)], out_o[2][l][b][torch.from_numpy(so)]) < 1e-4

@@ -1,0 +1,81 @@
+"""CPU: pins the oracle (oracle/loss_oracle.py, oracle/bev_nms_oracle.c) against the golden vectors
+that tests/golden/make_golden.py produced by running the REFERENCE's own code."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import bev, loss_oracle as lo
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_assigner_oracle():
+    d = np.load(os.path.join(G, 'assigner.npz'))
+    for ci in range(int(d['n_cases'])):
+        L = int(d[f'c{ci}_n_scales'])
+        pts = [torch.from_numpy(d[f'c{ci}_points{l}']) for l in range(L)]
+        ct, bt, lb = lo.assign(pts, torch.from_numpy(d[f'c{ci}_gt']), torch.from_numpy(d[f'c{ci}_labels']), n_scales=L)
+        ref = d[f'c{ci}_assigned']
+        assert np.array_equal(lb.numpy(), ref)
+        pos = ref >= 0
+        assert np.allclose(ct.numpy()[pos], d[f'c{ci}_centerness'][pos], atol=1e-6)
+        assert np.allclose(bt.numpy()[pos], d[f'c{ci}_bbox_targets'][pos], atol=1e-6)
+
+
+def test_decode_oracle():
+    d = np.load(os.path.join(G, 'decode.npz'))
+    p = torch.from_numpy(d['points'])
+    assert np.allclose(lo.bbox_pred_to_bbox(p, torch.from_numpy(d['pred6'])).numpy(), d['out6'], atol=1e-6)
+    for mode in ('fcaf3d', 'sin-cos'):
+        assert np.allclose(lo.bbox_pred_to_bbox(p, torch.from_numpy(d['pred8']), mode).numpy(), d[f'out8_{mode}'], atol=1e-6)
+    assert np.allclose(lo.bbox_pred_to_bbox(p, torch.from_numpy(d['pred8'][:, :7]), 'naive').numpy(), d['out7_naive'], atol=1e-6)
+    assert np.allclose(lo.compute_centerness(torch.from_numpy(d['cent_in'])).numpy(), d['cent_out'], atol=1e-6)
+
+
+def test_aligned_and_rotated_iou_oracle():
+    d = np.load(os.path.join(G, 'iou3d.npz'))
+    for key, fn in (('al', lo.axis_aligned_iou), ('ro', lo.rotated_iou_3d)):
+        pred = torch.from_numpy(d[f'{key}_pred']).requires_grad_(True)
+        tgt = torch.from_numpy(d[f'{key}_target'])
+        iou = fn(pred, tgt)
+        ((1 - iou) * torch.from_numpy(d[f'{key}_w'])).sum().backward()
+        assert np.allclose(iou.detach().numpy(), d[f'{key}_iou'], atol=2e-6), key
+        assert np.allclose(pred.grad.numpy(), d[f'{key}_grad'], atol=1e-4, rtol=1e-4), key
+
+
+def test_bev_iou_oracle_matches_compiled_reference():
+    d = np.load(os.path.join(G, 'bev_iou.npz'))
+    for n in ('1', '63', '64', '65', '300', '_hand'):
+        b = d[f'boxes{n}']
+        assert np.allclose(bev.iou_matrix(b, b, True), d[f'iou{n}'], atol=1e-6), n
+    hand = d['iou_hand']
+    assert abs(hand[0, 1] - 1 / 3) < 1e-6 and abs(hand[0, 2] - 0.70710677) < 1e-5 and hand[0, 3] == 1.0
+    # greedy keep lists == greedy scan over the reference's IoU matrix (iou3d_nms.cpp:119-132)
+    for n in (63, 64, 65, 300):
+        b = d[f'boxes{n}']
+        scores = np.linspace(1, 0, len(b)).astype(np.float32)
+        keep = bev.nms(b, scores, 0.3, True)
+        ref = lo.greedy_nms_from_iou(d[f'iou{n}'], 0.3)
+        assert np.array_equal(keep, ref)
+
+
+def test_focal_closed_form():
+    x = torch.tensor([[0.3, -1.2, 2.0], [0.1, 0.0, -0.5]], requires_grad=True)
+    lb = torch.tensor([1, -1])
+    v = lo.sigmoid_focal_loss_sum(x, lb)
+    p = torch.sigmoid(x.detach())
+    exp = 0.0
+    for n in range(2):
+        for c in range(3):
+            pc = float(p[n, c])
+            exp += (-0.25 * (1 - pc) ** 2 * np.log(pc)) if int(lb[n]) == c else (-0.75 * pc ** 2 * np.log(1 - pc))
+    assert abs(float(v) - exp) < 1e-6
+
+
+def test_rotation_golden_matches_assigner_convention():
+    d = np.load(os.path.join(G, 'rotation.npz'))
+    p = torch.from_numpy(d['points']); a = torch.from_numpy(d['angles'])
+    c, s = torch.cos(a)[:, None], torch.sin(a)[:, None]
+    out = torch.stack([p[..., 0] * c + p[..., 1] * s, -p[..., 0] * s + p[..., 1] * c, p[..., 2]], -1)
+    assert np.allclose(out.numpy(), d['out'], atol=1e-6)
