@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-points', type=int, default=0, help='points of the cpu_baseline sample scene (0 = same as workload)')
     ap.add_argument('--no-instrument', action='store_true', help='skip per-kernel HIP events (roofline = null)')
+    ap.add_argument('--breakdown', action='store_true', help='diagnostic: HIP-event time per C-ABI entry point and per conv shape (stderr)')
     return ap.parse_args()
 
 
@@ -72,6 +73,47 @@ def make_batches(args, rank, dev, n_batches=2):
         batches.append(dict(points=pts, gt_bboxes_3d=gts, gt_labels_3d=labs,
                             img_metas=[dict(box_type_3d=fa.DepthInstance3DBoxes)] * args.batch))
     return batches
+
+
+class Breakdown:
+    """Diagnostic only (perturbs the timing): events around EVERY C-ABI call, grouped by name / conv shape."""
+
+    def __init__(self):
+        self.rec = []
+
+    def install(self):
+        import fcaf3d_amd._lib as L
+        orig = L.call
+        rec = self.rec
+
+        def call(name, *a):
+            s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+            s.record(); orig(name, *a); e.record()
+            key = name
+            if name == 'fc_conv_fwd':
+                key = f'conv_fwd n={a[5]} K={a[6]} {a[7]}->{a[8]}'
+            elif name == 'fc_conv_wgrad':
+                key = f'wgrad n={a[5]} K={a[6]} {a[7]}->{a[8]}'
+            rec.append((key, name, s, e))
+        L.call = call
+
+    def report(self, steps, t_total_ms):
+        torch.cuda.synchronize()
+        by_key, by_name = {}, {}
+        for key, name, s, e in self.rec:
+            t = s.elapsed_time(e)
+            by_key.setdefault(key, [0, 0.0]); by_key[key][0] += 1; by_key[key][1] += t
+            by_name.setdefault(name, [0, 0.0]); by_name[name][0] += 1; by_name[name][1] += t
+        print(f'--- breakdown per step ({steps} steps, wall {t_total_ms / steps:.2f} ms/step) ---', file=sys.stderr)
+        tot = 0.0
+        for name, (c, t) in sorted(by_name.items(), key=lambda kv: -kv[1][1]):
+            print(f'{name:28s} calls/step {c / steps:7.1f}  ms/step {t / steps:8.3f}', file=sys.stderr)
+            tot += t
+        print(f'{"sum of C-ABI kernels":28s} {"":18s} ms/step {tot / steps:8.3f}', file=sys.stderr)
+        print('--- top conv shapes ---', file=sys.stderr)
+        for key, (c, t) in sorted(by_key.items(), key=lambda kv: -kv[1][1])[:40]:
+            if key.startswith(('conv_fwd', 'wgrad')):
+                print(f'{key:44s} calls/step {c / steps:6.1f}  ms/step {t / steps:8.3f}  us/call {t / c * 1e3:9.1f}', file=sys.stderr)
 
 
 class ConvProbe:
@@ -184,6 +226,11 @@ def main():
     batches = make_batches(args, rank, dev)
 
     probe = None
+    bd = None
+    if args.breakdown and rank == 0:
+        bd = Breakdown()
+        bd.install()
+        args.no_instrument = True
     if not args.no_instrument and rank == 0:
         probe = ConvProbe()
         probe.install()
@@ -204,6 +251,9 @@ def main():
     if probe:
         torch.cuda.synchronize()
         probe.records.clear()
+    if bd:
+        torch.cuda.synchronize()
+        bd.rec.clear()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -219,6 +269,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    if bd:
+        bd.report(args.steps, dt * 1e3)
     assert np.isfinite(final_loss), 'loss diverged'
 
     if rank == 0:

@@ -19,6 +19,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LDA (BK + 4)     // A row stride in floats: 16B-aligned rows, conflict-free ds_read_b128 (9r mod 16)
 
 // ------------------------------------------------------------------------------------------------
+// Pipeline per workgroup: (1) OR-reduce, over the tile's rows, which kernel offsets have any neighbour
+// (offsets without one are skipped outright); (2) walk the surviving (offset, Cin-slab) stages with the
+// NEXT stage's gathers + weight loads issued into registers before the current stage's MFMAs run
+// (single LDS buffer, global-load latency hidden behind the matrix pipe).
+// gridDim.z > 1 = split over kernel offsets (offset k handled by split k % gridDim.z) for layers whose
+// row count cannot fill the chip; partial tiles go to `out` + z*n_out*Cout and are summed by k_sum_parts.
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
                                                    const int* __restrict__ nbr, float* __restrict__ out, int64_t n_out,
@@ -28,12 +34,14 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
   constexpr int BR = BN / 32;                    // float4 weight loads per thread per stage
   __shared__ __attribute__((aligned(16))) float As[BM * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+  __shared__ unsigned int kmask_s;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
+  const int S = gridDim.z, z = blockIdx.z;
   const int a_c4 = tid & 7, a_r = tid >> 3;      // A staging: 8 float4 per row, 32 rows per pass
 
   f32x16 acc[TM][TN];
@@ -44,32 +52,60 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  for (int k = 0; k < K; ++k) {
-    int idx[AR];
-    int any = 0;
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      int64_t row = m0 + a_r + 32 * i;
-      int v = -1;
-      if (row < n_out) v = nbr ? nbr[(int64_t)k * n_out + row] : (int)row;
-      idx[i] = v;
-      any |= (v >= 0);
+  // ---- (1) which of this split's offsets have a neighbour anywhere in the tile ---------------------
+  if (tid == 0) kmask_s = 0u;
+  __syncthreads();
+  if (tid < BM) {
+    unsigned int mk = 0u;
+    int64_t row = m0 + tid;
+    if (row < n_out) {
+      if (nbr) {
+        for (int k = z; k < K; k += S)
+          if (nbr[(int64_t)k * n_out + row] >= 0) mk |= 1u << k;
+      } else {
+        mk = 1u;
+      }
     }
-    if (!__syncthreads_or(any)) continue;        // nobody in this tile has a neighbour at offset k
-    const float* Wk = W + (int64_t)k * Cin * Cout;
-    for (int c0 = 0; c0 < Cin; c0 += BK) {
-      float4 av[AR], bv[BR];
+    // wave-level OR, one LDS atomic per wave
+    for (int off = 32; off > 0; off >>= 1) mk |= __shfl_xor(mk, off, 64);
+    if (lane == 0 && mk) atomicOr(&kmask_s, mk);
+  }
+  __syncthreads();
+  unsigned int kmask = kmask_s;
+
+  // ---- (2) software-pipelined stage loop -------------------------------------------------------------
+  if (kmask) {
+    int k = __ffs(kmask) - 1;
+    kmask &= kmask - 1;
+    int c0 = 0;
+    int idx[AR];
+    float4 av[AR], bv[BR];
+    auto load_idx = [&](int kk) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        int64_t row = m0 + a_r + 32 * i;
+        int v = -1;
+        if (row < n_out) v = nbr ? nbr[(int64_t)kk * n_out + row] : (int)row;
+        idx[i] = v;
+      }
+    };
+    auto load_stage = [&](int kk, int cc) {
+      const float* Wk = W + (int64_t)kk * Cin * Cout;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx[i] >= 0) av[i] = *reinterpret_cast<const float4*>(in + (int64_t)idx[i] * Cin + c0 + a_c4 * 4);
+        if (idx[i] >= 0) av[i] = *reinterpret_cast<const float4*>(in + (int64_t)idx[i] * Cin + cc + a_c4 * 4);
       }
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         int lin = tid + 256 * i;
-        int kk = lin / (BN / 4), c4 = lin % (BN / 4);
-        bv[i] = *reinterpret_cast<const float4*>(Wk + (int64_t)(c0 + kk) * Cout + n0 + c4 * 4);
+        int kr = lin / (BN / 4), c4 = lin % (BN / 4);
+        bv[i] = *reinterpret_cast<const float4*>(Wk + (int64_t)(cc + kr) * Cout + n0 + c4 * 4);
       }
+    };
+    load_idx(k);
+    load_stage(k, c0);
+    while (true) {
       __syncthreads();                           // previous stage fully consumed
 #pragma unroll
       for (int i = 0; i < AR; ++i)
@@ -77,10 +113,21 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         int lin = tid + 256 * i;
-        int kk = lin / (BN / 4), c4 = lin % (BN / 4);
-        *reinterpret_cast<float4*>(&Bs[kk * BN + c4 * 4]) = bv[i];
+        int kr = lin / (BN / 4), c4 = lin % (BN / 4);
+        *reinterpret_cast<float4*>(&Bs[kr * BN + c4 * 4]) = bv[i];
       }
       __syncthreads();
+      // issue the next stage's global loads before computing this one
+      int nk = k, nc0 = c0 + BK;
+      if (nc0 >= Cin) {
+        nc0 = 0;
+        nk = kmask ? __ffs(kmask) - 1 : -1;
+        kmask &= kmask - 1;
+      }
+      if (nk >= 0) {
+        if (nk != k) load_idx(nk);
+        load_stage(nk, nc0);
+      }
 #pragma unroll
       for (int q = 0; q < BK / 8; ++q) {
         float4 a[TM];
@@ -102,9 +149,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
           }
         }
       }
+      if (nk < 0) break;
+      k = nk;
+      c0 = nc0;
     }
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float* dst = out + (int64_t)z * n_out * Cout;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -113,8 +164,20 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
       for (int e = 0; e < 16; ++e) {
         int64_t row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         int col = n0 + wc * (BN / 2) + j * 32 + r;
-        if (row < n_out) out[row * Cout + col] = acc[i][j][e];
+        if (row < n_out) dst[row * Cout + col] = acc[i][j][e];
       }
+}
+
+// out[i] = sum_z part[z][i]   (fixed order; elems % 4 == 0)
+__global__ void k_sum_parts(const float* __restrict__ part, float* __restrict__ out, int64_t elems4, int S) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= elems4) return;
+  float4 a = reinterpret_cast<const float4*>(part)[i];
+  for (int s = 1; s < S; ++s) {
+    float4 b = reinterpret_cast<const float4*>(part)[(int64_t)s * elems4 + i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = a;
 }
 
 // generic fallback (any Cin/Cout): one thread per (row, cout).  Used for the Cin=3 stem and as the
@@ -138,29 +201,52 @@ __global__ void k_conv_fma(const float* __restrict__ in, const float* __restrict
 
 extern "C" {
 
+static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* mfma, int* bm, int* bn, int* S) {
+  *mfma = !(flags & 1) && (Cin % BK == 0) && (Cout % 64 == 0) && K <= 32;
+  *bn = (Cout % 128 == 0) ? 128 : 64;
+  const int64_t wg128 = fc_cdiv(n_out, 128) * (Cout / *bn);
+  *bm = wg128 >= 512 ? 128 : 64;                // enough workgroups to fill 256 CUs twice over
+  const int64_t tiles = fc_cdiv(n_out, *bm) * (Cout / *bn);
+  int s = 1;
+  if (*mfma && K > 1 && tiles < 512) {           // split over kernel offsets until ~1024 workgroups
+    s = (int)fc_cdiv(1024, tiles);
+    if (s > K) s = K;
+  }
+  *S = s;
+}
+
+int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags) {
+  bool mfma; int bm, bn, S;
+  conv_plan(n_out > 0 ? n_out : 1, K, Cin, Cout, flags, &mfma, &bm, &bn, &S);
+  return S > 1 ? (int64_t)S * n_out * Cout * (int64_t)sizeof(float) : 0;
+}
+
 // flags: bit0 = force the generic FMA kernel.
 int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int64_t n_in, int64_t n_out, int K, int Cin,
-                int Cout, int flags, hipStream_t stream) {
+                int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
   if (n_out == 0) return FC_OK;
-  bool mfma_ok = !(flags & 1) && (Cin % BK == 0) && (Cout % 64 == 0);
+  bool mfma_ok; int bm, bn, S;
+  conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S);
   if (!mfma_ok) {
     k_conv_fma<<<(unsigned)fc_cdiv(n_out * Cout, 256), 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
-  const bool wide = (Cout % 128 == 0);
-  const int bn = wide ? 128 : 64;
-  const int64_t wg128 = fc_cdiv(n_out, 128) * (Cout / bn);
-  const bool tall = wg128 >= 512;               // enough workgroups to fill 256 CUs twice over
-  const int bm = tall ? 128 : 64;
-  dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn);
-  if (tall && wide) k_conv_mfma<128, 128><<<grid, 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
-  else if (tall) k_conv_mfma<128, 64><<<grid, 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
-  else if (wide) k_conv_mfma<64, 128><<<grid, 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
-  else k_conv_mfma<64, 64><<<grid, 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
+  if (S > 1 && ws_bytes < (int64_t)S * n_out * Cout * (int64_t)sizeof(float)) return FC_EWS;
+  float* dst = S > 1 ? (float*)ws : out;
+  dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
+  if (bm == 128 && bn == 128) k_conv_mfma<128, 128><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
+  else if (bm == 128) k_conv_mfma<128, 64><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
+  else if (bn == 128) k_conv_mfma<64, 128><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
+  else k_conv_mfma<64, 64><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
   FC_CHECK_LAUNCH();
+  if (S > 1) {
+    int64_t e4 = n_out * Cout / 4;
+    k_sum_parts<<<(unsigned)fc_cdiv(e4, 256), 256, 0, stream>>>(dst, out, e4, S);
+    FC_CHECK_LAUNCH();
+  }
   return FC_OK;
 }
 

@@ -8,6 +8,8 @@
 //     fused kernel: the gradient is propagated in forward mode (7 dual parts per value) through the
 //     same arithmetic graph torch autograd differentiates in the reference.
 #include "fc_common.h"
+// exact products as in the reference's torch / host code (e.g. num == 0 for parallel edges): no FMA contraction
+#pragma clang fp contract(off)
 #include <float.h>
 
 // ---------------------------------------------------------------------------------------------------

@@ -10,6 +10,8 @@
 // Kernel 2: one wavefront per class runs the greedy scan on the device (the reference copies the whole
 //           mask to the host and scans there, iou3d_nms.cpp:111-132): lane j owns removed-word j.
 #include "fc_common.h"
+// exact products as in the reference's torch / host code (e.g. num == 0 for parallel edges): no FMA contraction
+#pragma clang fp contract(off)
 
 #define NMS_EPS 1e-8f
 

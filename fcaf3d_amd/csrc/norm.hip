@@ -8,58 +8,80 @@
 // BasicBlock (MinkowskiEngine.modules.resnet_block), fcaf3d_neck_with_head.py:53-54,67-71,76,125.
 #include "fc_common.h"
 
-#define ROWS_PER_BLOCK 256   // rows reduced by one block in the partial pass
 #define MAXSEG 64
+#define MAXBLOCKS 1024       // partial-sum blocks of the two-level reductions
 
 __device__ static inline int seg_of(const int* seg, int seg_stride, int64_t row) {
   return seg ? seg[row * seg_stride] : 0;
 }
 
+// segment range touched by rows [r0,r1) — block-parallel min/max (rows are nearly segment-contiguous)
+__device__ static inline void seg_range(const int* seg, int seg_stride, int64_t r0, int64_t r1, int* lo, int* hi,
+                                        int* sh /*[2] shared*/) {
+  if (!seg) { *lo = 0; *hi = 0; return; }
+  if (threadIdx.x == 0) { sh[0] = 0x7fffffff; sh[1] = -1; }
+  __syncthreads();
+  int l = 0x7fffffff, h = -1;
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+    int s = seg[r * seg_stride];
+    l = s < l ? s : l;
+    h = s > h ? s : h;
+  }
+  if (h >= 0) { atomicMin(&sh[0], l); atomicMax(&sh[1], h); }
+  __syncthreads();
+  *lo = sh[0]; *hi = sh[1];
+  __syncthreads();
+}
+
 // ---- pass 1: partial sums of f(x) per (block, segment, channel) --------------------------------
 // mode 0: sum x ; mode 1: sum (x-mean[seg])^2
-// block = 256 threads laid out as (C/4 lanes of float4) x (256/(C/4) row lanes); C % 4 == 0, C <= 1024
+// block = (C/4 lanes of float4) x (row lanes); C % 4 == 0, C <= 1024; rows [b*rpb, (b+1)*rpb)
 __global__ void k_stats_partial(const float* __restrict__ x, const int* __restrict__ seg, int seg_stride, int64_t n, int C,
-                                int nseg, const float* __restrict__ mean, int mode, float* __restrict__ part,
+                                int nseg, const float* __restrict__ mean, int mode, int64_t rpb, float* __restrict__ part,
                                 float* __restrict__ part_cnt) {
   extern __shared__ float sm[];               // [rl][C] staging for the cross-row-lane reduction
+  __shared__ int srange[2];
   const int c4n = C / 4;
   const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
   const int nrl = blockDim.x / c4n;
-  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-  int64_t r1 = r0 + ROWS_PER_BLOCK;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  int64_t r1 = r0 + rpb;
   if (r1 > n) r1 = n;
-  // segments are (nearly) contiguous in row order: handle the block's segment range one at a time
-  int s_lo = seg_of(seg, seg_stride, r0), s_hi = s_lo;
-  if (seg) {
-    // rows inside a block may interleave segments in general -> scan min/max cheaply
-    for (int64_t r = r0; r < r1; ++r) {
-      int s = seg[r * seg_stride];
-      s_lo = s < s_lo ? s : s_lo;
-      s_hi = s > s_hi ? s : s_hi;
-    }
-  }
+  int s_lo, s_hi;
+  seg_range(seg, seg_stride, r0, r1, &s_lo, &s_hi, srange);
   for (int s = 0; s < nseg; ++s) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc[4];
     float cnt = 0.f;
-    if (s >= s_lo && s <= s_hi && rl < nrl) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s >= s_lo && s <= s_hi) {
       float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
       if (mode == 1) mu = *reinterpret_cast<const float4*>(mean + (int64_t)s * C + cl * 4);
-      for (int64_t r = r0 + rl; r < r1; r += nrl) {
-        if (seg_of(seg, seg_stride, r) != s) continue;
-        float4 v = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
-        if (mode == 1) {
-          v.x -= mu.x; v.y -= mu.y; v.z -= mu.z; v.w -= mu.w;
-          v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w;
+      for (int64_t rb = r0 + rl; rb < r1; rb += 4 * nrl) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int64_t r = rb + (int64_t)u * nrl;
+          if (r >= r1) continue;
+          if (seg && seg[r * seg_stride] != s) continue;
+          float4 v = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
+          if (mode == 1) {
+            v.x -= mu.x; v.y -= mu.y; v.z -= mu.z; v.w -= mu.w;
+            v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w;
+          }
+          acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+          cnt += 1.f;
         }
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        cnt += 1.f;
       }
     }
+    float4 a;
+    a.x = (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x);
+    a.y = (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y);
+    a.z = (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z);
+    a.w = (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w);
     __syncthreads();
-    if (rl < nrl) *reinterpret_cast<float4*>(&sm[(rl * c4n + cl) * 4]) = acc;
-    // counts: reuse tail of shared memory
+    *reinterpret_cast<float4*>(&sm[(rl * c4n + cl) * 4]) = a;
     float* smc = sm + nrl * C;
-    if (cl == 0 && rl < nrl) smc[rl] = cnt;
+    if (cl == 0) smc[rl] = cnt;
     __syncthreads();
     if (rl == 0) {
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -77,26 +99,40 @@ __global__ void k_stats_partial(const float* __restrict__ x, const int* __restri
   }
 }
 
-// ---- pass 2: sum partials over blocks in order; thread per (seg, channel) ------------------------
-// mode 0: out = sum / cnt (mean), also writes cnt[seg];  mode 1: out = sum / cnt (biased variance)
-// mode 2: out = sum (plain)
-__global__ void k_stats_final(const float* __restrict__ part, const float* __restrict__ part_cnt, int64_t nblocks, int nseg,
-                              int C, int mode, float* __restrict__ out, float* __restrict__ cnt_io) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nseg * C) return;
-  int s = t / C;
+// ---- pass 2: sum partials over blocks (fixed order); block = 64 channels x 16 slices -----------------
+// mode 0: out = sum / cnt (mean), also writes cnt[seg];  mode 1: out = sum / cnt (biased variance); mode 2: out = sum
+__global__ __launch_bounds__(1024) void k_stats_final(const float* __restrict__ part, const float* __restrict__ part_cnt,
+                                                      int64_t nblocks, int nseg, int C, int mode, float* __restrict__ out,
+                                                      float* __restrict__ cnt_io) {
+  __shared__ float red[16][65];
+  __shared__ float redc[16];
+  const int cgroups = (C + 63) / 64;
+  const int s = blockIdx.x / cgroups, cg = blockIdx.x % cgroups;
+  const int c = cg * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;
   float acc = 0.f;
-  for (int64_t b = 0; b < nblocks; ++b) acc += part[(b * nseg) * C + t];
-  float cnt = 1.f;
-  if (mode == 0) {
-    float c = 0.f;
-    for (int64_t b = 0; b < nblocks; ++b) c += part_cnt[b * nseg + s];
-    if (t % C == 0) cnt_io[s] = c;
-    cnt = c;
-  } else if (mode == 1) {
-    cnt = cnt_io[s];
+  if (c < C)
+    for (int64_t b = j; b < nblocks; b += 16) acc += part[(b * nseg + s) * C + c];
+  red[j][threadIdx.x & 63] = acc;
+  if (mode == 0 && (threadIdx.x & 63) == 0) {
+    float cc = 0.f;
+    for (int64_t b = j; b < nblocks; b += 16) cc += part_cnt[b * nseg + s];
+    redc[j] = cc;
   }
-  out[t] = (mode == 2) ? acc : (cnt > 0.f ? acc / cnt : 0.f);
+  __syncthreads();
+  if (j == 0 && c < C) {
+    float t = 0.f;
+    for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x & 63];
+    float cnt = 1.f;
+    if (mode == 0) {
+      float cc = 0.f;
+      for (int q = 0; q < 16; ++q) cc += redc[q];
+      if (c == 0) cnt_io[s] = cc;
+      cnt = cc;
+    } else if (mode == 1) {
+      cnt = cnt_io[s];
+    }
+    out[(int64_t)s * C + c] = (mode == 2) ? t : (cnt > 0.f ? t / cnt : 0.f);
+  }
 }
 
 __device__ static inline float act_fwd(float v, int act) {
@@ -145,48 +181,50 @@ __global__ void k_norm_act_fwd(const float* __restrict__ x, const int* __restric
 __global__ void k_norm_bwd_partial(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
                                    const int* __restrict__ seg, int seg_stride, int64_t n, int C, int nseg,
                                    const float* __restrict__ mean, const float* __restrict__ var, float eps, int act,
-                                   float* __restrict__ part) {
+                                   int64_t rpb, float* __restrict__ part) {
   extern __shared__ float sm[];               // [rl][2][C]
+  __shared__ int srange[2];
   const int c4n = C / 4;
   const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
   const int nrl = blockDim.x / c4n;
-  const int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-  int64_t r1 = r0 + ROWS_PER_BLOCK;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  int64_t r1 = r0 + rpb;
   if (r1 > n) r1 = n;
-  int s_lo = seg_of(seg, seg_stride, r0), s_hi = s_lo;
-  if (seg) {
-    for (int64_t r = r0; r < r1; ++r) {
-      int s = seg[r * seg_stride];
-      s_lo = s < s_lo ? s : s_lo;
-      s_hi = s > s_hi ? s : s_hi;
-    }
-  }
+  int s_lo, s_hi;
+  seg_range(seg, seg_stride, r0, r1, &s_lo, &s_hi, srange);
   for (int s = 0; s < nseg; ++s) {
-    float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
-    if (s >= s_lo && s <= s_hi && rl < nrl) {
+    float4 a1[2], a2[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { a1[u] = make_float4(0.f, 0.f, 0.f, 0.f); a2[u] = a1[u]; }
+    if (s >= s_lo && s <= s_hi) {
       float4 mu = *reinterpret_cast<const float4*>(mean + (int64_t)s * C + cl * 4);
       float4 va = *reinterpret_cast<const float4*>(var + (int64_t)s * C + cl * 4);
       float4 is = make_float4(1.f / sqrtf(va.x + eps), 1.f / sqrtf(va.y + eps), 1.f / sqrtf(va.z + eps),
                               1.f / sqrtf(va.w + eps));
-      for (int64_t r = r0 + rl; r < r1; r += nrl) {
-        if (seg_of(seg, seg_stride, r) != s) continue;
-        float4 xv = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
-        float4 g = *reinterpret_cast<const float4*>(gy + r * C + cl * 4);
-        if (act) {
-          float4 yv = *reinterpret_cast<const float4*>(y + r * C + cl * 4);
-          g.x *= act_bwd_from_y(yv.x, act); g.y *= act_bwd_from_y(yv.y, act);
-          g.z *= act_bwd_from_y(yv.z, act); g.w *= act_bwd_from_y(yv.w, act);
+      for (int64_t rb = r0 + rl; rb < r1; rb += 2 * nrl) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          int64_t r = rb + (int64_t)u * nrl;
+          if (r >= r1) continue;
+          if (seg && seg[r * seg_stride] != s) continue;
+          float4 xv = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
+          float4 g = *reinterpret_cast<const float4*>(gy + r * C + cl * 4);
+          if (act) {
+            float4 yv = *reinterpret_cast<const float4*>(y + r * C + cl * 4);
+            g.x *= act_bwd_from_y(yv.x, act); g.y *= act_bwd_from_y(yv.y, act);
+            g.z *= act_bwd_from_y(yv.z, act); g.w *= act_bwd_from_y(yv.w, act);
+          }
+          a1[u].x += g.x; a1[u].y += g.y; a1[u].z += g.z; a1[u].w += g.w;
+          a2[u].x += g.x * (xv.x - mu.x) * is.x; a2[u].y += g.y * (xv.y - mu.y) * is.y;
+          a2[u].z += g.z * (xv.z - mu.z) * is.z; a2[u].w += g.w * (xv.w - mu.w) * is.w;
         }
-        a1.x += g.x; a1.y += g.y; a1.z += g.z; a1.w += g.w;
-        a2.x += g.x * (xv.x - mu.x) * is.x; a2.y += g.y * (xv.y - mu.y) * is.y;
-        a2.z += g.z * (xv.z - mu.z) * is.z; a2.w += g.w * (xv.w - mu.w) * is.w;
       }
     }
+    float4 b1 = make_float4(a1[0].x + a1[1].x, a1[0].y + a1[1].y, a1[0].z + a1[1].z, a1[0].w + a1[1].w);
+    float4 b2 = make_float4(a2[0].x + a2[1].x, a2[0].y + a2[1].y, a2[0].z + a2[1].z, a2[0].w + a2[1].w);
     __syncthreads();
-    if (rl < nrl) {
-      *reinterpret_cast<float4*>(&sm[(rl * 2 + 0) * C + cl * 4]) = a1;
-      *reinterpret_cast<float4*>(&sm[(rl * 2 + 1) * C + cl * 4]) = a2;
-    }
+    *reinterpret_cast<float4*>(&sm[(rl * 2 + 0) * C + cl * 4]) = b1;
+    *reinterpret_cast<float4*>(&sm[(rl * 2 + 1) * C + cl * 4]) = b2;
     __syncthreads();
     if (rl == 0) {
       float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
@@ -301,8 +339,17 @@ static int stats_geometry(int C, int* threads, size_t* smem_fwd, size_t* smem_bw
   return FC_OK;
 }
 
+static void red_plan(int64_t n, int64_t* nb, int64_t* rpb) {
+  int64_t m = n > 0 ? n : 1;
+  int64_t g = fc_cdiv(m, 64);
+  if (g > MAXBLOCKS) g = MAXBLOCKS;
+  *rpb = fc_cdiv(m, g);
+  *nb = fc_cdiv(m, *rpb);
+}
+
 int64_t fc_col_stats_ws_bytes(int64_t n, int C, int nseg) {
-  int64_t nb = fc_cdiv(n > 0 ? n : 1, ROWS_PER_BLOCK);
+  int64_t nb, rpb;
+  red_plan(n, &nb, &rpb);
   return nb * nseg * ((int64_t)C + 1) * (int64_t)sizeof(float);
 }
 
@@ -313,7 +360,8 @@ int fc_col_stats(const float* x, const int* seg, int seg_stride, int64_t n, int 
   int threads; size_t sf, sb;
   if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
   if (ws_bytes < fc_col_stats_ws_bytes(n, C, nseg)) return FC_EWS;
-  int64_t nb = fc_cdiv(n > 0 ? n : 1, ROWS_PER_BLOCK);
+  int64_t nb, rpb;
+  red_plan(n, &nb, &rpb);
   float* part = (float*)ws;
   float* part_cnt = part + nb * nseg * C;
   if (n == 0) {
@@ -322,14 +370,14 @@ int fc_col_stats(const float* x, const int* seg, int seg_stride, int64_t n, int 
     FC_HIP(hipMemsetAsync(cnt, 0, sizeof(float) * nseg, stream));
     return FC_OK;
   }
-  unsigned gfin = (unsigned)fc_cdiv((int64_t)nseg * C, 256);
-  k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, nullptr, 0, part, part_cnt);
+  unsigned gfin = (unsigned)(nseg * ((C + 63) / 64));
+  k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, nullptr, 0, rpb, part, part_cnt);
   FC_CHECK_LAUNCH();
-  k_stats_final<<<gfin, 256, 0, stream>>>(part, part_cnt, nb, nseg, C, 0, mean, cnt);
+  k_stats_final<<<gfin, 1024, 0, stream>>>(part, part_cnt, nb, nseg, C, 0, mean, cnt);
   FC_CHECK_LAUNCH();
-  k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, mean, 1, part, nullptr);
+  k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, mean, 1, rpb, part, nullptr);
   FC_CHECK_LAUNCH();
-  k_stats_final<<<gfin, 256, 0, stream>>>(part, nullptr, nb, nseg, C, 1, var, cnt);
+  k_stats_final<<<gfin, 1024, 0, stream>>>(part, nullptr, nb, nseg, C, 1, var, cnt);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
@@ -346,7 +394,8 @@ int fc_norm_act_fwd(const float* x, const int* seg, int seg_stride, int64_t n, i
 }
 
 int64_t fc_norm_act_bwd_ws_bytes(int64_t n, int C, int nseg) {
-  int64_t nb = fc_cdiv(n > 0 ? n : 1, ROWS_PER_BLOCK);
+  int64_t nb, rpb;
+  red_plan(n, &nb, &rpb);
   return nb * nseg * 2 * (int64_t)C * (int64_t)sizeof(float);
 }
 
@@ -362,12 +411,13 @@ int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* 
     FC_HIP(hipMemsetAsync(sums, 0, sizeof(float) * nseg * 2 * C, stream));
     return FC_OK;
   }
-  int64_t nb = fc_cdiv(n, ROWS_PER_BLOCK);
+  int64_t nb, rpb;
+  red_plan(n, &nb, &rpb);
   float* part = (float*)ws;
-  k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, seg, seg_stride, n, C, nseg, mean, var, eps, act, part);
+  k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, seg, seg_stride, n, C, nseg, mean, var, eps, act, rpb,
+                                                          part);
   FC_CHECK_LAUNCH();
-  k_stats_final<<<(unsigned)fc_cdiv((int64_t)nseg * 2 * C, 256), 256, 0, stream>>>(part, nullptr, nb, nseg, 2 * C, 2, sums,
-                                                                                  nullptr);
+  k_stats_final<<<(unsigned)(nseg * ((2 * C + 63) / 64)), 1024, 0, stream>>>(part, nullptr, nb, nseg, 2 * C, 2, sums, nullptr);
   FC_CHECK_LAUNCH();
   k_norm_bwd_apply<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, y, gy, seg, seg_stride, n, C, mean, var, eps,
                                                                            gamma, sums, cnt, act, gx, gres);

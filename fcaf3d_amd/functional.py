@@ -49,6 +49,13 @@ def gather_rows(src, idx):
 
 
 # ---- convolution -----------------------------------------------------------------------------------
+def _conv_fwd(x, w, nbr, out, n_in, n_out, K, Cin, Cout):
+    wsb = L.query('fc_conv_fwd_ws_bytes', n_out, K, Cin, Cout, FLAGS)
+    ws = L.workspace(wsb, x.device) if wsb else None
+    L.call('fc_conv_fwd', L.ptr(x), L.ptr(w), L.ptr(nbr), L.ptr(out), n_in, n_out, K, Cin, Cout, FLAGS,
+           L.ptr(ws), ws.numel() if ws is not None else 0, L.stream())
+
+
 class _SparseConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weight, kmap, n_out):
@@ -60,8 +67,7 @@ class _SparseConv(torch.autograd.Function):
         n_in = feats.shape[0]
         out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
         nbr = kmap.nbr if kmap is not None else None
-        L.call('fc_conv_fwd', L.ptr(feats), L.ptr(weight), L.ptr(nbr), L.ptr(out), n_in, n_out, K, Cin, Cout, FLAGS,
-               L.stream())
+        _conv_fwd(feats, weight, nbr, out, n_in, n_out, K, Cin, Cout)
         ctx.save_for_backward(feats, weight)
         ctx.kmap = kmap
         return out
@@ -80,8 +86,7 @@ class _SparseConv(torch.autograd.Function):
             L.call('fc_transpose_weight', L.ptr(weight), L.ptr(wt), K, Cin, Cout, L.stream())
             gin = torch.empty((n_in, Cin), dtype=torch.float32, device=dev)
             nbr_t = kmap.nbr_t if kmap is not None else None
-            L.call('fc_conv_fwd', L.ptr(gout), L.ptr(wt), L.ptr(nbr_t), L.ptr(gin), n_out, n_in, K, Cout, Cin, FLAGS,
-                   L.stream())
+            _conv_fwd(gout, wt, nbr_t, gin, n_out, n_in, K, Cout, Cin)
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(weight)
             nbr = kmap.nbr if kmap is not None else None

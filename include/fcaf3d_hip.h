@@ -80,9 +80,11 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
  * its backward-data pass (call with the transposed table and fc_transpose_weight'ed kernel), and with
  * nbr == NULL (K = 1, identity) the dense GEMMs of MinkowskiGenerativeConvolutionTranspose (:60-66)
  * and of the 1x1 head convolutions (:83-85, :257-263).  out[o] = sum_k in[nbr[k][o]] @ W[k].
- * flags bit0: force the generic FMA kernel instead of the MFMA kernel. */
+ * flags bit0: force the generic FMA kernel instead of the MFMA kernel.  Layers with too few rows to fill
+ * the chip are split over kernel offsets into `ws` and summed in a fixed order (deterministic). */
+int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);
 int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int64_t n_in, int64_t n_out, int K, int Cin,
-                int Cout, int flags, hipStream_t stream);
+                int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* backward-weights: gW[k] = sum_o in[nbr[k][o]]^T (x) gout[o]; deterministic two-level reduction. */
 int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);

@@ -129,7 +129,7 @@ def extract_feat(P, cfg, points):
     c, f = mo.batch_sparse_collate([p[:, :3] / np.float32(vs) for p in points],
                                    [p[:, 3:] / np.float32(255.) for p in points])
     uc, uf = mo.sparse_tensor(c, f)
-    x = SP(uc, torch.from_numpy(uf), 1)
+    x = SP(uc, torch.from_numpy(uf).to(P['backbone.conv1.0.kernel'].dtype), 1)   # fp64 params => fp64 oracle
     feats = backbone(x, P, cfg['backbone']['depth'], cfg['backbone'].get('n_outs', 4))
     return neck_head(feats, P, nh['voxel_size'], nh['pts_threshold'], nh['n_reg_outs'])
 

@@ -88,12 +88,17 @@ def test_forward_train_parity(name, levels, B, n_points, kw):
         assert _rel(losses_g[k], losses_o[k]) < 1e-4, (k, float(losses_g[k]), float(losses_o[k]))
     sum(losses_g.values()).backward()
     sum(losses_o.values()).backward()
+    # Gradients after ~40 normalised layers carry fp32 round-off of either implementation (tests/diag_grad.py:
+    # the fp32 ORACLE itself sits up to ~1e-2 from the same oracle in fp64 on the 4-level case).  Yardstick:
+    # the fp64 oracle; the HIP path may be at most 2x as far from it as the fp32 oracle is (+1e-3 floor).
+    P64 = {k: (v.detach().double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in P.items()}
+    sum(MO.forward_train(P64, m, pts, gts, labs).values()).backward()
     worst = 0.0
     for k, p in model.named_parameters():
-        r = _rel(p.grad, P[k].grad)
-        worst = max(worst, r)
-        assert r < 2e-3, (k, r)
-    print(f'{name} L={levels} B={B}: worst grad rel err {worst:.2e}')
+        e_gpu, e_o32 = _rel(p.grad, P64[k].grad), _rel(P[k].grad, P64[k].grad)
+        worst = max(worst, e_gpu)
+        assert e_gpu < 2 * e_o32 + 1e-3, (k, e_gpu, e_o32)
+    print(f'{name} L={levels} B={B}: worst grad rel err vs fp64 oracle {worst:.2e}')
 
 
 def test_simple_test_parity():
@@ -189,6 +194,8 @@ def test_pruning_path_bites():
     """pts_threshold smaller than the level sizes -> interpolation + top-k + MinkowskiPruning run."""
     dev = _dev()
     model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 3, pts_threshold=1500)
+    with torch.no_grad():                                     # spread the scores so that top-k has no near-ties
+        model.neck_with_head.cls_conv.kernel.normal_(0, 0.5)
     P = _oracle_params(model)
     model = model.to(dev).train()
     pts, gts, labs = _scenes([31, 32], n_points=20000)
