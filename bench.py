@@ -217,6 +217,7 @@ def main():
 
     model, cfg = build_model(args)
     model = model.to(dev).train()
+    model.async_maps = True           # scenes are resident in HBM: coordinate work may run on its side stream
     if world > 1:
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)

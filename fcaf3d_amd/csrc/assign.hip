@@ -1,0 +1,191 @@
+// FCAF3D target assignment for a whole batch in four launches on gfx950 (integer atomics only —
+// deterministic), replacing the ~80 torch elementwise launches PER SCENE of
+// Fcaf3DAssigner.assign (mmdet3d/models/dense_heads/fcaf3d_neck_with_head.py:394-466) and
+// compute_centerness (:377-384), incl. rotation_3d_in_axis(axis=2) (core/bbox/structures/utils.py:21-61).
+//
+//   k_count : per location, per GT box of its scene: inside test -> counts[scene][box][level]++
+//   k_best  : per box: best pyramid level = last level before the first one with < `limit` inside locations
+//   k_kth   : per box: (topk+1)-th largest centerness among its candidates (inside & on best level)
+//   k_final : per location: among boxes where it is a top-k candidate pick the smallest volume (first wins ties)
+#include "fc_common.h"
+#pragma clang fp contract(off)     // the same products at every call site: `centerness > kth` compares equal values
+
+#define FLOAT_MAX_VOL 1e8f
+
+struct Face6 { float d[6]; };
+
+// distances of point p to the 6 faces of box b = [cx,cy,cz,w,l,h,yaw] in the box frame
+__device__ static inline Face6 face_distances(const float* __restrict__ b, float px, float py, float pz) {
+  float sx = px - b[0], sy = py - b[1], sz = pz - b[2];
+  float a = -b[6];
+  float ca = cosf(a), sa = sinf(a);
+  float rx = sx * ca + sy * sa;
+  float ry = -sx * sa + sy * ca;
+  float cx = b[0] + rx, cy = b[1] + ry, cz = b[2] + sz;
+  Face6 f;
+  f.d[0] = cx - b[0] + b[3] / 2;
+  f.d[1] = b[0] + b[3] / 2 - cx;
+  f.d[2] = cy - b[1] + b[4] / 2;
+  f.d[3] = b[1] + b[4] / 2 - cy;
+  f.d[4] = cz - b[2] + b[5] / 2;
+  f.d[5] = b[2] + b[5] / 2 - cz;
+  return f;
+}
+
+__device__ static inline bool is_inside(const Face6& f) {
+  float m = fminf(fminf(fminf(f.d[0], f.d[1]), fminf(f.d[2], f.d[3])), fminf(f.d[4], f.d[5]));
+  return m > 0.f;
+}
+
+__device__ static inline float centerness_of(const Face6& f) {
+  float v = fminf(f.d[0], f.d[1]) / fmaxf(f.d[0], f.d[1]);
+  v = v * fminf(f.d[2], f.d[3]) / fmaxf(f.d[2], f.d[3]);
+  v = v * fminf(f.d[4], f.d[5]) / fmaxf(f.d[4], f.d[5]);
+  return sqrtf(v);
+}
+
+__global__ void k_count(const float* __restrict__ pts, const int* __restrict__ scene, const int* __restrict__ level, int64_t N,
+                        const float* __restrict__ boxes, const int* __restrict__ box_count, int M, int L,
+                        int* __restrict__ counts) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int s = scene[i], l = level[i];
+  float px = pts[i * 3], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+  int m = box_count[s];
+  for (int j = 0; j < m; ++j) {
+    Face6 f = face_distances(boxes + ((int64_t)s * M + j) * 7, px, py, pz);
+    if (is_inside(f)) atomicAdd(&counts[((int64_t)s * M + j) * L + l], 1);
+  }
+}
+
+__global__ void k_best(const int* __restrict__ counts, int BM, int L, int limit, int* __restrict__ best) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= BM) return;
+  int first_starved = -1;
+  for (int l = 0; l < L; ++l)
+    if (counts[(int64_t)t * L + l] < limit) { first_starved = l; break; }
+  int b;
+  if (first_starved < 0) b = L - 1;
+  else b = first_starved - 1 < 0 ? 0 : first_starved - 1;
+  best[t] = b;
+}
+
+// one block per (scene, box); rows of (level, scene) are order[seg_start[l*B+s] .. seg_start[l*B+s+1])
+__global__ __launch_bounds__(256) void k_kth(const float* __restrict__ pts, const float* __restrict__ boxes,
+                                             const int* __restrict__ box_count, const int* __restrict__ best,
+                                             const int* __restrict__ order, const int* __restrict__ seg_start, int B, int M,
+                                             int L, int topk, float* __restrict__ kth) {
+  const int s = blockIdx.x / M, j = blockIdx.x % M;
+  if (j >= box_count[s]) return;
+  const float* b = boxes + ((int64_t)s * M + j) * 7;
+  const int l = best[s * M + j];
+  const int r0 = seg_start[l * B + s], r1 = seg_start[l * B + s + 1];
+  // n_scene = all locations of the scene over all levels (torch.topk is taken over all of them, padded with -1)
+  int n_scene = 0;
+  for (int q = 0; q < L; ++q) n_scene += seg_start[q * B + s + 1] - seg_start[q * B + s];
+  const int rank = min(topk + 1, n_scene);
+  __shared__ float red_v[4];
+  __shared__ int red_c[4];
+  float prev = INFINITY;        // values >= prev are already accounted for
+  int seen = 0;
+  float answer = -1.f;
+  for (int round = 0; round <= topk; ++round) {
+    // largest candidate value strictly below `prev`, and its multiplicity
+    float best_v = -2.f;
+    int cnt = 0;
+    for (int t = r0 + threadIdx.x; t < r1; t += 256) {
+      int i = order[t];
+      Face6 f = face_distances(b, pts[(int64_t)i * 3], pts[(int64_t)i * 3 + 1], pts[(int64_t)i * 3 + 2]);
+      if (!is_inside(f)) continue;
+      float c = centerness_of(f);
+      if (!(c < prev)) continue;
+      if (c > best_v) { best_v = c; cnt = 1; }
+      else if (c == best_v) ++cnt;
+    }
+    // wave reduce (max value, summed multiplicity of that value)
+    for (int off = 32; off > 0; off >>= 1) {
+      float ov = __shfl_xor(best_v, off, 64);
+      int oc = __shfl_xor(cnt, off, 64);
+      if (ov > best_v) { best_v = ov; cnt = oc; }
+      else if (ov == best_v) cnt += oc;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red_v[threadIdx.x >> 6] = best_v; red_c[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    float bv = red_v[0];
+    int bc = red_c[0];
+    for (int w = 1; w < 4; ++w) {
+      if (red_v[w] > bv) { bv = red_v[w]; bc = red_c[w]; }
+      else if (red_v[w] == bv) bc += red_c[w];
+    }
+    if (bv < 0.f) break;                    // candidates exhausted: the rank-th value is the -1 padding
+    seen += bc;
+    if (seen >= rank) { answer = bv; break; }
+    prev = bv;
+  }
+  if (threadIdx.x == 0) kth[s * M + j] = answer;
+}
+
+__global__ void k_final(const float* __restrict__ pts, const int* __restrict__ scene, const int* __restrict__ level, int64_t N,
+                        const float* __restrict__ boxes, const long long* __restrict__ labels,
+                        const int* __restrict__ box_count, const int* __restrict__ best, const float* __restrict__ kth, int M,
+                        float* __restrict__ ct_out, float* __restrict__ bt_out, long long* __restrict__ lab_out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int s = scene[i], l = level[i];
+  float px = pts[i * 3], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
+  int m = box_count[s];
+  float best_vol = FLOAT_MAX_VOL;
+  int owner = 0;
+  float owner_c = 0.f;
+  for (int j = 0; j < m; ++j) {
+    const float* b = boxes + ((int64_t)s * M + j) * 7;
+    if (best[s * M + j] != l) continue;
+    Face6 f = face_distances(b, px, py, pz);
+    if (!is_inside(f)) continue;
+    float c = centerness_of(f);
+    if (!(c > kth[s * M + j])) continue;
+    float vol = b[3] * b[4] * b[5];
+    if (vol < best_vol) { best_vol = vol; owner = j; owner_c = c; }
+  }
+  bool pos = best_vol != FLOAT_MAX_VOL;
+  lab_out[i] = pos ? labels[(int64_t)s * M + owner] : -1;
+  ct_out[i] = pos ? owner_c : 0.f;
+  const float* ob = boxes + ((int64_t)s * M + owner) * 7;
+  for (int e = 0; e < 7; ++e) bt_out[i * 7 + e] = m > 0 ? ob[e] : 0.f;
+}
+
+extern "C" {
+
+int64_t fc_assign_ws_bytes(int B, int M, int L) {
+  return (int64_t)B * M * (L + 2) * 4 + 256;
+}
+
+// points (N,3); scene/level (N) int32; boxes (B,M,7) [cx,cy,cz,w,l,h,yaw] gravity centre, padded; labels (B,M) int64;
+// box_count (B); order (N) = location rows grouped by (level, scene); seg_start (L*B+1) offsets into `order`.
+// outputs: centerness targets (N) (0 for background), box targets (N,7), labels (N) int64 (-1 = background).
+int fc_assign_targets(const float* points, const int* scene, const int* level, int64_t N, const float* boxes,
+                      const long long* labels, const int* box_count, int B, int M, int L, const int* order,
+                      const int* seg_start, int limit, int topk, float* centerness_t, float* bbox_t, long long* labels_out,
+                      void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (N < 0 || B < 1 || M < 1 || L < 1 || topk < 0) return FC_EINVAL;
+  if (ws_bytes < fc_assign_ws_bytes(B, M, L)) return FC_EWS;
+  if (N == 0) return FC_OK;
+  int* counts = (int*)ws;
+  int* best = counts + (int64_t)B * M * L;
+  float* kth = (float*)(best + (int64_t)B * M);
+  FC_HIP(hipMemsetAsync(counts, 0, sizeof(int) * (size_t)B * M * L, stream));
+  unsigned g = (unsigned)fc_cdiv(N, 256);
+  k_count<<<g, 256, 0, stream>>>(points, scene, level, N, boxes, box_count, M, L, counts);
+  FC_CHECK_LAUNCH();
+  k_best<<<(unsigned)fc_cdiv(B * M, 64), 64, 0, stream>>>(counts, B * M, L, limit, best);
+  FC_CHECK_LAUNCH();
+  k_kth<<<(unsigned)(B * M), 256, 0, stream>>>(points, boxes, box_count, best, order, seg_start, B, M, L, topk, kth);
+  FC_CHECK_LAUNCH();
+  k_final<<<g, 256, 0, stream>>>(points, scene, level, N, boxes, labels, box_count, best, kth, M, centerness_t, bbox_t,
+                                 labels_out);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+}  // extern "C"

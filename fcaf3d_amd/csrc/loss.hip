@@ -13,22 +13,26 @@
 #include <float.h>
 
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_focal_fwd(const float* __restrict__ x, const long long* __restrict__ label, int64_t n, int C,
-                            float gamma, float alpha, float* __restrict__ loss) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * C) return;
-  int64_t r = t / C;
-  int c = (int)(t % C);
-  long long y = label[r];
-  float p = 1.f / (1.f + expf(-x[t]));
-  float v;
-  if (y == c) v = -alpha * powf(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
-  else v = -(1.f - alpha) * powf(p, gamma) * logf(fmaxf(1.f - p, FLT_MIN));
-  loss[t] = v;
+__device__ static inline float focal_elem(float x, bool is_pos, float gamma, float alpha) {
+  float p = 1.f / (1.f + expf(-x));
+  if (is_pos) return -alpha * powf(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
+  return -(1.f - alpha) * powf(p, gamma) * logf(fmaxf(1.f - p, FLT_MIN));
 }
 
-__global__ void k_focal_bwd(const float* __restrict__ x, const long long* __restrict__ label, int64_t n, int C,
-                            float gamma, float alpha, const float* __restrict__ gscale, float* __restrict__ gx) {
+// one thread per row: loss_rows[r] = w[r] * sum_c focal(x[r,c])   (class order fixed -> deterministic)
+__global__ void k_focal_fwd(const float* __restrict__ x, const long long* __restrict__ label, const float* __restrict__ w,
+                            int64_t n, int C, float gamma, float alpha, float* __restrict__ loss_rows) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  long long y = label[r];
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) acc += focal_elem(x[r * C + c], y == c, gamma, alpha);
+  loss_rows[r] = w ? acc * w[r] : acc;
+}
+
+__global__ void k_focal_bwd(const float* __restrict__ x, const long long* __restrict__ label, const float* __restrict__ w,
+                            int64_t n, int C, float gamma, float alpha, const float* __restrict__ gscale,
+                            float* __restrict__ gx) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * C) return;
   int64_t r = t / C;
@@ -38,7 +42,7 @@ __global__ void k_focal_bwd(const float* __restrict__ x, const long long* __rest
   float g;
   if (y == c) g = -alpha * powf(1.f - p, gamma) * (1.f - p - gamma * p * logf(fmaxf(p, FLT_MIN)));
   else g = -(1.f - alpha) * powf(p, gamma) * (gamma * (1.f - p) * logf(fmaxf(1.f - p, FLT_MIN)) - p);
-  gx[t] = g * gscale[0];
+  gx[t] = g * gscale[0] * (w ? w[r] : 1.f);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -98,20 +102,21 @@ __global__ void k_aiou3d(const float* __restrict__ pred, const float* __restrict
 
 extern "C" {
 
-int fc_focal_loss_fwd(const float* logits, const long long* labels, int64_t n, int C, float gamma, float alpha,
-                      float* loss, hipStream_t stream) {
+int fc_focal_loss_fwd(const float* logits, const long long* labels, const float* row_weight, int64_t n, int C, float gamma,
+                      float alpha, float* loss_rows, hipStream_t stream) {
   if (n < 0 || C < 1) return FC_EINVAL;
   if (n == 0) return FC_OK;
-  k_focal_fwd<<<(unsigned)fc_cdiv(n * C, 256), 256, 0, stream>>>(logits, labels, n, C, gamma, alpha, loss);
+  k_focal_fwd<<<(unsigned)fc_cdiv(n, 256), 256, 0, stream>>>(logits, labels, row_weight, n, C, gamma, alpha, loss_rows);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
 
-int fc_focal_loss_bwd(const float* logits, const long long* labels, int64_t n, int C, float gamma, float alpha,
-                      const float* gscale_dev, float* glogits, hipStream_t stream) {
+int fc_focal_loss_bwd(const float* logits, const long long* labels, const float* row_weight, int64_t n, int C, float gamma,
+                      float alpha, const float* gscale_dev, float* glogits, hipStream_t stream) {
   if (n < 0 || C < 1) return FC_EINVAL;
   if (n == 0) return FC_OK;
-  k_focal_bwd<<<(unsigned)fc_cdiv(n * C, 256), 256, 0, stream>>>(logits, labels, n, C, gamma, alpha, gscale_dev, glogits);
+  k_focal_bwd<<<(unsigned)fc_cdiv(n * C, 256), 256, 0, stream>>>(logits, labels, row_weight, n, C, gamma, alpha, gscale_dev,
+                                                                glogits);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }

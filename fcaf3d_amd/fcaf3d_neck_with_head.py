@@ -13,12 +13,38 @@ import math
 import torch
 from torch import nn
 
+from . import _lib as L
 from . import functional as Fn
 from . import nn as MEnn
 from .dist import reduce_mean
 from .nms import nms_bev
 from .registry import BBOX_ASSIGNERS, HEADS, build_assigner, build_loss
 from .sparse import SparseTensor
+
+
+class SceneList:
+    """What the reference returns as a python list of per-scene tensors (`x[permutation]` for every
+    decomposition permutation, fcaf3d_neck_with_head.py:266-275), kept as ONE (N,C) tensor on its coordinate
+    map; the per-scene tensors are materialised only when indexed.  `loss()` consumes `.full` directly."""
+
+    def __init__(self, full, cmap):
+        self.full, self.cmap = full, cmap
+        self._items = {}
+
+    def __len__(self):
+        return self.cmap.batch_size
+
+    def __getitem__(self, i):
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        if i not in self._items:
+            self._items[i] = self.full[self.cmap.decomposition_permutations[i]]
+        return self._items[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
 
 
 class Scale(nn.Module):
@@ -150,18 +176,18 @@ class Fcaf3DNeckWithHead(nn.Module):
         reg_distance = torch.exp(scale(reg_final[:, :6]))
         bbox_pred = torch.cat((reg_distance, reg_final[:, 6:]), dim=1)
 
-        centernesses, bbox_preds, cls_scores, points = [], [], [], []
-        for perm in x.decomposition_permutations:
-            centernesses.append(centerness[perm])
-            bbox_preds.append(bbox_pred[perm])
-            cls_scores.append(cls_score[perm])
-            points.append(x.C[perm, 1:].float() * self.voxel_size)
-        return centernesses, bbox_preds, cls_scores, points, prune_scores
+        points = x.C[:, 1:].float() * self.voxel_size          # voxel corner, as the reference (:276-277)
+        cm = x.cmap
+        return (SceneList(centerness, cm), SceneList(bbox_pred, cm), SceneList(cls_score, cm), SceneList(points, cm),
+                prune_scores)
 
     # ---- loss (reference :128-203) -----------------------------------------------------------------
     def loss(self, centernesses, bbox_preds, cls_scores, points, gt_bboxes, gt_labels, img_metas):
         assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) \
             == len(points[0]) == len(img_metas) == len(gt_bboxes) == len(gt_labels)
+        if all(isinstance(v, SceneList) for group in (centernesses, bbox_preds, cls_scores, points) for v in group) \
+                and hasattr(self.assigner, 'assign_batched'):
+            return self._loss_batched(centernesses, bbox_preds, cls_scores, points, gt_bboxes, gt_labels)
         n_img = len(img_metas)
         per_img = []
         for i in range(n_img):
@@ -191,6 +217,35 @@ class Fcaf3DNeckWithHead(nn.Module):
             loss_centerness=torch.mean(torch.stack(loss_centerness)),
             loss_bbox=torch.mean(torch.stack(loss_bbox)),
             loss_cls=torch.mean(torch.stack(loss_cls)))
+
+    def _loss_batched(self, centernesses, bbox_preds, cls_scores, points, gt_bboxes, gt_labels):
+        """The same three losses as the per-scene loop (reference :140-157, :160-203), evaluated over all
+        locations of all scenes at once: every row carries the weight 1/(B * normaliser of its scene), so
+        the weighted sums equal the mean over scenes of the per-scene losses."""
+        B = len(gt_bboxes)
+        dev = points[0].full.device
+        with torch.no_grad():
+            pts = torch.cat([p.full for p in points])
+            scene = torch.cat([p.cmap.coords[:, 0] for p in points])
+            level = torch.cat([torch.full((p.full.shape[0],), l, dtype=torch.int32, device=dev)
+                               for l, p in enumerate(points)])
+            ct, bt, labels = self.assigner.assign_batched(pts, scene, level, [p.cmap for p in points],
+                                                          gt_bboxes, gt_labels)
+            posf = (labels >= 0).float()
+            onehot = (scene[None, :] == torch.arange(B, device=dev, dtype=scene.dtype)[:, None]).float()
+            norms = reduce_mean(onehot @ torch.stack((posf, ct), dim=1))            # (B,2): n_pos, Σ centerness
+            inv_pos = 1.0 / (B * norms[:, 0].clamp(min=1.))
+            inv_den = 1.0 / (B * norms[:, 1].clamp(min=1e-6))
+            sl = scene.long()
+            w_pos, w_den = inv_pos[sl], inv_den[sl]
+        centerness = torch.cat([c.full for c in centernesses])
+        bbox_pred = torch.cat([b.full for b in bbox_preds])
+        cls_score = torch.cat([c.full for c in cls_scores])
+        loss_cls = self.loss_cls(cls_score, labels, weight=w_pos, avg_factor=1.0)
+        loss_centerness = self.loss_centerness(centerness, ct.unsqueeze(1), weight=(posf * w_pos).unsqueeze(1),
+                                               avg_factor=1.0)
+        loss_bbox = self.loss_bbox(self._bbox_pred_to_bbox(pts, bbox_pred), bt, weight=ct * w_den, avg_factor=1.0)
+        return dict(loss_centerness=loss_centerness, loss_bbox=loss_bbox, loss_cls=loss_cls)
 
     def _loss_single(self, d, n_pos, centerness_denorm):
         posf = d['pos'].float()
@@ -298,6 +353,43 @@ class Fcaf3DAssigner:
         self.n_scales = n_scales
 
     @torch.no_grad()
+    def assign_batched(self, pts, scene, level, cmaps, gt_bboxes, gt_labels):
+        """All scenes, all levels, in four kernel launches (csrc/assign.hip).
+        pts (N,3) locations, scene/level (N) int32, cmaps: the coordinate map of each level (for the
+        per-(level, scene) row groups).  Returns (centerness_targets (N), bbox_targets (N,7), labels (N))."""
+        if not pts.is_cuda:
+            raise RuntimeError('batched target assignment runs on the GPU only (HIP)')
+        dev = pts.device
+        B, Lv = len(gt_bboxes), len(cmaps)
+        assert Lv == self.n_scales
+        M = max(1, max(len(g) for g in gt_bboxes))
+        boxes = pts.new_zeros((B, M, 7))
+        labels = torch.zeros((B, M), dtype=torch.int64, device=dev)
+        for i, (g, l) in enumerate(zip(gt_bboxes, gt_labels)):
+            if len(g):
+                boxes[i, :len(g)] = torch.cat((g.gravity_center, g.tensor[:, 3:]), dim=1).to(dev)
+                labels[i, :len(g)] = l.to(dev)
+        box_count = torch.tensor([len(g) for g in gt_bboxes], dtype=torch.int32, device=dev)
+        order, counts, off = [], [], 0
+        for cm in cmaps:
+            cm._decompose()
+            order.append(cm._order + off)
+            counts.append(cm._counts_dev)
+            off += cm.n
+        order = torch.cat(order).to(torch.int32)
+        seg_start = torch.cat((torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(torch.cat(counts), 0))).to(torch.int32)
+        N = pts.shape[0]
+        ct = torch.empty(N, dtype=torch.float32, device=dev)
+        bt = torch.empty((N, 7), dtype=torch.float32, device=dev)
+        lab = torch.empty(N, dtype=torch.int64, device=dev)
+        pts = pts.contiguous()
+        ws = L.workspace(L.query('fc_assign_ws_bytes', B, M, Lv), dev)
+        L.call('fc_assign_targets', L.ptr(pts), L.ptr(scene.contiguous()), L.ptr(level.contiguous()), N, L.ptr(boxes),
+               L.ptr(labels), L.ptr(box_count), B, M, Lv, L.ptr(order), L.ptr(seg_start), int(self.limit), int(self.topk),
+               L.ptr(ct), L.ptr(bt), L.ptr(lab), L.ptr(ws), ws.numel(), L.stream())
+        return ct, bt, lab
+
+    @torch.no_grad()
     def assign(self, points, gt_bboxes, gt_labels):
         float_max = 1e8
         dev = points[0].device
@@ -325,7 +417,10 @@ class Fcaf3DAssigner:
         inside = targets[..., :6].min(-1).values > 0                          # (n,m)
 
         # best level per box
-        per_level = torch.stack([inside[level == i].sum(dim=0) for i in range(self.n_scales)])   # (L,m)
+        # inside-counts per (level, box) as one small GEMM: no boolean-mask indexing, hence no host sync
+        # (exact: counts < 2^24 in fp32)
+        onehot = (level[None, :] == torch.arange(self.n_scales, device=dev, dtype=level.dtype)[:, None]).float()
+        per_level = onehot @ inside.float()                                                        # (L,m)
         starved = per_level < self.limit
         first_starved = torch.argmax(starved.int(), dim=0) - 1
         first_starved = first_starved.clamp(min=0)

@@ -30,32 +30,35 @@ def _reduce(loss, weight, reduction, avg_factor):
 
 class _FocalFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels, gamma, alpha):
+    def forward(ctx, logits, labels, row_weight, gamma, alpha):
         if not logits.is_cuda:
             raise RuntimeError('sigmoid focal loss runs on the GPU only (HIP)')
         logits = logits.contiguous()
         labels = labels.to(torch.int64).contiguous()
+        w = row_weight.to(torch.float32).contiguous() if row_weight is not None else None
         n, C = logits.shape
-        loss = torch.empty_like(logits)
-        L.call('fc_focal_loss_fwd', L.ptr(logits), L.ptr(labels), n, C, float(gamma), float(alpha), L.ptr(loss), L.stream())
-        ctx.save_for_backward(logits, labels)
+        rows = torch.empty(n, dtype=torch.float32, device=logits.device)
+        L.call('fc_focal_loss_fwd', L.ptr(logits), L.ptr(labels), L.ptr(w), n, C, float(gamma), float(alpha), L.ptr(rows),
+               L.stream())
+        ctx.save_for_backward(logits, labels, w)
         ctx.cfg = (float(gamma), float(alpha))
-        return loss.sum()
+        return rows.sum()
 
     @staticmethod
     def backward(ctx, g):
-        logits, labels = ctx.saved_tensors
+        logits, labels, w = ctx.saved_tensors
         gamma, alpha = ctx.cfg
         n, C = logits.shape
         gx = torch.empty_like(logits)
         gs = g.reshape(1).to(torch.float32).contiguous()
-        L.call('fc_focal_loss_bwd', L.ptr(logits), L.ptr(labels), n, C, gamma, alpha, L.ptr(gs), L.ptr(gx), L.stream())
-        return gx, None, None, None
+        L.call('fc_focal_loss_bwd', L.ptr(logits), L.ptr(labels), L.ptr(w), n, C, gamma, alpha, L.ptr(gs), L.ptr(gx),
+               L.stream())
+        return gx, None, None, None, None
 
 
-def sigmoid_focal_loss_sum(logits, labels, gamma=2.0, alpha=0.25):
-    """Σ over (N,C) of the sigmoid focal loss; labels (N,) in {-1, 0..C-1}, -1 = background."""
-    return _FocalFn.apply(logits, labels, gamma, alpha)
+def sigmoid_focal_loss_sum(logits, labels, gamma=2.0, alpha=0.25, row_weight=None):
+    """Σ_n w_n Σ_c focal(logits[n,c]); labels (N,) in {-1, 0..C-1}, -1 = background."""
+    return _FocalFn.apply(logits, labels, row_weight, gamma, alpha)
 
 
 @LOSSES.register_module()
@@ -66,10 +69,10 @@ class FocalLoss(nn.Module):
         self.gamma, self.alpha, self.reduction, self.loss_weight = gamma, alpha, reduction, loss_weight
 
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        """weight: optional per-sample weight (N,), as mmdet's FocalLoss."""
         assert reduction_override in (None, 'mean', 'sum')
-        assert weight is None, 'per-sample weights are not used by the FCAF3D head'
         reduction = reduction_override or self.reduction
-        total = sigmoid_focal_loss_sum(pred, target, self.gamma, self.alpha)
+        total = sigmoid_focal_loss_sum(pred, target, self.gamma, self.alpha, row_weight=weight)
         if reduction == 'mean':
             total = total / (avg_factor if avg_factor is not None else pred.numel())
         return self.loss_weight * total

@@ -6,7 +6,7 @@ from torch import nn
 from . import _lib as L
 from .boxes import bbox3d2result
 from .registry import DETECTORS, build_backbone, build_head
-from .sparse import SparseTensor
+from .sparse import SparseTensor, _rec, on_map_stream
 
 
 @DETECTORS.register_module()
@@ -21,6 +21,9 @@ class SingleStageSparse3DDetector(nn.Module):
         self.voxel_size = voxel_size
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
+        # True: voxelisation + every coordinate/kernel map of the step are built on a side HIP stream,
+        # overlapping whatever the main stream still runs (inputs must already be resident on the device)
+        self.async_maps = False
         self.init_weights()
 
     def init_weights(self, pretrained=None):
@@ -44,9 +47,48 @@ class SingleStageSparse3DDetector(nn.Module):
             off += n
         return coords, feats
 
-    def extract_feat(self, points, img_metas):
+    def _sparse_input(self, points):
         coordinates, features = self.voxelize(points)
         x = SparseTensor(features, coordinates=coordinates, batch_size=len(points))
+        _rec(x.F)
+        self.plan_maps(x.cmap)
+        return x
+
+    def plan_maps(self, cm0):
+        """Build, up front, every coordinate set and kernel map the step will use: they depend on the input
+        coordinates only (unless pts_threshold pruning bites, where planning stops and the rest is built
+        on demand).  The data-dependent sizes are read back here, while the queue holds only these small
+        integer kernels — no host sync is left inside the convolution sequence."""
+        bb, nh = self.backbone, self.neck_with_head
+        m1 = cm0.strided(2); cm0.kernel_map(m1, 3)                 # stem conv k3 s2
+        m2 = m1.strided(2); m1.kernel_map(m2, 2)                   # max-pool k2 s2
+        prev, levels = m2, []
+        bottleneck = getattr(bb.BLOCK, 'expansion', 1) == 4
+        for _ in range(min(bb.n_outs, 4)):
+            mi = prev.strided(2)
+            prev.kernel_map(mi, 3); prev.kernel_map(mi, 1); mi.kernel_map(mi, 3)
+            if bottleneck:
+                break                                              # 1x1-3x3-1x1 blocks: keep it lazy
+            levels.append(mi)
+            prev = mi
+        if bottleneck or not levels:
+            return
+        x = levels[-1]
+        x.scene_counts
+        for i in range(len(levels) - 2, -1, -1):
+            g = x.generate(); g.kernel_map(g, 3)
+            u, _ = levels[i].union(g)
+            if nh.pts_threshold >= 0 and any(c > nh.pts_threshold for c in u.scene_counts):
+                return
+            u.kernel_map(u, 3)
+            x = u
+
+    def extract_feat(self, points, img_metas):
+        if self.async_maps:
+            with on_map_stream(points[0].device):
+                x = self._sparse_input(points)
+        else:
+            x = self._sparse_input(points)
         x = self.backbone(x)
         x = self.neck_with_head(x)
         return x

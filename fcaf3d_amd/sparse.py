@@ -13,6 +13,52 @@ import torch
 from . import _lib as L
 
 
+# ---- side stream for coordinate work --------------------------------------------------------------
+# Hash / kernel-map construction depends only on the input coordinates, so it can run on its own HIP
+# stream while the main stream is still busy with the previous step; its count read-backs then wait for
+# microseconds of integer kernels instead of a full backward pass.  Tensors allocated under the side
+# stream and consumed on the main stream are pinned with record_stream().
+_side = {}
+_record_to = None
+
+
+def map_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=key)
+    return _side[key]
+
+
+class on_map_stream:
+    """with on_map_stream(dev): ...   -> coordinate kernels go to the side stream; main waits on exit."""
+
+    def __init__(self, device):
+        self.side = map_stream(device)
+
+    def __enter__(self):
+        global _record_to
+        self.main = torch.cuda.current_stream()
+        self.prev = _record_to
+        _record_to = self.main
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        global _record_to
+        self.ctx.__exit__(*a)
+        _record_to = self.prev
+        self.main.wait_stream(self.side)
+
+
+def _rec(*tensors):
+    if _record_to is not None:
+        for t in tensors:
+            if t is not None:
+                t.record_stream(_record_to)
+    return tensors[0] if len(tensors) == 1 else tensors
+
+
 def _next_pow2(n):
     p = 2
     while p < n:
@@ -20,8 +66,18 @@ def _next_pow2(n):
     return p
 
 
+_offs_cache = {}
+
+
 def kernel_offsets(kernel_size, tensor_stride, device):
     """(K,3) int32, x fastest; centred for odd kernels, {0..k-1} for even (Appendix A.3)."""
+    key = (kernel_size, tensor_stride, str(device))
+    if key not in _offs_cache:
+        _offs_cache[key] = _kernel_offsets(kernel_size, tensor_stride, device)
+    return _offs_cache[key]
+
+
+def _kernel_offsets(kernel_size, tensor_stride, device):
     if kernel_size % 2 == 1:
         r = [i - kernel_size // 2 for i in range(kernel_size)]
     else:
@@ -35,7 +91,7 @@ class KernelMap:
     """nbr (K, n_out) int32 plus, lazily, its transpose for the backward-data pass."""
 
     def __init__(self, nbr, n_in, n_out):
-        self.nbr = nbr
+        self.nbr = _rec(nbr)
         self.n_in = n_in
         self.n_out = n_out
         self.K = nbr.shape[0]
@@ -46,7 +102,7 @@ class KernelMap:
         if self._nbr_t is None:
             t = torch.empty((self.K, self.n_in), dtype=torch.int32, device=self.nbr.device)
             L.call('fc_kernel_map_transpose', L.ptr(self.nbr), self.n_out, self.n_in, self.K, L.ptr(t), L.stream())
-            self._nbr_t = t
+            self._nbr_t = _rec(t)
         return self._nbr_t
 
     def n_pairs(self):
@@ -57,21 +113,23 @@ class CoordMap:
     """One coordinate set: coords (N,4) int32 [b,x,y,z], tensor stride, voxel hash, cached maps."""
 
     def __init__(self, coords, stride, keys, vals, batch_size):
-        self.coords = coords
+        self.coords, self.keys, self.vals = _rec(coords, keys, vals)
         self.stride = stride
-        self.keys = keys
-        self.vals = vals
         self.cap = keys.numel()
         self.batch_size = batch_size
         self.n = coords.shape[0]
         self._kmaps = {}
         self._strided = {}
+        self._unions = {}
+        self._generated = None
         self._perm = None
+        self._counts = None
 
     # ---- construction -------------------------------------------------------------------------
     @staticmethod
-    def from_coords(coords, stride, batch_size, q=1, want_first=False, want_inverse=False):
-        """Unique rows of floor(coords/q)*q in order of first occurrence + hash of the result."""
+    def from_coords(coords, stride, batch_size, q=1, want_first=False, want_inverse=False, expect_n=None):
+        """Unique rows of floor(coords/q)*q in order of first occurrence + hash of the result.
+        expect_n: the caller knows the number of unique rows (no host read-back)."""
         assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
         coords = coords.contiguous()
         dev = coords.device
@@ -87,8 +145,9 @@ class CoordMap:
         ws = L.workspace(wsb, dev)
         L.call('fc_hash_unique', L.ptr(coords), n, q, L.ptr(keys), L.ptr(vals), cap, L.ptr(out), L.ptr(first),
                L.ptr(inv), L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
-        m = int(cnt.item())                      # the one host read-back of this op
-        cm = CoordMap(out[:m].contiguous() if m != n else out, stride, keys, vals, batch_size)
+        m = int(cnt.item()) if expect_n is None else expect_n     # the one host read-back of this op
+        cm = CoordMap(out[:m] if m != n else out, stride, keys, vals, batch_size)
+        _rec(first, inv)
         return cm, (first[:m] if want_first else None), inv
 
     def strided(self, s):
@@ -102,13 +161,14 @@ class CoordMap:
 
     def generate(self):
         """Children set of MinkowskiGenerativeConvolutionTranspose(k2,s2): row 8i+k."""
-        assert self.stride % 2 == 0
-        half = self.stride // 2
-        out = torch.empty((self.n * 8, 4), dtype=torch.int32, device=self.coords.device)
-        L.call('fc_gen_coords', L.ptr(self.coords), self.n, half, L.ptr(out), L.stream())
-        cm, _, _ = CoordMap.from_coords(out, half, self.batch_size)
-        assert cm.n == 8 * self.n, 'children of a unique stride-T set are unique'
-        return cm
+        if self._generated is None:
+            assert self.stride % 2 == 0
+            half = self.stride // 2
+            out = torch.empty((self.n * 8, 4), dtype=torch.int32, device=self.coords.device)
+            L.call('fc_gen_coords', L.ptr(self.coords), self.n, half, L.ptr(out), L.stream())
+            # children of a unique stride-T set are unique: 8n rows, no read-back needed
+            self._generated, _, _ = CoordMap.from_coords(out, half, self.batch_size, expect_n=8 * self.n)
+        return self._generated
 
     def kernel_map(self, out_map, kernel_size):
         """KernelMap from this (input) set to `out_map`, offsets in units of this set's stride."""
@@ -128,6 +188,8 @@ class CoordMap:
     def union(self, other):
         """Union map for `self + other` (rows of self first). Returns (map, row_of_other_rows)."""
         assert self.stride == other.stride
+        if id(other) in self._unions:
+            return self._unions[id(other)][:2]
         dev = self.coords.device
         row_b = torch.empty(other.n, dtype=torch.int32, device=dev)
         newc = torch.empty((other.n, 4), dtype=torch.int32, device=dev)
@@ -136,27 +198,42 @@ class CoordMap:
         L.call('fc_union_map', L.ptr(other.coords), other.n, L.ptr(self.keys), L.ptr(self.vals), self.cap, self.n,
                L.ptr(row_b), L.ptr(newc), L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
         n_new = int(cnt.item())
+        _rec(row_b)
         if n_new == 0:
-            return self, row_b
-        coords = torch.cat([self.coords, newc[:n_new]])
-        cm, _, _ = CoordMap.from_coords(coords, self.stride, self.batch_size)
-        assert cm.n == coords.shape[0]
+            cm = self
+        else:
+            coords = torch.cat([self.coords, newc[:n_new]])
+            cm, _, _ = CoordMap.from_coords(coords, self.stride, self.batch_size, expect_n=coords.shape[0])
+        self._unions[id(other)] = (cm, row_b, other)       # keep `other` alive so id() stays unique
         return cm, row_b
 
     def pruned(self, kept):
         """Map of the kept rows (int32 ascending row indices), order preserved."""
         out = torch.empty((kept.numel(), 4), dtype=torch.int32, device=self.coords.device)
         L.call('fc_gather_coords', L.ptr(self.coords), L.ptr(kept), kept.numel(), L.ptr(out), L.stream())
-        cm, _, _ = CoordMap.from_coords(out, self.stride, self.batch_size)
+        cm, _, _ = CoordMap.from_coords(out, self.stride, self.batch_size, expect_n=kept.numel())
         return cm
 
     # ---- per-scene decomposition --------------------------------------------------------------
+    def _decompose(self):
+        if self._perm is None:
+            b = self.coords[:, 0].long()
+            order = torch.argsort(b, stable=True)            # rows grouped by scene, ascending inside
+            counts_dev = torch.bincount(b, minlength=self.batch_size)
+            counts = counts_dev.cpu().tolist()                                      # one read-back per map
+            self._order, self._counts_dev = _rec(order, counts_dev)
+            self._counts = counts
+            self._perm = list(order.split(counts))
+
     @property
     def decomposition_permutations(self):
-        if self._perm is None:
-            b = self.coords[:, 0]
-            self._perm = [torch.nonzero(b == i).squeeze(1) for i in range(self.batch_size)]
+        self._decompose()
         return self._perm
+
+    @property
+    def scene_counts(self):
+        self._decompose()
+        return self._counts
 
 
 def compact_mask(mask):

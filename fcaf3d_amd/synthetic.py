@@ -91,7 +91,7 @@ def make_scene(seed, n_points=100000, n_boxes=15, n_classes=18,
     else:
         rgb = rng.integers(0, 256, size=(n_points, 3)).astype(np.float64)
     points = np.concatenate([xyz, rgb], axis=1).astype(np.float32)
-    gt = np.stack(boxes).astype(np.float32)
+    gt = np.stack(boxes).astype(np.float32) if boxes else np.zeros((0, 7), np.float32)
     labels = rng.integers(0, n_classes, size=n_boxes).astype(np.int64)
     return points, gt, labels
 

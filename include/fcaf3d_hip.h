@@ -124,12 +124,12 @@ int fc_scatter_rows_add(const float* src, const int* idx, int64_t n, int C, floa
 /* ---- losses ------------------------------------------------------------------------------- */
 
 /* mmcv sigmoid_focal_loss forward/backward (through mmdet FocalLoss, fcaf3d_neck_with_head.py:29-34,:180):
- * loss[n,c] elementwise; labels int64 in {-1,0..C-1}, -1 = background (all classes negative).
- * backward: glogits = dloss/dlogits * gscale_dev[0]. */
-int fc_focal_loss_fwd(const float* logits, const long long* labels, int64_t n, int C, float gamma, float alpha,
-                      float* loss, hipStream_t stream);
-int fc_focal_loss_bwd(const float* logits, const long long* labels, int64_t n, int C, float gamma, float alpha,
-                      const float* gscale_dev, float* glogits, hipStream_t stream);
+ * loss_rows[n] = row_weight[n] * sum_c loss[n,c] (row_weight nullable = 1); labels int64 in {-1,0..C-1},
+ * -1 = background (all classes negative).  backward: glogits = dloss/dlogits * row_weight[n] * gscale_dev[0]. */
+int fc_focal_loss_fwd(const float* logits, const long long* labels, const float* row_weight, int64_t n, int C, float gamma,
+                      float alpha, float* loss_rows, hipStream_t stream);
+int fc_focal_loss_bwd(const float* logits, const long long* labels, const float* row_weight, int64_t n, int C, float gamma,
+                      float alpha, const float* gscale_dev, float* glogits, hipStream_t stream);
 
 /* axis-aligned 3D IoU of (n,6) [cx,cy,cz,w,l,h] boxes and its gradient w.r.t. pred —
  * iou3d_loss.py:21-35 over iou3d_calculator.py:201-330 (is_aligned=True). dpred may be NULL. */
@@ -141,6 +141,16 @@ int fc_aiou3d_fwd_bwd(const float* pred, const float* target, int target_stride,
  * weight (nullable): rows with weight <= 0 are skipped (iou = 0, dpred = 0). */
 int fc_riou3d_fwd_bwd(const float* pred, const float* target, const float* weight, int64_t n, float* iou, float* dpred,
                       hipStream_t stream);
+
+/* Fcaf3DAssigner.assign + compute_centerness (fcaf3d_neck_with_head.py:377-384, :394-466) for ALL scenes of the
+ * batch: points (N,3) = locations of every level and scene; scene/level (N) ids; boxes (B,M,7) gravity-centre GT
+ * boxes padded to M per scene, box_count (B); order (N) = rows grouped by (level, scene), seg_start (L*B+1).
+ * Outputs per location: centerness target (0 for background), box target (7), label (-1 = background). */
+int64_t fc_assign_ws_bytes(int B, int M, int L);
+int fc_assign_targets(const float* points, const int* scene, const int* level, int64_t N, const float* boxes,
+                      const long long* labels, const int* box_count, int B, int M, int L, const int* order,
+                      const int* seg_start, int limit, int topk, float* centerness_t, float* bbox_t, long long* labels_out,
+                      void* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* ---- NMS ---------------------------------------------------------------------------------- */
 

@@ -101,6 +101,118 @@ def test_forward_train_parity(name, levels, B, n_points, kw):
     print(f'{name} L={levels} B={B}: worst grad rel err vs fp64 oracle {worst:.2e}')
 
 
+def test_async_map_stream_is_bitwise_equivalent():
+    """Coordinate work on the side HIP stream (bench mode) must not change a single bit."""
+    dev = _dev()
+    model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 3)
+    model = model.to(dev).train()
+    pts, gts, labs = _scenes([41, 42, 43], n_points=30000)
+    outs = []
+    for mode in (False, True, True):
+        model.async_maps = mode
+        model.zero_grad()
+        losses = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
+        sum(losses.values()).backward()
+        outs.append(([float(v) for v in losses.values()],
+                     model.backbone.layer1[0].conv1.kernel.grad.clone(), model.neck_with_head.reg_conv.kernel.grad.clone()))
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert o[0] == outs[0][0]
+        assert torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+
+
+def _fake_cmap(scene_ids, dev):
+    from fcaf3d_amd.sparse import CoordMap
+    c = torch.zeros((len(scene_ids), 4), dtype=torch.int32, device=dev)
+    c[:, 0] = torch.as_tensor(scene_ids, dtype=torch.int32)
+    cm = CoordMap.__new__(CoordMap)
+    cm.coords, cm.batch_size, cm.n, cm._perm = c, int(max(scene_ids)) + 1 if len(scene_ids) else 1, len(scene_ids), None
+    return cm
+
+
+def test_hip_assigner_vs_reference_goldens():
+    """csrc/assign.hip (whole batch, 4 launches) == the reference's Fcaf3DAssigner.assign goldens."""
+    dev = _dev()
+    d = np.load(os.path.join(G, 'assigner.npz'))
+    for ci in range(int(d['n_cases'])):
+        Lv = int(d[f'c{ci}_n_scales'])
+        lv_pts = [torch.from_numpy(d[f'c{ci}_points{l}']).to(dev) for l in range(Lv)]
+        a = fa.Fcaf3DAssigner(limit=27, topk=18, n_scales=Lv)
+        pts = torch.cat(lv_pts)
+        scene = torch.zeros(len(pts), dtype=torch.int32, device=dev)
+        level = torch.cat([torch.full((len(p),), l, dtype=torch.int32, device=dev) for l, p in enumerate(lv_pts)])
+        cmaps = [_fake_cmap([0] * len(p), dev) for p in lv_pts]
+        gt = fa.DepthInstance3DBoxes(torch.from_numpy(d[f'c{ci}_gt']), origin=(.5, .5, .5))
+        ct, bt, lb = a.assign_batched(pts, scene, level, cmaps, [gt], [torch.from_numpy(d[f'c{ci}_labels']).to(dev)])
+        ref = d[f'c{ci}_assigned']
+        assert np.array_equal(lb.cpu().numpy(), ref), ci
+        pos = ref >= 0
+        assert np.allclose(ct.cpu().numpy()[pos], d[f'c{ci}_centerness'][pos], atol=1e-6)
+        assert np.allclose(bt.cpu().numpy()[pos], d[f'c{ci}_bbox_targets'][pos], atol=1e-6)
+        assert float(ct.cpu()[~torch.from_numpy(pos)].abs().sum()) == 0.0
+
+
+def test_hip_assigner_batched_vs_per_scene_torch():
+    dev = _dev()
+    rng = np.random.default_rng(0)
+    B, Lv = 3, 3
+    a = fa.Fcaf3DAssigner(limit=27, topk=18, n_scales=Lv)
+    gts, labs, per_scene_pts = [], [], []
+    for s in range(B):
+        p, g, l = make_scene(50 + s, n_points=8000, n_boxes=[5, 0, 9][s], rotated=(s == 2))
+        per_scene_pts.append([torch.from_numpy(np.unique(np.floor(p[:, :3] / (0.16 * 2 ** k)), axis=0).astype(np.float32)
+                                               * np.float32(0.16 * 2 ** k)).to(dev) for k in range(Lv)])
+        gts.append(fa.DepthInstance3DBoxes(torch.from_numpy(g.reshape(-1, 7)), origin=(.5, .5, .5)))
+        labs.append(torch.from_numpy(l).to(dev))
+    # batched layout: level-major, scenes interleaved randomly inside a level
+    lvl_pts, lvl_scene = [], []
+    for k in range(Lv):
+        p = torch.cat([per_scene_pts[s][k] for s in range(B)])
+        sc = torch.cat([torch.full((len(per_scene_pts[s][k]),), s, dtype=torch.int32) for s in range(B)])
+        perm = torch.from_numpy(rng.permutation(len(p)))
+        lvl_pts.append(p[perm.to(dev)]); lvl_scene.append(sc[perm])
+    pts = torch.cat(lvl_pts)
+    scene = torch.cat(lvl_scene).to(dev)
+    level = torch.cat([torch.full((len(p),), k, dtype=torch.int32, device=dev) for k, p in enumerate(lvl_pts)])
+    cmaps = [_fake_cmap(sc.tolist(), dev) for sc in lvl_scene]
+    for cm in cmaps:
+        cm.batch_size = B
+    ct, bt, lb = a.assign_batched(pts, scene, level, cmaps, gts, labs)
+    for s in range(B):
+        ct_r, bt_r, lb_r = a.assign(per_scene_pts[s], gts[s], labs[s])
+        rows = torch.cat([torch.nonzero((scene == s) & (level == k)).squeeze(1) for k in range(Lv)])
+        # map the per-scene reference rows onto the batched rows through the coordinates
+        ref_pts = torch.cat(per_scene_pts[s])
+        key = lambda t: (t * 1000).round().long() @ torch.tensor([1, 100003, 10000600009], device=t.device)  # noqa: E731
+        lvl_key = torch.cat([torch.full((len(per_scene_pts[s][k]),), k, device=dev) for k in range(Lv)]) * 7
+        order_ref = torch.argsort(key(ref_pts) * 16 + lvl_key)
+        order_bat = torch.argsort(key(pts[rows]) * 16 + level[rows].long() * 7)
+        assert torch.equal(lb[rows][order_bat], lb_r[order_ref]), s
+        pos = lb_r[order_ref] >= 0
+        assert torch.allclose(ct[rows][order_bat][pos], ct_r[order_ref][pos], atol=1e-6)
+        if len(gts[s]):
+            assert torch.allclose(bt[rows][order_bat][pos], bt_r[order_ref][pos], atol=1e-6)
+
+
+def test_batched_loss_equals_per_scene_loop():
+    """loss() over SceneLists (one pass over all scenes) == the reference-shaped per-scene loop."""
+    dev = _dev()
+    model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 3)
+    model = model.to(dev).train()
+    pts, gts, labs = _scenes([61, 62, 63], n_points=30000)
+    batch = _to_gpu_batch(pts, gts, labs, dev)
+    x = [list(v) for v in model.extract_feat(batch['points'], batch['img_metas'])]
+    head = model.neck_with_head
+    fast = head.loss(*x, batch['gt_bboxes_3d'], batch['gt_labels_3d'], batch['img_metas'])
+    as_lists = [[[lvl[i] for i in range(len(lvl))] for lvl in kind] for kind in x]      # plain python lists
+    slow = head.loss(*as_lists, batch['gt_bboxes_3d'], batch['gt_labels_3d'], batch['img_metas'])
+    for k in fast:
+        assert _rel(fast[k], slow[k]) < 2e-6, (k, float(fast[k]), float(slow[k]))
+    g_fast = torch.autograd.grad(sum(fast.values()), head.out_block_0[0].kernel, retain_graph=True)[0]
+    g_slow = torch.autograd.grad(sum(slow.values()), head.out_block_0[0].kernel)[0]
+    assert _rel(g_fast, g_slow) < 1e-4
+
+
 def test_simple_test_parity():
     dev = _dev()
     model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 3)

@@ -17,6 +17,7 @@ def main():
     dev = torch.device('cuda:0')
     model, cfg = bench.build_model(args)
     model = model.to(dev).train()
+    model.async_maps = True
     batches = bench.make_batches(args, 0, dev)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
 
