@@ -70,7 +70,11 @@ __global__ void k_best(const int* __restrict__ counts, int BM, int L, int limit,
   best[t] = b;
 }
 
-// one block per (scene, box); rows of (level, scene) are order[seg_start[l*B+s] .. seg_start[l*B+s+1])
+// one block per (scene, box); rows of (level, scene) are order[seg_start[l*B+s] .. seg_start[l*B+s+1]).
+// Pass 1 collects the candidates' centerness values into LDS (one scan of the scene's rows on that level);
+// the (topk+1)-th largest is then peeled off the LDS list value by value (with multiplicity).  More than
+// KTH_CAP candidates (only possible for a huge box on a fine level) falls back to rescanning global memory.
+#define KTH_CAP 8192
 __global__ __launch_bounds__(256) void k_kth(const float* __restrict__ pts, const float* __restrict__ boxes,
                                              const int* __restrict__ box_count, const int* __restrict__ best,
                                              const int* __restrict__ order, const int* __restrict__ seg_start, int B, int M,
@@ -84,8 +88,22 @@ __global__ __launch_bounds__(256) void k_kth(const float* __restrict__ pts, cons
   int n_scene = 0;
   for (int q = 0; q < L; ++q) n_scene += seg_start[q * B + s + 1] - seg_start[q * B + s];
   const int rank = min(topk + 1, n_scene);
+  __shared__ float cand[KTH_CAP];
+  __shared__ int ncand_s;
   __shared__ float red_v[4];
   __shared__ int red_c[4];
+  if (threadIdx.x == 0) ncand_s = 0;
+  __syncthreads();
+  for (int t = r0 + threadIdx.x; t < r1; t += 256) {
+    int i = order[t];
+    Face6 f = face_distances(b, pts[(int64_t)i * 3], pts[(int64_t)i * 3 + 1], pts[(int64_t)i * 3 + 2]);
+    if (!is_inside(f)) continue;
+    int p = atomicAdd(&ncand_s, 1);
+    if (p < KTH_CAP) cand[p] = centerness_of(f);
+  }
+  __syncthreads();
+  const int ncand = ncand_s;
+  const bool in_lds = ncand <= KTH_CAP;
   float prev = INFINITY;        // values >= prev are already accounted for
   int seen = 0;
   float answer = -1.f;
@@ -93,14 +111,23 @@ __global__ __launch_bounds__(256) void k_kth(const float* __restrict__ pts, cons
     // largest candidate value strictly below `prev`, and its multiplicity
     float best_v = -2.f;
     int cnt = 0;
-    for (int t = r0 + threadIdx.x; t < r1; t += 256) {
-      int i = order[t];
-      Face6 f = face_distances(b, pts[(int64_t)i * 3], pts[(int64_t)i * 3 + 1], pts[(int64_t)i * 3 + 2]);
-      if (!is_inside(f)) continue;
-      float c = centerness_of(f);
-      if (!(c < prev)) continue;
-      if (c > best_v) { best_v = c; cnt = 1; }
-      else if (c == best_v) ++cnt;
+    if (in_lds) {
+      for (int t = threadIdx.x; t < ncand; t += 256) {
+        float c = cand[t];
+        if (!(c < prev)) continue;
+        if (c > best_v) { best_v = c; cnt = 1; }
+        else if (c == best_v) ++cnt;
+      }
+    } else {
+      for (int t = r0 + threadIdx.x; t < r1; t += 256) {
+        int i = order[t];
+        Face6 f = face_distances(b, pts[(int64_t)i * 3], pts[(int64_t)i * 3 + 1], pts[(int64_t)i * 3 + 2]);
+        if (!is_inside(f)) continue;
+        float c = centerness_of(f);
+        if (!(c < prev)) continue;
+        if (c > best_v) { best_v = c; cnt = 1; }
+        else if (c == best_v) ++cnt;
+      }
     }
     // wave reduce (max value, summed multiplicity of that value)
     for (int off = 32; off > 0; off >>= 1) {

@@ -180,6 +180,103 @@ __global__ void k_sum_parts(const float* __restrict__ part, float* __restrict__ 
   reinterpret_cast<float4*>(out)[i] = a;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stem convolution (Cin = 3 colour channels -> 64, k3 s2; me_resnet.py:19-21): too thin for the matrix
+// cores and bound by the 148 MB output write.  64 output rows per workgroup; the 27x3 gathered inputs of
+// every row and the whole (81,64) kernel sit in LDS; thread = (row, 16 output channels).
+#define STEM_CIN 3
+#define STEM_COUT 64
+#define STEM_ROWS 64
+__global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ in, const float* __restrict__ W,
+                                                  const int* __restrict__ nbr, float* __restrict__ out, int64_t n_out, int K) {
+  extern __shared__ float sm[];
+  const int KC = K * STEM_CIN;
+  float* in_s = sm;                          // [STEM_ROWS][KC]  (odd stride -> conflict-free row reads)
+  float* W_s = sm + STEM_ROWS * KC;          // [KC][64]
+  const int tid = threadIdx.x;
+  const int64_t m0 = (int64_t)blockIdx.x * STEM_ROWS;
+  for (int t = tid; t < STEM_ROWS * K; t += 256) {
+    int k = t / STEM_ROWS, row = t % STEM_ROWS;
+    int64_t o = m0 + row;
+    int i = o < n_out ? nbr[(int64_t)k * n_out + o] : -1;
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (i >= 0) { a = in[(int64_t)i * 3]; b = in[(int64_t)i * 3 + 1]; c = in[(int64_t)i * 3 + 2]; }
+    in_s[row * KC + k * 3] = a; in_s[row * KC + k * 3 + 1] = b; in_s[row * KC + k * 3 + 2] = c;
+  }
+  for (int t = tid; t < KC * 16; t += 256) reinterpret_cast<float4*>(W_s)[t] = reinterpret_cast<const float4*>(W)[t];
+  __syncthreads();
+  const int row = tid >> 2, cg = tid & 3;
+  float acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int j = 0; j < KC; ++j) {
+    float a = in_s[row * KC + j];
+    const float4* w = reinterpret_cast<const float4*>(W_s + j * 64 + cg * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = w[q];
+      acc[4 * q] = fmaf(a, v.x, acc[4 * q]); acc[4 * q + 1] = fmaf(a, v.y, acc[4 * q + 1]);
+      acc[4 * q + 2] = fmaf(a, v.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(a, v.w, acc[4 * q + 3]);
+    }
+  }
+  int64_t o = m0 + row;
+  if (o < n_out) {
+    float4* dst = reinterpret_cast<float4*>(out + o * 64 + cg * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+  }
+}
+
+// stem wgrad: part[block][j][co] = sum over the block's rows of in[nbr][j] * gout[row][co];  thread = (co, j mod 4)
+__global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ in, const float* __restrict__ gout,
+                                                    const int* __restrict__ nbr, float* __restrict__ part, int64_t n_out,
+                                                    int K, int64_t rows_per_block) {
+  extern __shared__ float sm[];
+  const int KC = K * STEM_CIN;
+  float* in_s = sm;                          // [STEM_ROWS][KC]
+  float* g_s = sm + STEM_ROWS * KC;          // [STEM_ROWS][64]
+  const int tid = threadIdx.x, co = tid & 63, jg = tid >> 6;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r_end = r_begin + rows_per_block;
+  if (r_end > n_out) r_end = n_out;
+  float acc[21];
+#pragma unroll
+  for (int e = 0; e < 21; ++e) acc[e] = 0.f;
+  for (int64_t rb = r_begin; rb < r_end; rb += STEM_ROWS) {
+    __syncthreads();
+    for (int t = tid; t < STEM_ROWS * K; t += 256) {
+      int k = t / STEM_ROWS, row = t % STEM_ROWS;
+      int64_t o = rb + row;
+      int i = o < r_end ? nbr[(int64_t)k * n_out + o] : -1;
+      float a = 0.f, b = 0.f, c = 0.f;
+      if (i >= 0) { a = in[(int64_t)i * 3]; b = in[(int64_t)i * 3 + 1]; c = in[(int64_t)i * 3 + 2]; }
+      in_s[row * KC + k * 3] = a; in_s[row * KC + k * 3 + 1] = b; in_s[row * KC + k * 3 + 2] = c;
+    }
+    for (int t = tid; t < STEM_ROWS * 16; t += 256) {
+      int row = t >> 4;
+      int64_t o = rb + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o < r_end) v = reinterpret_cast<const float4*>(gout + o * 64)[t & 15];
+      reinterpret_cast<float4*>(g_s)[t] = v;
+    }
+    __syncthreads();
+    for (int row = 0; row < STEM_ROWS; ++row) {
+      float g = g_s[row * 64 + co];
+#pragma unroll
+      for (int e = 0; e < 21; ++e) {
+        int j = jg + 4 * e;
+        if (j < KC) acc[e] = fmaf(in_s[row * KC + j], g, acc[e]);
+      }
+    }
+  }
+  float* dst = part + (int64_t)blockIdx.x * KC * 64;
+#pragma unroll
+  for (int e = 0; e < 21; ++e) {
+    int j = jg + 4 * e;
+    if (j < KC) dst[j * 64 + co] = acc[e];
+  }
+}
+
 // generic fallback (any Cin/Cout): one thread per (row, cout).  Used for the Cin=3 stem and as the
 // cross-check path of the parity tests (flags & 1).
 __global__ void k_conv_fma(const float* __restrict__ in, const float* __restrict__ W, const int* __restrict__ nbr,
@@ -212,7 +309,21 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
     s = (int)fc_cdiv(1024, tiles);
     if (s > K) s = K;
   }
+  // tuning overrides: flags[4:5] BM (1=64, 2=128), flags[6:7] BN (1=64, 2=128), flags[8:15] S
+  int fbm = (flags >> 4) & 3, fbn = (flags >> 6) & 3, fs = (flags >> 8) & 255;
+  if (fbm) *bm = fbm == 1 ? 64 : 128;
+  if (fbn && (Cout % (fbn == 1 ? 64 : 128) == 0)) *bn = fbn == 1 ? 64 : 128;
+  if (fbm || fbn) {
+    const int64_t t2 = fc_cdiv(n_out, *bm) * (Cout / *bn);
+    s = 1;
+    if (*mfma && K > 1 && t2 < 512) { s = (int)fc_cdiv(1024, t2); if (s > K) s = K; }
+  }
+  if (fs) s = fs > K ? K : fs;
   *S = s;
+}
+
+static inline bool is_stem(const int* nbr, int K, int Cin, int Cout, int flags) {
+  return !(flags & 1) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27;
 }
 
 int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags) {
@@ -227,6 +338,12 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
   if (n_out == 0) return FC_OK;
+  if (is_stem(nbr, K, Cin, Cout, flags)) {
+    size_t smem = (size_t)(STEM_ROWS * K * STEM_CIN + K * STEM_CIN * 64) * sizeof(float);
+    k_stem_fwd<<<(unsigned)fc_cdiv(n_out, STEM_ROWS), 256, smem, stream>>>(in, W, nbr, out, n_out, K);
+    FC_CHECK_LAUNCH();
+    return FC_OK;
+  }
   bool mfma_ok; int bm, bn, S;
   conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S);
   if (!mfma_ok) {
@@ -403,16 +520,34 @@ __global__ void k_transpose_w(const float* __restrict__ W, float* __restrict__ W
 
 extern "C" {
 
+static void wgrad_tiles(int Cin, int Cout, int flags, int* bm, int* bn) {
+  *bm = (Cin % 128 == 0) ? 128 : 64;
+  *bn = (Cout % 128 == 0) ? 128 : 64;
+  int fbm = (flags >> 4) & 3, fbn = (flags >> 6) & 3;      // tuning overrides
+  if (fbm == 1) *bm = 64;
+  if (fbm == 2 && Cin % 128 == 0) *bm = 128;
+  if (fbn == 1) *bn = 64;
+  if (fbn == 2 && Cout % 128 == 0) *bn = 128;
+}
+
 static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, int* S, int64_t* rows_per_split) {
+  if (!(flags & 1) && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27) {     // stem: 4096 rows per block
+    int64_t m = n_out > 0 ? n_out : 1;
+    *rows_per_split = 4096;
+    *S = (int)fc_cdiv(m, 4096);
+    return;
+  }
   bool mfma_ok = !(flags & 1) && (Cin % 64 == 0) && (Cout % 64 == 0);
-  int64_t tiles = mfma_ok ? (int64_t)K * (Cin / (Cin % 128 == 0 ? 128 : 64)) * (Cout / (Cout % 128 == 0 ? 128 : 64))
-                          : (int64_t)K;
+  int tbm, tbn;
+  wgrad_tiles(Cin, Cout, flags, &tbm, &tbn);
+  int64_t tiles = mfma_ok ? (int64_t)K * (Cin / tbm) * (Cout / tbn) : (int64_t)K;
   // aim for ~2048 workgroups, at least 512 rows per split, at most 256 splits
   int64_t s = fc_cdiv(2048, tiles);
   int64_t max_by_rows = fc_cdiv(n_out > 0 ? n_out : 1, mfma_ok ? 512 : 2048);
   if (s > max_by_rows) s = max_by_rows;
   if (s > 256) s = 256;
   if (s < 1) s = 1;
+  if ((flags >> 8) & 255) s = (flags >> 8) & 255;         // tuning override
   int64_t rps = fc_align(fc_cdiv(n_out > 0 ? n_out : 1, s), BK);
   s = fc_cdiv(n_out > 0 ? n_out : 1, rps);
   *S = (int)s;
@@ -439,8 +574,12 @@ int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, float* gW,
   if (ws_bytes < (int64_t)S * elems * (int64_t)sizeof(float)) return FC_EWS;
   float* part = (S == 1) ? gW : (float*)ws;
   bool mfma_ok = !(flags & 1) && (Cin % 64 == 0) && (Cout % 64 == 0);
-  if (mfma_ok) {
-    const int bm = (Cin % 128 == 0) ? 128 : 64, bn = (Cout % 128 == 0) ? 128 : 64;
+  if (!(flags & 1) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27) {
+    size_t smem = (size_t)(STEM_ROWS * K * STEM_CIN + STEM_ROWS * 64) * sizeof(float);
+    k_stem_wgrad<<<(unsigned)S, 256, smem, stream>>>(in, gout, nbr, part, n_out, K, rps);
+  } else if (mfma_ok) {
+    int bm, bn;
+    wgrad_tiles(Cin, Cout, flags, &bm, &bn);
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
     if (bm == 128 && bn == 128) k_wgrad_mfma<128, 128><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
     else if (bm == 128) k_wgrad_mfma<128, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);

@@ -382,6 +382,49 @@ int fc_col_stats(const float* x, const int* seg, int seg_stride, int64_t n, int 
   return FC_OK;
 }
 
+// out (nseg,C) = per-segment column sums of x (N,C) — deterministic two-level reduction
+int fc_seg_col_sums(const float* x, const int* seg, int seg_stride, int64_t n, int C, int nseg, float* out, void* ws,
+                    int64_t ws_bytes, hipStream_t stream) {
+  if (n < 0 || nseg < 1 || nseg > MAXSEG) return FC_EINVAL;
+  int threads; size_t sf, sb;
+  if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
+  if (ws_bytes < fc_col_stats_ws_bytes(n, C, nseg)) return FC_EWS;
+  if (n == 0) {
+    FC_HIP(hipMemsetAsync(out, 0, sizeof(float) * nseg * C, stream));
+    return FC_OK;
+  }
+  int64_t nb, rpb;
+  red_plan(n, &nb, &rpb);
+  float* part = (float*)ws;
+  k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, nullptr, 0, rpb, part, nullptr);
+  FC_CHECK_LAUNCH();
+  k_stats_final<<<(unsigned)(nseg * ((C + 63) / 64)), 1024, 0, stream>>>(part, nullptr, nb, nseg, C, 2, out, nullptr);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+// BatchNorm1d running statistics (momentum update with the unbiased variance) + num_batches_tracked, one launch
+__global__ void k_bn_running(const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ cnt,
+                             float momentum, int C, float* __restrict__ rmean, float* __restrict__ rvar,
+                             long long* __restrict__ nbt) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  float n = cnt[0];
+  float unbias = n / fmaxf(n - 1.f, 1.f);
+  rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[c];
+  rvar[c] = (1.f - momentum) * rvar[c] + momentum * var[c] * unbias;
+}
+
+int fc_bn_running_update(const float* mean, const float* var, const float* cnt, float momentum, int C, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, hipStream_t stream) {
+  if (C < 1) return FC_EINVAL;
+  k_bn_running<<<(unsigned)fc_cdiv(C, 256), 256, 0, stream>>>(mean, var, cnt, momentum, C, running_mean, running_var,
+                                                             num_batches_tracked);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
 int fc_norm_act_fwd(const float* x, const int* seg, int seg_stride, int64_t n, int C, const float* mean, const float* var,
                     float eps, const float* gamma, const float* beta, const float* residual, int act, float* y,
                     hipStream_t stream) {

@@ -232,8 +232,8 @@ class Fcaf3DNeckWithHead(nn.Module):
             ct, bt, labels = self.assigner.assign_batched(pts, scene, level, [p.cmap for p in points],
                                                           gt_bboxes, gt_labels)
             posf = (labels >= 0).float()
-            onehot = (scene[None, :] == torch.arange(B, device=dev, dtype=scene.dtype)[:, None]).float()
-            norms = reduce_mean(onehot @ torch.stack((posf, ct), dim=1))            # (B,2): n_pos, Σ centerness
+            cols = torch.stack((posf, ct, torch.zeros_like(ct), torch.zeros_like(ct)), dim=1)
+            norms = reduce_mean(Fn.seg_col_sums(cols, scene, B)[:, :2])             # (B,2): n_pos, Σ centerness
             inv_pos = 1.0 / (B * norms[:, 0].clamp(min=1.))
             inv_den = 1.0 / (B * norms[:, 1].clamp(min=1e-6))
             sl = scene.long()

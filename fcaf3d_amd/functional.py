@@ -118,6 +118,16 @@ def col_stats(x, seg, nseg):
     return mean, var, cnt
 
 
+def seg_col_sums(x, seg, nseg):
+    """(nseg,C) per-segment column sums of x (N,C), C % 4 == 0; seg int32 (N,) — deterministic."""
+    n, C = x.shape
+    out = torch.empty((nseg, C), dtype=torch.float32, device=x.device)
+    ws = L.workspace(L.query('fc_col_stats_ws_bytes', n, C, nseg), x.device)
+    L.call('fc_seg_col_sums', L.ptr(x.contiguous()), L.ptr(seg.contiguous()), 1, n, C, nseg, L.ptr(out), L.ptr(ws),
+           ws.numel(), L.stream())
+    return out
+
+
 class _NormAct(torch.autograd.Function):
     """y = act(norm(x)*gamma + beta (+ residual)); statistics over segments (1 = batch norm, B = instance norm).
     In eval mode the caller passes fixed mean/var (stats_const=True) and the backward treats them as constants."""
@@ -154,8 +164,12 @@ class _NormAct(torch.autograd.Function):
                L.ptr(ws), ws.numel(), L.stream())
         if stats_const:
             raise RuntimeError('backward through eval-mode normalisation is not supported')
-        ggamma = sums[:, 1].sum(0).reshape(gshape) if gshape is not None else None
-        gbeta = sums[:, 0].sum(0).reshape(bshape) if bshape is not None else None
+        if nseg == 1:
+            ggamma = sums[0, 1].reshape(gshape) if gshape is not None else None
+            gbeta = sums[0, 0].reshape(bshape) if bshape is not None else None
+        else:
+            ggamma = sums[:, 1].sum(0).reshape(gshape) if gshape is not None else None
+            gbeta = sums[:, 0].sum(0).reshape(bshape) if bshape is not None else None
         return gx, ggamma, gbeta, gres, None, None, None, None, None, None, None, None
 
 

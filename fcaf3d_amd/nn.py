@@ -12,6 +12,7 @@ import math
 import torch
 from torch import nn
 
+from . import _lib as L
 from . import functional as Fn
 from .sparse import SparseTensor
 
@@ -103,12 +104,8 @@ class MinkowskiBatchNorm(nn.Module):
         bn = self.bn
         if self.training:
             y, (mean, var, cnt) = Fn.norm_act(x.F, bn.weight, bn.bias, residual=residual, eps=bn.eps, act=act)
-            with torch.no_grad():
-                n = cnt[0]
-                m = bn.momentum
-                bn.running_mean.mul_(1 - m).add_(mean[0], alpha=m)
-                bn.running_var.mul_(1 - m).add_(var[0] * (n / torch.clamp(n - 1, min=1.0)) * m)
-                bn.num_batches_tracked += 1
+            L.call('fc_bn_running_update', L.ptr(mean), L.ptr(var), L.ptr(cnt), float(bn.momentum), mean.shape[1],
+                   L.ptr(bn.running_mean), L.ptr(bn.running_var), L.ptr(bn.num_batches_tracked), L.stream())
         else:
             C = x.F.shape[1]
             stats = (bn.running_mean.reshape(1, C).contiguous(), bn.running_var.reshape(1, C).contiguous(),

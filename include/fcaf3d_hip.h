@@ -102,6 +102,13 @@ int64_t fc_col_stats_ws_bytes(int64_t n, int C, int nseg);
 int fc_col_stats(const float* x, const int* seg, int seg_stride, int64_t n, int C, int nseg, float* mean, float* var,
                  float* cnt, void* ws, int64_t ws_bytes, hipStream_t stream);
 
+/* per-segment column sums (deterministic): the per-scene loss normalisers of fcaf3d_neck_with_head.py:178-187. */
+int fc_seg_col_sums(const float* x, const int* seg, int seg_stride, int64_t n, int C, int nseg, float* out, void* ws,
+                    int64_t ws_bytes, hipStream_t stream);
+/* nn.BatchNorm1d training-mode buffer update inside ME.MinkowskiBatchNorm (momentum, unbiased variance). */
+int fc_bn_running_update(const float* mean, const float* var, const float* cnt, float momentum, int C, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, hipStream_t stream);
+
 /* y = act((x-mean)/sqrt(var+eps)*gamma + beta (+ residual)); act 0 none, 1 ReLU, 2 ELU —
  * MinkowskiBatchNorm/InstanceNorm + MinkowskiReLU/ELU (+ BasicBlock's `out += residual`). */
 int fc_norm_act_fwd(const float* x, const int* seg, int seg_stride, int64_t n, int C, const float* mean, const float* var,

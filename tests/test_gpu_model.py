@@ -183,7 +183,9 @@ def test_hip_assigner_batched_vs_per_scene_torch():
         rows = torch.cat([torch.nonzero((scene == s) & (level == k)).squeeze(1) for k in range(Lv)])
         # map the per-scene reference rows onto the batched rows through the coordinates
         ref_pts = torch.cat(per_scene_pts[s])
-        key = lambda t: (t * 1000).round().long() @ torch.tensor([1, 100003, 10000600009], device=t.device)  # noqa: E731
+        def key(t):
+            q = (t * 1000).round().long()
+            return q[:, 0] + q[:, 1] * 100003 + q[:, 2] * 10000600009
         lvl_key = torch.cat([torch.full((len(per_scene_pts[s][k]),), k, device=dev) for k in range(Lv)]) * 7
         order_ref = torch.argsort(key(ref_pts) * 16 + lvl_key)
         order_bat = torch.argsort(key(pts[rows]) * 16 + level[rows].long() * 7)
