@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-points', type=int, default=0, help='points of the cpu_baseline sample scene (0 = same as workload)')
     ap.add_argument('--no-instrument', action='store_true', help='skip per-kernel HIP events (roofline = null)')
+    ap.add_argument('--spatial-sort', action='store_true', help='Z-order sort of the collated points (measured: no gain, r1)')
     ap.add_argument('--breakdown', action='store_true', help='diagnostic: HIP-event time per C-ABI entry point and per conv shape (stderr)')
     return ap.parse_args()
 
@@ -218,6 +219,7 @@ def main():
     model, cfg = build_model(args)
     model = model.to(dev).train()
     model.async_maps = True           # scenes are resident in HBM: coordinate work may run on its side stream
+    model.spatial_sort = args.spatial_sort
     if world > 1:
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)

@@ -38,6 +38,38 @@ int fc_voxelize(const float* points, int64_t n, int pt_stride, int batch_idx, fl
 }
 
 // ----------------------------------------------------------------------------------------------
+// Morton (Z-order) keys: batch index in the top bits, then x/y/z bit-interleaved.  Sorting the points by
+// this key before the hash insert makes "order of first occurrence" a space-filling-curve order on EVERY
+// pyramid level (a Z-order prefix is the Z-order of the parent cell), so the rows a convolution tile gathers
+// are neighbours in memory as well as in space (L2 locality of the gather).
+__device__ static inline unsigned long long spread3(unsigned int v) {      // 16 bits -> every third bit
+  unsigned long long x = v & 0xFFFFull;
+  x = (x | (x << 32)) & 0x00FF00000000FFFFull;   // not needed for 16 bits but keeps the classic ladder
+  x = (x | (x << 16)) & 0x00FF0000FF0000FFull;
+  x = (x | (x << 8)) & 0xF00F00F00F00F00Full;
+  x = (x | (x << 4)) & 0x30C30C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x9249249249249249ull;
+  return x;
+}
+
+__global__ void k_morton(const int4* __restrict__ coords, int64_t n, long long* __restrict__ keys) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  unsigned long long m = spread3((unsigned)(c.y + 32768)) | (spread3((unsigned)(c.z + 32768)) << 1) |
+                         (spread3((unsigned)(c.w + 32768)) << 2);
+  keys[i] = (long long)(((unsigned long long)(unsigned)c.x << 48) | (m & 0xFFFFFFFFFFFFull));
+}
+
+int fc_morton_keys(const int* coords, int64_t n, long long* keys, hipStream_t stream) {
+  if (n < 0) return FC_EINVAL;
+  if (n == 0) return FC_OK;
+  k_morton<<<(unsigned)fc_cdiv(n, 256), 256, 0, stream>>>((const int4*)coords, n, keys);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
 // device-wide exclusive scan of byte flags:  pos[i] = #flags set before i ; *total = #set.
 // 1024 items per 256-thread block, 4 rounds of 256 so that order is preserved.
 __device__ static inline int block_excl_scan_flag(int flag, int* wave_sums /*[4]*/, int* block_total) {

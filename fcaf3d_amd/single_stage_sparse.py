@@ -24,6 +24,9 @@ class SingleStageSparse3DDetector(nn.Module):
         # True: voxelisation + every coordinate/kernel map of the step are built on a side HIP stream,
         # overlapping whatever the main stream still runs (inputs must already be resident on the device)
         self.async_maps = False
+        # True: collated points are sorted along a Z-order curve before de-duplication, so that every level's row
+        # order is spatially coherent (gather locality).  Only the ROW ORDER changes; per-scene results are sets.
+        self.spatial_sort = False
         self.init_weights()
 
     def init_weights(self, pretrained=None):
@@ -45,6 +48,11 @@ class SingleStageSparse3DDetector(nn.Module):
             L.call('fc_voxelize', L.ptr(p), n, p.shape[1], b, float(self.voxel_size), 255.0, nfeat,
                    L.ptr(coords[off:]), L.ptr(feats[off:]), L.stream())
             off += n
+        if self.spatial_sort and total:
+            keys = torch.empty(total, dtype=torch.int64, device=dev)
+            L.call('fc_morton_keys', L.ptr(coords), total, L.ptr(keys), L.stream())
+            order = torch.argsort(keys)
+            coords, feats = coords[order], feats[order]
         return coords, feats
 
     def _sparse_input(self, points):

@@ -35,6 +35,10 @@ extern "C" {
 int fc_voxelize(const float* points, int64_t n, int pt_stride, int batch_idx, float voxel_size, float feat_div,
                 int nfeat, int* coords, float* feats, hipStream_t stream);
 
+/* Z-order key per voxel coordinate [b | x,y,z bit-interleaved]; sorting the collated points by it before
+ * fc_hash_unique turns "order of first occurrence" into a space-filling-curve order on every pyramid level. */
+int fc_morton_keys(const int* coords, int64_t n, long long* keys, hipStream_t stream);
+
 /* Order-preserving compaction primitive (wave ballot + prefix sum): pos[i] = #set flags before i. */
 int fc_scan_flags(const unsigned char* flags, int64_t n, int* pos, int* total_dev, void* ws, int64_t ws_bytes,
                   hipStream_t stream);

@@ -28,6 +28,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--wgrad', action='store_true')
+    ap.add_argument('--only', default='')
+    ap.add_argument('--default-only', action='store_true')
     a = ap.parse_args()
     sys.argv = [sys.argv[0], '--batch', str(a.batch)]
     args = bench.parse()
@@ -65,6 +67,8 @@ def main():
         ('L2 k3s2 64->128', levels[1][0].kernel_map(levels[1][1], 3), 64, 128),
     ]
     for name, km, Cin, Cout in cases:
+        if a.only and a.only not in name:
+            continue
         K = km.K
         pairs = km.n_pairs()
         xin = torch.randn(km.n_in, Cin, device=dev)
@@ -74,7 +78,7 @@ def main():
         gw = torch.empty_like(w)
         gflop = 2.0 * pairs * Cin * Cout / 1e9
         res = []
-        for bm in (1, 2):
+        for bm in (() if a.default_only else (1, 2)):
             for bn in ((1, 2) if Cout % 128 == 0 else (1,)):
                 for S in ((0,) if a.wgrad else (0, 1, 2, 3, 4, 6, 9, 14, 27)):
                     if a.wgrad and bm == 2 and Cin % 128:
@@ -101,6 +105,8 @@ def main():
                                        K, Cin, Cout, 0, L.ptr(ws), ws.numel(), L.stream()))
         else:
             t0 = timeit(lambda: Fn._conv_fwd(xin, w, km.nbr, out, km.n_in, km.n_out, K, Cin, Cout))
+        if not res:
+            res = [(t0, 0, 0, 0)]
         res.sort()
         best = ', '.join(f'{t:.0f}us({bm}x{bn},S{S})' for t, bm, bn, S in res[:4])
         print(f'{name:20s} n={km.n_out:7d} P={pairs:9d} {gflop:7.1f} GF  default {t0:7.0f}us = {gflop / t0 * 1e3:5.1f} TF | best: {best} '
