@@ -1,0 +1,77 @@
+"""CPU, world_size 2, gloo: the data-parallel plumbing of fcaf3d_amd/dist.py (reduce_mean and the bucketed
+gradient averager that bench.py uses on RCCL) — multi-process, rendezvous on 127.0.0.1."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from fcaf3d_amd import dist as D
+    D.init_dist(backend='gloo')
+    assert D.is_dist() and D.world_size() == world
+    # reduce_mean == mmdet.core.reduce_mean
+    t = torch.tensor([float(rank + 1), 10.0 * (rank + 1)])
+    r = D.reduce_mean(t)
+    assert torch.allclose(r, torch.tensor([1.5, 15.0])), r
+    assert torch.equal(t, torch.tensor([float(rank + 1), 10.0 * (rank + 1)]))      # input untouched
+    # the batched normalisers of Fcaf3DNeckWithHead.loss travel in ONE all-reduce
+    norms = torch.arange(6, dtype=torch.float32).reshape(3, 2) * (rank + 1)
+    assert torch.allclose(D.reduce_mean(norms), torch.arange(6, dtype=torch.float32).reshape(3, 2) * 1.5)
+    # bucketed gradient averaging: tiny buckets force several async all-reduces + the flush of unused params
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    unused = torch.nn.Parameter(torch.ones(5))
+    params = list(model.parameters()) + [unused]
+    avg = D.GradientAverager(params, bucket_mb=1e-5)
+    assert len(avg.buckets) >= 3
+    for step in range(2):                                   # hooks must re-arm after finish()
+        for p in params:
+            p.grad = None
+        x = torch.full((3, 8), float(rank + 1 + step))
+        model(x).sum().backward()
+        local = [p.grad.clone() for p in model.parameters()]
+        avg.finish()
+        gathered = [[torch.zeros_like(g) for _ in range(world)] for g in local]
+        for g, lst in zip(local, gathered):
+            dist.all_gather(lst, g)
+        for p, lst in zip(model.parameters(), gathered):
+            assert torch.allclose(p.grad, sum(lst) / world, atol=1e-6)
+        assert torch.equal(unused.grad, torch.zeros(5))
+    if rank == 0:
+        out.put('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_mean_and_gradient_averager_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == 'ok'
+
+
+def test_single_process_is_identity():
+    from fcaf3d_amd import dist as D
+    t = torch.tensor([3.0])
+    assert D.reduce_mean(t) is t and D.world_size() == 1
+    avg = D.GradientAverager([torch.nn.Parameter(torch.ones(2))])
+    avg.finish()                                             # no-op without a process group
