@@ -14,6 +14,8 @@
 #include "fc_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: struct float4 copies lower to memcpy and
+                                                          // pin the prefetch registers in scratch (r1 finding)
 
 #define BK 32            // reduction slab (input channels per stage / rows per stage for wgrad)
 #define LDA (BK + 4)     // A row stride in floats: 16B-aligned rows, conflict-free ds_read_b128 (9r mod 16)
@@ -26,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // gridDim.z > 1 = split over kernel offsets (offset k handled by split k % gridDim.z) for layers whose
 // row count cannot fill the chip; partial tiles go to `out` + z*n_out*Cout and are summed by k_sum_parts.
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
+__global__ __launch_bounds__(256, 2) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
                                                    const int* __restrict__ nbr, float* __restrict__ out, int64_t n_out,
                                                    int K, int Cin, int Cout) {
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave
@@ -78,43 +80,37 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
     int k = __ffs(kmask) - 1;
     kmask &= kmask - 1;
     int c0 = 0;
-    int idx[AR];
-    float4 av[AR], bv[BR];
-    auto load_idx = [&](int kk) {
+    f32x4 av[AR], bv[BR];
+    // (the neighbour indices are re-read per stage: keeping them in a captured array across iterations made the
+    //  compiler spill the whole prefetch set to scratch — 80 B/lane, 2 GB of extra HBM writes per launch, r1 PMC)
+    auto load_stage = [&](int kk, int cc) {
+      const float* Wk = W + (int64_t)kk * Cin * Cout;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         int64_t row = m0 + a_r + 32 * i;
         int v = -1;
         if (row < n_out) v = nbr ? nbr[(int64_t)kk * n_out + row] : (int)row;
-        idx[i] = v;
-      }
-    };
-    auto load_stage = [&](int kk, int cc) {
-      const float* Wk = W + (int64_t)kk * Cin * Cout;
-#pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx[i] >= 0) av[i] = *reinterpret_cast<const float4*>(in + (int64_t)idx[i] * Cin + cc + a_c4 * 4);
+        av[i] = (f32x4)(0.f);
+        if (v >= 0) av[i] = *reinterpret_cast<const f32x4*>(in + (int64_t)v * Cin + cc + a_c4 * 4);
       }
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         int lin = tid + 256 * i;
         int kr = lin / (BN / 4), c4 = lin % (BN / 4);
-        bv[i] = *reinterpret_cast<const float4*>(Wk + (int64_t)(cc + kr) * Cout + n0 + c4 * 4);
+        bv[i] = *reinterpret_cast<const f32x4*>(Wk + (int64_t)(cc + kr) * Cout + n0 + c4 * 4);
       }
     };
-    load_idx(k);
     load_stage(k, c0);
     while (true) {
       __syncthreads();                           // previous stage fully consumed
 #pragma unroll
       for (int i = 0; i < AR; ++i)
-        *reinterpret_cast<float4*>(&As[(a_r + 32 * i) * LDA + a_c4 * 4]) = av[i];
+        *reinterpret_cast<f32x4*>(&As[(a_r + 32 * i) * LDA + a_c4 * 4]) = av[i];
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         int lin = tid + 256 * i;
         int kr = lin / (BN / 4), c4 = lin % (BN / 4);
-        *reinterpret_cast<float4*>(&Bs[kr * BN + c4 * 4]) = bv[i];
+        *reinterpret_cast<f32x4*>(&Bs[kr * BN + c4 * 4]) = bv[i];
       }
       __syncthreads();
       // issue the next stage's global loads before computing this one
@@ -124,17 +120,16 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
         nk = kmask ? __ffs(kmask) - 1 : -1;
         kmask &= kmask - 1;
       }
-      if (nk >= 0) {
-        if (nk != k) load_idx(nk);
-        load_stage(nk, nc0);
-      }
+      // unconditional (the last iteration re-reads its own stage): a conditionally assigned float4 array is not
+      // promoted to registers by the compiler and lands in scratch
+      load_stage(nk >= 0 ? nk : k, nk >= 0 ? nc0 : c0);
 #pragma unroll
       for (int q = 0; q < BK / 8; ++q) {
-        float4 a[TM];
+        f32x4 a[TM];
         float b[TN][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          a[i] = *reinterpret_cast<const float4*>(&As[(wr * (BM / 2) + i * 32 + r) * LDA + 8 * q + 4 * h]);
+          a[i] = *reinterpret_cast<const f32x4*>(&As[(wr * (BM / 2) + i * 32 + r) * LDA + 8 * q + 4 * h]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -143,7 +138,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            float ae = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
+            float ae = a[i][e];
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, b[j][e], acc[i][j], 0, 0, 0);
           }
@@ -377,7 +372,7 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int
 // partial products are written to the workspace and summed by k_wgrad_reduce in a fixed order
 // (deterministic, no atomics).
 template <int BMc, int BNc>
-__global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ gout,
+__global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ gout,
                                                     const int* __restrict__ nbr, float* __restrict__ part, int64_t n_out,
                                                     int K, int Cin, int Cout, int64_t rows_per_split) {
   constexpr int TM = BMc / 64, TN = BNc / 64;
@@ -406,7 +401,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ in
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // register-prefetch pipeline: the gathers + gout rows of chunk t+1 are in flight while chunk t is multiplied
-  float4 av[AR], gv[GR];
+  f32x4 av[AR], gv[GR];
   auto load_chunk = [&](int64_t rb) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
@@ -415,16 +410,16 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ in
       int64_t row = rb + rr;
       int src = -1;
       if (row < r_end) src = nbr ? nbr[(int64_t)k * n_out + row] : (int)row;
-      av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (src >= 0) av[i] = *reinterpret_cast<const float4*>(in + (int64_t)src * Cin + ci0 + c4 * 4);
+      av[i] = (f32x4)(0.f);
+      if (src >= 0) av[i] = *reinterpret_cast<const f32x4*>(in + (int64_t)src * Cin + ci0 + c4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < GR; ++i) {
       int lin = tid + 256 * i;
       int rr = lin / (BNc / 4), c4 = lin % (BNc / 4);
       int64_t row = rb + rr;
-      gv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < r_end) gv[i] = *reinterpret_cast<const float4*>(gout + row * Cout + co0 + c4 * 4);
+      gv[i] = (f32x4)(0.f);
+      if (row < r_end) gv[i] = *reinterpret_cast<const f32x4*>(gout + row * Cout + co0 + c4 * 4);
     }
   };
   if (r_begin < r_end) load_chunk(r_begin);
@@ -434,13 +429,13 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ in
     for (int i = 0; i < AR; ++i) {
       int lin = tid + 256 * i;
       int rr = lin / (BMc / 4), c4 = lin % (BMc / 4);
-      *reinterpret_cast<float4*>(&As[rr * BMc + c4 * 4]) = av[i];
+      *reinterpret_cast<f32x4*>(&As[rr * BMc + c4 * 4]) = av[i];
     }
 #pragma unroll
     for (int i = 0; i < GR; ++i) {
       int lin = tid + 256 * i;
       int rr = lin / (BNc / 4), c4 = lin % (BNc / 4);
-      *reinterpret_cast<float4*>(&Gs[rr * BNc + c4 * 4]) = gv[i];
+      *reinterpret_cast<f32x4*>(&Gs[rr * BNc + c4 * 4]) = gv[i];
     }
     __syncthreads();
     if (rb + BK < r_end) load_chunk(rb + BK);
