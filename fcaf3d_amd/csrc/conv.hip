@@ -27,15 +27,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: str
 // (single LDS buffer, global-load latency hidden behind the matrix pipe).
 // gridDim.z > 1 = split over kernel offsets (offset k handled by split k % gridDim.z) for layers whose
 // row count cannot fill the chip; partial tiles go to `out` + z*n_out*Cout and are summed by k_sum_parts.
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
+template <int BM, int BN, int BKT>
+__global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
                                                    const int* __restrict__ nbr, float* __restrict__ out, int64_t n_out,
                                                    int K, int Cin, int Cout) {
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave
-  constexpr int AR = BM / 32;                    // float4 gathers per thread per stage
-  constexpr int BR = BN / 32;                    // float4 weight loads per thread per stage
-  __shared__ __attribute__((aligned(16))) float As[BM * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+  constexpr int LDAT = BKT + 4;                  // (BKT+4)/4 odd -> conflict-free ds_read_b128 of the A fragments
+  constexpr int A4 = BKT / 4;                    // float4 per gathered row slab
+  constexpr int APASS = 256 / A4;                // rows staged per pass
+  constexpr int AR = BM / APASS;                 // float4 gathers per thread per stage
+  constexpr int BR = BKT * BN / 1024;            // float4 weight loads per thread per stage
+  __shared__ __attribute__((aligned(16))) float As[BM * LDAT];
+  __shared__ __attribute__((aligned(16))) float Bs[BKT * BN];
   __shared__ unsigned int kmask_s;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const float* __restrict__ 
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int S = gridDim.z, z = blockIdx.z;
-  const int a_c4 = tid & 7, a_r = tid >> 3;      // A staging: 8 float4 per row, 32 rows per pass
+  const int a_c4 = tid % A4, a_r = tid / A4;     // A staging: A4 float4 per row, APASS rows per pass
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const float* __restrict__ 
       const float* Wk = W + (int64_t)kk * Cin * Cout;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
-        int64_t row = m0 + a_r + 32 * i;
+        int64_t row = m0 + a_r + APASS * i;
         int v = -1;
         if (row < n_out) v = nbr ? nbr[(int64_t)kk * n_out + row] : (int)row;
         av[i] = (f32x4)(0.f);
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const float* __restrict__ 
       __syncthreads();                           // previous stage fully consumed
 #pragma unroll
       for (int i = 0; i < AR; ++i)
-        *reinterpret_cast<f32x4*>(&As[(a_r + 32 * i) * LDA + a_c4 * 4]) = av[i];
+        *reinterpret_cast<f32x4*>(&As[(a_r + APASS * i) * LDAT + a_c4 * 4]) = av[i];
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         int lin = tid + 256 * i;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const float* __restrict__ 
       }
       __syncthreads();
       // issue the next stage's global loads before computing this one
-      int nk = k, nc0 = c0 + BK;
+      int nk = k, nc0 = c0 + BKT;
       if (nc0 >= Cin) {
         nc0 = 0;
         nk = kmask ? __ffs(kmask) - 1 : -1;
@@ -124,12 +127,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const float* __restrict__ 
       // promoted to registers by the compiler and lands in scratch
       load_stage(nk >= 0 ? nk : k, nk >= 0 ? nc0 : c0);
 #pragma unroll
-      for (int q = 0; q < BK / 8; ++q) {
+      for (int q = 0; q < BKT / 8; ++q) {
         f32x4 a[TM];
         float b[TN][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          a[i] = *reinterpret_cast<const f32x4*>(&As[(wr * (BM / 2) + i * 32 + r) * LDA + 8 * q + 4 * h]);
+          a[i] = *reinterpret_cast<const f32x4*>(&As[(wr * (BM / 2) + i * 32 + r) * LDAT + 8 * q + 4 * h]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -293,7 +296,7 @@ __global__ void k_conv_fma(const float* __restrict__ in, const float* __restrict
 
 extern "C" {
 
-static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* mfma, int* bm, int* bn, int* S) {
+static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* mfma, int* bm, int* bn, int* S, int* bk) {
   *mfma = !(flags & 1) && (Cin % BK == 0) && (Cout % 64 == 0) && K <= 32;
   *bn = (Cout % 128 == 0) ? 128 : 64;
   const int64_t wg128 = fc_cdiv(n_out, 128) * (Cout / *bn);
@@ -317,6 +320,10 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   }
   if (fs) s = fs > K ? K : fs;
   *S = s;
+  // 64-deep reduction slabs (half the barriers per FLOP) when the tile is 128 rows and Cin allows; flags bit16/17 force 32/64
+  *bk = 32;     // measured r1: 64-deep slabs LOSE 5-10 % on the 437k-row layers (LDS 68 KB -> 2 workgroups/CU instead of 3)
+  if (flags & (1 << 16)) *bk = 32;
+  if ((flags & (1 << 17)) && Cin % 64 == 0 && *bm == 128) *bk = 64;
 }
 
 static inline bool is_stem(const int* nbr, int K, int Cin, int Cout, int flags) {
@@ -324,8 +331,8 @@ static inline bool is_stem(const int* nbr, int K, int Cin, int Cout, int flags) 
 }
 
 int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags) {
-  bool mfma; int bm, bn, S;
-  conv_plan(n_out > 0 ? n_out : 1, K, Cin, Cout, flags, &mfma, &bm, &bn, &S);
+  bool mfma; int bm, bn, S, bk;
+  conv_plan(n_out > 0 ? n_out : 1, K, Cin, Cout, flags, &mfma, &bm, &bn, &S, &bk);
   return S > 1 ? (int64_t)S * n_out * Cout * (int64_t)sizeof(float) : 0;
 }
 
@@ -341,8 +348,8 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
-  bool mfma_ok; int bm, bn, S;
-  conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S);
+  bool mfma_ok; int bm, bn, S, bk;
+  conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S, &bk);
   if (!mfma_ok) {
     k_conv_fma<<<(unsigned)fc_cdiv(n_out * Cout, 256), 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
     FC_CHECK_LAUNCH();
@@ -351,10 +358,12 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int
   if (S > 1 && ws_bytes < (int64_t)S * n_out * Cout * (int64_t)sizeof(float)) return FC_EWS;
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
-  if (bm == 128 && bn == 128) k_conv_mfma<128, 128><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
-  else if (bm == 128) k_conv_mfma<128, 64><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
-  else if (bn == 128) k_conv_mfma<64, 128><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
-  else k_conv_mfma<64, 64><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
+  if (bm == 128 && bn == 128 && bk == 64) k_conv_mfma<128, 128, 64><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
+  else if (bm == 128 && bk == 64) k_conv_mfma<128, 64, 64><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
+  else if (bm == 128 && bn == 128) k_conv_mfma<128, 128, 32><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
+  else if (bm == 128) k_conv_mfma<128, 64, 32><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
+  else if (bn == 128) k_conv_mfma<64, 128, 32><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
+  else k_conv_mfma<64, 64, 32><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
   FC_CHECK_LAUNCH();
   if (S > 1) {
     int64_t e4 = n_out * Cout / 4;

@@ -14,6 +14,7 @@ from . import loss_oracle as lo
 from . import me_oracle as mo
 
 LAYERS = {14: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
+TRAINING = True     # False: BatchNorm uses the running statistics of the state_dict (model.eval())
 
 
 class SP:
@@ -46,7 +47,11 @@ def conv(x, w, ks, s=1):
 
 
 def bn(x, P, pre, act=None, residual=None):
-    f = mo.batch_norm(x.F, P[pre + '.bn.weight'], P[pre + '.bn.bias'])
+    if TRAINING:
+        f = mo.batch_norm(x.F, P[pre + '.bn.weight'], P[pre + '.bn.bias'])
+    else:
+        f = torch.nn.functional.batch_norm(x.F, P[pre + '.bn.running_mean'], P[pre + '.bn.running_var'],
+                                           P[pre + '.bn.weight'], P[pre + '.bn.bias'], False, 0.1, 1e-5)
     if residual is not None:
         f = f + residual
     if act == 'relu':

@@ -324,3 +324,89 @@ def test_pruning_path_bites():
             so, sg = np.lexsort(po.T[::-1]), np.lexsort(pg.T[::-1])
             assert np.array_equal(po[so], pg[sg])
             assert _rel(out_g[2][l][b][torch.from_numpy(sg).to(dev)], out_o[2][l][b][torch.from_numpy(so)]) < 1e-4
+
+
+def test_eval_mode_inference_and_running_stats():
+    """model.eval(): BatchNorm runs on the running statistics that training steps accumulated
+    (nn.BatchNorm1d semantics inside ME.MinkowskiBatchNorm): the buffers, and the detections, match the oracle."""
+    dev = _dev()
+    model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 2)
+    with torch.no_grad():
+        model.neck_with_head.cls_conv.bias.fill_(0.0)
+        model.neck_with_head.cls_conv.kernel.normal_(0, 0.3)
+    model = model.to(dev).train()
+    pts, gts, labs = _scenes([71, 72], n_points=20000)
+    # two training forwards update running_mean / running_var / num_batches_tracked
+    ref_bn = torch.nn.BatchNorm1d(64)
+    for _ in range(2):
+        model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
+    bn = model.backbone.layer1[0].norm1.bn
+    assert int(bn.num_batches_tracked) == 2
+    P = _oracle_params(model)
+    # replay the first BN of layer1 on the CPU to check the momentum / unbiased-variance update
+    x = MO.SP(*MO.mo.sparse_tensor(*MO.mo.batch_sparse_collate([p[:, :3] / np.float32(0.02) for p in pts],
+                                                                [p[:, 3:] / np.float32(255.) for p in pts])), 1)
+    x = MO.SP(x.C, torch.from_numpy(x.F), 1)
+    P0 = {k: v.detach() for k, v in P.items()}
+    h = MO.conv(x, P0['backbone.conv1.0.kernel'], 3, 2)
+    f = MO.mo.instance_norm(h.F, h.C[:, 0], P0['backbone.conv1.1.weight'], P0['backbone.conv1.1.bias'])
+    h = MO.SP(h.C, torch.relu(f), h.stride, h.cache)
+    oc, ocache = MO._strided(h, 2)
+    h = MO.SP(oc, MO.mo.max_pool(h.F, MO._kmap(h, oc, 2, 'down')), h.stride * 2, ocache)
+    pre = MO.conv(h, P0['backbone.layer1.0.conv1.kernel'], 3, 2).F
+    ref_bn.train()
+    ref_bn(pre); ref_bn(pre)
+    assert _rel(bn.running_mean, ref_bn.running_mean) < 1e-4 and _rel(bn.running_var, ref_bn.running_var) < 1e-4
+    # eval-mode detections vs the oracle on running statistics
+    model.eval()
+    MO.TRAINING = False
+    try:
+        res_o = MO.simple_test(P, m, pts)
+    finally:
+        MO.TRAINING = True
+    with torch.no_grad():
+        res_g = model(return_loss=False, points=[torch.from_numpy(p).to(dev) for p in pts],
+                      img_metas=[dict(box_type_3d=fa.DepthInstance3DBoxes)] * 2)
+    for (bo, so, lo_), rg in zip(res_o, res_g):
+        assert len(so) > 5 and len(rg['scores_3d']) == len(so)
+        assert torch.equal(rg['labels_3d'], lo_) and _rel(rg['scores_3d'], so) < 1e-4
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 at full size (100k points/scene, 4 levels, 2 cm) — size-independent properties:
+    bitwise determinism run to run, invariance of the losses to a permutation of the input points (row order
+    changes, sets do not), voxel-count sanity and kernel-map symmetry (nbr_t of a same-set map is its own flip)."""
+    dev = _dev()
+    model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 4)
+    model = model.to(dev).train()
+    pts, gts, labs = _scenes([81, 82], n_points=100000)
+    batch = _to_gpu_batch(pts, gts, labs, dev)
+    l1 = model(return_loss=True, **batch)
+    l2 = model(return_loss=True, **batch)
+    assert all(float(l1[k]) == float(l2[k]) for k in l1), 'two identical steps must agree bit for bit'
+    rng = np.random.default_rng(0)
+    perm_pts = [p[rng.permutation(len(p))] for p in pts]
+    l3 = model(return_loss=True, **_to_gpu_batch(perm_pts, gts, labs, dev))
+    for k in l1:
+        assert _rel(l3[k], l1[k]) < 1e-4, (k, float(l3[k]), float(l1[k]))
+    # coordinate-level properties on the real maps
+    coords, feats = model.voxelize(batch['points'])
+    from fcaf3d_amd.sparse import SparseTensor
+    x = SparseTensor(feats, coordinates=coords, batch_size=2)
+    n0 = x.cmap.n
+    assert 2 * 85000 < n0 < 2 * 100000                                  # ~92.6k voxels per scene (SURVEY.md Appendix C)
+    keys = x.C.long() @ torch.tensor([1 << 48, 1 << 32, 1 << 16, 1], device=dev) if False else None
+    uniq = torch.unique(x.C, dim=0)
+    assert uniq.shape[0] == n0                                           # de-duplicated
+    lvl = x.cmap.strided(2).strided(2).strided(2)                        # stride 8 (backbone level 1)
+    km = lvl.kernel_map(lvl, 3)
+    assert torch.equal(km.nbr_t, km.nbr.flip(0))                         # same-set k3 map: transpose == offset flip
+    centre = km.nbr[13]
+    assert torch.equal(centre, torch.arange(lvl.n, device=dev, dtype=torch.int32))   # every voxel is its own centre
+    # linearity of the sparse convolution on the full-size map
+    w = torch.randn(27, 64, 64, device=dev)
+    a, b = torch.randn(lvl.n, 64, device=dev), torch.randn(lvl.n, 64, device=dev)
+    import fcaf3d_amd.functional as Fn
+    lhs = Fn.sparse_conv(2.0 * a + b, w, km, lvl.n)
+    rhs = 2.0 * Fn.sparse_conv(a, w, km, lvl.n) + Fn.sparse_conv(b, w, km, lvl.n)
+    assert _rel(lhs, rhs) < 1e-5

@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--wgrad', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--flags', type=int, default=0, help='extra flags for the default run (bit16: BK=32, bit17: BK=64)')
     ap.add_argument('--default-only', action='store_true')
     a = ap.parse_args()
     sys.argv = [sys.argv[0], '--batch', str(a.batch)]
@@ -97,7 +98,7 @@ def main():
                         finally:
                             Fn.FLAGS = 0
                         res.append((t, bm * 64, bn * 64, S or Sw))
-        Fn.FLAGS = 0
+        Fn.FLAGS = a.flags
         if a.wgrad:
             wsb = L.query('fc_conv_wgrad_ws_bytes', km.n_out, K, Cin, Cout, 0)
             ws = L.workspace(wsb, dev)
