@@ -141,7 +141,8 @@ class ConvProbe:
             s.record()
             orig(name, *a)
             e.record()
-            probe.records.append((s, e, probe._pairs, 2.0 * Cin * Cout, n_out))
+            nbytes = 4.0 * (a[4] * Cin + n_out * Cout + K * Cin * Cout) + (4.0 * K * n_out if a[2] else 0.0)
+            probe.records.append((s, e, probe._pairs, 2.0 * Cin * Cout, n_out, nbytes))
         L.call = call
         self._orig = orig
         self._pairs = None
@@ -172,15 +173,24 @@ class ConvProbe:
         torch.cuda.synchronize()
         flops = 0.0
         ms = 0.0
-        for s, e, pairs, per_pair, n_out in self.records:
+        alg_bytes = 0.0
+        for s, e, pairs, per_pair, n_out, nbytes in self.records:
             p = float(pairs.item()) if pairs is not None else float(n_out)
             flops += p * per_pair
+            alg_bytes += nbytes
             ms += s.elapsed_time(e)
         n = len(self.records)
         achieved = flops / (ms * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
+        if os.path.exists(tj):          # PMC passes cannot run inside the timed region: committed rocprofv3 result
+            t = json.load(open(tj))
+            traffic, traffic_src = t['hbm_bytes_per_launch'], 'profiles/r1_traffic.json (' + t['method'] + ')'
+
         return dict(bound='mfma', kernel='k_conv_mfma (sparse conv fwd + dgrad, dense GEMMs of convT/heads)',
                     achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, launches=n,
+                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_unit='B/launch',
+                    traffic_source=traffic_src, algorithmic_bytes_per_launch=round(alg_bytes / n), launches=n,
                     avg_launch_us=round(ms * 1e3 / n, 2), flops_per_launch=round(flops / n / 1e9, 4),
                     time_share_ms_per_step=None)
 

@@ -384,8 +384,17 @@ def test_full_size_properties_config2():
     l1 = model(return_loss=True, **batch)
     l2 = model(return_loss=True, **batch)
     assert all(float(l1[k]) == float(l2[k]) for k in l1), 'two identical steps must agree bit for bit'
+    # idempotence of de-duplication: feeding only the first point of every voxel (same order) changes nothing
     rng = np.random.default_rng(0)
-    perm_pts = [p[rng.permutation(len(p))] for p in pts]
+    firsts = []
+    for p in pts:
+        q = np.floor(p[:, :3] / np.float32(0.02)).astype(np.int64)
+        _, idx = np.unique(q, axis=0, return_index=True)
+        firsts.append(p[np.sort(idx)])
+    l_first = model(return_loss=True, **_to_gpu_batch(firsts, gts, labs, dev))
+    assert all(float(l_first[k]) == float(l1[k]) for k in l1), 'duplicates after the first occurrence must not matter'
+    # ... and permuting those unique points only permutes rows: the losses move by fp32 summation order only
+    perm_pts = [p[rng.permutation(len(p))] for p in firsts]
     l3 = model(return_loss=True, **_to_gpu_batch(perm_pts, gts, labs, dev))
     for k in l1:
         assert _rel(l3[k], l1[k]) < 1e-4, (k, float(l3[k]), float(l1[k]))
@@ -395,7 +404,6 @@ def test_full_size_properties_config2():
     x = SparseTensor(feats, coordinates=coords, batch_size=2)
     n0 = x.cmap.n
     assert 2 * 85000 < n0 < 2 * 100000                                  # ~92.6k voxels per scene
-    keys = x.C.long() @ torch.tensor([1 << 48, 1 << 32, 1 << 16, 1], device=dev) if False else None
     uniq = torch.unique(x.C, dim=0)
     assert uniq.shape[0] == n0                                           # de-duplicated
     lvl = x.cmap.strided(2).strided(2).strided(2)                        # stride 8 (backbone level 1)

@@ -1,0 +1,36 @@
+"""profiles/<tag>_traffic.json from two rocprofv3 PMC passes over bench.py (one --pmc FETCH_SIZE, one --pmc WRITE_SIZE,
+as MI355X_MICROARCH.md §HBM prescribes: separate passes; FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950 ->
+x2, calibrated here with tools/pmc_calib.py: 1 GiB copy -> FETCH 0.5 GiB, WRITE 1.0 GiB).
+usage: traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter, match):
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == counter and match in r['Kernel_Name']:
+            tot += float(r['Counter_Value'])
+            n += 1
+    return tot, n
+
+
+def main():
+    fetch_csv, write_csv, out = sys.argv[1:4]
+    match = 'k_conv_mfma'
+    f, nf = per_kernel(fetch_csv, 'FETCH_SIZE', match)
+    w, nw = per_kernel(write_csv, 'WRITE_SIZE', match)
+    fetch_b = 2.0 * f * 1024 / max(nf, 1)        # KB -> B, x2 gfx950 correction
+    write_b = w * 1024 / max(nw, 1)
+    json.dump(dict(kernel=match, launches_fetch_pass=nf, launches_write_pass=nw,
+                   fetch_bytes_per_launch=round(fetch_b), write_bytes_per_launch=round(write_b),
+                   hbm_bytes_per_launch=round(fetch_b + write_b),
+                   method='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py; FETCH_SIZE x2 '
+                          '(gfx950 under-count, calibrated on a 1 GiB copy: tools/pmc_calib.py)'),
+              open(out, 'w'), indent=1)
+    print(open(out).read())
+
+
+if __name__ == '__main__':
+    main()
