@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--cpu-points', type=int, default=0, help='points of the cpu_baseline sample scene (0 = same as workload)')
     ap.add_argument('--no-instrument', action='store_true', help='skip per-kernel HIP events (roofline = null)')
     ap.add_argument('--spatial-sort', action='store_true', help='Z-order sort of the collated points (measured: no gain, r1)')
+    ap.add_argument('--no-wgrad-overlap', action='store_true', help='keep weight-gradient kernels on the main stream')
     ap.add_argument('--breakdown', action='store_true', help='diagnostic: HIP-event time per C-ABI entry point and per conv shape (stderr)')
     return ap.parse_args()
 
@@ -92,9 +93,9 @@ class Breakdown:
             s.record(); orig(name, *a); e.record()
             key = name
             if name == 'fc_conv_fwd':
-                key = f'conv_fwd n={a[5]} K={a[6]} {a[7]}->{a[8]}'
+                key = f'conv_fwd n={a[6]} K={a[7]} {a[8]}->{a[9]}'
             elif name == 'fc_conv_wgrad':
-                key = f'wgrad n={a[5]} K={a[6]} {a[7]}->{a[8]}'
+                key = f'wgrad n={a[6]} K={a[7]} {a[8]}->{a[9]}'
             rec.append((key, name, s, e))
         L.call = call
 
@@ -132,8 +133,8 @@ class ConvProbe:
         def call(name, *a):
             if name != 'fc_conv_fwd':
                 return orig(name, *a)
-            # (in, W, nbr, out, n_in, n_out, K, Cin, Cout, flags, stream)
-            n_out, K, Cin, Cout = a[5], a[6], a[7], a[8]
+            # (in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream)
+            n_out, K, Cin, Cout = a[6], a[7], a[8], a[9]
             if Cin % 32 or Cout % 64:
                 return orig(name, *a)          # generic FMA path (stem): not the kernel under the probe
             s = torch.cuda.Event(enable_timing=True)
@@ -141,7 +142,7 @@ class ConvProbe:
             s.record()
             orig(name, *a)
             e.record()
-            nbytes = 4.0 * (a[4] * Cin + n_out * Cout + K * Cin * Cout) + (4.0 * K * n_out if a[2] else 0.0)
+            nbytes = 4.0 * (a[5] * Cin + n_out * Cout + K * Cin * Cout) + (4.0 * K * n_out if a[2] else 0.0)
             probe.records.append((s, e, probe._pairs, 2.0 * Cin * Cout, n_out, nbytes))
         L.call = call
         self._orig = orig
@@ -230,6 +231,8 @@ def main():
     model = model.to(dev).train()
     model.async_maps = True           # scenes are resident in HBM: coordinate work may run on its side stream
     model.spatial_sort = args.spatial_sort
+    import fcaf3d_amd.functional as Fn
+    Fn.WGRAD_ASYNC = not args.no_wgrad_overlap
     if world > 1:
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)

@@ -29,8 +29,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: str
 // row count cannot fill the chip; partial tiles go to `out` + z*n_out*Cout and are summed by k_sum_parts.
 template <int BM, int BN, int BKT>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
-                                                   const int* __restrict__ nbr, float* __restrict__ out, int64_t n_out,
-                                                   int K, int Cin, int Cout) {
+                                                   const int* __restrict__ nbr, const int* __restrict__ out_index,
+                                                   float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout) {
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave
   constexpr int LDAT = BKT + 4;                  // (BKT+4)/4 odd -> conflict-free ds_read_b128 of the A fragments
   constexpr int A4 = BKT / 4;                    // float4 per gathered row slab
@@ -162,7 +162,10 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
       for (int e = 0; e < 16; ++e) {
         int64_t row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         int col = n0 + wc * (BN / 2) + j * 32 + r;
-        if (row < n_out) dst[row * Cout + col] = acc[i][j][e];
+        if (row < n_out) {
+          if (out_index) row = out_index[row];           // rows are processed in mask-sorted order
+          dst[row * Cout + col] = acc[i][j][e];
+        }
       }
 }
 
@@ -337,12 +340,13 @@ int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags)
 }
 
 // flags: bit0 = force the generic FMA kernel.
-int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int64_t n_in, int64_t n_out, int K, int Cin,
-                int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
+int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
+                int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
   if (n_out == 0) return FC_OK;
-  if (is_stem(nbr, K, Cin, Cout, flags)) {
+  if (out_index && !nbr) return FC_EINVAL;
+  if (is_stem(nbr, K, Cin, Cout, flags) && !out_index) {
     size_t smem = (size_t)(STEM_ROWS * K * STEM_CIN + K * STEM_CIN * 64) * sizeof(float);
     k_stem_fwd<<<(unsigned)fc_cdiv(n_out, STEM_ROWS), 256, smem, stream>>>(in, W, nbr, out, n_out, K);
     FC_CHECK_LAUNCH();
@@ -351,6 +355,7 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int
   bool mfma_ok; int bm, bn, S, bk;
   conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S, &bk);
   if (!mfma_ok) {
+    if (out_index) return FC_EINVAL;              // sorted-row tables are an MFMA-path feature
     k_conv_fma<<<(unsigned)fc_cdiv(n_out * Cout, 256), 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
     FC_CHECK_LAUNCH();
     return FC_OK;
@@ -358,12 +363,12 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int
   if (S > 1 && ws_bytes < (int64_t)S * n_out * Cout * (int64_t)sizeof(float)) return FC_EWS;
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
-  if (bm == 128 && bn == 128 && bk == 64) k_conv_mfma<128, 128, 64><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
-  else if (bm == 128 && bk == 64) k_conv_mfma<128, 64, 64><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
-  else if (bm == 128 && bn == 128) k_conv_mfma<128, 128, 32><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
-  else if (bm == 128) k_conv_mfma<128, 64, 32><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
-  else if (bn == 128) k_conv_mfma<64, 128, 32><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
-  else k_conv_mfma<64, 64, 32><<<grid, 256, 0, stream>>>(in, W, nbr, dst, n_out, K, Cin, Cout);
+  if (bm == 128 && bn == 128 && bk == 64) k_conv_mfma<128, 128, 64><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
+  else if (bm == 128 && bk == 64) k_conv_mfma<128, 64, 64><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
+  else if (bm == 128 && bn == 128) k_conv_mfma<128, 128, 32><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
+  else if (bm == 128) k_conv_mfma<128, 64, 32><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
+  else if (bn == 128) k_conv_mfma<64, 128, 32><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
+  else k_conv_mfma<64, 64, 32><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
   FC_CHECK_LAUNCH();
   if (S > 1) {
     int64_t e4 = n_out * Cout / 4;
@@ -382,8 +387,9 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int
 // (deterministic, no atomics).
 template <int BMc, int BNc>
 __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ gout,
-                                                    const int* __restrict__ nbr, float* __restrict__ part, int64_t n_out,
-                                                    int K, int Cin, int Cout, int64_t rows_per_split) {
+                                                    const int* __restrict__ nbr, const int* __restrict__ row_index,
+                                                    float* __restrict__ part, int64_t n_out, int K, int Cin, int Cout,
+                                                    int64_t rows_per_split) {
   constexpr int TM = BMc / 64, TN = BNc / 64;
   constexpr int AR = BMc / 32, GR = BNc / 32;    // float4 loads per thread per stage (32 rows)
   __shared__ __attribute__((aligned(16))) float As[BK * BMc];
@@ -409,9 +415,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // register-prefetch pipeline: the gathers + gout rows of chunk t+1 are in flight while chunk t is multiplied
+  // register-prefetch pipeline: the gathers + gout rows of chunk t+1 are in flight while chunk t is multiplied.
+  // A chunk of 32 rows none of which has a neighbour at this offset is skipped (frequent once the rows are
+  // processed in occupancy-mask order: row_index != NULL, nbr already permuted).
   f32x4 av[AR], gv[GR];
+  int have = 0;
   auto load_chunk = [&](int64_t rb) {
+    int any = 0;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       int lin = tid + 256 * i;
@@ -420,7 +430,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
       int src = -1;
       if (row < r_end) src = nbr ? nbr[(int64_t)k * n_out + row] : (int)row;
       av[i] = (f32x4)(0.f);
-      if (src >= 0) av[i] = *reinterpret_cast<const f32x4*>(in + (int64_t)src * Cin + ci0 + c4 * 4);
+      if (src >= 0) {
+        av[i] = *reinterpret_cast<const f32x4*>(in + (int64_t)src * Cin + ci0 + c4 * 4);
+        any = 1;
+      }
     }
 #pragma unroll
     for (int i = 0; i < GR; ++i) {
@@ -428,42 +441,50 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
       int rr = lin / (BNc / 4), c4 = lin % (BNc / 4);
       int64_t row = rb + rr;
       gv[i] = (f32x4)(0.f);
-      if (row < r_end) gv[i] = *reinterpret_cast<const f32x4*>(gout + row * Cout + co0 + c4 * 4);
+      if (row < r_end) {
+        int64_t grow = row_index ? row_index[row] : row;
+        gv[i] = *reinterpret_cast<const f32x4*>(gout + grow * Cout + co0 + c4 * 4);
+      }
     }
+    have = any;
   };
   if (r_begin < r_end) load_chunk(r_begin);
   for (int64_t rb = r_begin; rb < r_end; rb += BK) {
-    __syncthreads();
+    const int live = __syncthreads_or(have);     // also: every wave is done reading the previous chunk from LDS
+    if (live) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      int lin = tid + 256 * i;
-      int rr = lin / (BMc / 4), c4 = lin % (BMc / 4);
-      *reinterpret_cast<f32x4*>(&As[rr * BMc + c4 * 4]) = av[i];
-    }
-#pragma unroll
-    for (int i = 0; i < GR; ++i) {
-      int lin = tid + 256 * i;
-      int rr = lin / (BNc / 4), c4 = lin % (BNc / 4);
-      *reinterpret_cast<f32x4*>(&Gs[rr * BNc + c4 * 4]) = gv[i];
-    }
-    __syncthreads();
-    if (rb + BK < r_end) load_chunk(rb + BK);
-#pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
-      float a[TM][4], b[TN][4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i][e] = As[(8 * q + 4 * h + e) * BMc + wr * (BMc / 2) + i * 32 + r];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j][e] = Gs[(8 * q + 4 * h + e) * BNc + wc * (BNc / 2) + j * 32 + r];
+      for (int i = 0; i < AR; ++i) {
+        int lin = tid + 256 * i;
+        int rr = lin / (BMc / 4), c4 = lin % (BMc / 4);
+        *reinterpret_cast<f32x4*>(&As[rr * BMc + c4 * 4]) = av[i];
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int i = 0; i < GR; ++i) {
+        int lin = tid + 256 * i;
+        int rr = lin / (BNc / 4), c4 = lin % (BNc / 4);
+        *reinterpret_cast<f32x4*>(&Gs[rr * BNc + c4 * 4]) = gv[i];
+      }
+      __syncthreads();
+    }
+    if (rb + BK < r_end) load_chunk(rb + BK);
+    if (live) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int q = 0; q < BK / 8; ++q) {
+        float a[TM][4], b[TN][4];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[i][e] = As[(8 * q + 4 * h + e) * BMc + wr * (BMc / 2) + i * 32 + r];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[j][e] = Gs[(8 * q + 4 * h + e) * BNc + wc * (BNc / 2) + j * 32 + r];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      }
     }
   }
   float* dst = part + ((int64_t)blockIdx.x * K + k) * Cin * Cout;
@@ -565,8 +586,8 @@ int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flag
   return (int64_t)S * K * Cin * Cout * (int64_t)sizeof(float);
 }
 
-int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, float* gW, int64_t n_in, int64_t n_out, int K,
-                  int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
+int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int* row_index, float* gW, int64_t n_in,
+                  int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
   const int64_t elems = (int64_t)K * Cin * Cout;
@@ -579,6 +600,7 @@ int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, float* gW,
   if (ws_bytes < (int64_t)S * elems * (int64_t)sizeof(float)) return FC_EWS;
   float* part = (S == 1) ? gW : (float*)ws;
   bool mfma_ok = !(flags & 1) && (Cin % 64 == 0) && (Cout % 64 == 0);
+  if (row_index && (!nbr || !mfma_ok)) return FC_EINVAL;
   if (!(flags & 1) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27) {
     size_t smem = (size_t)(STEM_ROWS * K * STEM_CIN + STEM_ROWS * 64) * sizeof(float);
     k_stem_wgrad<<<(unsigned)S, 256, smem, stream>>>(in, gout, nbr, part, n_out, K, rps);
@@ -586,10 +608,10 @@ int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, float* gW,
     int bm, bn;
     wgrad_tiles(Cin, Cout, flags, &bm, &bn);
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
-    if (bm == 128 && bn == 128) k_wgrad_mfma<128, 128><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
-    else if (bm == 128) k_wgrad_mfma<128, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
-    else if (bn == 128) k_wgrad_mfma<64, 128><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
-    else k_wgrad_mfma<64, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
+    if (bm == 128 && bn == 128) k_wgrad_mfma<128, 128><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps);
+    else if (bm == 128) k_wgrad_mfma<128, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps);
+    else if (bn == 128) k_wgrad_mfma<64, 128><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps);
+    else k_wgrad_mfma<64, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps);
   } else {
     dim3 grid((unsigned)S, (unsigned)K);
     k_wgrad_fma<<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);

@@ -334,6 +334,44 @@ int fc_kernel_map_transpose(const int* nbr, int64_t n_out, int64_t n_in, int K, 
 }
 
 // ----------------------------------------------------------------------------------------------
+// occupancy mask of every output row (bit k = it has a neighbour at offset k) and the neighbour table permuted
+// into a given row order: convolution tiles / wgrad chunks made of rows with similar masks can skip the
+// offsets none of their rows has (the redundancy of the dense (K,N) table on surface-like data, ~38 %).
+__global__ void k_row_masks(const int* __restrict__ nbr, int64_t n_out, int K, int* __restrict__ masks) {
+  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  unsigned int m = 0;
+  for (int k = 0; k < K; ++k)
+    if (nbr[(int64_t)k * n_out + o] >= 0) m |= 1u << k;
+  masks[o] = (int)m;
+}
+
+int fc_nbr_row_masks(const int* nbr, int64_t n_out, int K, int* masks, hipStream_t stream) {
+  if (n_out < 0 || K < 1 || K > 31) return FC_EINVAL;
+  if (n_out == 0) return FC_OK;
+  k_row_masks<<<(unsigned)fc_cdiv(n_out, 256), 256, 0, stream>>>(nbr, n_out, K, masks);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+__global__ void k_permute_nbr(const int* __restrict__ nbr, const int* __restrict__ order, int64_t n_out,
+                              int* __restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  if (t >= n_out) return;
+  out[(int64_t)k * n_out + t] = nbr[(int64_t)k * n_out + order[t]];
+}
+
+int fc_permute_nbr(const int* nbr, const int* order, int64_t n_out, int K, int* nbr_sorted, hipStream_t stream) {
+  if (n_out < 0 || K < 1 || K > 65535) return FC_EINVAL;
+  if (n_out == 0) return FC_OK;
+  dim3 grid((unsigned)fc_cdiv(n_out, 256), K);
+  k_permute_nbr<<<grid, 256, 0, stream>>>(nbr, order, n_out, nbr_sorted);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
 // generative transposed conv k2 s2: child row 8*i + k at c_i + {0,half}^3 (x fastest) — Appendix A.4
 __global__ void k_gen_coords(const int4* __restrict__ coords, int64_t n, int half, int4* __restrict__ out) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -81,6 +81,9 @@ class GradientAverager:
             self._launch(bi)
 
     def _launch(self, bi):
+        from . import functional as Fn
+        if Fn.WGRAD_ASYNC:
+            Fn.join_wgrad_stream()            # weight gradients may still be in flight on their side stream
         flat = self._flat[bi]
         off = 0
         for p in self.buckets[bi]:

@@ -6,6 +6,29 @@ from . import _lib as L
 
 FLAGS = 0   # bit0: force the generic FMA conv kernels (parity cross-check)
 
+# Weight-gradient kernels are leaves of the backward graph: with WGRAD_ASYNC they are enqueued on a second HIP
+# stream and overlap the backward-data chain on the main stream (the many small layers of the backbone do not
+# fill 256 CUs on their own).  The main stream re-joins at the end of the backward pass (engine callback) and
+# before any gradient is consumed earlier (dist.GradientAverager).
+WGRAD_ASYNC = False
+_wg_streams = {}
+_join_queued = False
+
+
+def wgrad_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _wg_streams:
+        _wg_streams[idx] = torch.cuda.Stream(device=idx)
+    return _wg_streams[idx]
+
+
+def join_wgrad_stream():
+    """Make the current stream wait for every weight-gradient kernel enqueued so far."""
+    global _join_queued
+    _join_queued = False
+    for s in _wg_streams.values():
+        torch.cuda.current_stream(s.device).wait_stream(s)
+
 
 def _chk(*ts):
     for t in ts:
@@ -49,10 +72,14 @@ def gather_rows(src, idx):
 
 
 # ---- convolution -----------------------------------------------------------------------------------
-def _conv_fwd(x, w, nbr, out, n_in, n_out, K, Cin, Cout):
+def _mfma_shape(Cin, Cout):
+    return not (FLAGS & 1) and Cin % 32 == 0 and Cout % 64 == 0
+
+
+def _conv_fwd(x, w, nbr, out, n_in, n_out, K, Cin, Cout, out_index=None):
     wsb = L.query('fc_conv_fwd_ws_bytes', n_out, K, Cin, Cout, FLAGS)
     ws = L.workspace(wsb, x.device) if wsb else None
-    L.call('fc_conv_fwd', L.ptr(x), L.ptr(w), L.ptr(nbr), L.ptr(out), n_in, n_out, K, Cin, Cout, FLAGS,
+    L.call('fc_conv_fwd', L.ptr(x), L.ptr(w), L.ptr(nbr), L.ptr(out_index), L.ptr(out), n_in, n_out, K, Cin, Cout, FLAGS,
            L.ptr(ws), ws.numel() if ws is not None else 0, L.stream())
 
 
@@ -62,12 +89,14 @@ class _SparseConv(torch.autograd.Function):
         """feats (n_in,Cin), weight (K,Cin,Cout), kmap KernelMap or None (identity, K==1)."""
         _chk(feats, weight)
         feats = feats.contiguous()
+        # only a LEAF kernel's gradient goes straight to AccumulateGrad (no kernel reads it before the join)
+        ctx.w_leaf = weight.is_leaf and weight.is_contiguous()
         weight = weight.contiguous()
         K, Cin, Cout = weight.shape
         n_in = feats.shape[0]
         out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
-        nbr = kmap.nbr if kmap is not None else None
-        _conv_fwd(feats, weight, nbr, out, n_in, n_out, K, Cin, Cout)
+        nbr, oidx = (kmap.sorted_fwd() if _mfma_shape(Cin, Cout) else (kmap.nbr, None)) if kmap is not None else (None, None)
+        _conv_fwd(feats, weight, nbr, out, n_in, n_out, K, Cin, Cout, oidx)
         ctx.save_for_backward(feats, weight)
         ctx.kmap = kmap
         return out
@@ -85,15 +114,36 @@ class _SparseConv(torch.autograd.Function):
             wt = torch.empty((K, Cout, Cin), dtype=torch.float32, device=dev)
             L.call('fc_transpose_weight', L.ptr(weight), L.ptr(wt), K, Cin, Cout, L.stream())
             gin = torch.empty((n_in, Cin), dtype=torch.float32, device=dev)
-            nbr_t = kmap.nbr_t if kmap is not None else None
-            _conv_fwd(gout, wt, nbr_t, gin, n_out, n_in, K, Cout, Cin)
+            nbr_t, tidx = ((kmap.sorted_bwd() if _mfma_shape(Cout, Cin) else (kmap.nbr_t, None))
+                           if kmap is not None else (None, None))
+            _conv_fwd(gout, wt, nbr_t, gin, n_out, n_in, K, Cout, Cin, tidx)
         if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(weight)
-            nbr = kmap.nbr if kmap is not None else None
-            wsb = L.query('fc_conv_wgrad_ws_bytes', n_out, K, Cin, Cout, FLAGS)
-            ws = L.workspace(wsb, dev)
-            L.call('fc_conv_wgrad', L.ptr(feats), L.ptr(gout), L.ptr(nbr), L.ptr(gw), n_in, n_out, K, Cin, Cout, FLAGS,
-                   L.ptr(ws), ws.numel(), L.stream())
+            wg_mfma = not (FLAGS & 1) and Cin % 64 == 0 and Cout % 64 == 0
+            nbr, ridx = ((kmap.sorted_fwd() if wg_mfma else (kmap.nbr, None)) if kmap is not None else (None, None))
+
+            def launch():
+                g = torch.empty_like(weight)
+                wsb = L.query('fc_conv_wgrad_ws_bytes', n_out, K, Cin, Cout, FLAGS)
+                ws = L.workspace(wsb, dev)
+                L.call('fc_conv_wgrad', L.ptr(feats), L.ptr(gout), L.ptr(nbr), L.ptr(ridx), L.ptr(g), n_in, n_out, K, Cin, Cout,
+                       FLAGS, L.ptr(ws), ws.numel(), L.stream())
+                return g
+            if WGRAD_ASYNC and ctx.w_leaf:
+                global _join_queued
+                main = torch.cuda.current_stream()
+                side = wgrad_stream(dev)
+                side.wait_stream(main)                      # gout / activations are ready on the main stream
+                with torch.cuda.stream(side):
+                    gw = launch()
+                for t in (feats, gout, nbr):
+                    if t is not None:
+                        t.record_stream(side)              # keep their memory until the side stream has read it
+                gw.record_stream(main)
+                if not _join_queued:
+                    _join_queued = True
+                    torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
+            else:
+                gw = launch()
         return gin, gw, None, None
 
 

@@ -66,6 +66,7 @@ def _next_pow2(n):
     return p
 
 
+SORT_ROWS = True      # process conv rows in occupancy-mask order on sparse 27-offset maps
 _offs_cache = {}
 
 
@@ -96,6 +97,9 @@ class KernelMap:
         self.n_out = n_out
         self.K = nbr.shape[0]
         self._nbr_t = None
+        self._sorted = None
+        self._sorted_t = None
+        self.sort_rows = False          # set by CoordMap.kernel_map for sparse-ish 27-offset maps
 
     @property
     def nbr_t(self):
@@ -107,6 +111,32 @@ class KernelMap:
 
     def n_pairs(self):
         return int((self.nbr >= 0).sum().item())
+
+    # ---- occupancy-mask row order (skips empty (tile, offset) work) ------------------------
+    @staticmethod
+    def _sort_table(nbr, n_rows, K):
+        masks = torch.empty(n_rows, dtype=torch.int32, device=nbr.device)
+        L.call('fc_nbr_row_masks', L.ptr(nbr), n_rows, K, L.ptr(masks), L.stream())
+        order = torch.argsort(masks).to(torch.int32)
+        tab = torch.empty_like(nbr)
+        L.call('fc_permute_nbr', L.ptr(nbr), L.ptr(order), n_rows, K, L.ptr(tab), L.stream())
+        return _rec(tab, order)
+
+    def sorted_fwd(self):
+        """(nbr permuted into mask order, order) for the forward / weight-gradient pass, or (nbr, None)."""
+        if not self.sort_rows:
+            return self.nbr, None
+        if self._sorted is None:
+            self._sorted = self._sort_table(self.nbr, self.n_out, self.K)
+        return self._sorted
+
+    def sorted_bwd(self):
+        """the same for the transposed table of the backward-data pass."""
+        if not self.sort_rows:
+            return self.nbr_t, None
+        if self._sorted_t is None:
+            self._sorted_t = self._sort_table(self.nbr_t, self.n_in, self.K)
+        return self._sorted_t
 
 
 class CoordMap:
@@ -124,6 +154,7 @@ class CoordMap:
         self._generated = None
         self._perm = None
         self._counts = None
+        self.dense_hint = False         # True for generated children sets and their unions
 
     # ---- construction -------------------------------------------------------------------------
     @staticmethod
@@ -168,6 +199,7 @@ class CoordMap:
             L.call('fc_gen_coords', L.ptr(self.coords), self.n, half, L.ptr(out), L.stream())
             # children of a unique stride-T set are unique: 8n rows, no read-back needed
             self._generated, _, _ = CoordMap.from_coords(out, half, self.batch_size, expect_n=8 * self.n)
+            self._generated.dense_hint = True
         return self._generated
 
     def kernel_map(self, out_map, kernel_size):
@@ -182,6 +214,8 @@ class CoordMap:
                    L.ptr(offs), K, L.ptr(nbr), L.stream())
             km = KernelMap(nbr, self.n, out_map.n)
             km._out_map = out_map            # keep alive so id() stays unique
+            # generated / union sets are ~94 % dense (2x2x2 blocks): nothing to skip there
+            km.sort_rows = SORT_ROWS and K == 27 and not (self.dense_hint and out_map.dense_hint)
             self._kmaps[key] = km
         return km
 
@@ -204,6 +238,7 @@ class CoordMap:
         else:
             coords = torch.cat([self.coords, newc[:n_new]])
             cm, _, _ = CoordMap.from_coords(coords, self.stride, self.batch_size, expect_n=coords.shape[0])
+            cm.dense_hint = other.dense_hint
         self._unions[id(other)] = (cm, row_b, other)       # keep `other` alive so id() stays unique
         return cm, row_b
 

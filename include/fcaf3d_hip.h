@@ -57,6 +57,9 @@ int fc_hash_unique(const int* coords, int64_t n, int q, unsigned long long* tabl
  * out_coords[o] + offsets[k] (every ME.MinkowskiConvolution / MinkowskiMaxPooling call). */
 int fc_kernel_map(const int* out_coords, int64_t n_out, const unsigned long long* table_keys, const int* table_vals,
                   int64_t cap, const int* offsets, int K, int* nbr, hipStream_t stream);
+/* per-row occupancy masks of a neighbour table, and the table permuted into a row order (mask-sorted rows). */
+int fc_nbr_row_masks(const int* nbr, int64_t n_out, int K, int* masks, hipStream_t stream);
+int fc_permute_nbr(const int* nbr, const int* order, int64_t n_out, int K, int* nbr_sorted, hipStream_t stream);
 /* nbr_t[k][i] = o  iff  nbr[k][o] == i  (the gather table of the backward-data pass). */
 int fc_kernel_map_transpose(const int* nbr, int64_t n_out, int64_t n_in, int K, int* nbr_t, hipStream_t stream);
 
@@ -85,15 +88,17 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
  * nbr == NULL (K = 1, identity) the dense GEMMs of MinkowskiGenerativeConvolutionTranspose (:60-66)
  * and of the 1x1 head convolutions (:83-85, :257-263).  out[o] = sum_k in[nbr[k][o]] @ W[k].
  * flags bit0: force the generic FMA kernel instead of the MFMA kernel.  Layers with too few rows to fill
- * the chip are split over kernel offsets into `ws` and summed in a fixed order (deterministic). */
+ * the chip are split over kernel offsets into `ws` and summed in a fixed order (deterministic).
+ * out_index (nullable): `nbr` is a table permuted into occupancy-mask order (fc_permute_nbr) and tile row t
+ * belongs to output row out_index[t] — tiles of similar rows skip the offsets none of them has. */
 int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);
-int fc_conv_fwd(const float* in, const float* W, const int* nbr, float* out, int64_t n_in, int64_t n_out, int K, int Cin,
-                int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);
+int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
+                int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* backward-weights: gW[k] = sum_o in[nbr[k][o]]^T (x) gout[o]; deterministic two-level reduction. */
 int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);
-int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, float* gW, int64_t n_in, int64_t n_out, int K,
-                  int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);
+int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int* row_index, float* gW, int64_t n_in,
+                  int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* (K,Cin,Cout) -> (K,Cout,Cin) */
 int fc_transpose_weight(const float* W, float* Wt, int K, int Cin, int Cout, hipStream_t stream);

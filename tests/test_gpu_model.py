@@ -108,14 +108,17 @@ def test_async_map_stream_is_bitwise_equivalent():
     model = model.to(dev).train()
     pts, gts, labs = _scenes([41, 42, 43], n_points=30000)
     outs = []
+    import fcaf3d_amd.functional as Fn
     for mode in (False, True, True):
         model.async_maps = mode
+        Fn.WGRAD_ASYNC = mode                # weight gradients on their own stream as well (bench mode)
         model.zero_grad()
         losses = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
         sum(losses.values()).backward()
         outs.append(([float(v) for v in losses.values()],
                      model.backbone.layer1[0].conv1.kernel.grad.clone(), model.neck_with_head.reg_conv.kernel.grad.clone()))
     torch.cuda.synchronize()
+    Fn.WGRAD_ASYNC = False
     for o in outs[1:]:
         assert o[0] == outs[0][0]
         assert torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])

@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--wgrad', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--unsorted', action='store_true', help='use the plain neighbour table (no occupancy-mask row order)')
     ap.add_argument('--flags', type=int, default=0, help='extra flags for the default run (bit16: BK=32, bit17: BK=64)')
     ap.add_argument('--default-only', action='store_true')
     a = ap.parse_args()
@@ -71,6 +72,8 @@ def main():
         if a.only and a.only not in name:
             continue
         K = km.K
+        km.sort_rows = not a.unsorted
+        nbr_f, oidx = km.sorted_fwd()
         pairs = km.n_pairs()
         xin = torch.randn(km.n_in, Cin, device=dev)
         w = torch.randn(K, Cin, Cout, device=dev)
@@ -91,10 +94,10 @@ def main():
                             if a.wgrad:
                                 wsb = L.query('fc_conv_wgrad_ws_bytes', km.n_out, K, Cin, Cout, fl)
                                 ws = L.workspace(wsb, dev)
-                                t = timeit(lambda: L.call('fc_conv_wgrad', L.ptr(xin), L.ptr(gout), L.ptr(km.nbr), L.ptr(gw),
+                                t = timeit(lambda: L.call('fc_conv_wgrad', L.ptr(xin), L.ptr(gout), L.ptr(nbr_f), L.ptr(oidx), L.ptr(gw),
                                                           km.n_in, km.n_out, K, Cin, Cout, fl, L.ptr(ws), ws.numel(), L.stream()))
                             else:
-                                t = timeit(lambda: Fn._conv_fwd(xin, w, km.nbr, out, km.n_in, km.n_out, K, Cin, Cout))
+                                t = timeit(lambda: Fn._conv_fwd(xin, w, nbr_f, out, km.n_in, km.n_out, K, Cin, Cout, oidx))
                         finally:
                             Fn.FLAGS = 0
                         res.append((t, bm * 64, bn * 64, S or Sw))
@@ -102,10 +105,10 @@ def main():
         if a.wgrad:
             wsb = L.query('fc_conv_wgrad_ws_bytes', km.n_out, K, Cin, Cout, 0)
             ws = L.workspace(wsb, dev)
-            t0 = timeit(lambda: L.call('fc_conv_wgrad', L.ptr(xin), L.ptr(gout), L.ptr(km.nbr), L.ptr(gw), km.n_in, km.n_out,
+            t0 = timeit(lambda: L.call('fc_conv_wgrad', L.ptr(xin), L.ptr(gout), L.ptr(nbr_f), L.ptr(oidx), L.ptr(gw), km.n_in, km.n_out,
                                        K, Cin, Cout, 0, L.ptr(ws), ws.numel(), L.stream()))
         else:
-            t0 = timeit(lambda: Fn._conv_fwd(xin, w, km.nbr, out, km.n_in, km.n_out, K, Cin, Cout))
+            t0 = timeit(lambda: Fn._conv_fwd(xin, w, nbr_f, out, km.n_in, km.n_out, K, Cin, Cout, oidx))
         if not res:
             res = [(t0, 0, 0, 0)]
         res.sort()
