@@ -38,7 +38,7 @@ def parse():
     ap.add_argument('--cpu-points', type=int, default=0, help='points of the cpu_baseline sample scene (0 = same as workload)')
     ap.add_argument('--no-instrument', action='store_true', help='skip per-kernel HIP events (roofline = null)')
     ap.add_argument('--spatial-sort', action='store_true', help='Z-order sort of the collated points (measured: no gain, r1)')
-    ap.add_argument('--no-wgrad-overlap', action='store_true', help='keep weight-gradient kernels on the main stream')
+    ap.add_argument('--wgrad-overlap', action='store_true', help='weight-gradient kernels on a second stream (measured r1: no gain, the GPU is already full)')
     ap.add_argument('--breakdown', action='store_true', help='diagnostic: HIP-event time per C-ABI entry point and per conv shape (stderr)')
     return ap.parse_args()
 
@@ -232,7 +232,7 @@ def main():
     model.async_maps = True           # scenes are resident in HBM: coordinate work may run on its side stream
     model.spatial_sort = args.spatial_sort
     import fcaf3d_amd.functional as Fn
-    Fn.WGRAD_ASYNC = not args.no_wgrad_overlap
+    Fn.WGRAD_ASYNC = args.wgrad_overlap
     if world > 1:
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)

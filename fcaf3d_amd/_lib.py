@@ -67,21 +67,42 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    """raw hipStream_t of torch's current stream on the current device (fast path: no Stream object)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+_fns = {}
 
 
 def call(name, *args):
     """Invoke an `int`-returning entry point; raises on a non-zero status."""
-    rc = getattr(lib(), name)(*args)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(lib(), name)
+    rc = fn(*args)
     if rc != 0:
         kind = 'invalid argument' if rc == -1 else 'workspace too small' if rc == -2 else f'hipError {rc}'
         raise RuntimeError(f'{name} failed: {kind}')
 
 
+_query_cache = {}
+
+
 def query(name, *args):
-    """Invoke an `int64_t`-returning size query."""
-    return int(getattr(lib(), name)(*args))
+    """Invoke an `int64_t`-returning size query (pure functions of their arguments: memoised)."""
+    key = (name,) + args
+    v = _query_cache.get(key)
+    if v is None:
+        if len(_query_cache) > 65536:
+            _query_cache.clear()
+        v = _query_cache[key] = int(getattr(lib(), name)(*args))
+    return v
 
 
 _ws_cache = {}

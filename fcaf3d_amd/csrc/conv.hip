@@ -416,12 +416,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // register-prefetch pipeline: the gathers + gout rows of chunk t+1 are in flight while chunk t is multiplied.
-  // A chunk of 32 rows none of which has a neighbour at this offset is skipped (frequent once the rows are
-  // processed in occupancy-mask order: row_index != NULL, nbr already permuted).
+  // (Measured r1: processing wgrad rows in occupancy-mask order with per-chunk skipping LOSES 15-35 % — gout rows stop
+  //  being sequential and the skip test costs a barrier per chunk — so wgrad always walks rows in natural order;
+  //  row_index is honoured for completeness only.)
   f32x4 av[AR], gv[GR];
-  int have = 0;
   auto load_chunk = [&](int64_t rb) {
-    int any = 0;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       int lin = tid + 256 * i;
@@ -430,10 +429,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
       int src = -1;
       if (row < r_end) src = nbr ? nbr[(int64_t)k * n_out + row] : (int)row;
       av[i] = (f32x4)(0.f);
-      if (src >= 0) {
-        av[i] = *reinterpret_cast<const f32x4*>(in + (int64_t)src * Cin + ci0 + c4 * 4);
-        any = 1;
-      }
+      if (src >= 0) av[i] = *reinterpret_cast<const f32x4*>(in + (int64_t)src * Cin + ci0 + c4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < GR; ++i) {
@@ -446,45 +442,40 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
         gv[i] = *reinterpret_cast<const f32x4*>(gout + grow * Cout + co0 + c4 * 4);
       }
     }
-    have = any;
   };
   if (r_begin < r_end) load_chunk(r_begin);
   for (int64_t rb = r_begin; rb < r_end; rb += BK) {
-    const int live = __syncthreads_or(have);     // also: every wave is done reading the previous chunk from LDS
-    if (live) {
+    __syncthreads();
 #pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        int lin = tid + 256 * i;
-        int rr = lin / (BMc / 4), c4 = lin % (BMc / 4);
-        *reinterpret_cast<f32x4*>(&As[rr * BMc + c4 * 4]) = av[i];
-      }
-#pragma unroll
-      for (int i = 0; i < GR; ++i) {
-        int lin = tid + 256 * i;
-        int rr = lin / (BNc / 4), c4 = lin % (BNc / 4);
-        *reinterpret_cast<f32x4*>(&Gs[rr * BNc + c4 * 4]) = gv[i];
-      }
-      __syncthreads();
+    for (int i = 0; i < AR; ++i) {
+      int lin = tid + 256 * i;
+      int rr = lin / (BMc / 4), c4 = lin % (BMc / 4);
+      *reinterpret_cast<f32x4*>(&As[rr * BMc + c4 * 4]) = av[i];
     }
+#pragma unroll
+    for (int i = 0; i < GR; ++i) {
+      int lin = tid + 256 * i;
+      int rr = lin / (BNc / 4), c4 = lin % (BNc / 4);
+      *reinterpret_cast<f32x4*>(&Gs[rr * BNc + c4 * 4]) = gv[i];
+    }
+    __syncthreads();
     if (rb + BK < r_end) load_chunk(rb + BK);
-    if (live) {
 #pragma unroll
-      for (int q = 0; q < BK / 8; ++q) {
-        float a[TM][4], b[TN][4];
+    for (int q = 0; q < BK / 8; ++q) {
+      float a[TM][4], b[TN][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < 4; ++e) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a[i][e] = As[(8 * q + 4 * h + e) * BMc + wr * (BMc / 2) + i * 32 + r];
+        for (int i = 0; i < TM; ++i) a[i][e] = As[(8 * q + 4 * h + e) * BMc + wr * (BMc / 2) + i * 32 + r];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) b[j][e] = Gs[(8 * q + 4 * h + e) * BNc + wc * (BNc / 2) + j * 32 + r];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) b[j][e] = Gs[(8 * q + 4 * h + e) * BNc + wc * (BNc / 2) + j * 32 + r];
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
     }
   }
   float* dst = part + ((int64_t)blockIdx.x * K + k) * Cin * Cout;

@@ -118,8 +118,7 @@ class _SparseConv(torch.autograd.Function):
                            if kmap is not None else (None, None))
             _conv_fwd(gout, wt, nbr_t, gin, n_out, n_in, K, Cout, Cin, tidx)
         if ctx.needs_input_grad[1]:
-            wg_mfma = not (FLAGS & 1) and Cin % 64 == 0 and Cout % 64 == 0
-            nbr, ridx = ((kmap.sorted_fwd() if wg_mfma else (kmap.nbr, None)) if kmap is not None else (None, None))
+            nbr, ridx = (kmap.nbr if kmap is not None else None), None      # wgrad walks rows in natural order (see conv.hip)
 
             def launch():
                 g = torch.empty_like(weight)

@@ -215,7 +215,9 @@ class CoordMap:
             km = KernelMap(nbr, self.n, out_map.n)
             km._out_map = out_map            # keep alive so id() stays unique
             # generated / union sets are ~94 % dense (2x2x2 blocks): nothing to skip there
-            km.sort_rows = SORT_ROWS and K == 27 and not (self.dense_hint and out_map.dense_hint)
+            # ... and below ~8k rows the masks do not group well enough to pay for themselves (tools/convbench.py)
+            km.sort_rows = (SORT_ROWS and K == 27 and out_map.n >= 8192
+                            and not (self.dense_hint and out_map.dense_hint))
             self._kmaps[key] = km
         return km
 

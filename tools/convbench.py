@@ -74,6 +74,8 @@ def main():
         K = km.K
         km.sort_rows = not a.unsorted
         nbr_f, oidx = km.sorted_fwd()
+        if a.wgrad:
+            nbr_f, oidx = km.nbr, None
         pairs = km.n_pairs()
         xin = torch.randn(km.n_in, Cin, device=dev)
         w = torch.randn(K, Cin, Cout, device=dev)
