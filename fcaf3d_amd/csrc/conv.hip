@@ -314,7 +314,8 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   }
   // tuning overrides: flags[4:5] BM (1=64, 2=128), flags[6:7] BN (1=64, 2=128), flags[8:15] S
   int fbm = (flags >> 4) & 3, fbn = (flags >> 6) & 3, fs = (flags >> 8) & 255;
-  if (fbm) *bm = fbm == 1 ? 64 : 128;
+  if (fbm) *bm = fbm == 1 ? 64 : (fbm == 2 ? 128 : 256);
+  if (*bm == 256 && *bn != 64) *bm = 128;       // the 256-row tile exists for 64-wide outputs only
   if (fbn && (Cout % (fbn == 1 ? 64 : 128) == 0)) *bn = fbn == 1 ? 64 : 128;
   if (fbm || fbn) {
     const int64_t t2 = fc_cdiv(n_out, *bm) * (Cout / *bn);
@@ -363,7 +364,8 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_
   if (S > 1 && ws_bytes < (int64_t)S * n_out * Cout * (int64_t)sizeof(float)) return FC_EWS;
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
-  if (bm == 128 && bn == 128 && bk == 64) k_conv_mfma<128, 128, 64><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
+  if (bm == 256) k_conv_mfma<256, 64, 32><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
+  else if (bm == 128 && bn == 128 && bk == 64) k_conv_mfma<128, 128, 64><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
   else if (bm == 128 && bk == 64) k_conv_mfma<128, 64, 64><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
   else if (bm == 128 && bn == 128) k_conv_mfma<128, 128, 32><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
   else if (bm == 128) k_conv_mfma<128, 64, 32><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);

@@ -325,6 +325,177 @@ __global__ void k_scatter_rows_add(const float* __restrict__ src, const int* __r
   if (i >= 0) dst[(int64_t)i * C + (t % C)] += src[t];
 }
 
+// ================================================================================================
+// Small-tensor BatchNorm (n*C <= 4 M elements: backbone levels 2-4, coarse neck levels): TWO launches per
+// direction instead of six / three.  Launch 1 writes per-block partial sums; launch 2 lets every block
+// re-reduce the (<= 64) partials in its prologue (a few hundred KB out of L2) and apply straight away.
+// Forward statistics in one pass: sums of (x - s) and (x - s)^2 with the shift s = x[0][c] (a sample of the
+// column, so |mean - s| ~ sigma and E[(x-s)^2] - E[x-s]^2 loses no digits).
+#define BN1_MAXB 64
+
+// part [nb][2][C]
+__global__ void k_bn1_partial(const float* __restrict__ x, int64_t n, int C, int64_t rpb, float* __restrict__ part) {
+  extern __shared__ float sm[];               // [rl][2][C]
+  const int c4n = C / 4;
+  const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+  const int nrl = blockDim.x / c4n;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  int64_t r1 = r0 + rpb;
+  if (r1 > n) r1 = n;
+  const float4 sh = *reinterpret_cast<const float4*>(x + cl * 4);
+  float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+  for (int64_t r = r0 + rl; r < r1; r += nrl) {
+    float4 v = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
+    v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; v.w -= sh.w;
+    a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+    a2.x += v.x * v.x; a2.y += v.y * v.y; a2.z += v.z * v.z; a2.w += v.w * v.w;
+  }
+  *reinterpret_cast<float4*>(&sm[(rl * 2 + 0) * C + cl * 4]) = a1;
+  *reinterpret_cast<float4*>(&sm[(rl * 2 + 1) * C + cl * 4]) = a2;
+  __syncthreads();
+  if (rl == 0) {
+    float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+    for (int j = 0; j < nrl; ++j) {
+      float4 u = *reinterpret_cast<const float4*>(&sm[(j * 2 + 0) * C + cl * 4]);
+      float4 w = *reinterpret_cast<const float4*>(&sm[(j * 2 + 1) * C + cl * 4]);
+      t1.x += u.x; t1.y += u.y; t1.z += u.z; t1.w += u.w;
+      t2.x += w.x; t2.y += w.y; t2.z += w.z; t2.w += w.w;
+    }
+    float* dst = part + ((int64_t)blockIdx.x * 2) * C;
+    *reinterpret_cast<float4*>(dst + cl * 4) = t1;
+    *reinterpret_cast<float4*>(dst + C + cl * 4) = t2;
+  }
+}
+
+// every block: reduce part[nb][2][C] -> (S1,S2) per channel (fixed order), then apply to its rows
+__device__ static inline void bn1_reduce_parts(const float* __restrict__ part, int nb, int C, int cl, int rl, int nrl,
+                                               float* sm /*[nrl][2][C]*/, float4* s1, float4* s2) {
+  float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+  for (int b = rl; b < nb; b += nrl) {
+    const float* src = part + ((int64_t)b * 2) * C;
+    float4 u = *reinterpret_cast<const float4*>(src + cl * 4);
+    float4 w = *reinterpret_cast<const float4*>(src + C + cl * 4);
+    a1.x += u.x; a1.y += u.y; a1.z += u.z; a1.w += u.w;
+    a2.x += w.x; a2.y += w.y; a2.z += w.z; a2.w += w.w;
+  }
+  *reinterpret_cast<float4*>(&sm[(rl * 2 + 0) * C + cl * 4]) = a1;
+  *reinterpret_cast<float4*>(&sm[(rl * 2 + 1) * C + cl * 4]) = a2;
+  __syncthreads();
+  float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+  for (int j = 0; j < nrl; ++j) {
+    float4 u = *reinterpret_cast<const float4*>(&sm[(j * 2 + 0) * C + cl * 4]);
+    float4 w = *reinterpret_cast<const float4*>(&sm[(j * 2 + 1) * C + cl * 4]);
+    t1.x += u.x; t1.y += u.y; t1.z += u.z; t1.w += u.w;
+    t2.x += w.x; t2.y += w.y; t2.z += w.z; t2.w += w.w;
+  }
+  *s1 = t1; *s2 = t2;
+}
+
+__global__ void k_bn1_apply(const float* __restrict__ x, int64_t n, int C, int64_t rpb, const float* __restrict__ part, int nb,
+                            float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                            const float* __restrict__ residual, int act, float momentum, float* __restrict__ y,
+                            float* __restrict__ mean_out, float* __restrict__ var_out, float* __restrict__ cnt_out,
+                            float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt) {
+  extern __shared__ float sm[];
+  const int c4n = C / 4;
+  const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+  const int nrl = blockDim.x / c4n;
+  float4 s1, s2;
+  bn1_reduce_parts(part, nb, C, cl, rl, nrl, sm, &s1, &s2);
+  const float4 sh = *reinterpret_cast<const float4*>(x + cl * 4);
+  const float inv_n = 1.f / (float)n;
+  float d[4] = {s1.x * inv_n, s1.y * inv_n, s1.z * inv_n, s1.w * inv_n};
+  float q[4] = {s2.x * inv_n, s2.y * inv_n, s2.z * inv_n, s2.w * inv_n};
+  float shv[4] = {sh.x, sh.y, sh.z, sh.w};
+  float mu[4], va[4], is[4], g[4], bt[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mu[j] = shv[j] + d[j];
+    va[j] = fmaxf(q[j] - d[j] * d[j], 0.f);
+    is[j] = 1.f / sqrtf(va[j] + eps);
+    g[j] = gamma ? gamma[cl * 4 + j] : 1.f;
+    bt[j] = beta ? beta[cl * 4 + j] : 0.f;
+  }
+  if (blockIdx.x == 0 && rl == 0) {
+    *reinterpret_cast<float4*>(mean_out + cl * 4) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+    *reinterpret_cast<float4*>(var_out + cl * 4) = make_float4(va[0], va[1], va[2], va[3]);
+    if (cl == 0) { cnt_out[0] = (float)n; if (nbt) nbt[0] += 1; }
+    if (rmean) {
+      float unbias = (float)n / fmaxf((float)n - 1.f, 1.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        rmean[cl * 4 + j] = (1.f - momentum) * rmean[cl * 4 + j] + momentum * mu[j];
+        rvar[cl * 4 + j] = (1.f - momentum) * rvar[cl * 4 + j] + momentum * va[j] * unbias;
+      }
+    }
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  int64_t r1 = r0 + rpb;
+  if (r1 > n) r1 = n;
+  for (int64_t r = r0 + rl; r < r1; r += nrl) {
+    float v[4], o[4];
+    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (v[j] - mu[j]) * is[j] * g[j] + bt[j];
+    if (residual) {
+      float rs[4];
+      *reinterpret_cast<float4*>(rs) = *reinterpret_cast<const float4*>(residual + r * C + cl * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] += rs[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = act_fwd(o[j], act);
+    *reinterpret_cast<float4*>(y + r * C + cl * 4) = *reinterpret_cast<float4*>(o);
+  }
+}
+
+// backward launch 2: reduce the partials of k_norm_bwd_partial (nseg = 1, layout [nb][1][2][C]) and apply
+__global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
+                                int64_t n, int C, int64_t rpb, const float* __restrict__ part, int nb,
+                                const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                const float* __restrict__ gamma, int act, float* __restrict__ gx, float* __restrict__ gres,
+                                float* __restrict__ sums /*[2][C]*/) {
+  extern __shared__ float sm[];
+  const int c4n = C / 4;
+  const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+  const int nrl = blockDim.x / c4n;
+  float4 t1, t2;
+  bn1_reduce_parts(part, nb, C, cl, rl, nrl, sm, &t1, &t2);
+  if (blockIdx.x == 0 && rl == 0) {
+    *reinterpret_cast<float4*>(sums + cl * 4) = t1;
+    *reinterpret_cast<float4*>(sums + C + cl * 4) = t2;
+  }
+  const float inv_n = 1.f / (float)n;
+  float s1[4] = {t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n};
+  float s2[4] = {t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n};
+  float mu[4], is[4], g[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mu[j] = mean[cl * 4 + j];
+    is[j] = 1.f / sqrtf(var[cl * 4 + j] + eps);
+    g[j] = gamma ? gamma[cl * 4 + j] : 1.f;
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  int64_t r1 = r0 + rpb;
+  if (r1 > n) r1 = n;
+  for (int64_t r = r0 + rl; r < r1; r += nrl) {
+    float xv[4], gv[4], yv[4], o[4], gr[4];
+    *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
+    *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(gy + r * C + cl * 4);
+    if (act) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y + r * C + cl * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gg = gv[j];
+      if (act) gg *= act_bwd_from_y(yv[j], act);
+      float xh = (xv[j] - mu[j]) * is[j];
+      gr[j] = gg;
+      o[j] = g[j] * is[j] * (gg - s1[j] - xh * s2[j]);
+    }
+    *reinterpret_cast<float4*>(gx + r * C + cl * 4) = *reinterpret_cast<float4*>(o);
+    if (gres) *reinterpret_cast<float4*>(gres + r * C + cl * 4) = *reinterpret_cast<float4*>(gr);
+  }
+}
+
 extern "C" {
 
 static int stats_geometry(int C, int* threads, size_t* smem_fwd, size_t* smem_bwd) {
@@ -421,6 +592,57 @@ int fc_bn_running_update(const float* mean, const float* var, const float* cnt, 
   if (C < 1) return FC_EINVAL;
   k_bn_running<<<(unsigned)fc_cdiv(C, 256), 256, 0, stream>>>(mean, var, cnt, momentum, C, running_mean, running_var,
                                                              num_batches_tracked);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+// ---- small-tensor BatchNorm, two launches per direction --------------------------------------------------
+static void bn1_plan(int64_t n, int64_t* nb, int64_t* rpb) {
+  int64_t m = n > 0 ? n : 1;
+  int64_t g = fc_cdiv(m, 64);
+  if (g > BN1_MAXB) g = BN1_MAXB;
+  *rpb = fc_cdiv(m, g);
+  *nb = fc_cdiv(m, *rpb);
+}
+
+int64_t fc_bn_small_ws_bytes(int C) { return (int64_t)BN1_MAXB * 2 * C * (int64_t)sizeof(float); }
+
+// training-mode BatchNorm forward for one segment: statistics + running-buffer update + normalise/affine/residual/act.
+// mean/var (C) and cnt (1) are written for the backward pass; running_* / num_batches_tracked may be NULL.
+int fc_bn_act_train_fwd(const float* x, int64_t n, int C, float eps, const float* gamma, const float* beta,
+                        const float* residual, int act, float momentum, float* y, float* mean, float* var, float* cnt,
+                        float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
+                        int64_t ws_bytes, hipStream_t stream) {
+  if (n < 1 || act < 0 || act > 2) return FC_EINVAL;
+  int threads; size_t sf, sb;
+  if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
+  if (ws_bytes < fc_bn_small_ws_bytes(C)) return FC_EWS;
+  int64_t nb, rpb;
+  bn1_plan(n, &nb, &rpb);
+  float* part = (float*)ws;
+  k_bn1_partial<<<(unsigned)nb, threads, sb, stream>>>(x, n, C, rpb, part);
+  FC_CHECK_LAUNCH();
+  k_bn1_apply<<<(unsigned)nb, threads, sb, stream>>>(x, n, C, rpb, part, (int)nb, eps, gamma, beta, residual, act, momentum, y,
+                                                    mean, var, cnt, running_mean, running_var, num_batches_tracked);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+// its backward: sums (2,C) = [d beta, d gamma]
+int fc_bn_act_train_bwd(const float* x, const float* y, const float* gy, int64_t n, int C, const float* mean,
+                        const float* var, float eps, const float* gamma, int act, float* gx, float* gres, float* sums,
+                        void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (n < 1 || act < 0 || act > 2) return FC_EINVAL;
+  int threads; size_t sf, sb;
+  if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
+  if (ws_bytes < fc_bn_small_ws_bytes(C)) return FC_EWS;
+  int64_t nb, rpb;
+  bn1_plan(n, &nb, &rpb);
+  float* part = (float*)ws;
+  k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, 0, n, C, 1, mean, var, eps, act, rpb, part);
+  FC_CHECK_LAUNCH();
+  k_bn1_bwd_apply<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, n, C, rpb, part, (int)nb, mean, var, eps, gamma, act, gx, gres,
+                                                        sums);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }

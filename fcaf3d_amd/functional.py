@@ -222,6 +222,63 @@ class _NormAct(torch.autograd.Function):
         return gx, ggamma, gbeta, gres, None, None, None, None, None, None, None, None
 
 
+BN_SMALL_ELEMS = 4 * 1024 * 1024     # feature matrices up to this size take the two-launch BatchNorm path
+
+
+class _BNTrainSmall(torch.autograd.Function):
+    """Training-mode BatchNorm (+act, +residual) of a small (N,C) matrix: 2 launches forward, 2 backward
+    (statistics, running-buffer update and apply fused; csrc/norm.hip k_bn1_*)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, eps, act, momentum, rmean, rvar, nbt):
+        _chk(x, gamma, beta, residual)
+        x = x.contiguous()
+        n, C = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        stats = torch.empty((2, C), dtype=torch.float32, device=dev)       # [mean, var]
+        cnt = torch.empty(1, dtype=torch.float32, device=dev)
+        res = residual.contiguous() if residual is not None else None
+        g = gamma.reshape(-1).contiguous()
+        b = beta.reshape(-1).contiguous()
+        ws = L.workspace(L.query('fc_bn_small_ws_bytes', C), dev)
+        L.call('fc_bn_act_train_fwd', L.ptr(x), n, C, float(eps), L.ptr(g), L.ptr(b), L.ptr(res), act, float(momentum),
+               L.ptr(y), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(cnt), L.ptr(rmean), L.ptr(rvar), L.ptr(nbt), L.ptr(ws),
+               ws.numel(), L.stream())
+        ctx.save_for_backward(x, y, g, stats)
+        ctx.cfg = (float(eps), act, residual is not None, gamma.shape, beta.shape)
+        ctx.mark_non_differentiable(stats, cnt)
+        return y, stats, cnt
+
+    @staticmethod
+    def backward(ctx, gy, _gs, _gc):
+        x, y, g, stats = ctx.saved_tensors
+        eps, act, has_res, gshape, bshape = ctx.cfg
+        gy = gy.contiguous()
+        n, C = x.shape
+        dev = x.device
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if has_res else None
+        sums = torch.empty((2, C), dtype=torch.float32, device=dev)
+        ws = L.workspace(L.query('fc_bn_small_ws_bytes', C), dev)
+        L.call('fc_bn_act_train_bwd', L.ptr(x), L.ptr(y), L.ptr(gy), n, C, L.ptr(stats[0]), L.ptr(stats[1]), eps, L.ptr(g),
+               act, L.ptr(gx), L.ptr(gres), L.ptr(sums), L.ptr(ws), ws.numel(), L.stream())
+        return gx, sums[1].reshape(gshape), sums[0].reshape(bshape), gres, None, None, None, None, None, None
+
+
+def bn_train(x, gamma, beta, residual, eps, act, momentum, rmean, rvar, nbt):
+    """BatchNorm in training mode with buffer update; picks the two-launch path for small matrices.
+    Returns y (and leaves mean/var/count of the batch on the device for inspection)."""
+    n, C = x.shape
+    if 0 < n * C <= BN_SMALL_ELEMS and gamma is not None and beta is not None:
+        y, stats, cnt = _BNTrainSmall.apply(x, gamma, beta, residual, eps, ACT[act], momentum, rmean, rvar, nbt)
+        return y, (stats[0:1], stats[1:2], cnt)
+    y, (mean, var, cnt) = norm_act(x, gamma, beta, residual=residual, eps=eps, act=act)
+    L.call('fc_bn_running_update', L.ptr(mean), L.ptr(var), L.ptr(cnt), float(momentum), C, L.ptr(rmean), L.ptr(rvar),
+           L.ptr(nbt), L.stream())
+    return y, (mean, var, cnt)
+
+
 def norm_act(x, gamma, beta, residual=None, seg=None, nseg=1, eps=1e-5, act=None, stats=None):
     """stats=None: batch statistics (training); stats=(mean,var,cnt): fixed statistics."""
     const = stats is not None

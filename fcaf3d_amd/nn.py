@@ -103,9 +103,8 @@ class MinkowskiBatchNorm(nn.Module):
     def forward(self, x, act=None, residual=None):
         bn = self.bn
         if self.training:
-            y, (mean, var, cnt) = Fn.norm_act(x.F, bn.weight, bn.bias, residual=residual, eps=bn.eps, act=act)
-            L.call('fc_bn_running_update', L.ptr(mean), L.ptr(var), L.ptr(cnt), float(bn.momentum), mean.shape[1],
-                   L.ptr(bn.running_mean), L.ptr(bn.running_var), L.ptr(bn.num_batches_tracked), L.stream())
+            y, _ = Fn.bn_train(x.F, bn.weight, bn.bias, residual, bn.eps, act, bn.momentum, bn.running_mean,
+                               bn.running_var, bn.num_batches_tracked)
         else:
             C = x.F.shape[1]
             stats = (bn.running_mean.reshape(1, C).contiguous(), bn.running_var.reshape(1, C).contiguous(),

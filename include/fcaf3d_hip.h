@@ -128,6 +128,17 @@ int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* 
                     int nseg, const float* mean, const float* var, const float* cnt, float eps, const float* gamma,
                     int act, float* gx, float* gres, float* sums, void* ws, int64_t ws_bytes, hipStream_t stream);
 
+/* Training-mode ME.MinkowskiBatchNorm (+ fused ReLU/ELU / residual) for small feature matrices in TWO launches per
+ * direction: batch statistics, running-buffer update (nn.BatchNorm1d momentum / unbiased variance) and apply. */
+int64_t fc_bn_small_ws_bytes(int C);
+int fc_bn_act_train_fwd(const float* x, int64_t n, int C, float eps, const float* gamma, const float* beta,
+                        const float* residual, int act, float momentum, float* y, float* mean, float* var, float* cnt,
+                        float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
+                        int64_t ws_bytes, hipStream_t stream);
+int fc_bn_act_train_bwd(const float* x, const float* y, const float* gy, int64_t n, int C, const float* mean,
+                        const float* var, float eps, const float* gamma, int act, float* gx, float* gres, float* sums,
+                        void* ws, int64_t ws_bytes, hipStream_t stream);
+
 /* ME.MinkowskiMaxPooling(k=2,s=2) — me_resnet.py:24. */
 int fc_maxpool_fwd(const float* in, const int* nbr, int64_t n_out, int K, int C, float* out, int* argrow,
                    hipStream_t stream);

@@ -269,3 +269,39 @@ def test_no_cpu_fallback():
     import fcaf3d_amd.functional as Fn
     with pytest.raises(RuntimeError):
         Fn.sparse_conv(torch.zeros(4, 64), torch.zeros(1, 64, 64), None, 4)
+
+
+@pytest.mark.parametrize('n,C,act,res', [(5003, 64, 'relu', True), (853, 512, 'elu', False), (70, 128, None, False),
+                                         (40000, 256, 'relu', False)])     # last one: > 4M elements -> six-launch path
+def test_bn_train_fused_paths(n, C, act, res):
+    """Training-mode BatchNorm (two-launch small path and the general path): output, gradients and the
+    nn.BatchNorm1d buffer update against torch on the CPU."""
+    import fcaf3d_amd.functional as Fn
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, C, generator=g) * 3 + 1.5
+    gamma = torch.rand(C, generator=g) + 0.5; beta = torch.randn(C, generator=g)
+    r = torch.randn(n, C, generator=g) if res else None
+    go = torch.randn(n, C, generator=g)
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    xr = x.clone().requires_grad_(True); rr = r.clone().requires_grad_(True) if res else None
+    y = bn(xr)
+    if res:
+        y = y + rr
+    y = {'relu': torch.relu, 'elu': torch.nn.functional.elu, None: lambda t: t}[act](y)
+    grads_r = torch.autograd.grad(y, [xr, bn.weight, bn.bias] + ([rr] if res else []), go)
+    xg = x.to(dev).requires_grad_(True); gg = gamma.to(dev).requires_grad_(True); bg = beta.to(dev).requires_grad_(True)
+    rg = r.to(dev).requires_grad_(True) if res else None
+    rmean = torch.zeros(C, device=dev); rvar = torch.ones(C, device=dev); nbt = torch.zeros((), dtype=torch.long, device=dev)
+    yg, (mean, var, cnt) = Fn.bn_train(xg, gg, bg, rg, 1e-5, act, 0.1, rmean, rvar, nbt)
+    grads_g = torch.autograd.grad(yg, [xg, gg, bg] + ([rg] if res else []), go.to(dev))
+    _close(yg, y, what='bn fwd')
+    for a, b, nm in zip(grads_g, grads_r, ['gx', 'ggamma', 'gbeta', 'gres']):
+        _close(a, b, tol=2e-4, what=f'bn {nm} n={n} C={C}')
+    _close(rmean, bn.running_mean, tol=1e-5, what='running_mean')
+    _close(rvar, bn.running_var, tol=1e-5, what='running_var')
+    assert int(nbt) == 1 and float(cnt[0]) == n
+    _close(mean[0], x.mean(0), tol=1e-5, what='batch mean')
+    _close(var[0], x.var(0, unbiased=False), tol=1e-5, what='batch var')

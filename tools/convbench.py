@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--wgrad', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--bm256', action='store_true')
     ap.add_argument('--unsorted', action='store_true', help='use the plain neighbour table (no occupancy-mask row order)')
     ap.add_argument('--flags', type=int, default=0, help='extra flags for the default run (bit16: BK=32, bit17: BK=64)')
     ap.add_argument('--default-only', action='store_true')
@@ -84,7 +85,7 @@ def main():
         gw = torch.empty_like(w)
         gflop = 2.0 * pairs * Cin * Cout / 1e9
         res = []
-        for bm in (() if a.default_only else (1, 2)):
+        for bm in (() if a.default_only else ((3,) if a.bm256 else (1, 2))):
             for bn in ((1, 2) if Cout % 128 == 0 else (1,)):
                 for S in ((0,) if a.wgrad else (0, 1, 2, 3, 4, 6, 9, 14, 27)):
                     if a.wgrad and bm == 2 and Cin % 128:
@@ -102,7 +103,7 @@ def main():
                                 t = timeit(lambda: Fn._conv_fwd(xin, w, nbr_f, out, km.n_in, km.n_out, K, Cin, Cout, oidx))
                         finally:
                             Fn.FLAGS = 0
-                        res.append((t, bm * 64, bn * 64, S or Sw))
+                        res.append((t, {1: 64, 2: 128, 3: 256}[bm], bn * 64, S or Sw))
         Fn.FLAGS = a.flags
         if a.wgrad:
             wsb = L.query('fc_conv_wgrad_ws_bytes', km.n_out, K, Cin, Cout, 0)
