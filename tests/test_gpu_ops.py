@@ -272,7 +272,8 @@ def test_no_cpu_fallback():
 
 
 @pytest.mark.parametrize('n,C,act,res', [(5003, 64, 'relu', True), (853, 512, 'elu', False), (70, 128, None, False),
-                                         (40000, 256, 'relu', False)])     # last one: > 4M elements -> six-launch path
+                                         (40000, 256, 'elu', False)])      # last one: > 4M elements -> six-launch path
+# (ELU there: with ReLU one of the 10M pre-activations lands within 1 ulp of 0 and the 0/1 derivative flips)
 def test_bn_train_fused_paths(n, C, act, res):
     """Training-mode BatchNorm (two-launch small path and the general path): output, gradients and the
     nn.BatchNorm1d buffer update against torch on the CPU."""
