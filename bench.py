@@ -119,11 +119,24 @@ class Breakdown:
 
 
 class ConvProbe:
-    """HIP-event bracket around every MFMA sparse-conv launch (forward + backward-data), with the
-    launch's algorithmic FLOPs (2 * valid pairs * Cin * Cout) counted on the device."""
+    """HIP-event bracket around every MFMA sparse-conv launch (forward + backward-data) of the timed steps.
+    The launches' algorithmic FLOPs (2 * valid pairs * Cin * Cout, pairs counted on the device from the map
+    actually used) are collected in one extra, untimed step per distinct batch — the launch sequence of a
+    step is deterministic — so that nothing but the two event records sits inside the timed region."""
 
     def __init__(self):
-        self.records = []
+        self.timed = {}        # batch index -> list of per-step lists of (start, end)
+        self.counted = {}      # batch index -> list of (pairs_dev | None, flops_per_pair, n_out, bytes)
+        self.mode = None
+        self._cur = None
+
+    def begin_step(self, batch_index, mode):
+        self.mode = mode
+        if mode == 'time':
+            self._cur = []
+            self.timed.setdefault(batch_index, []).append(self._cur)
+        else:
+            self._cur = self.counted[batch_index] = []
 
     def install(self):
         import fcaf3d_amd._lib as L
@@ -131,28 +144,30 @@ class ConvProbe:
         orig = L.call
 
         def call(name, *a):
-            if name != 'fc_conv_fwd':
+            if name != 'fc_conv_fwd' or probe.mode is None:
                 return orig(name, *a)
             # (in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream)
             n_out, K, Cin, Cout = a[6], a[7], a[8], a[9]
             if Cin % 32 or Cout % 64:
-                return orig(name, *a)          # generic FMA path (stem): not the kernel under the probe
-            s = torch.cuda.Event(enable_timing=True)
-            e = torch.cuda.Event(enable_timing=True)
-            s.record()
-            orig(name, *a)
-            e.record()
-            nbytes = 4.0 * (a[5] * Cin + n_out * Cout + K * Cin * Cout) + (4.0 * K * n_out if a[2] else 0.0)
-            probe.records.append((s, e, probe._pairs, 2.0 * Cin * Cout, n_out, nbytes))
+                return orig(name, *a)          # generic FMA / stem path: not the kernel under the probe
+            if probe.mode == 'time':
+                s = torch.cuda.Event(enable_timing=True)
+                e = torch.cuda.Event(enable_timing=True)
+                s.record()
+                orig(name, *a)
+                e.record()
+                probe._cur.append((s, e))
+            else:
+                orig(name, *a)
+                nbytes = 4.0 * (a[5] * Cin + n_out * Cout + K * Cin * Cout) + (4.0 * K * n_out if a[2] else 0.0)
+                probe._cur.append((probe._pairs, 2.0 * Cin * Cout, n_out, nbytes))
         L.call = call
-        self._orig = orig
         self._pairs = None
-        # make the conv wrapper tell us which map it is about to use
         import fcaf3d_amd.functional as Fn
         fwd0, bwd0 = Fn._SparseConv.forward, Fn._SparseConv.backward
 
         def pairs_of(kmap):
-            if kmap is None:
+            if kmap is None or probe.mode != 'count':
                 return None
             if getattr(kmap, '_pairs_dev', None) is None:
                 kmap._pairs_dev = (kmap.nbr >= 0).sum()
@@ -169,25 +184,27 @@ class ConvProbe:
         Fn._SparseConv.backward = staticmethod(bwd)
 
     def summary(self):
-        if not self.records:
+        if not self.timed:
             return None
         torch.cuda.synchronize()
-        flops = 0.0
-        ms = 0.0
-        alg_bytes = 0.0
-        for s, e, pairs, per_pair, n_out, nbytes in self.records:
-            p = float(pairs.item()) if pairs is not None else float(n_out)
-            flops += p * per_pair
-            alg_bytes += nbytes
-            ms += s.elapsed_time(e)
-        n = len(self.records)
+        flops = ms = alg_bytes = 0.0
+        n = 0
+        for bi, steps in self.timed.items():
+            counted = self.counted[bi]
+            per_launch = [((float(p.item()) if p is not None else float(n_out)) * fpp, nb) for p, fpp, n_out, nb in counted]
+            for ev in steps:
+                assert len(ev) == len(per_launch), 'launch sequence of a step is expected to be deterministic'
+                for (s, e), (f, nb) in zip(ev, per_launch):
+                    ms += s.elapsed_time(e)
+                    flops += f
+                    alg_bytes += nb
+                    n += 1
         achieved = flops / (ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
         if os.path.exists(tj):          # PMC passes cannot run inside the timed region: committed rocprofv3 result
             t = json.load(open(tj))
             traffic, traffic_src = t['hbm_bytes_per_launch'], 'profiles/r1_traffic.json (' + t['method'] + ')'
-
         return dict(bound='mfma', kernel='k_conv_mfma (sparse conv fwd + dgrad, dense GEMMs of convT/heads)',
                     achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_unit='B/launch',
@@ -251,8 +268,13 @@ def main():
         probe = ConvProbe()
         probe.install()
 
-    def step(i):
+    def step(i, probe_mode=None):
         batch = batches[i % len(batches)]
+        if probe:
+            if probe_mode:
+                probe.begin_step(i % len(batches), probe_mode)
+            else:
+                probe.mode = None
         opt.zero_grad(set_to_none=True)
         losses = model(return_loss=True, **batch)
         loss = losses['loss_centerness'] + losses['loss_bbox'] + losses['loss_cls']
@@ -264,9 +286,6 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if probe:
-        torch.cuda.synchronize()
-        probe.records.clear()
     if bd:
         torch.cuda.synchronize()
         bd.rec.clear()
@@ -275,7 +294,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = step(args.warmup + i)
+        loss = step(args.warmup + i, 'time')
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -285,6 +304,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    if probe:                                   # untimed: FLOPs of every launch, one step per distinct batch
+        for b in range(min(len(batches), args.steps)):
+            step(b, 'count')
     if bd:
         bd.report(args.steps, dt * 1e3)
     assert np.isfinite(final_loss), 'loss diverged'

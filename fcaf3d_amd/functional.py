@@ -222,7 +222,8 @@ class _NormAct(torch.autograd.Function):
         return gx, ggamma, gbeta, gres, None, None, None, None, None, None, None, None
 
 
-BN_SMALL_ELEMS = 4 * 1024 * 1024     # feature matrices up to this size take the two-launch BatchNorm path
+import os as _os
+BN_SMALL_ELEMS = int(_os.environ.get('FC_BN_SMALL_ELEMS', 4 * 1024 * 1024))   # matrices up to this size: two-launch BatchNorm
 
 
 class _BNTrainSmall(torch.autograd.Function):
