@@ -62,6 +62,14 @@ class GradientAverager:
             self.buckets.append(cur)
         self._flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
                       for b in self.buckets]
+        self._views = []                       # per bucket: the flat buffer sliced into the parameters' shapes
+        for flat, b in zip(self._flat, self.buckets):
+            off, views = 0, []
+            for p in b:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            self._views.append(views)
+        self._avg = dist.get_backend() == 'nccl'   # RCCL averages in the collective; gloo: sum then divide
         self._pending = [0] * len(self.buckets)
         self._bucket_of = {}
         for bi, b in enumerate(self.buckets):
@@ -84,15 +92,15 @@ class GradientAverager:
         from . import functional as Fn
         if Fn.WGRAD_ASYNC:
             Fn.join_wgrad_stream()            # weight gradients may still be in flight on their side stream
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.buckets[bi]]
+        torch._foreach_copy_(self._views[bi], grads)          # one multi-tensor launch per bucket
         flat = self._flat[bi]
-        off = 0
-        for p in self.buckets[bi]:
-            n = p.numel()
-            g = p.grad if p.grad is not None else torch.zeros_like(p)
-            flat[off:off + n].copy_(g.reshape(-1))
-            off += n
-        flat.div_(world_size())
-        self._handles.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)))
+        if self._avg:
+            h = dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True)
+        else:
+            flat.div_(world_size())
+            h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        self._handles.append((bi, h))
 
     def finish(self):
         """Call after backward: flush buckets whose hooks did not all fire, wait, scatter back."""
@@ -103,11 +111,9 @@ class GradientAverager:
                 self._launch(bi)
         for bi, h in self._handles:
             h.wait()
-            off = 0
-            for p in self.buckets[bi]:
-                n = p.numel()
+            params = self.buckets[bi]
+            for p in params:
                 if p.grad is None:
                     p.grad = torch.empty_like(p)
-                p.grad.copy_(self._flat[bi][off:off + n].view_as(p))
-                off += n
+            torch._foreach_copy_([p.grad for p in params], self._views[bi])
         self._reset()
