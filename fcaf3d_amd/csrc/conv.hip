@@ -17,6 +17,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: struct float4 copies lower to memcpy and
                                                           // pin the prefetch registers in scratch (r1 finding)
 
+__device__ __attribute__((aligned(16))) float g_zero_row[64];   // what an absent neighbour gathers from (BKT <= 64 floats)
+
 #define BK 32            // reduction slab (input channels per stage / rows per stage for wgrad)
 #define LDA (BK + 4)     // A row stride in floats: 16B-aligned rows, conflict-free ds_read_b128 (9r mod 16)
 
@@ -84,23 +86,30 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
     kmask &= kmask - 1;
     int c0 = 0;
     f32x4 av[AR], bv[BR];
-    // (the neighbour indices are re-read per stage: keeping them in a captured array across iterations made the
-    //  compiler spill the whole prefetch set to scratch — 80 B/lane, 2 GB of extra HBM writes per launch, r1 PMC)
+    // Prefetch of one stage, written branch-free so that the compiler issues it as batches (the AR neighbour
+    // indices, the weights, then the AR gathers) instead of AR serialised index->wait->gather chains with the data
+    // waited for on the spot (r1 ISA reading).  An absent neighbour gathers from a row of zeros (pointer select
+    // BEFORE the load), so nothing touches the loaded registers until the next stage's LDS store.
     auto load_stage = [&](int kk, int cc) {
       const float* Wk = W + (int64_t)kk * Cin * Cout;
+      int v[AR];
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         int64_t row = m0 + a_r + APASS * i;
-        int v = -1;
-        if (row < n_out) v = nbr ? nbr[(int64_t)kk * n_out + row] : (int)row;
-        av[i] = (f32x4)(0.f);
-        if (v >= 0) av[i] = *reinterpret_cast<const f32x4*>(in + (int64_t)v * Cin + cc + a_c4 * 4);
+        int64_t rc = row < n_out ? row : n_out - 1;
+        int t = nbr ? nbr[(int64_t)kk * n_out + rc] : (int)rc;
+        v[i] = row < n_out ? t : -1;
       }
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         int lin = tid + 256 * i;
         int kr = lin / (BN / 4), c4 = lin % (BN / 4);
         bv[i] = *reinterpret_cast<const f32x4*>(Wk + (int64_t)(cc + kr) * Cout + n0 + c4 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const float* src = v[i] < 0 ? g_zero_row + a_c4 * 4 : in + (int64_t)v[i] * Cin + cc + a_c4 * 4;
+        av[i] = *reinterpret_cast<const f32x4*>(src);
       }
     };
     load_stage(k, c0);
