@@ -29,7 +29,7 @@ __device__ __attribute__((aligned(16))) float g_zero_row[64];   // what an absen
 // (single LDS buffer, global-load latency hidden behind the matrix pipe).
 // gridDim.z > 1 = split over kernel offsets (offset k handled by split k % gridDim.z) for layers whose
 // row count cannot fill the chip; partial tiles go to `out` + z*n_out*Cout and are summed by k_sum_parts.
-template <int BM, int BN, int BKT>
+template <int BM, int BN, int BKT, bool HAS_NBR>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
                                                    const int* __restrict__ nbr, const int* __restrict__ out_index,
                                                    float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout) {
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
     unsigned int mk = 0u;
     int64_t row = m0 + tid;
     if (row < n_out) {
-      if (nbr) {
+      if (HAS_NBR) {
         for (int k = z; k < K; k += S)
           if (nbr[(int64_t)k * n_out + row] >= 0) mk |= 1u << k;
       } else {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
       for (int i = 0; i < AR; ++i) {
         int64_t row = m0 + a_r + APASS * i;
         int64_t rc = row < n_out ? row : n_out - 1;
-        int t = nbr ? nbr[(int64_t)kk * n_out + rc] : (int)rc;
+        int t = HAS_NBR ? nbr[(int64_t)kk * n_out + rc] : (int)rc;    // compile-time: no null test between the loads
         v[i] = row < n_out ? t : -1;
       }
 #pragma unroll
@@ -373,13 +373,13 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_
   if (S > 1 && ws_bytes < (int64_t)S * n_out * Cout * (int64_t)sizeof(float)) return FC_EWS;
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
-  if (bm == 256) k_conv_mfma<256, 64, 32><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
-  else if (bm == 128 && bn == 128 && bk == 64) k_conv_mfma<128, 128, 64><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
-  else if (bm == 128 && bk == 64) k_conv_mfma<128, 64, 64><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
-  else if (bm == 128 && bn == 128) k_conv_mfma<128, 128, 32><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
-  else if (bm == 128) k_conv_mfma<128, 64, 32><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
-  else if (bn == 128) k_conv_mfma<64, 128, 32><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
-  else k_conv_mfma<64, 64, 32><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout);
+  if (bm == 256) { if (nbr) k_conv_mfma<256, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<256, 64, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
+  else if (bm == 128 && bn == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 128, 64, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 64, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
+  else if (bm == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 64, 64, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 64, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
+  else if (bm == 128 && bn == 128) { if (nbr) k_conv_mfma<128, 128, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
+  else if (bm == 128) { if (nbr) k_conv_mfma<128, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
+  else if (bn == 128) { if (nbr) k_conv_mfma<64, 128, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<64, 128, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
+  else { if (nbr) k_conv_mfma<64, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<64, 64, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
   FC_CHECK_LAUNCH();
   if (S > 1) {
     int64_t e4 = n_out * Cout / 4;
@@ -396,7 +396,7 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_
 // GEMM with M = Cin, N = Cout and the reduction over output rows, split over `S` row ranges whose
 // partial products are written to the workspace and summed by k_wgrad_reduce in a fixed order
 // (deterministic, no atomics).
-template <int BMc, int BNc>
+template <int BMc, int BNc, bool HAS_NBR>
 __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ gout,
                                                     const int* __restrict__ nbr, const int* __restrict__ row_index,
                                                     float* __restrict__ part, int64_t n_out, int K, int Cin, int Cout,
@@ -428,30 +428,35 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
 
   // register-prefetch pipeline: the gathers + gout rows of chunk t+1 are in flight while chunk t is multiplied.
   // (Measured r1: processing wgrad rows in occupancy-mask order with per-chunk skipping LOSES 15-35 % — gout rows stop
-  //  being sequential and the skip test costs a barrier per chunk — so wgrad always walks rows in natural order;
-  //  row_index is honoured for completeness only.)
+  //  being sequential and the skip test costs a barrier per chunk — so wgrad always walks rows in natural order
+  //  and row_index must be NULL.)
   f32x4 av[AR], gv[GR];
-  auto load_chunk = [&](int64_t rb) {
+  auto load_chunk = [&](int64_t rb) {        // branch-free, batched (see k_conv_mfma): indices, gout rows, gathers
+    int src[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       int lin = tid + 256 * i;
-      int rr = lin / (BMc / 4), c4 = lin % (BMc / 4);
+      int rr = lin / (BMc / 4);
       int64_t row = rb + rr;
-      int src = -1;
-      if (row < r_end) src = nbr ? nbr[(int64_t)k * n_out + row] : (int)row;
-      av[i] = (f32x4)(0.f);
-      if (src >= 0) av[i] = *reinterpret_cast<const f32x4*>(in + (int64_t)src * Cin + ci0 + c4 * 4);
+      int64_t rc = row < r_end ? row : r_end - 1;
+      int t = HAS_NBR ? nbr[(int64_t)k * n_out + rc] : (int)rc;      // compile-time: no null test between the loads
+      src[i] = row < r_end ? t : -1;
     }
 #pragma unroll
     for (int i = 0; i < GR; ++i) {
       int lin = tid + 256 * i;
       int rr = lin / (BNc / 4), c4 = lin % (BNc / 4);
       int64_t row = rb + rr;
-      gv[i] = (f32x4)(0.f);
-      if (row < r_end) {
-        int64_t grow = row_index ? row_index[row] : row;
-        gv[i] = *reinterpret_cast<const f32x4*>(gout + grow * Cout + co0 + c4 * 4);
-      }
+      int64_t rc = row < r_end ? row : r_end - 1;
+      const float* gp = row < r_end ? gout + rc * Cout + co0 + c4 * 4 : g_zero_row + (c4 & 15) * 4;
+      gv[i] = *reinterpret_cast<const f32x4*>(gp);
+    }
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      int lin = tid + 256 * i;
+      int c4 = lin % (BMc / 4);
+      const float* ap = src[i] < 0 ? g_zero_row + (c4 & 15) * 4 : in + (int64_t)src[i] * Cin + ci0 + c4 * 4;
+      av[i] = *reinterpret_cast<const f32x4*>(ap);
     }
   };
   if (r_begin < r_end) load_chunk(r_begin);
@@ -602,7 +607,7 @@ int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int*
   if (ws_bytes < (int64_t)S * elems * (int64_t)sizeof(float)) return FC_EWS;
   float* part = (S == 1) ? gW : (float*)ws;
   bool mfma_ok = !(flags & 1) && (Cin % 64 == 0) && (Cout % 64 == 0);
-  if (row_index && (!nbr || !mfma_ok)) return FC_EINVAL;
+  if (row_index) return FC_EINVAL;             // reserved (see k_wgrad_mfma)
   if (!(flags & 1) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27) {
     size_t smem = (size_t)(STEM_ROWS * K * STEM_CIN + STEM_ROWS * 64) * sizeof(float);
     k_stem_wgrad<<<(unsigned)S, 256, smem, stream>>>(in, gout, nbr, part, n_out, K, rps);
@@ -610,10 +615,10 @@ int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int*
     int bm, bn;
     wgrad_tiles(Cin, Cout, flags, &bm, &bn);
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
-    if (bm == 128 && bn == 128) k_wgrad_mfma<128, 128><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps);
-    else if (bm == 128) k_wgrad_mfma<128, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps);
-    else if (bn == 128) k_wgrad_mfma<64, 128><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps);
-    else k_wgrad_mfma<64, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps);
+    if (bm == 128 && bn == 128) { if (nbr) k_wgrad_mfma<128, 128, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<128, 128, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
+    else if (bm == 128) { if (nbr) k_wgrad_mfma<128, 64, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<128, 64, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
+    else if (bn == 128) { if (nbr) k_wgrad_mfma<64, 128, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<64, 128, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
+    else { if (nbr) k_wgrad_mfma<64, 64, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<64, 64, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
   } else {
     dim3 grid((unsigned)S, (unsigned)K);
     k_wgrad_fma<<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
