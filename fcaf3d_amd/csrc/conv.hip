@@ -396,15 +396,15 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_
 // GEMM with M = Cin, N = Cout and the reduction over output rows, split over `S` row ranges whose
 // partial products are written to the workspace and summed by k_wgrad_reduce in a fixed order
 // (deterministic, no atomics).
-template <int BMc, int BNc, bool HAS_NBR>
+template <int BMc, int BNc, bool HAS_NBR, int BKR>
 __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ gout,
                                                     const int* __restrict__ nbr, const int* __restrict__ row_index,
                                                     float* __restrict__ part, int64_t n_out, int K, int Cin, int Cout,
                                                     int64_t rows_per_split) {
   constexpr int TM = BMc / 64, TN = BNc / 64;
-  constexpr int AR = BMc / 32, GR = BNc / 32;    // float4 loads per thread per stage (32 rows)
-  __shared__ __attribute__((aligned(16))) float As[BK * BMc];
-  __shared__ __attribute__((aligned(16))) float Gs[BK * BNc];
+  constexpr int AR = BMc * BKR / 1024, GR = BNc * BKR / 1024;    // float4 loads per thread per stage (BKR rows)
+  __shared__ __attribute__((aligned(16))) float As[BKR * BMc];
+  __shared__ __attribute__((aligned(16))) float Gs[BKR * BNc];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int r = lane & 31, h = lane >> 5;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
     }
   };
   if (r_begin < r_end) load_chunk(r_begin);
-  for (int64_t rb = r_begin; rb < r_end; rb += BK) {
+  for (int64_t rb = r_begin; rb < r_end; rb += BKR) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
@@ -475,9 +475,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
       *reinterpret_cast<f32x4*>(&Gs[rr * BNc + c4 * 4]) = gv[i];
     }
     __syncthreads();
-    if (rb + BK < r_end) load_chunk(rb + BK);
+    if (rb + BKR < r_end) load_chunk(rb + BKR);
 #pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
+    for (int q = 0; q < BKR / 8; ++q) {
       float a[TM][4], b[TN][4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -581,7 +581,7 @@ static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, int* 
   if (s > 256) s = 256;
   if (s < 1) s = 1;
   if ((flags >> 8) & 255) s = (flags >> 8) & 255;         // tuning override
-  int64_t rps = fc_align(fc_cdiv(n_out > 0 ? n_out : 1, s), BK);
+  int64_t rps = fc_align(fc_cdiv(n_out > 0 ? n_out : 1, s), 64);
   s = fc_cdiv(n_out > 0 ? n_out : 1, rps);
   *S = (int)s;
   *rows_per_split = rps;
@@ -615,10 +615,15 @@ int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int*
     int bm, bn;
     wgrad_tiles(Cin, Cout, flags, &bm, &bn);
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
-    if (bm == 128 && bn == 128) { if (nbr) k_wgrad_mfma<128, 128, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<128, 128, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
-    else if (bm == 128) { if (nbr) k_wgrad_mfma<128, 64, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<128, 64, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
-    else if (bn == 128) { if (nbr) k_wgrad_mfma<64, 128, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<64, 128, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
-    else { if (nbr) k_wgrad_mfma<64, 64, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<64, 64, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
+    const bool deep = (flags & (1 << 19)) && bm == 64 && nbr;          // 64-row chunks (tuning flag)
+    if (deep) {
+      if (bn == 128) k_wgrad_mfma<64, 128, true, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps);
+      else k_wgrad_mfma<64, 64, true, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps);
+    } else
+    if (bm == 128 && bn == 128) { if (nbr) k_wgrad_mfma<128, 128, true, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<128, 128, false, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
+    else if (bm == 128) { if (nbr) k_wgrad_mfma<128, 64, true, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<128, 64, false, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
+    else if (bn == 128) { if (nbr) k_wgrad_mfma<64, 128, true, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<64, 128, false, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
+    else { if (nbr) k_wgrad_mfma<64, 64, true, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<64, 64, false, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
   } else {
     dim3 grid((unsigned)S, (unsigned)K);
     k_wgrad_fma<<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
