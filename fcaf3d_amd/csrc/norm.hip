@@ -449,6 +449,43 @@ __global__ void k_bn1_apply(const float* __restrict__ x, int64_t n, int C, int64
   }
 }
 
+// general-size BatchNorm statistics, finalisation: one 1024-thread block per 64 channels reduces the
+// [nb][2][C] shifted partial sums of k_bn1_partial (fixed order), writes mean / biased var / count and applies the
+// nn.BatchNorm1d running-buffer update — 3 launches per training-mode BatchNorm forward instead of 6.
+__global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ part, int nb, int C, int64_t n,
+                                                      const float* __restrict__ x, float momentum, float* __restrict__ mean,
+                                                      float* __restrict__ var, float* __restrict__ cnt,
+                                                      float* __restrict__ rmean, float* __restrict__ rvar,
+                                                      long long* __restrict__ nbt) {
+  __shared__ float r1[16][65], r2[16][65];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;
+  float a1 = 0.f, a2 = 0.f;
+  if (c < C)
+    for (int b = j; b < nb; b += 16) {
+      a1 += part[((int64_t)b * 2) * C + c];
+      a2 += part[((int64_t)b * 2 + 1) * C + c];
+    }
+  r1[j][threadIdx.x & 63] = a1;
+  r2[j][threadIdx.x & 63] = a2;
+  __syncthreads();
+  if (j == 0 && c < C) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = 0; q < 16; ++q) { s1 += r1[q][threadIdx.x & 63]; s2 += r2[q][threadIdx.x & 63]; }
+    const float inv_n = 1.f / (float)n;
+    float d = s1 * inv_n;
+    float mu = x[c] + d;
+    float va = fmaxf(s2 * inv_n - d * d, 0.f);
+    mean[c] = mu;
+    var[c] = va;
+    if (c == 0) { cnt[0] = (float)n; if (nbt) nbt[0] += 1; }
+    if (rmean) {
+      float unbias = (float)n / fmaxf((float)n - 1.f, 1.f);
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * va * unbias;
+    }
+  }
+}
+
 // backward launch 2: reduce the partials of k_norm_bwd_partial (nseg = 1, layout [nb][1][2][C]) and apply
 __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
                                 int64_t n, int C, int64_t rpb, const float* __restrict__ part, int nb,
@@ -606,6 +643,32 @@ static void bn1_plan(int64_t n, int64_t* nb, int64_t* rpb) {
 }
 
 int64_t fc_bn_small_ws_bytes(int C) { return (int64_t)BN1_MAXB * 2 * C * (int64_t)sizeof(float); }
+
+int64_t fc_bn_stats_ws_bytes(int64_t n, int C) {
+  int64_t nb, rpb;
+  red_plan(n, &nb, &rpb);
+  return nb * 2 * (int64_t)C * (int64_t)sizeof(float);
+}
+
+// training-mode BatchNorm statistics of a feature matrix of any size in one pass over x (+ buffer update):
+// mean (C), biased var (C), cnt (1).  Follow with fc_norm_act_fwd.
+int fc_bn_stats_train(const float* x, int64_t n, int C, float momentum, float* mean, float* var, float* cnt,
+                      float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
+                      int64_t ws_bytes, hipStream_t stream) {
+  if (n < 1) return FC_EINVAL;
+  int threads; size_t sf, sb;
+  if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
+  if (ws_bytes < fc_bn_stats_ws_bytes(n, C)) return FC_EWS;
+  int64_t nb, rpb;
+  red_plan(n, &nb, &rpb);
+  float* part = (float*)ws;
+  k_bn1_partial<<<(unsigned)nb, threads, sb, stream>>>(x, n, C, rpb, part);
+  FC_CHECK_LAUNCH();
+  k_bn_finalize<<<(unsigned)((C + 63) / 64), 1024, 0, stream>>>(part, (int)nb, C, n, x, momentum, mean, var, cnt, running_mean,
+                                                                running_var, num_batches_tracked);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
 
 // training-mode BatchNorm forward for one segment: statistics + running-buffer update + normalise/affine/residual/act.
 // mean/var (C) and cnt (1) are written for the backward pass; running_* / num_batches_tracked may be NULL.

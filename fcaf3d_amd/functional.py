@@ -277,9 +277,16 @@ def bn_train(x, gamma, beta, residual, eps, act, momentum, rmean, rvar, nbt):
     if 0 < n * C <= BN_SMALL_ELEMS and gamma is not None and beta is not None:
         y, stats, cnt = _BNTrainSmall.apply(x, gamma, beta, residual, eps, ACT[act], momentum, rmean, rvar, nbt)
         return y, (stats[0:1], stats[1:2], cnt)
-    y, (mean, var, cnt) = norm_act(x, gamma, beta, residual=residual, eps=eps, act=act)
-    L.call('fc_bn_running_update', L.ptr(mean), L.ptr(var), L.ptr(cnt), float(momentum), C, L.ptr(rmean), L.ptr(rvar),
-           L.ptr(nbt), L.stream())
+    # general size: one statistics pass (shifted sums) + finalise/buffer update + apply = 3 launches
+    xc = x.detach().contiguous()
+    dev = x.device
+    mean = torch.empty((1, C), dtype=torch.float32, device=dev)
+    var = torch.empty((1, C), dtype=torch.float32, device=dev)
+    cnt = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = L.workspace(L.query('fc_bn_stats_ws_bytes', n, C), dev)
+    L.call('fc_bn_stats_train', L.ptr(xc), n, C, float(momentum), L.ptr(mean), L.ptr(var), L.ptr(cnt), L.ptr(rmean),
+           L.ptr(rvar), L.ptr(nbt), L.ptr(ws), ws.numel(), L.stream())
+    y = _NormAct.apply(x, gamma, beta, residual, None, 1, eps, ACT[act], mean, var, cnt, False)
     return y, (mean, var, cnt)
 
 

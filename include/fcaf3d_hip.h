@@ -130,6 +130,10 @@ int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* 
 
 /* Training-mode ME.MinkowskiBatchNorm (+ fused ReLU/ELU / residual) for small feature matrices in TWO launches per
  * direction: batch statistics, running-buffer update (nn.BatchNorm1d momentum / unbiased variance) and apply. */
+int64_t fc_bn_stats_ws_bytes(int64_t n, int C);
+int fc_bn_stats_train(const float* x, int64_t n, int C, float momentum, float* mean, float* var, float* cnt,
+                      float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
+                      int64_t ws_bytes, hipStream_t stream);
 int64_t fc_bn_small_ws_bytes(int C);
 int fc_bn_act_train_fwd(const float* x, int64_t n, int C, float eps, const float* gamma, const float* beta,
                         const float* residual, int act, float momentum, float* y, float* mean, float* var, float* cnt,
