@@ -353,5 +353,7 @@ def union_add(a, b):
     from .sparse import SparseTensor
     if a.cmap is b.cmap:
         return SparseTensor(a.F + b.F, coordinate_map_key=a.cmap)
-    cm, row_b = a.cmap.union(b.cmap)
-    return SparseTensor(_UnionAdd.apply(a.F, b.F, row_b, cm.n), coordinate_map_key=cm)
+    cm, rows, swapped = a.cmap.union(b.cmap)
+    if swapped:          # a's voxels all lie in b: result on b's map = b.F with a.F added at a's rows
+        return SparseTensor(_UnionAdd.apply(b.F, a.F, rows, cm.n), coordinate_map_key=cm)
+    return SparseTensor(_UnionAdd.apply(a.F, b.F, rows, cm.n), coordinate_map_key=cm)

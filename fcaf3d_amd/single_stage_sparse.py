@@ -85,7 +85,7 @@ class SingleStageSparse3DDetector(nn.Module):
         x.scene_counts
         for i in range(len(levels) - 2, -1, -1):
             g = x.generate(); g.kernel_map(g, 3)
-            u, _ = levels[i].union(g)
+            u, _, _ = levels[i].union(g)
             if nh.pts_threshold >= 0 and any(c > nh.pts_threshold for c in u.scene_counts):
                 return
             u.kernel_map(u, 3)

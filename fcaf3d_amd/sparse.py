@@ -222,27 +222,40 @@ class CoordMap:
         return km
 
     def union(self, other):
-        """Union map for `self + other` (rows of self first). Returns (map, row_of_other_rows)."""
+        """Union map for `self + other`.  Returns (map, rows, swapped):
+          swapped False: rows of self first, then other's new voxels; rows[i] = union row of other's row i;
+          swapped True : every voxel of self already lies in `other` (the usual case: backbone level inside the
+                         generated children set) -> the union IS other's set and other's map (with its cached
+                         kernel maps) is reused; rows[i] = row in `other` of self's row i."""
         assert self.stride == other.stride
         if id(other) in self._unions:
-            return self._unions[id(other)][:2]
+            return self._unions[id(other)][:3]
         dev = self.coords.device
-        row_b = torch.empty(other.n, dtype=torch.int32, device=dev)
-        newc = torch.empty((other.n, 4), dtype=torch.int32, device=dev)
-        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-        ws = L.workspace(L.query('fc_union_map_ws_bytes', other.n), dev)
-        L.call('fc_union_map', L.ptr(other.coords), other.n, L.ptr(self.keys), L.ptr(self.vals), self.cap, self.n,
-               L.ptr(row_b), L.ptr(newc), L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+
+        def probe(q, table):
+            rows = torch.empty(q.n, dtype=torch.int32, device=dev)
+            newc = torch.empty((q.n, 4), dtype=torch.int32, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            ws = L.workspace(L.query('fc_union_map_ws_bytes', q.n), dev)
+            L.call('fc_union_map', L.ptr(q.coords), q.n, L.ptr(table.keys), L.ptr(table.vals), table.cap, table.n,
+                   L.ptr(rows), L.ptr(newc), L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
+            return rows, newc, cnt
+        row_b, newc, cnt = probe(other, self)
         n_new = int(cnt.item())
-        _rec(row_b)
+        swapped = False
         if n_new == 0:
-            cm = self
+            cm, rows = self, row_b
+        elif n_new == other.n - self.n:
+            rows, _, _ = probe(self, other)                # all found: no count read-back needed
+            cm, swapped = other, True
         else:
             coords = torch.cat([self.coords, newc[:n_new]])
             cm, _, _ = CoordMap.from_coords(coords, self.stride, self.batch_size, expect_n=coords.shape[0])
             cm.dense_hint = other.dense_hint
-        self._unions[id(other)] = (cm, row_b, other)       # keep `other` alive so id() stays unique
-        return cm, row_b
+            rows = row_b
+        _rec(rows)
+        self._unions[id(other)] = (cm, rows, swapped, other)       # keep `other` alive so id() stays unique
+        return cm, rows, swapped
 
     def pruned(self, kept):
         """Map of the kept rows (int32 ascending row indices), order preserved."""

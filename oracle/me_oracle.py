@@ -165,8 +165,18 @@ def batch_norm(feats, weight, bias, eps=1e-5):
 
 def union_add(coords_a, feats_a, coords_b, feats_b):
     """SparseTensor a + b with different maps (A.8): rows of a first, then rows
-    of b absent from a; features zero-filled then added."""
+    of b absent from a; features zero-filled then added.
+    Row-order rule shared with the HIP path: when every voxel of a already lies in b (the backbone level inside the
+    generated children set) the union is b's coordinate set IN b's ORDER (the map, and its kernel maps, are reused)."""
     ka, kb = pack_keys(coords_a), pack_keys(coords_b)
+    if len(ka) and len(kb) and np.isin(ka, kb).all() and len(kb) > len(ka):
+        order_b = np.argsort(kb, kind='stable')
+        pos = np.searchsorted(kb[order_b], ka)
+        row_a = order_b[pos]
+        out = feats_b.new_zeros((len(kb), feats_b.shape[1]))
+        out = out.index_add(0, torch.arange(len(kb)), feats_b)
+        out = out.index_add(0, torch.from_numpy(row_a), feats_a)
+        return coords_b, out
     order = np.argsort(ka, kind='stable')
     ska = ka[order]
     pos = np.minimum(np.searchsorted(ska, kb), max(len(ska) - 1, 0))

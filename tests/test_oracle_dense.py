@@ -108,9 +108,13 @@ def test_union_interp_prune():
     a_c = np.array([[0, 0, 0, 0], [0, 2, 0, 0]], np.int32)
     b_c = np.array([[0, 2, 0, 0], [0, 4, 0, 0], [0, 0, 0, 0]], np.int32)
     a_f = torch.tensor([[1.0], [2.0]]); b_f = torch.tensor([[10.0], [20.0], [30.0]])
-    uc, uf = mo.union_add(a_c, a_f, b_c, b_f)
-    assert uc.tolist() == [[0, 0, 0, 0], [0, 2, 0, 0], [0, 4, 0, 0]]
-    assert uf[:, 0].tolist() == [31.0, 12.0, 20.0]
+    uc, uf = mo.union_add(a_c, a_f, b_c, b_f)              # a inside b: b's set in b's order
+    assert uc.tolist() == [[0, 2, 0, 0], [0, 4, 0, 0], [0, 0, 0, 0]]
+    assert uf[:, 0].tolist() == [12.0, 20.0, 31.0]
+    c_c = np.array([[0, 2, 0, 0], [0, 4, 0, 0]], np.int32)  # general case: a's rows first, then b's new voxels
+    gc, gf = mo.union_add(a_c, a_f, c_c, torch.tensor([[10.0], [20.0]]))
+    assert gc.tolist() == [[0, 0, 0, 0], [0, 2, 0, 0], [0, 4, 0, 0]] and gf[:, 0].tolist() == [1.0, 12.0, 20.0]
+    uc, uf = gc, torch.tensor([[31.0], [12.0], [20.0]])
     # interpolation: parents at stride 2, query halfway along x between two parents
     q = np.array([[0, 1, 0, 0], [0, 0, 0, 0], [0, 4, 1, 0]], np.float32)
     v = mo.features_at_coordinates(uc, uf, 2, q)

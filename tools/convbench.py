@@ -53,7 +53,7 @@ def main():
     necks = []
     xm = lv[-1]
     for i in (2, 1, 0):
-        g = xm.generate(); u, _ = lv[i].union(g); necks.append((g, u)); xm = u
+        g = xm.generate(); u, _, _ = lv[i].union(g); necks.append((g, u)); xm = u
     cases = [
         ('L1 k3s1 64->64', lv[0].kernel_map(lv[0], 3), 64, 64),
         ('L2 k3s1 128->128', lv[1].kernel_map(lv[1], 3), 128, 128),
