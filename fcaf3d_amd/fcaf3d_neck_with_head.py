@@ -369,7 +369,8 @@ class Fcaf3DAssigner:
             if len(g):
                 boxes[i, :len(g)] = torch.cat((g.gravity_center, g.tensor[:, 3:]), dim=1).to(dev)
                 labels[i, :len(g)] = l.to(dev)
-        box_count = torch.tensor([len(g) for g in gt_bboxes], dtype=torch.int32, device=dev)
+        # pinned + non_blocking: a pageable host->device copy would block the host until the whole forward has drained
+        box_count = torch.tensor([len(g) for g in gt_bboxes], dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
         order, counts, off = [], [], 0
         for cm in cmaps:
             cm._decompose()
