@@ -237,54 +237,85 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ in, 
   }
 }
 
-// stem wgrad: part[block][j][co] = sum over the block's rows of in[nbr][j] * gout[row][co];  thread = (co, j mod 4)
+// stem wgrad on the matrix cores: part[block][j][co] = sum over the block's rows of A[row][j] * gout[row][co], with
+// A[row][j = 3k+c] = in[nbr[k][row]][c] staged in LDS (81 real columns padded to 96 = 3 MFMA tiles, gout 64 = 2 tiles).
+// Each of the 4 waves owns a quarter of every 64-row chunk as its reduction slice and all 6 tiles; the four partial
+// tiles are summed through LDS in wave order (deterministic) at the end.
+#define STEM_JP 96
 __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ in, const float* __restrict__ gout,
                                                     const int* __restrict__ nbr, float* __restrict__ part, int64_t n_out,
                                                     int K, int64_t rows_per_block) {
   extern __shared__ float sm[];
   const int KC = K * STEM_CIN;
-  float* in_s = sm;                          // [STEM_ROWS][KC]
-  float* g_s = sm + STEM_ROWS * KC;          // [STEM_ROWS][64]
-  const int tid = threadIdx.x, co = tid & 63, jg = tid >> 6;
+  float* in_s = sm;                          // [STEM_ROWS][STEM_JP]   (columns >= KC stay zero)
+  float* g_s = sm + STEM_ROWS * STEM_JP;     // [STEM_ROWS][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
   int64_t r_end = r_begin + rows_per_block;
   if (r_end > n_out) r_end = n_out;
-  float acc[21];
+  for (int t = tid; t < STEM_ROWS * STEM_JP; t += 256) in_s[t] = 0.f;
+  f32x16 acc[3][2];
 #pragma unroll
-  for (int e = 0; e < 21; ++e) acc[e] = 0.f;
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   for (int64_t rb = r_begin; rb < r_end; rb += STEM_ROWS) {
     __syncthreads();
     for (int t = tid; t < STEM_ROWS * K; t += 256) {
       int k = t / STEM_ROWS, row = t % STEM_ROWS;
       int64_t o = rb + row;
-      int i = o < r_end ? nbr[(int64_t)k * n_out + o] : -1;
-      float a = 0.f, b = 0.f, c = 0.f;
-      if (i >= 0) { a = in[(int64_t)i * 3]; b = in[(int64_t)i * 3 + 1]; c = in[(int64_t)i * 3 + 2]; }
-      in_s[row * KC + k * 3] = a; in_s[row * KC + k * 3 + 1] = b; in_s[row * KC + k * 3 + 2] = c;
+      int64_t oc = o < r_end ? o : r_end - 1;
+      int i = nbr[(int64_t)k * n_out + oc];
+      if (o >= r_end) i = -1;
+      const float* src = i < 0 ? g_zero_row : in + (int64_t)i * 3;
+      float a = src[0], b = src[1], c = src[2];
+      in_s[row * STEM_JP + k * 3] = a; in_s[row * STEM_JP + k * 3 + 1] = b; in_s[row * STEM_JP + k * 3 + 2] = c;
     }
     for (int t = tid; t < STEM_ROWS * 16; t += 256) {
       int row = t >> 4;
       int64_t o = rb + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (o < r_end) v = reinterpret_cast<const float4*>(gout + o * 64)[t & 15];
-      reinterpret_cast<float4*>(g_s)[t] = v;
+      const float* gp = o < r_end ? gout + o * 64 + (t & 15) * 4 : g_zero_row;
+      reinterpret_cast<f32x4*>(g_s)[t] = *reinterpret_cast<const f32x4*>(gp);
     }
     __syncthreads();
-    for (int row = 0; row < STEM_ROWS; ++row) {
-      float g = g_s[row * 64 + co];
 #pragma unroll
-      for (int e = 0; e < 21; ++e) {
-        int j = jg + 4 * e;
-        if (j < KC) acc[e] = fmaf(in_s[row * KC + j], g, acc[e]);
-      }
+    for (int sidx = 0; sidx < 8; ++sidx) {
+      const int row = wave * 16 + 2 * sidx + h;
+      float a[3], b[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a[i] = in_s[row * STEM_JP + i * 32 + r];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = g_s[row * 64 + j * 32 + r];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
-  float* dst = part + (int64_t)blockIdx.x * KC * 64;
+  // cross-wave sum in wave order through LDS ([96][64] floats = 24 KB, reusing the staging area)
+  __syncthreads();
+  float* red = sm;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int e = 0; e < 21; ++e) {
-    int j = jg + 4 * e;
-    if (j < KC) dst[j * 64 + co] = acc[e];
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            int jj = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, co = j * 32 + r;
+            float v = acc[i][j][e];
+            if (w > 0) v += red[jj * 64 + co];
+            red[jj * 64 + co] = v;
+          }
+    }
+    __syncthreads();
   }
+  float* dst = part + (int64_t)blockIdx.x * KC * 64;
+  for (int t = tid; t < KC * 64; t += 256) dst[t] = red[t];
 }
 
 // generic fallback (any Cin/Cout): one thread per (row, cout).  Used for the Cin=3 stem and as the
@@ -609,7 +640,7 @@ int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int*
   bool mfma_ok = !(flags & 1) && (Cin % 64 == 0) && (Cout % 64 == 0);
   if (row_index) return FC_EINVAL;             // reserved (see k_wgrad_mfma)
   if (!(flags & 1) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27) {
-    size_t smem = (size_t)(STEM_ROWS * K * STEM_CIN + STEM_ROWS * 64) * sizeof(float);
+    size_t smem = (size_t)(STEM_ROWS * STEM_JP + STEM_ROWS * 64) * sizeof(float);
     k_stem_wgrad<<<(unsigned)S, 256, smem, stream>>>(in, gout, nbr, part, n_out, K, rps);
   } else if (mfma_ok) {
     int bm, bn;
