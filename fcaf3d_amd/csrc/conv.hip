@@ -427,9 +427,12 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_
 // GEMM with M = Cin, N = Cout and the reduction over output rows, split over `S` row ranges whose
 // partial products are written to the workspace and summed by k_wgrad_reduce in a fixed order
 // (deterministic, no atomics).
-template <int BMc, int BNc, bool HAS_NBR, int BKR>
+// PAIRS: `nbr` / `row_index` are the exact pair lists of fc_kernel_map_pairs (input row, output row; `cnt[k]` valid
+// entries per offset) and the reduction runs over the pairs only, split evenly over gridDim.x on the device.
+template <int BMc, int BNc, bool HAS_NBR, int BKR, bool PAIRS>
 __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ gout,
                                                     const int* __restrict__ nbr, const int* __restrict__ row_index,
+                                                    const int* __restrict__ cnt,
                                                     float* __restrict__ part, int64_t n_out, int K, int Cin, int Cout,
                                                     int64_t rows_per_split) {
   constexpr int TM = BMc / 64, TN = BNc / 64;
@@ -445,9 +448,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
   const int tm = y % tiles_m; y /= tiles_m;
   const int k = y;
   const int ci0 = tm * BMc, co0 = tn * BNc;
+  int64_t total = n_out;
+  if (PAIRS) {
+    total = cnt[k];
+    rows_per_split = ((total + gridDim.x - 1) / gridDim.x + BKR - 1) / BKR * BKR;
+  }
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_split;
   int64_t r_end = r_begin + rows_per_split;
-  if (r_end > n_out) r_end = n_out;
+  if (r_end > total) r_end = total;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -479,6 +487,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
       int rr = lin / (BNc / 4), c4 = lin % (BNc / 4);
       int64_t row = rb + rr;
       int64_t rc = row < r_end ? row : r_end - 1;
+      if (PAIRS) rc = row_index[(int64_t)k * n_out + rc];
       const float* gp = row < r_end ? gout + rc * Cout + co0 + c4 * 4 : g_zero_row + (c4 & 15) * 4;
       gv[i] = *reinterpret_cast<const f32x4*>(gp);
     }
@@ -624,8 +633,9 @@ int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flag
   return (int64_t)S * K * Cin * Cout * (int64_t)sizeof(float);
 }
 
-int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int* row_index, float* gW, int64_t n_in,
-                  int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
+static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, const int* row_index, const int* cnt,
+                           float* gW, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
+                           int64_t ws_bytes, hipStream_t stream) {
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
   const int64_t elems = (int64_t)K * Cin * Cout;
@@ -638,23 +648,28 @@ int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int*
   if (ws_bytes < (int64_t)S * elems * (int64_t)sizeof(float)) return FC_EWS;
   float* part = (S == 1) ? gW : (float*)ws;
   bool mfma_ok = !(flags & 1) && (Cin % 64 == 0) && (Cout % 64 == 0);
-  if (row_index) return FC_EINVAL;             // reserved (see k_wgrad_mfma)
+  if (cnt && !mfma_ok) return FC_EINVAL;       // pair lists are an MFMA-path feature
   if (!(flags & 1) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27) {
     size_t smem = (size_t)(STEM_ROWS * STEM_JP + STEM_ROWS * 64) * sizeof(float);
     k_stem_wgrad<<<(unsigned)S, 256, smem, stream>>>(in, gout, nbr, part, n_out, K, rps);
   } else if (mfma_ok) {
     int bm, bn;
     wgrad_tiles(Cin, Cout, flags, &bm, &bn);
+    if (cnt) bm = 64;
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
     const bool deep = (flags & (1 << 19)) && bm == 64 && nbr;          // 64-row chunks (tuning flag)
-    if (deep) {
-      if (bn == 128) k_wgrad_mfma<64, 128, true, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps);
-      else k_wgrad_mfma<64, 64, true, 64><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps);
+    if (cnt) {
+      if (bn == 128) k_wgrad_mfma<64, 128, true, 32, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
+      else k_wgrad_mfma<64, 64, true, 32, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
     } else
-    if (bm == 128 && bn == 128) { if (nbr) k_wgrad_mfma<128, 128, true, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<128, 128, false, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
-    else if (bm == 128) { if (nbr) k_wgrad_mfma<128, 64, true, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<128, 64, false, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
-    else if (bn == 128) { if (nbr) k_wgrad_mfma<64, 128, true, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<64, 128, false, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
-    else { if (nbr) k_wgrad_mfma<64, 64, true, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<64, 64, false, 32><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, part, n_out, K, Cin, Cout, rps); }
+    if (deep) {
+      if (bn == 128) k_wgrad_mfma<64, 128, true, 64, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
+      else k_wgrad_mfma<64, 64, true, 64, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
+    } else
+    if (bm == 128 && bn == 128) { if (nbr) k_wgrad_mfma<128, 128, true, 32, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<128, 128, false, 32, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); }
+    else if (bm == 128) { if (nbr) k_wgrad_mfma<128, 64, true, 32, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<128, 64, false, 32, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); }
+    else if (bn == 128) { if (nbr) k_wgrad_mfma<64, 128, true, 32, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<64, 128, false, 32, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); }
+    else { if (nbr) k_wgrad_mfma<64, 64, true, 32, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); else k_wgrad_mfma<64, 64, false, 32, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); }
   } else {
     dim3 grid((unsigned)S, (unsigned)K);
     k_wgrad_fma<<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
@@ -665,6 +680,20 @@ int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int*
     FC_CHECK_LAUNCH();
   }
   return FC_OK;
+}
+
+int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int* row_index, float* gW, int64_t n_in,
+                  int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (row_index) return FC_EINVAL;             // reserved (see k_wgrad_mfma)
+  return conv_wgrad_impl(in, gout, nbr, nullptr, nullptr, gW, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream);
+}
+
+int fc_conv_wgrad_pairs(const float* in, const float* gout, const int* pair_in, const int* pair_out, const int* pair_cnt,
+                        float* gW, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
+                        int64_t ws_bytes, hipStream_t stream) {
+  if (!pair_in || !pair_out || !pair_cnt) return FC_EINVAL;
+  return conv_wgrad_impl(in, gout, pair_in, pair_out, pair_cnt, gW, n_in, n_out, K, Cin, Cout, flags & ~(1 << 19), ws,
+                         ws_bytes, stream);
 }
 
 int fc_transpose_weight(const float* W, float* Wt, int K, int Cin, int Cout, hipStream_t stream) {

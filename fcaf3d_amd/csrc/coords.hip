@@ -372,6 +372,68 @@ int fc_permute_nbr(const int* nbr, const int* order, int64_t n_out, int K, int* 
 }
 
 // ----------------------------------------------------------------------------------------------
+// Exact pair lists of a neighbour table, per kernel offset, in ascending output-row order (deterministic):
+// pair_out[k][j] = j-th output row o with nbr[k][o] >= 0, pair_in[k][j] = nbr[k][o], cnt[k] = number of pairs.
+// The weight-gradient GEMM reduces over these lists, so absent neighbours cost no MFMA work.
+#define PAIR_BLK 1024
+__global__ __launch_bounds__(PAIR_BLK) void k_pairs_count(const int* __restrict__ nbr, int64_t n, int nblk,
+                                                          int* __restrict__ blk_cnt) {
+  const int k = blockIdx.y;
+  int64_t row = (int64_t)blockIdx.x * PAIR_BLK + threadIdx.x;
+  int present = row < n && nbr[(int64_t)k * n + row] >= 0;
+  int c = __syncthreads_count(present);
+  if (threadIdx.x == 0) blk_cnt[k * nblk + blockIdx.x] = c;
+}
+
+__global__ __launch_bounds__(PAIR_BLK) void k_pairs_fill(const int* __restrict__ nbr, int64_t n, int nblk,
+                                                         const int* __restrict__ blk_cnt, int* __restrict__ pair_in,
+                                                         int* __restrict__ pair_out, int* __restrict__ cnt) {
+  __shared__ int wave_cnt[PAIR_BLK / 64];
+  __shared__ int base_s;
+  const int k = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {                                   // pairs of offset k in the blocks before this one
+    int a = 0;
+    for (int b = lane; b < blk; b += 64) a += blk_cnt[k * nblk + b];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) base_s = a;
+  }
+  int64_t row = (int64_t)blk * PAIR_BLK + tid;
+  int v = row < n ? nbr[(int64_t)k * n + row] : -1;
+  unsigned long long bal = __ballot(v >= 0);
+  if (lane == 0) wave_cnt[wave] = __popcll(bal);
+  __syncthreads();
+  int pre = base_s;
+  for (int w = 0; w < wave; ++w) pre += wave_cnt[w];
+  if (v >= 0) {
+    int64_t pos = (int64_t)k * n + pre + __popcll(bal & ((1ull << lane) - 1ull));
+    pair_in[pos] = v;
+    pair_out[pos] = (int)row;
+  }
+  if (blk == nblk - 1 && tid == PAIR_BLK - 1) cnt[k] = pre + __popcll(bal);
+}
+
+int64_t fc_kernel_map_pairs_ws_bytes(int64_t n_out, int K) {
+  return (int64_t)K * fc_cdiv(n_out > 0 ? n_out : 1, PAIR_BLK) * (int64_t)sizeof(int);
+}
+
+int fc_kernel_map_pairs(const int* nbr, int64_t n_out, int K, int* pair_in, int* pair_out, int* cnt, void* ws,
+                        int64_t ws_bytes, hipStream_t stream) {
+  if (n_out < 0 || K < 1 || K > 65535) return FC_EINVAL;
+  if (n_out == 0) {
+    FC_HIP(hipMemsetAsync(cnt, 0, (size_t)K * sizeof(int), stream));
+    return FC_OK;
+  }
+  if (ws_bytes < fc_kernel_map_pairs_ws_bytes(n_out, K)) return FC_EWS;
+  int nblk = (int)fc_cdiv(n_out, PAIR_BLK);
+  dim3 grid((unsigned)nblk, K);
+  k_pairs_count<<<grid, PAIR_BLK, 0, stream>>>(nbr, n_out, nblk, (int*)ws);
+  FC_CHECK_LAUNCH();
+  k_pairs_fill<<<grid, PAIR_BLK, 0, stream>>>(nbr, n_out, nblk, (const int*)ws, pair_in, pair_out, cnt);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
 // generative transposed conv k2 s2: child row 8*i + k at c_i + {0,half}^3 (x fastest) — Appendix A.4
 __global__ void k_gen_coords(const int4* __restrict__ coords, int64_t n, int half, int4* __restrict__ out) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -124,8 +124,13 @@ class _SparseConv(torch.autograd.Function):
                 g = torch.empty_like(weight)
                 wsb = L.query('fc_conv_wgrad_ws_bytes', n_out, K, Cin, Cout, FLAGS)
                 ws = L.workspace(wsb, dev)
-                L.call('fc_conv_wgrad', L.ptr(feats), L.ptr(gout), L.ptr(nbr), L.ptr(ridx), L.ptr(g), n_in, n_out, K, Cin, Cout,
-                       FLAGS, L.ptr(ws), ws.numel(), L.stream())
+                if kmap is not None and kmap.use_pairs and not (FLAGS & 1) and Cin % 64 == 0 and Cout % 64 == 0:
+                    pi, po, cnt = kmap.pairs()
+                    L.call('fc_conv_wgrad_pairs', L.ptr(feats), L.ptr(gout), L.ptr(pi), L.ptr(po), L.ptr(cnt), L.ptr(g), n_in,
+                           n_out, K, Cin, Cout, FLAGS, L.ptr(ws), ws.numel(), L.stream())
+                else:
+                    L.call('fc_conv_wgrad', L.ptr(feats), L.ptr(gout), L.ptr(nbr), L.ptr(ridx), L.ptr(g), n_in, n_out, K, Cin,
+                           Cout, FLAGS, L.ptr(ws), ws.numel(), L.stream())
                 return g
             if WGRAD_ASYNC and ctx.w_leaf:
                 global _join_queued

@@ -7,6 +7,7 @@ that produced it (ME's CPU rule) — deterministic, and 
 oracle's, so parity is checked row for row.
 """
 import itertools
+import os
 
 import torch
 
@@ -67,6 +68,7 @@ def _next_pow2(n):
 
 
 SORT_ROWS = True      # process conv rows in occupancy-mask order on sparse 27-offset maps
+WGRAD_PAIRS = os.environ.get('FC_WGRAD_PAIRS', '1') != '0'    # weight gradients reduce over exact pair lists there
 _offs_cache = {}
 
 
@@ -100,6 +102,8 @@ class KernelMap:
         self._sorted = None
         self._sorted_t = None
         self.sort_rows = False          # set by CoordMap.kernel_map for sparse-ish 27-offset maps
+        self.use_pairs = False          # ditto: the weight-gradient pass walks exact pair lists
+        self._pairs = None
 
     @property
     def nbr_t(self):
@@ -121,6 +125,19 @@ class KernelMap:
         tab = torch.empty_like(nbr)
         L.call('fc_permute_nbr', L.ptr(nbr), L.ptr(order), n_rows, K, L.ptr(tab), L.stream())
         return _rec(tab, order)
+
+    def pairs(self):
+        """(pair_in, pair_out, cnt): per offset, the (input row, output row) pairs in ascending output row."""
+        if self._pairs is None:
+            dev = self.nbr.device
+            pi = torch.empty_like(self.nbr)
+            po = torch.empty_like(self.nbr)
+            cnt = torch.empty(self.K, dtype=torch.int32, device=dev)
+            ws = L.workspace(L.query('fc_kernel_map_pairs_ws_bytes', self.n_out, self.K), dev)
+            L.call('fc_kernel_map_pairs', L.ptr(self.nbr), self.n_out, self.K, L.ptr(pi), L.ptr(po), L.ptr(cnt),
+                   L.ptr(ws), ws.numel(), L.stream())
+            self._pairs = _rec(pi, po, cnt)
+        return self._pairs
 
     def sorted_fwd(self):
         """(nbr permuted into mask order, order) for the forward / weight-gradient pass, or (nbr, None)."""
@@ -218,6 +235,7 @@ class CoordMap:
             # ... and below ~8k rows the masks do not group well enough to pay for themselves (tools/convbench.py)
             km.sort_rows = (SORT_ROWS and K == 27 and out_map.n >= 8192
                             and not (self.dense_hint and out_map.dense_hint))
+            km.use_pairs = WGRAD_PAIRS and K == 27 and not (self.dense_hint and out_map.dense_hint)
             self._kmaps[key] = km
         return km
 

@@ -60,6 +60,12 @@ int fc_kernel_map(const int* out_coords, int64_t n_out, const unsigned long long
 /* per-row occupancy masks of a neighbour table, and the table permuted into a row order (mask-sorted rows). */
 int fc_nbr_row_masks(const int* nbr, int64_t n_out, int K, int* masks, hipStream_t stream);
 int fc_permute_nbr(const int* nbr, const int* order, int64_t n_out, int K, int* nbr_sorted, hipStream_t stream);
+/* exact (input row, output row) pair lists per kernel offset, ascending in the output row — what ME's kernel map
+ * (in_maps / out_maps per offset) holds; the weight-gradient pass reduces over them (fc_conv_wgrad_pairs).
+ * pair_in / pair_out are (K, n_out) int32 with the first cnt[k] entries of row k valid. */
+int64_t fc_kernel_map_pairs_ws_bytes(int64_t n_out, int K);
+int fc_kernel_map_pairs(const int* nbr, int64_t n_out, int K, int* pair_in, int* pair_out, int* cnt, void* ws,
+                        int64_t ws_bytes, hipStream_t stream);
 /* nbr_t[k][i] = o  iff  nbr[k][o] == i  (the gather table of the backward-data pass). */
 int fc_kernel_map_transpose(const int* nbr, int64_t n_out, int64_t n_in, int K, int* nbr_t, hipStream_t stream);
 
@@ -99,6 +105,11 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_
 int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);
 int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int* row_index, float* gW, int64_t n_in,
                   int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);
+/* the same over the exact pair lists of fc_kernel_map_pairs (Cin, Cout multiples of 64): the reduction skips absent
+ * neighbours, which is ~40 % of a 27-offset table on surface-like scenes.  Workspace as fc_conv_wgrad_ws_bytes. */
+int fc_conv_wgrad_pairs(const float* in, const float* gout, const int* pair_in, const int* pair_out, const int* pair_cnt,
+                        float* gW, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
+                        int64_t ws_bytes, hipStream_t stream);
 
 /* (K,Cin,Cout) -> (K,Cout,Cin) */
 int fc_transpose_weight(const float* W, float* Wt, int K, int Cin, int Cout, hipStream_t stream);

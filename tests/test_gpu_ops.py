@@ -124,6 +124,26 @@ def _conv_case(dev, n_points, Cin, Cout, ks, s, flags, seed=5, B=2, level_q=1):
     _close(gw_g, gw_r, what=tag + ' wgrad')
 
 
+def test_kernel_map_pairs_bit_exact():
+    """pair lists == np.nonzero of the oracle's table, offset by offset, in ascending output row (bit-exact)"""
+    from fcaf3d_amd.sparse import CoordMap
+    dev = _dev()
+    _, c_ref, _ = _scene_coords(11, n_points=30000, B=2)
+    c_ref = c_ref.copy(); c_ref[:, 1:] = np.floor_divide(c_ref[:, 1:], 4) * 4
+    uc, _, _ = mo.unique_first(c_ref)
+    cm, _, _ = CoordMap.from_coords(torch.from_numpy(uc).to(dev), 4, 2)
+    for s in (1, 2):
+        om = cm.strided(s)
+        oc = mo.stride_coords(uc, 4, s) if s > 1 else uc
+        nbr = mo.kernel_map(uc, oc, mo.kernel_offsets(3, 4))
+        km = cm.kernel_map(om, 3)
+        pi, po, cnt = (t.cpu().numpy() for t in km.pairs())
+        for k in range(27):
+            o = np.nonzero(nbr[k] >= 0)[0]
+            assert cnt[k] == len(o)
+            assert np.array_equal(po[k, :len(o)], o) and np.array_equal(pi[k, :len(o)], nbr[k, o])
+
+
 @pytest.mark.parametrize('Cin,Cout', [(64, 64), (64, 128), (128, 128), (128, 64), (32, 64), (256, 256)])
 def test_conv_mfma_small_tiles(Cin, Cout):
     _conv_case(_dev(), 6000, Cin, Cout, 3, 1, 0, level_q=4)
