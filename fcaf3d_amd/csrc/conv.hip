@@ -32,6 +32,7 @@ __device__ __attribute__((aligned(16))) float g_zero_row[64];   // what an absen
 template <int BM, int BN, int BKT, bool HAS_NBR>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
                                                    const int* __restrict__ nbr, const int* __restrict__ out_index,
+                                                   const int* __restrict__ cnt,
                                                    float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout) {
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave
   constexpr int LDAT = BKT + 4;                  // (BKT+4)/4 odd -> conflict-free ds_read_b128 of the A fragments
@@ -48,7 +49,19 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
   const int r = lane & 31, h = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const int S = gridDim.z, z = blockIdx.z;
+  int S = gridDim.z, z = blockIdx.z;
+  if (cnt) {
+    // pair mode (fc_conv_fwd_pairs): grid.z = kernel offset; `nbr` row z lists the input rows of that offset's cnt[z]
+    // pairs and the tile computes those compacted rows only: T_z[j] = in[pair_in[z][j]] @ W[z], written to slab z
+    // of the workspace.  From here on it is a one-offset convolution over cnt[z] rows.
+    const int64_t stride = n_out;
+    n_out = cnt[z];
+    if ((int64_t)blockIdx.x * BM >= n_out) return;
+    nbr += (int64_t)z * stride;
+    W += (int64_t)z * Cin * Cout;
+    out += (int64_t)z * stride * Cout;
+    K = 1; S = 1; z = 0;
+  }
   const int a_c4 = tid % A4, a_r = tid / A4;     // A staging: A4 float4 per row, APASS rows per pass
 
   f32x16 acc[TM][TN];
@@ -188,6 +201,22 @@ __global__ void k_sum_parts(const float* __restrict__ part, float* __restrict__ 
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
   }
   reinterpret_cast<float4*>(out)[i] = a;
+}
+
+// out[o] = sum_k T_k[pos[k][o]] over the offsets that have a neighbour at o (fixed k order: deterministic)
+__global__ void k_sum_pairs(const float* __restrict__ part, const int* __restrict__ pos, float* __restrict__ out,
+                            int64_t n_out, int K, int Cout) {
+  const int c4n = Cout / 4;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out * c4n) return;
+  int64_t o = t / c4n;
+  int c4 = (int)(t % c4n);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < K; ++k) {
+    int j = pos[(int64_t)k * n_out + o];
+    if (j >= 0) a += *reinterpret_cast<const f32x4*>(part + ((int64_t)k * n_out + j) * Cout + c4 * 4);
+  }
+  *reinterpret_cast<f32x4*>(out + o * Cout + c4 * 4) = a;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -404,19 +433,44 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_
   if (S > 1 && ws_bytes < (int64_t)S * n_out * Cout * (int64_t)sizeof(float)) return FC_EWS;
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
-  if (bm == 256) { if (nbr) k_conv_mfma<256, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<256, 64, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
-  else if (bm == 128 && bn == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 128, 64, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 64, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
-  else if (bm == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 64, 64, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 64, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
-  else if (bm == 128 && bn == 128) { if (nbr) k_conv_mfma<128, 128, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
-  else if (bm == 128) { if (nbr) k_conv_mfma<128, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
-  else if (bn == 128) { if (nbr) k_conv_mfma<64, 128, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<64, 128, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
-  else { if (nbr) k_conv_mfma<64, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); else k_conv_mfma<64, 64, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, dst, n_out, K, Cin, Cout); }
+  if (bm == 256) { if (nbr) k_conv_mfma<256, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<256, 64, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  else if (bm == 128 && bn == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 128, 64, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 64, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  else if (bm == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 64, 64, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 64, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  else if (bm == 128 && bn == 128) { if (nbr) k_conv_mfma<128, 128, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  else if (bm == 128) { if (nbr) k_conv_mfma<128, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  else if (bn == 128) { if (nbr) k_conv_mfma<64, 128, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<64, 128, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  else { if (nbr) k_conv_mfma<64, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<64, 64, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
   FC_CHECK_LAUNCH();
   if (S > 1) {
     int64_t e4 = n_out * Cout / 4;
     k_sum_parts<<<(unsigned)fc_cdiv(e4, 256), 256, 0, stream>>>(dst, out, e4, S);
     FC_CHECK_LAUNCH();
   }
+  return FC_OK;
+}
+
+int64_t fc_conv_fwd_pairs_ws_bytes(int64_t n_out, int K, int Cout) {
+  return (int64_t)K * n_out * Cout * (int64_t)sizeof(float);
+}
+
+// Convolution over the exact pair lists: per offset a compacted gather-GEMM into the workspace, then a gather-sum.
+int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
+                      float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
+                      int64_t ws_bytes, hipStream_t stream) {
+  if (n_in < 0 || n_out < 0 || K < 1 || K > 65535 || Cin < 1 || Cout < 1) return FC_EINVAL;
+  if (!pair_in || !pair_cnt || !pair_pos) return FC_EINVAL;
+  if (Cin % 32 != 0 || Cout % 64 != 0) return FC_EINVAL;       // MFMA shapes only; callers use fc_conv_fwd otherwise
+  if (n_out == 0) return FC_OK;
+  if (ws_bytes < fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout)) return FC_EWS;
+  float* part = (float*)ws;
+  const bool wide = (Cout % 128 == 0) && !(((flags >> 6) & 3) == 1);
+  const int bn = wide ? 128 : 64;
+  dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
+  if (wide) k_conv_mfma<128, 128, 32, true><<<grid, 256, 0, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
+  else k_conv_mfma<128, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
+  FC_CHECK_LAUNCH();
+  k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);
+  FC_CHECK_LAUNCH();
   return FC_OK;
 }
 

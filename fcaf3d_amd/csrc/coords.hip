@@ -373,7 +373,8 @@ int fc_permute_nbr(const int* nbr, const int* order, int64_t n_out, int K, int* 
 
 // ----------------------------------------------------------------------------------------------
 // Exact pair lists of a neighbour table, per kernel offset, in ascending output-row order (deterministic):
-// pair_out[k][j] = j-th output row o with nbr[k][o] >= 0, pair_in[k][j] = nbr[k][o], cnt[k] = number of pairs.
+// pair_out[k][j] = j-th output row o with nbr[k][o] >= 0, pair_in[k][j] = nbr[k][o], cnt[k] = number of pairs,
+// pos[k][o] = j (or -1): where output row o sits in list k (nullable).
 // The weight-gradient GEMM reduces over these lists, so absent neighbours cost no MFMA work.
 #define PAIR_BLK 1024
 __global__ __launch_bounds__(PAIR_BLK) void k_pairs_count(const int* __restrict__ nbr, int64_t n, int nblk,
@@ -387,7 +388,8 @@ __global__ __launch_bounds__(PAIR_BLK) void k_pairs_count(const int* __restrict_
 
 __global__ __launch_bounds__(PAIR_BLK) void k_pairs_fill(const int* __restrict__ nbr, int64_t n, int nblk,
                                                          const int* __restrict__ blk_cnt, int* __restrict__ pair_in,
-                                                         int* __restrict__ pair_out, int* __restrict__ cnt) {
+                                                         int* __restrict__ pair_out, int* __restrict__ pos,
+                                                         int* __restrict__ cnt) {
   __shared__ int wave_cnt[PAIR_BLK / 64];
   __shared__ int base_s;
   const int k = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -404,11 +406,12 @@ __global__ __launch_bounds__(PAIR_BLK) void k_pairs_fill(const int* __restrict__
   __syncthreads();
   int pre = base_s;
   for (int w = 0; w < wave; ++w) pre += wave_cnt[w];
+  const int j = pre + __popcll(bal & ((1ull << lane) - 1ull));
   if (v >= 0) {
-    int64_t pos = (int64_t)k * n + pre + __popcll(bal & ((1ull << lane) - 1ull));
-    pair_in[pos] = v;
-    pair_out[pos] = (int)row;
+    pair_in[(int64_t)k * n + j] = v;
+    pair_out[(int64_t)k * n + j] = (int)row;
   }
+  if (pos && row < n) pos[(int64_t)k * n + row] = v >= 0 ? j : -1;
   if (blk == nblk - 1 && tid == PAIR_BLK - 1) cnt[k] = pre + __popcll(bal);
 }
 
@@ -416,8 +419,8 @@ int64_t fc_kernel_map_pairs_ws_bytes(int64_t n_out, int K) {
   return (int64_t)K * fc_cdiv(n_out > 0 ? n_out : 1, PAIR_BLK) * (int64_t)sizeof(int);
 }
 
-int fc_kernel_map_pairs(const int* nbr, int64_t n_out, int K, int* pair_in, int* pair_out, int* cnt, void* ws,
-                        int64_t ws_bytes, hipStream_t stream) {
+int fc_kernel_map_pairs(const int* nbr, int64_t n_out, int K, int* pair_in, int* pair_out, int* pair_pos, int* cnt,
+                        void* ws, int64_t ws_bytes, hipStream_t stream) {
   if (n_out < 0 || K < 1 || K > 65535) return FC_EINVAL;
   if (n_out == 0) {
     FC_HIP(hipMemsetAsync(cnt, 0, (size_t)K * sizeof(int), stream));
@@ -428,7 +431,7 @@ int fc_kernel_map_pairs(const int* nbr, int64_t n_out, int K, int* pair_in, int*
   dim3 grid((unsigned)nblk, K);
   k_pairs_count<<<grid, PAIR_BLK, 0, stream>>>(nbr, n_out, nblk, (int*)ws);
   FC_CHECK_LAUNCH();
-  k_pairs_fill<<<grid, PAIR_BLK, 0, stream>>>(nbr, n_out, nblk, (const int*)ws, pair_in, pair_out, cnt);
+  k_pairs_fill<<<grid, PAIR_BLK, 0, stream>>>(nbr, n_out, nblk, (const int*)ws, pair_in, pair_out, pair_pos, cnt);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }

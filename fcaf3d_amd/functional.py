@@ -76,6 +76,20 @@ def _mfma_shape(Cin, Cout):
     return not (FLAGS & 1) and Cin % 32 == 0 and Cout % 64 == 0
 
 
+def _pair_conv(kmap, n_rows, Cin, Cout):
+    """run this convolution per offset over the exact pair lists? (small, sparsely occupied 27-offset maps)"""
+    from . import sparse as SP
+    return (kmap is not None and kmap.use_pairs and n_rows <= SP.PAIR_CONV_ROWS and not (FLAGS & 1)
+            and Cin % 32 == 0 and Cout % 64 == 0)
+
+
+def _conv_pairs(x, w, lists, out, n_in, n_out, K, Cin, Cout):
+    pi, _, pos, cnt = lists
+    ws = L.workspace(L.query('fc_conv_fwd_pairs_ws_bytes', n_out, K, Cout), x.device)
+    L.call('fc_conv_fwd_pairs', L.ptr(x), L.ptr(w), L.ptr(pi), L.ptr(cnt), L.ptr(pos), L.ptr(out), n_in, n_out, K, Cin, Cout,
+           FLAGS, L.ptr(ws), ws.numel(), L.stream())
+
+
 def _conv_fwd(x, w, nbr, out, n_in, n_out, K, Cin, Cout, out_index=None):
     wsb = L.query('fc_conv_fwd_ws_bytes', n_out, K, Cin, Cout, FLAGS)
     ws = L.workspace(wsb, x.device) if wsb else None
@@ -95,8 +109,12 @@ class _SparseConv(torch.autograd.Function):
         K, Cin, Cout = weight.shape
         n_in = feats.shape[0]
         out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
-        nbr, oidx = (kmap.sorted_fwd() if _mfma_shape(Cin, Cout) else (kmap.nbr, None)) if kmap is not None else (None, None)
-        _conv_fwd(feats, weight, nbr, out, n_in, n_out, K, Cin, Cout, oidx)
+        if _pair_conv(kmap, n_out, Cin, Cout):
+            _conv_pairs(feats, weight, kmap.pairs(), out, n_in, n_out, K, Cin, Cout)
+        else:
+            nbr, oidx = ((kmap.sorted_fwd() if _mfma_shape(Cin, Cout) else (kmap.nbr, None))
+                         if kmap is not None else (None, None))
+            _conv_fwd(feats, weight, nbr, out, n_in, n_out, K, Cin, Cout, oidx)
         ctx.save_for_backward(feats, weight)
         ctx.kmap = kmap
         return out
@@ -114,9 +132,12 @@ class _SparseConv(torch.autograd.Function):
             wt = torch.empty((K, Cout, Cin), dtype=torch.float32, device=dev)
             L.call('fc_transpose_weight', L.ptr(weight), L.ptr(wt), K, Cin, Cout, L.stream())
             gin = torch.empty((n_in, Cin), dtype=torch.float32, device=dev)
-            nbr_t, tidx = ((kmap.sorted_bwd() if _mfma_shape(Cout, Cin) else (kmap.nbr_t, None))
-                           if kmap is not None else (None, None))
-            _conv_fwd(gout, wt, nbr_t, gin, n_out, n_in, K, Cout, Cin, tidx)
+            if _pair_conv(kmap, n_in, Cout, Cin):
+                _conv_pairs(gout, wt, kmap.pairs_t(), gin, n_out, n_in, K, Cout, Cin)
+            else:
+                nbr_t, tidx = ((kmap.sorted_bwd() if _mfma_shape(Cout, Cin) else (kmap.nbr_t, None))
+                               if kmap is not None else (None, None))
+                _conv_fwd(gout, wt, nbr_t, gin, n_out, n_in, K, Cout, Cin, tidx)
         if ctx.needs_input_grad[1]:
             nbr, ridx = (kmap.nbr if kmap is not None else None), None      # wgrad walks rows in natural order (see conv.hip)
 
@@ -125,7 +146,7 @@ class _SparseConv(torch.autograd.Function):
                 wsb = L.query('fc_conv_wgrad_ws_bytes', n_out, K, Cin, Cout, FLAGS)
                 ws = L.workspace(wsb, dev)
                 if kmap is not None and kmap.use_pairs and not (FLAGS & 1) and Cin % 64 == 0 and Cout % 64 == 0:
-                    pi, po, cnt = kmap.pairs()
+                    pi, po, _, cnt = kmap.pairs()
                     L.call('fc_conv_wgrad_pairs', L.ptr(feats), L.ptr(gout), L.ptr(pi), L.ptr(po), L.ptr(cnt), L.ptr(g), n_in,
                            n_out, K, Cin, Cout, FLAGS, L.ptr(ws), ws.numel(), L.stream())
                 else:

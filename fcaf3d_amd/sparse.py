@@ -68,7 +68,10 @@ def _next_pow2(n):
 
 
 SORT_ROWS = True      # process conv rows in occupancy-mask order on sparse 27-offset maps
+SORT_MIN_ROWS = int(os.environ.get('FC_SORT_MIN_ROWS', '8192'))
 WGRAD_PAIRS = os.environ.get('FC_WGRAD_PAIRS', '1') != '0'    # weight gradients reduce over exact pair lists there
+# ... and with at most this many result rows the convolution itself runs per offset over the pair lists
+PAIR_CONV_ROWS = int(os.environ.get('FC_PAIR_CONV_ROWS', '16384'))
 _offs_cache = {}
 
 
@@ -104,6 +107,7 @@ class KernelMap:
         self.sort_rows = False          # set by CoordMap.kernel_map for sparse-ish 27-offset maps
         self.use_pairs = False          # ditto: the weight-gradient pass walks exact pair lists
         self._pairs = None
+        self._pairs_t = None
 
     @property
     def nbr_t(self):
@@ -126,18 +130,30 @@ class KernelMap:
         L.call('fc_permute_nbr', L.ptr(nbr), L.ptr(order), n_rows, K, L.ptr(tab), L.stream())
         return _rec(tab, order)
 
+    @staticmethod
+    def _pair_lists(nbr, n_rows, K):
+        dev = nbr.device
+        pi = torch.empty_like(nbr)
+        po = torch.empty_like(nbr)
+        pos = torch.empty_like(nbr)
+        cnt = torch.empty(K, dtype=torch.int32, device=dev)
+        ws = L.workspace(L.query('fc_kernel_map_pairs_ws_bytes', n_rows, K), dev)
+        L.call('fc_kernel_map_pairs', L.ptr(nbr), n_rows, K, L.ptr(pi), L.ptr(po), L.ptr(pos), L.ptr(cnt),
+               L.ptr(ws), ws.numel(), L.stream())
+        return _rec(pi, po, pos, cnt)
+
     def pairs(self):
-        """(pair_in, pair_out, cnt): per offset, the (input row, output row) pairs in ascending output row."""
+        """(pair_in, pair_out, pair_pos, cnt): per offset, the (input row, output row) pairs in ascending output row,
+        and where each output row sits in each list (ME's in_maps / out_maps)."""
         if self._pairs is None:
-            dev = self.nbr.device
-            pi = torch.empty_like(self.nbr)
-            po = torch.empty_like(self.nbr)
-            cnt = torch.empty(self.K, dtype=torch.int32, device=dev)
-            ws = L.workspace(L.query('fc_kernel_map_pairs_ws_bytes', self.n_out, self.K), dev)
-            L.call('fc_kernel_map_pairs', L.ptr(self.nbr), self.n_out, self.K, L.ptr(pi), L.ptr(po), L.ptr(cnt),
-                   L.ptr(ws), ws.numel(), L.stream())
-            self._pairs = _rec(pi, po, cnt)
+            self._pairs = self._pair_lists(self.nbr, self.n_out, self.K)
         return self._pairs
+
+    def pairs_t(self):
+        """the same for the transposed table (backward-data pass): lists ascending in the INPUT row."""
+        if self._pairs_t is None:
+            self._pairs_t = self._pair_lists(self.nbr_t, self.n_in, self.K)
+        return self._pairs_t
 
     def sorted_fwd(self):
         """(nbr permuted into mask order, order) for the forward / weight-gradient pass, or (nbr, None)."""
@@ -233,7 +249,7 @@ class CoordMap:
             km._out_map = out_map            # keep alive so id() stays unique
             # generated / union sets are ~94 % dense (2x2x2 blocks): nothing to skip there
             # ... and below ~8k rows the masks do not group well enough to pay for themselves (tools/convbench.py)
-            km.sort_rows = (SORT_ROWS and K == 27 and out_map.n >= 8192
+            km.sort_rows = (SORT_ROWS and K == 27 and out_map.n >= SORT_MIN_ROWS
                             and not (self.dense_hint and out_map.dense_hint))
             km.use_pairs = WGRAD_PAIRS and K == 27 and not (self.dense_hint and out_map.dense_hint)
             self._kmaps[key] = km

@@ -62,10 +62,11 @@ int fc_nbr_row_masks(const int* nbr, int64_t n_out, int K, int* masks, hipStream
 int fc_permute_nbr(const int* nbr, const int* order, int64_t n_out, int K, int* nbr_sorted, hipStream_t stream);
 /* exact (input row, output row) pair lists per kernel offset, ascending in the output row — what ME's kernel map
  * (in_maps / out_maps per offset) holds; the weight-gradient pass reduces over them (fc_conv_wgrad_pairs).
- * pair_in / pair_out are (K, n_out) int32 with the first cnt[k] entries of row k valid. */
+ * pair_in / pair_out are (K, n_out) int32 with the first cnt[k] entries of row k valid; pair_pos (nullable,
+ * (K, n_out)) is the inverse: pair_pos[k][o] = j with pair_out[k][j] == o, or -1. */
 int64_t fc_kernel_map_pairs_ws_bytes(int64_t n_out, int K);
-int fc_kernel_map_pairs(const int* nbr, int64_t n_out, int K, int* pair_in, int* pair_out, int* cnt, void* ws,
-                        int64_t ws_bytes, hipStream_t stream);
+int fc_kernel_map_pairs(const int* nbr, int64_t n_out, int K, int* pair_in, int* pair_out, int* pair_pos, int* cnt,
+                        void* ws, int64_t ws_bytes, hipStream_t stream);
 /* nbr_t[k][i] = o  iff  nbr[k][o] == i  (the gather table of the backward-data pass). */
 int fc_kernel_map_transpose(const int* nbr, int64_t n_out, int64_t n_in, int K, int* nbr_t, hipStream_t stream);
 
@@ -100,6 +101,15 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
 int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);
 int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
                 int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);
+
+/* the same convolution as ME itself runs it (per offset: gather -> GEMM -> scatter) over the exact pair lists:
+ * T_k = in[pair_in[k][:cnt[k]]] @ W[k] into the workspace, then out[o] = sum_k T_k[pair_pos[k][o]] in fixed k order.
+ * No MFMA work is issued for absent neighbours; pays off on the small, ~60 % occupied deep levels.  MFMA shapes only
+ * (Cin % 32 == 0, Cout % 64 == 0).  For the backward-data pass pass the lists of the transposed table. */
+int64_t fc_conv_fwd_pairs_ws_bytes(int64_t n_out, int K, int Cout);
+int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
+                      float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
+                      int64_t ws_bytes, hipStream_t stream);
 
 /* backward-weights: gW[k] = sum_o in[nbr[k][o]]^T (x) gout[o]; deterministic two-level reduction. */
 int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);

@@ -137,11 +137,21 @@ def test_kernel_map_pairs_bit_exact():
         oc = mo.stride_coords(uc, 4, s) if s > 1 else uc
         nbr = mo.kernel_map(uc, oc, mo.kernel_offsets(3, 4))
         km = cm.kernel_map(om, 3)
-        pi, po, cnt = (t.cpu().numpy() for t in km.pairs())
+        pi, po, pos, cnt = (t.cpu().numpy() for t in km.pairs())
         for k in range(27):
             o = np.nonzero(nbr[k] >= 0)[0]
             assert cnt[k] == len(o)
             assert np.array_equal(po[k, :len(o)], o) and np.array_equal(pi[k, :len(o)], nbr[k, o])
+            want = np.full(nbr.shape[1], -1, np.int32); want[o] = np.arange(len(o))
+            assert np.array_equal(pos[k], want)
+        # the transposed lists: ascending in the input row, same pair multiset
+        pit, pot, _, cntt = (t.cpu().numpy() for t in km.pairs_t())
+        for k in range(27):
+            o = np.nonzero(nbr[k] >= 0)[0]
+            i = nbr[k, o]
+            order = np.argsort(i, kind='stable')
+            assert cntt[k] == len(o)
+            assert np.array_equal(pot[k, :len(o)], i[order]) and np.array_equal(pit[k, :len(o)], o[order])
 
 
 @pytest.mark.parametrize('Cin,Cout', [(64, 64), (64, 128), (128, 128), (128, 64), (32, 64), (256, 256)])

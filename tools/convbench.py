@@ -33,6 +33,8 @@ def main():
     ap.add_argument('--unsorted', action='store_true', help='use the plain neighbour table (no occupancy-mask row order)')
     ap.add_argument('--flags', type=int, default=0, help='extra flags for the default run (bit16: BK=32, bit17: BK=64)')
     ap.add_argument('--default-only', action='store_true')
+    ap.add_argument('--pairconv', action='store_true', help='forward: per-offset gather-GEMM over the pair lists')
+    ap.add_argument('--pairs', action='store_true', help='with --wgrad: reduce over the exact pair lists')
     a = ap.parse_args()
     sys.argv = [sys.argv[0], '--batch', str(a.batch)]
     args = bench.parse()
@@ -88,13 +90,19 @@ def main():
         for bm in (() if a.default_only else ((3,) if a.bm256 else (1, 2))):
             for bn in ((1, 2) if Cout % 128 == 0 else (1,)):
                 for S in ((0,) if a.wgrad else (0, 1, 2, 3, 4, 6, 9, 14, 27)):
-                    if a.wgrad and bm == 2 and Cin % 128:
+                    if a.wgrad and bm == 2 and (Cin % 128 or a.pairs):
                         continue
                     for Sw in ((0, 2, 4, 8, 16, 32, 64, 128) if a.wgrad else (0,)):
                         fl = (bm << 4) | (bn << 6) | ((S or Sw) << 8)
                         Fn.FLAGS = fl
                         try:
-                            if a.wgrad:
+                            if a.wgrad and a.pairs:
+                                wsb = L.query('fc_conv_wgrad_ws_bytes', km.n_out, K, Cin, Cout, fl)
+                                ws = L.workspace(wsb, dev)
+                                pi, po, _, cnt = km.pairs()
+                                t = timeit(lambda: L.call('fc_conv_wgrad_pairs', L.ptr(xin), L.ptr(gout), L.ptr(pi), L.ptr(po), L.ptr(cnt),
+                                                          L.ptr(gw), km.n_in, km.n_out, K, Cin, Cout, fl, L.ptr(ws), ws.numel(), L.stream()))
+                            elif a.wgrad:
                                 wsb = L.query('fc_conv_wgrad_ws_bytes', km.n_out, K, Cin, Cout, fl)
                                 ws = L.workspace(wsb, dev)
                                 t = timeit(lambda: L.call('fc_conv_wgrad', L.ptr(xin), L.ptr(gout), L.ptr(nbr_f), L.ptr(oidx), L.ptr(gw),
@@ -105,11 +113,20 @@ def main():
                             Fn.FLAGS = 0
                         res.append((t, {1: 64, 2: 128, 3: 256}[bm], bn * 64, S or Sw))
         Fn.FLAGS = a.flags
-        if a.wgrad:
+        if a.wgrad and a.pairs:
+            wsb = L.query('fc_conv_wgrad_ws_bytes', km.n_out, K, Cin, Cout, 0)
+            ws = L.workspace(wsb, dev)
+            pi, po, _, cnt = km.pairs()
+            t0 = timeit(lambda: L.call('fc_conv_wgrad_pairs', L.ptr(xin), L.ptr(gout), L.ptr(pi), L.ptr(po), L.ptr(cnt), L.ptr(gw),
+                                       km.n_in, km.n_out, K, Cin, Cout, 0, L.ptr(ws), ws.numel(), L.stream()))
+        elif a.wgrad:
             wsb = L.query('fc_conv_wgrad_ws_bytes', km.n_out, K, Cin, Cout, 0)
             ws = L.workspace(wsb, dev)
             t0 = timeit(lambda: L.call('fc_conv_wgrad', L.ptr(xin), L.ptr(gout), L.ptr(nbr_f), L.ptr(oidx), L.ptr(gw), km.n_in, km.n_out,
                                        K, Cin, Cout, 0, L.ptr(ws), ws.numel(), L.stream()))
+        elif a.pairconv:
+            lists = km.pairs()
+            t0 = timeit(lambda: Fn._conv_pairs(xin, w, lists, out, km.n_in, km.n_out, K, Cin, Cout))
         else:
             t0 = timeit(lambda: Fn._conv_fwd(xin, w, nbr_f, out, km.n_in, km.n_out, K, Cin, Cout, oidx))
         if not res:
