@@ -1,10 +1,12 @@
 """torch.autograd wrappers over the C ABI (libfcaf3d_hip.so).  fp32 only; every forward/backward is
 HIP — there is no eager/CPU fallback (tensors on the CPU raise)."""
+import os
+
 import torch
 
 from . import _lib as L
 
-FLAGS = 0   # bit0: force the generic FMA conv kernels (parity cross-check)
+FLAGS = int(os.environ.get('FC_FLAGS', '0'), 0)   # bit0: force the generic FMA conv kernels (parity cross-check); tuning bits: conv.hip
 
 # Weight-gradient kernels are leaves of the backward graph: with WGRAD_ASYNC they are enqueued on a second HIP
 # stream and overlap the backward-data chain on the main stream (the many small layers of the backbone do not
