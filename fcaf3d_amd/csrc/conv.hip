@@ -399,6 +399,16 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   if ((flags & (1 << 17)) && Cin % 64 == 0 && *bm == 128) *bk = 64;
 }
 
+// Workgroups-per-CU cap by LDS padding.  The dispatcher fills a CU up to its occupancy limit before it moves on, so
+// a launch with fewer workgroups than 256 CUs x occupancy leaves CUs idle while others time-share their matrix pipe;
+// asking for more (unused) dynamic LDS lowers the per-CU limit and spreads the workgroups.  cap in 1..3, 0 = off.
+static inline size_t lds_pad_for_cap(int cap, size_t static_bytes) {
+  if (cap < 2 || cap > 3) return 0;                       // cap 1 would need > 64 KB (opt-in attribute): not used
+  size_t want = 163840 / (size_t)(cap + 1) + 2048;
+  return want > static_bytes ? want - static_bytes : 0;
+}
+static inline size_t conv_static_lds(int bm, int bn, int bk) { return (size_t)(bm * (bk + 4) + bk * bn) * 4 + 64; }
+
 static inline bool is_stem(const int* nbr, int K, int Cin, int Cout, int flags) {
   return !(flags & 1) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27;
 }
@@ -433,13 +443,14 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_
   if (S > 1 && ws_bytes < (int64_t)S * n_out * Cout * (int64_t)sizeof(float)) return FC_EWS;
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
-  if (bm == 256) { if (nbr) k_conv_mfma<256, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<256, 64, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  else if (bm == 128 && bn == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 128, 64, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 64, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  else if (bm == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 64, 64, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 64, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  else if (bm == 128 && bn == 128) { if (nbr) k_conv_mfma<128, 128, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  else if (bm == 128) { if (nbr) k_conv_mfma<128, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  else if (bn == 128) { if (nbr) k_conv_mfma<64, 128, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<64, 128, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  else { if (nbr) k_conv_mfma<64, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<64, 64, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  const size_t pad = lds_pad_for_cap((flags >> 21) & 3, conv_static_lds(bm, bn, bk));
+  if (bm == 256) { if (nbr) k_conv_mfma<256, 64, 32, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<256, 64, 32, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  else if (bm == 128 && bn == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 128, 64, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 64, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  else if (bm == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 64, 64, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 64, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  else if (bm == 128 && bn == 128) { if (nbr) k_conv_mfma<128, 128, 32, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 32, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  else if (bm == 128) { if (nbr) k_conv_mfma<128, 64, 32, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 32, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  else if (bn == 128) { if (nbr) k_conv_mfma<64, 128, 32, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<64, 128, 32, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
+  else { if (nbr) k_conv_mfma<64, 64, 32, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<64, 64, 32, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
   FC_CHECK_LAUNCH();
   if (S > 1) {
     int64_t e4 = n_out * Cout / 4;
@@ -466,8 +477,9 @@ int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const
   const bool wide = (Cout % 128 == 0) && !(((flags >> 6) & 3) == 1);
   const int bn = wide ? 128 : 64;
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
-  if (wide) k_conv_mfma<128, 128, 32, true><<<grid, 256, 0, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
-  else k_conv_mfma<128, 64, 32, true><<<grid, 256, 0, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
+  const size_t pad = lds_pad_for_cap((flags >> 21) & 3, conv_static_lds(128, bn, 32));
+  if (wide) k_conv_mfma<128, 128, 32, true><<<grid, 256, pad, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
+  else k_conv_mfma<128, 64, 32, true><<<grid, 256, pad, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
   FC_CHECK_LAUNCH();
   k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);
   FC_CHECK_LAUNCH();

@@ -285,7 +285,66 @@ __global__ void k_riou3d(const float* __restrict__ pred, const float* __restrict
   for (int e = 0; e < 7; ++e) dpred[i * 7 + e] = r.d[e];
 }
 
+// ----------------------------------------------------------------------------------------------
+// Standalone `sort_v` (Rotated_IoU cuda_op, bound by the reference at box_intersection_2d.py:147; SURVEY.md
+// Appendix D): for every box pair, the indices of the valid intersection-polygon vertices in angular order about the
+// origin (the caller has centred them on their mean, box_intersection_2d.py:144-146), coincident neighbours
+// dropped, polygon closed, padded with a masked intersection slot.  One thread per pair.
+__global__ void k_sort_v(const float* __restrict__ vertices, const unsigned char* __restrict__ mask,
+                         const int* __restrict__ num_valid, int64_t n, int* __restrict__ idx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* v = vertices + i * 48;
+  const unsigned char* m = mask + i * 24;
+  int pad = 8;
+  for (int k = 8; k < 24; ++k)
+    if (!m[k]) { pad = k; break; }
+  int* out = idx + i * 9;
+  int order[24];
+  float ang[24];
+  int cnt = 0;
+  if (num_valid[i] >= 3) {
+    for (int k = 0; k < 24; ++k) {
+      if (!m[k]) continue;
+      float g = atan2f(v[2 * k + 1], v[2 * k]);
+      int q = cnt - 1;
+      while (q >= 0 && ang[q] > g) { ang[q + 1] = ang[q]; order[q + 1] = order[q]; --q; }     // stable insertion
+      ang[q + 1] = g; order[q + 1] = k;
+      ++cnt;
+    }
+    int kept = 0;
+    for (int k = 0; k < cnt; ++k) {
+      if (kept > 0) {
+        int q = order[kept - 1], c = order[k];
+        if (fmaxf(fabsf(v[2 * c] - v[2 * q]), fabsf(v[2 * c + 1] - v[2 * q + 1])) <= 1e-6f) continue;
+      }
+      order[kept++] = order[k];
+    }
+    if (kept > 1) {
+      int a0 = order[0], q = order[kept - 1];
+      if (fmaxf(fabsf(v[2 * a0] - v[2 * q]), fabsf(v[2 * a0 + 1] - v[2 * q + 1])) <= 1e-6f) --kept;
+    }
+    cnt = kept > 8 ? 8 : kept;
+  }
+  if (cnt < 3) {
+    for (int k = 0; k < 9; ++k) out[k] = pad;
+    return;
+  }
+  for (int k = 0; k < cnt; ++k) out[k] = order[k];
+  out[cnt] = order[0];
+  for (int k = cnt + 1; k < 9; ++k) out[k] = pad;
+}
+
 extern "C" {
+
+int fc_sort_v(const float* vertices, const unsigned char* mask, const int* num_valid, int64_t n_pairs, int* idx,
+              hipStream_t stream) {
+  if (n_pairs < 0) return FC_EINVAL;
+  if (n_pairs == 0) return FC_OK;
+  k_sort_v<<<(unsigned)fc_cdiv(n_pairs, 64), 64, 0, stream>>>(vertices, mask, num_valid, n_pairs, idx);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
 
 int fc_riou3d_fwd_bwd(const float* pred, const float* target, const float* weight, int64_t n, float* iou, float* dpred,
                       hipStream_t stream) {

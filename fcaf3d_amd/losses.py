@@ -146,6 +146,21 @@ def rotated_iou_3d(pred, target, weight=None):
     return _RotatedIoUFn.apply(pred, target, weight)
 
 
+def sort_v(vertices, mask, num_valid):
+    """Drop-in for `cuda_op.cuda_ext.sort_v` of the Rotated_IoU extension (call site:
+    rotated_iou/box_intersection_2d.py:147): vertices (B,N,24,2) f32 centred on the mean of the valid ones,
+    mask (B,N,24) bool, num_valid (B,N) int -> (B,N,9) int32 indices of the intersection polygon in angular order."""
+    if not vertices.is_cuda:
+        raise RuntimeError('fcaf3d_amd ops run on the GPU only (HIP); got a CPU tensor')
+    B, N = vertices.shape[:2]
+    v = vertices.detach().float().contiguous()
+    m = mask.to(torch.uint8).contiguous()
+    nv = num_valid.to(torch.int32).contiguous()
+    idx = torch.empty((B, N, 9), dtype=torch.int32, device=v.device)
+    L.call('fc_sort_v', L.ptr(v), L.ptr(m), L.ptr(nv), B * N, L.ptr(idx), L.stream())
+    return idx
+
+
 @LOSSES.register_module()
 class IoU3DLoss(nn.Module):
     """loss_weight * Σ w·(1 − IoU3D) / avg_factor  (iou3d_loss.py:38-75)."""

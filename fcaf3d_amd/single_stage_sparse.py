@@ -72,9 +72,10 @@ class SingleStageSparse3DDetector(nn.Module):
         m2 = m1.strided(2); m1.kernel_map(m2, 2)                   # max-pool k2 s2
         prev, levels = m2, []
         bottleneck = getattr(bb.BLOCK, 'expansion', 1) == 4
+        bwd = self.training and torch.is_grad_enabled()
         for _ in range(min(bb.n_outs, 4)):
             mi = prev.strided(2)
-            prev.kernel_map(mi, 3); prev.kernel_map(mi, 1); mi.kernel_map(mi, 3)
+            prev.kernel_map(mi, 3).prefetch(bwd); prev.kernel_map(mi, 1); mi.kernel_map(mi, 3).prefetch(bwd)
             if bottleneck:
                 break                                              # 1x1-3x3-1x1 blocks: keep it lazy
             levels.append(mi)
@@ -84,11 +85,11 @@ class SingleStageSparse3DDetector(nn.Module):
         x = levels[-1]
         x.scene_counts
         for i in range(len(levels) - 2, -1, -1):
-            g = x.generate(); g.kernel_map(g, 3)
+            g = x.generate(); g.kernel_map(g, 3).prefetch(bwd)
             u, _, _ = levels[i].union(g)
             if nh.pts_threshold >= 0 and any(c > nh.pts_threshold for c in u.scene_counts):
                 return
-            u.kernel_map(u, 3)
+            u.kernel_map(u, 3).prefetch(bwd)
             x = u
 
     def extract_feat(self, points, img_metas):

@@ -155,6 +155,25 @@ class KernelMap:
             self._pairs_t = self._pair_lists(self.nbr_t, self.n_in, self.K)
         return self._pairs_t
 
+    def prefetch(self, backward=True):
+        """Build now (i.e. on the coordinate side stream, SingleStageSparse3DDetector.plan_maps) every derived table
+        the MFMA convolutions on this map will ask for, instead of lazily on the main stream in the middle of the
+        convolution sequence: mask-sorted tables (an argsort each), pair lists, the transposed table."""
+        if self.K != 27:
+            return
+        if self.use_pairs and self.n_out <= PAIR_CONV_ROWS:
+            self.pairs()
+        else:
+            self.sorted_fwd()
+        if backward:
+            self.nbr_t
+            if self.use_pairs:
+                self.pairs()
+            if self.use_pairs and self.n_in <= PAIR_CONV_ROWS:
+                self.pairs_t()
+            else:
+                self.sorted_bwd()
+
     def sorted_fwd(self):
         """(nbr permuted into mask order, order) for the forward / weight-gradient pass, or (nbr, None)."""
         if not self.sort_rows:

@@ -194,6 +194,14 @@ int fc_aiou3d_fwd_bwd(const float* pred, const float* target, int target_stride,
 int fc_riou3d_fwd_bwd(const float* pred, const float* target, const float* weight, int64_t n, float* iou, float* dpred,
                       hipStream_t stream);
 
+/* `cuda_ext.sort_v(vertices, mask, num_valid)` of the un-vendored Rotated_IoU extension (docker/Dockerfile:35-40),
+ * bound by the reference at rotated_iou/box_intersection_2d.py:147: vertices (n_pairs,24,2) f32 centred on the mean
+ * of the valid ones, mask (n_pairs,24) bool bytes, num_valid (n_pairs) i32 -> idx (n_pairs,9) i32: valid vertices in
+ * angular order, closed (idx[nv] = idx[0]), padded with the first masked intersection slot.
+ * fc_riou3d_fwd_bwd has this step fused in; this entry point is the drop-in for the Python-level op. */
+int fc_sort_v(const float* vertices, const unsigned char* mask, const int* num_valid, int64_t n_pairs, int* idx,
+              hipStream_t stream);
+
 /* Fcaf3DAssigner.assign + compute_centerness (fcaf3d_neck_with_head.py:377-384, :394-466) for ALL scenes of the
  * batch: points (N,3) = locations of every level and scene; scene/level (N) ids; boxes (B,M,7) gravity-centre GT
  * boxes padded to M per scene, box_count (B); order (N) = rows grouped by (level, scene), seg_start (L*B+1).

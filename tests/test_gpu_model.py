@@ -307,6 +307,36 @@ def test_bev_iou_and_nms_vs_reference():
     assert np.array_equal(idx.cpu().numpy(), np.concatenate(exp_i)) and np.array_equal(cls.cpu().numpy(), np.concatenate(exp_c))
 
 
+def test_pcdet_named_entry_points():
+    """the names the reference imports (mmdet3d/ops/pcdet_nms/__init__.py): (keep, None) tuples, pre_maxsize, and the
+    IoU-matrix helpers of pcdet_nms_utils.py:28-78"""
+    from fcaf3d_amd.nms import boxes_iou3d_gpu, boxes_iou_bev, pcdet_nms_gpu, pcdet_nms_normal_gpu
+    dev = _dev()
+    rng = np.random.default_rng(4)
+    n = 500
+    boxes = np.concatenate([rng.uniform(0, 8, (n, 3)), rng.uniform(0.3, 2.0, (n, 3)), rng.uniform(-3, 3, (n, 1))], 1).astype(np.float32)
+    scores = rng.permutation(n).astype(np.float32) / n
+    bt, st = torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev)
+    keep, extra = pcdet_nms_gpu(bt, st, 0.4)
+    assert extra is None and keep.dtype == torch.long
+    assert np.array_equal(keep.cpu().numpy(), bev.nms(boxes, scores, 0.4, True))
+    keep, _ = pcdet_nms_gpu(bt, st, 0.4, pre_maxsize=100)
+    top = np.argsort(-scores, kind='stable')[:100]
+    assert np.array_equal(keep.cpu().numpy(), top[bev.nms(boxes[top], scores[top], 0.4, True)])
+    keep, _ = pcdet_nms_normal_gpu(bt, st, 0.4)
+    assert np.array_equal(keep.cpu().numpy(), bev.nms(boxes, scores, 0.4, False))
+    a, b = boxes[:60], boxes[60:130]
+    iou = bev.iou_matrix(a, b, True)
+    assert np.allclose(boxes_iou_bev(bt[:60], bt[60:130]).cpu().numpy(), iou, atol=2e-5)
+    sa, sb = (a[:, 3] * a[:, 4])[:, None], (b[:, 3] * b[:, 4])[None]
+    ov = iou * (sa + sb) / (1 + iou)
+    oh = np.clip(np.minimum(a[:, 2:3] + a[:, 5:6] / 2, (b[:, 2] + b[:, 5] / 2)[None])
+                 - np.maximum(a[:, 2:3] - a[:, 5:6] / 2, (b[:, 2] - b[:, 5] / 2)[None]), 0, None)
+    o3 = ov * oh
+    ref3 = o3 / np.clip((a[:, 3] * a[:, 4] * a[:, 5])[:, None] + (b[:, 3] * b[:, 4] * b[:, 5])[None] - o3, 1e-6, None)
+    assert np.allclose(boxes_iou3d_gpu(bt[:60], bt[60:130]).cpu().numpy(), ref3, atol=5e-5)
+
+
 def test_pruning_path_bites():
     """pts_threshold smaller than the level sizes -> interpolation + top-k + MinkowskiPruning run."""
     dev = _dev()

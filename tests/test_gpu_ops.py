@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import loss_oracle as lo
 from oracle import me_oracle as mo
 
 pytestmark = pytest.mark.gpu
@@ -336,3 +337,33 @@ def test_bn_train_fused_paths(n, C, act, res):
     assert int(nbt) == 1 and float(cnt[0]) == n
     _close(mean[0], x.mean(0), tol=1e-5, what='batch mean')
     _close(var[0], x.var(0, unbiased=False), tol=1e-5, what='batch var')
+
+
+def test_sort_v_matches_restatement():
+    """standalone sort_v (Rotated_IoU cuda_ext, box_intersection_2d.py:147): indices bit-exact vs the Appendix-D
+    restatement on random rotated pairs, and the shoelace area of the selected polygon equals the IoU kernel's."""
+    from fcaf3d_amd.losses import sort_v
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    n = 4000
+    b1 = torch.cat([torch.rand(n, 2, generator=g) * 2, torch.rand(n, 2, generator=g) * 2 + 0.3,
+                    (torch.rand(n, 1, generator=g) - 0.5) * 6.28], 1)
+    b2 = torch.cat([b1[:, :2] + (torch.rand(n, 2, generator=g) - 0.5) * 1.5, torch.rand(n, 2, generator=g) * 2 + 0.3,
+                    (torch.rand(n, 1, generator=g) - 0.5) * 6.28], 1)
+    b2[:50] = b1[:50]                                   # identical boxes: every corner listed twice
+    b2[50:100, :2] += 10.0                              # disjoint: fewer than 3 valid vertices
+    verts, mask = lo.intersection_vertices(b1, b2)
+    nv = mask.sum(1).int()
+    ctr = (verts * mask[..., None]).sum(1, keepdim=True) / nv.clamp(min=1)[:, None, None]
+    vc = (verts - ctr) * mask[..., None]
+    want = lo.sort_v(vc[None].numpy(), mask[None].numpy(), nv[None].numpy())[0]
+    got = sort_v(vc[None].to(dev), mask[None].to(dev), nv[None].to(dev))[0].cpu().numpy()
+    same = (want == got).all(1)
+    # atan2 of the two libms may order vertices that are ~1 ulp apart in angle differently: allow a handful
+    assert same.mean() > 0.995, same.mean()
+    sel = np.take_along_axis(vc.numpy(), got[:, :, None].astype(np.int64), 1)
+    area = np.abs((sel[:, :-1, 0] * sel[:, 1:, 1] - sel[:, :-1, 1] * sel[:, 1:, 0]).sum(1)) / 2
+    sel_w = np.take_along_axis(vc.numpy(), want[:, :, None].astype(np.int64), 1)
+    area_w = np.abs((sel_w[:, :-1, 0] * sel_w[:, 1:, 1] - sel_w[:, :-1, 1] * sel_w[:, 1:, 0]).sum(1)) / 2
+    assert np.abs(area - area_w).max() < 1e-5
+    assert (got[50:100] >= 8).all() and (got[50:100] == got[50:100, :1]).all()     # all pad

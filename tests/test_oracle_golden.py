@@ -79,3 +79,33 @@ def test_rotation_golden_matches_assigner_convention():
     c, s = torch.cos(a)[:, None], torch.sin(a)[:, None]
     out = torch.stack([p[..., 0] * c + p[..., 1] * s, -p[..., 0] * s + p[..., 1] * c, p[..., 2]], -1)
     assert np.allclose(out.numpy(), d['out'], atol=1e-6)
+
+
+def test_sort_v_restatement_gives_the_pinned_iou():
+    """oracle.sort_v (Appendix D, standalone op) selects the same polygon as the pinned rotated-IoU path"""
+    import numpy as np
+    import torch
+    from oracle import loss_oracle as lo
+    g = torch.Generator().manual_seed(3)
+    n = 300
+    b1 = torch.cat([torch.rand(n, 2, generator=g) * 2, torch.rand(n, 2, generator=g) * 2 + 0.3,
+                    (torch.rand(n, 1, generator=g) - 0.5) * 6.28], 1)
+    b2 = torch.cat([b1[:, :2] + (torch.rand(n, 2, generator=g) - 0.5) * 1.5, torch.rand(n, 2, generator=g) * 2 + 0.3,
+                    (torch.rand(n, 1, generator=g) - 0.5) * 6.28], 1)
+    b2[:20] = b1[:20]
+    b2[20:40, :2] += 10.0
+    verts, mask = lo.intersection_vertices(b1, b2)
+    nv = mask.sum(1).int()
+    ctr = (verts * mask[..., None]).sum(1, keepdim=True) / nv.clamp(min=1)[:, None, None]
+    vc = (verts - ctr) * mask[..., None]
+    idx = lo.sort_v(vc[None].numpy(), mask[None].numpy(), nv[None].numpy())[0]
+    assert idx.shape == (n, 9) and idx.dtype == np.int32
+    sel = np.take_along_axis(vc.numpy(), idx[:, :, None].astype(np.int64), 1)
+    area = np.abs((sel[:, :-1, 0] * sel[:, 1:, 1] - sel[:, :-1, 1] * sel[:, 1:, 0]).sum(1)) / 2
+    z, h = torch.zeros(n, 1), torch.ones(n, 1)
+    B1 = torch.cat([b1[:, :2], z, b1[:, 2:4], h, b1[:, 4:5]], 1)
+    B2 = torch.cat([b2[:, :2], z, b2[:, 2:4], h, b2[:, 4:5]], 1)
+    iou = lo.rotated_iou_3d(B1, B2).numpy()
+    a1, a2 = (b1[:, 2] * b1[:, 3]).numpy(), (b2[:, 2] * b2[:, 3]).numpy()
+    assert np.abs(area / (a1 + a2 - area) - iou).max() < 1e-5
+    assert (idx[20:40] >= 8).all()                       # disjoint pairs: every slot is the pad index
