@@ -220,49 +220,56 @@ __global__ void k_sum_pairs(const float* __restrict__ part, const int* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stem convolution (Cin = 3 colour channels -> 64, k3 s2; me_resnet.py:19-21): too thin for the matrix
-// cores and bound by the 148 MB output write.  64 output rows per workgroup; the 27x3 gathered inputs of
-// every row and the whole (81,64) kernel sit in LDS; thread = (row, 16 output channels).
+// Stem convolution (Cin = 3 colour channels -> 64, k3 s2; me_resnet.py:19-21): bound by the 148 MB output
+// write.  64 output rows per workgroup; the 27x3 gathered inputs of every row and the whole (81,64) kernel sit in
+// LDS, zero-padded to a reduction depth of 96, and each wave multiplies one 32x32 tile on the matrix cores.
 #define STEM_CIN 3
 #define STEM_COUT 64
 #define STEM_ROWS 64
+#define STEM_FWD_LDA 97
 __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ in, const float* __restrict__ W,
                                                   const int* __restrict__ nbr, float* __restrict__ out, int64_t n_out, int K) {
+  // out[64 rows][64] = A[64][81 -> 96] x W[96][64] on the matrix cores: one 32x32 tile per wave, 48 MFMA steps.
   extern __shared__ float sm[];
+  constexpr int SLD = STEM_FWD_LDA;          // odd row stride -> conflict-free column reads of A
   const int KC = K * STEM_CIN;
-  float* in_s = sm;                          // [STEM_ROWS][KC]  (odd stride -> conflict-free row reads)
-  float* W_s = sm + STEM_ROWS * KC;          // [KC][64]
-  const int tid = threadIdx.x;
+  float* in_s = sm;                          // [STEM_ROWS][SLD]   (columns >= KC are zero)
+  float* W_s = sm + STEM_ROWS * SLD;         // [96][64]           (rows >= KC are zero)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.x * STEM_ROWS;
+  for (int t = tid; t < STEM_ROWS * (SLD - KC); t += 256) {
+    int row = t / (SLD - KC), c = KC + t % (SLD - KC);
+    in_s[row * SLD + c] = 0.f;
+  }
   for (int t = tid; t < STEM_ROWS * K; t += 256) {
     int k = t / STEM_ROWS, row = t % STEM_ROWS;
     int64_t o = m0 + row;
-    int i = o < n_out ? nbr[(int64_t)k * n_out + o] : -1;
-    float a = 0.f, b = 0.f, c = 0.f;
-    if (i >= 0) { a = in[(int64_t)i * 3]; b = in[(int64_t)i * 3 + 1]; c = in[(int64_t)i * 3 + 2]; }
-    in_s[row * KC + k * 3] = a; in_s[row * KC + k * 3 + 1] = b; in_s[row * KC + k * 3 + 2] = c;
+    int64_t oc = o < n_out ? o : n_out - 1;
+    int i = nbr[(int64_t)k * n_out + oc];
+    if (o >= n_out) i = -1;
+    const float* src = i < 0 ? g_zero_row : in + (int64_t)i * 3;
+    float a = src[0], b = src[1], c = src[2];
+    in_s[row * SLD + k * 3] = a; in_s[row * SLD + k * 3 + 1] = b; in_s[row * SLD + k * 3 + 2] = c;
   }
-  for (int t = tid; t < KC * 16; t += 256) reinterpret_cast<float4*>(W_s)[t] = reinterpret_cast<const float4*>(W)[t];
+  for (int t = tid; t < 96 * 16; t += 256) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t < KC * 16) v = reinterpret_cast<const f32x4*>(W)[t];
+    reinterpret_cast<f32x4*>(W_s)[t] = v;
+  }
   __syncthreads();
-  const int row = tid >> 2, cg = tid & 3;
-  float acc[16];
+  f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  for (int j = 0; j < KC; ++j) {
-    float a = in_s[row * KC + j];
-    const float4* w = reinterpret_cast<const float4*>(W_s + j * 64 + cg * 16);
+  const float* ap = in_s + (wr * 32 + r) * SLD + h;
+  const float* bp = W_s + h * 64 + wc * 32 + r;
+#pragma unroll 8
+  for (int sidx = 0; sidx < 48; ++sidx)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * sidx], bp[2 * sidx * 64], acc, 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 v = w[q];
-      acc[4 * q] = fmaf(a, v.x, acc[4 * q]); acc[4 * q + 1] = fmaf(a, v.y, acc[4 * q + 1]);
-      acc[4 * q + 2] = fmaf(a, v.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(a, v.w, acc[4 * q + 3]);
-    }
-  }
-  int64_t o = m0 + row;
-  if (o < n_out) {
-    float4* dst = reinterpret_cast<float4*>(out + o * 64 + cg * 16);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+  for (int e = 0; e < 16; ++e) {
+    int64_t o = m0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    if (o < n_out) out[o * 64 + wc * 32 + r] = acc[e];
   }
 }
 
@@ -427,7 +434,7 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_
   if (n_out == 0) return FC_OK;
   if (out_index && !nbr) return FC_EINVAL;
   if (is_stem(nbr, K, Cin, Cout, flags) && !out_index) {
-    size_t smem = (size_t)(STEM_ROWS * K * STEM_CIN + K * STEM_CIN * 64) * sizeof(float);
+    size_t smem = (size_t)(STEM_ROWS * STEM_FWD_LDA + 96 * 64) * sizeof(float);
     k_stem_fwd<<<(unsigned)fc_cdiv(n_out, STEM_ROWS), 256, smem, stream>>>(in, W, nbr, out, n_out, K);
     FC_CHECK_LAUNCH();
     return FC_OK;

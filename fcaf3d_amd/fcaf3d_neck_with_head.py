@@ -169,12 +169,10 @@ class Fcaf3DNeckWithHead(nn.Module):
         if pad:
             w = torch.cat((w, w.new_zeros(w.shape[0], pad)), dim=1)
         y = Fn.sparse_conv(x.F, w.unsqueeze(0), None, x.F.shape[0])
-        centerness = y[:, :1]
-        reg_final = y[:, 1:1 + n_r]
-        cls_score = y[:, 1 + n_r:used] + self.cls_conv.bias
-        prune_scores = SparseTensor(cls_score.detach().max(dim=1, keepdim=True).values, coordinate_map_key=x.cmap)
-        reg_distance = torch.exp(scale(reg_final[:, :6]))
-        bbox_pred = torch.cat((reg_distance, reg_final[:, 6:]), dim=1)
+        # centerness | exp(scale * reg[:, :6]), reg[:, 6:] | cls + bias, and the max class logit `_prune` interpolates:
+        # one fused pass forward, one backward (csrc/head.hip)
+        centerness, bbox_pred, cls_score, cls_max = Fn.head_split(y, self.cls_conv.bias, scale.scale, n_r, n_c)
+        prune_scores = SparseTensor(cls_max, coordinate_map_key=x.cmap)
 
         points = x.C[:, 1:].float() * self.voxel_size          # voxel corner, as the reference (:276-277)
         cm = x.cmap

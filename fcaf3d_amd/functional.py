@@ -385,3 +385,47 @@ def union_add(a, b):
     if swapped:          # a's voxels all lie in b: result on b's map = b.F with a.F added at a's rows
         return SparseTensor(_UnionAdd.apply(b.F, a.F, rows, cm.n), coordinate_map_key=cm)
     return SparseTensor(_UnionAdd.apply(a.F, b.F, rows, cm.n), coordinate_map_key=cm)
+
+
+# ---- head epilogue ------------------------------------------------------------------------------------
+class _HeadSplit(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, bias, scale, n_reg, n_cls):
+        """y (N, ld) = fused 1x1 head GEMM output -> centerness (N,1), bbox_pred (N,n_reg), cls_score (N,n_cls),
+        cls_max (N,1, no gradient)  (fcaf3d_neck_with_head.py:256-279)."""
+        _chk(y, bias, scale)
+        y = y.contiguous()
+        n, ld = y.shape
+        dev = y.device
+        b = bias.reshape(-1).contiguous()
+        sc = scale.reshape(1).contiguous()
+        cent = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        bbox = torch.empty((n, n_reg), dtype=torch.float32, device=dev)
+        cls = torch.empty((n, n_cls), dtype=torch.float32, device=dev)
+        cmax = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        L.call('fc_head_split_fwd', L.ptr(y), ld, L.ptr(b), L.ptr(sc), n, n_reg, n_cls, L.ptr(cent), L.ptr(bbox), L.ptr(cls),
+               L.ptr(cmax), L.stream())
+        ctx.save_for_backward(y, sc, bbox)
+        ctx.dims = (n_reg, n_cls, bias.shape, scale.shape)
+        ctx.mark_non_differentiable(cmax)
+        return cent, bbox, cls, cmax
+
+    @staticmethod
+    def backward(ctx, g_cent, g_bbox, g_cls, _g_max):
+        y, sc, bbox = ctx.saved_tensors
+        n_reg, n_cls, bias_shape, scale_shape = ctx.dims
+        n, ld = y.shape
+        g_cent = g_cent.contiguous() if g_cent is not None else None
+        g_bbox = g_bbox.contiguous() if g_bbox is not None else None
+        g_cls = g_cls.contiguous() if g_cls is not None else None
+        gy = torch.empty_like(y)
+        gs_row = torch.empty(n, dtype=torch.float32, device=y.device)
+        L.call('fc_head_split_bwd', L.ptr(y), ld, L.ptr(sc), L.ptr(bbox), L.ptr(g_cent), L.ptr(g_bbox), L.ptr(g_cls), n, n_reg,
+               n_cls, L.ptr(gy), L.ptr(gs_row), L.stream())
+        gbias = g_cls.sum(0).reshape(bias_shape) if g_cls is not None and ctx.needs_input_grad[1] else None
+        gscale = gs_row.sum().reshape(scale_shape) if ctx.needs_input_grad[2] else None
+        return gy, gbias, gscale, None, None
+
+
+def head_split(y, bias, scale, n_reg, n_cls):
+    return _HeadSplit.apply(y, bias, scale, n_reg, n_cls)

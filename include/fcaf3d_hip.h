@@ -194,6 +194,17 @@ int fc_aiou3d_fwd_bwd(const float* pred, const float* target, int target_stride,
 int fc_riou3d_fwd_bwd(const float* pred, const float* target, const float* weight, int64_t n, float* iou, float* dpred,
                       hipStream_t stream);
 
+/* Epilogue of Fcaf3DNeckWithHead.forward_single (fcaf3d_neck_with_head.py:256-279) on the output y (n, ld <= 64) of the
+ * fused 1x1 head GEMM, columns [centerness | reg (n_reg = 6 or 8) | cls (n_cls) | padding]:
+ *   centerness (n,1) = y[:,0];  bbox_pred (n,n_reg) = [exp(scale * reg[:, :6]) | reg[:, 6:]];
+ *   cls_score (n,n_cls) = y[:, 1+n_reg:] + bias;  cls_max (n) = max_c cls_score (the score `_prune` interpolates, :117-121).
+ * bwd: gy (n, ld) from the three output gradients (any may be NULL = zero), gscale_row (n) = per-row d/dscale. */
+int fc_head_split_fwd(const float* y, int ld, const float* bias, const float* scale_dev, int64_t n, int n_reg, int n_cls,
+                      float* centerness, float* bbox_pred, float* cls_score, float* cls_max, hipStream_t stream);
+int fc_head_split_bwd(const float* y, int ld, const float* scale_dev, const float* bbox_pred, const float* g_centerness,
+                      const float* g_bbox, const float* g_cls, int64_t n, int n_reg, int n_cls, float* gy,
+                      float* gscale_row, hipStream_t stream);
+
 /* `cuda_ext.sort_v(vertices, mask, num_valid)` of the un-vendored Rotated_IoU extension (docker/Dockerfile:35-40),
  * bound by the reference at rotated_iou/box_intersection_2d.py:147: vertices (n_pairs,24,2) f32 centred on the mean
  * of the valid ones, mask (n_pairs,24) bool bytes, num_valid (n_pairs) i32 -> idx (n_pairs,9) i32: valid vertices in

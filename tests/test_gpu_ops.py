@@ -367,3 +367,34 @@ def test_sort_v_matches_restatement():
     area_w = np.abs((sel_w[:, :-1, 0] * sel_w[:, 1:, 1] - sel_w[:, :-1, 1] * sel_w[:, 1:, 0]).sum(1)) / 2
     assert np.abs(area - area_w).max() < 1e-5
     assert (got[50:100] >= 8).all() and (got[50:100] == got[50:100, :1]).all()     # all pad
+
+
+@pytest.mark.parametrize('n_reg,n_cls', [(6, 18), (8, 10), (6, 5)])
+def test_head_split_matches_torch(n_reg, n_cls):
+    """fused head epilogue (fcaf3d_neck_with_head.py:256-279) == the slice / exp(scale*reg) / +bias / max torch ops,
+    values and gradients (y, bias, scale)"""
+    import fcaf3d_amd.functional as Fn
+    dev = _dev()
+    g = torch.Generator().manual_seed(n_reg + n_cls)
+    n = 5003
+    y = torch.randn(n, 64, generator=g)
+    bias = torch.randn(1, n_cls, generator=g)
+    scale = torch.tensor(1.3)
+    go = [torch.randn(n, 1, generator=g), torch.randn(n, n_reg, generator=g), torch.randn(n, n_cls, generator=g)]
+
+    def ref(y, bias, scale):
+        reg = y[:, 1:1 + n_reg]
+        cls = y[:, 1 + n_reg:1 + n_reg + n_cls] + bias
+        return y[:, :1], torch.cat((torch.exp(reg[:, :6] * scale), reg[:, 6:]), 1), cls
+    yr, br, sr = y.clone().requires_grad_(True), bias.clone().requires_grad_(True), scale.clone().requires_grad_(True)
+    outs_r = ref(yr, br, sr)
+    grads_r = torch.autograd.grad(outs_r, [yr, br, sr], go)
+    yg, bg, sg = (t.clone().to(dev).requires_grad_(True) for t in (y, bias, scale))
+    c, b, s, m = Fn.head_split(yg, bg, sg, n_reg, n_cls)
+    grads_g = torch.autograd.grad((c, b, s), [yg, bg, sg], [t.to(dev) for t in go])
+    for a, r_, what in zip((c, b, s), outs_r, ('centerness', 'bbox', 'cls')):
+        _close(a, r_, what='head ' + what)
+    assert torch.equal(m.cpu(), outs_r[2].max(1, keepdim=True).values.detach())
+    assert not m.requires_grad
+    for a, r_, what in zip(grads_g, grads_r, ('gy', 'gbias', 'gscale')):
+        _close(a, r_, what='head ' + what)
