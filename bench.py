@@ -37,6 +37,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-points', type=int, default=0, help='points of the cpu_baseline sample scene (0 = same as workload)')
     ap.add_argument('--no-instrument', action='store_true', help='skip per-kernel HIP events (roofline = null)')
+    ap.add_argument('--probe-every', type=int, default=4, help='HIP events bracket the conv launches of every n-th timed step '
+                    '(each event pair is a pipeline bubble: sampling keeps the probe from slowing the thing it measures)')
     ap.add_argument('--spatial-sort', action='store_true', help='Z-order sort of the collated points (measured: no gain, r1)')
     ap.add_argument('--wgrad-overlap', action='store_true', help='weight-gradient kernels on a second stream (measured r1: no gain, the GPU is already full)')
     ap.add_argument('--breakdown', action='store_true', help='diagnostic: HIP-event time per C-ABI entry point and per conv shape (stderr)')
@@ -144,10 +146,14 @@ class ConvProbe:
         orig = L.call
 
         def call(name, *a):
-            if name != 'fc_conv_fwd' or probe.mode is None:
+            if name not in ('fc_conv_fwd', 'fc_conv_fwd_pairs') or probe.mode is None:
                 return orig(name, *a)
-            # (in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream)
-            n_out, K, Cin, Cout = a[6], a[7], a[8], a[9]
+            if name == 'fc_conv_fwd':
+                # (in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream)
+                n_in, n_out, K, Cin, Cout, has_map = a[5], a[6], a[7], a[8], a[9], bool(a[2])
+            else:
+                # (in, W, pair_in, pair_cnt, pair_pos, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream)
+                n_in, n_out, K, Cin, Cout, has_map = a[6], a[7], a[8], a[9], a[10], True
             if Cin % 32 or Cout % 64:
                 return orig(name, *a)          # generic FMA / stem path: not the kernel under the probe
             if probe.mode == 'time':
@@ -159,7 +165,7 @@ class ConvProbe:
                 probe._cur.append((s, e))
             else:
                 orig(name, *a)
-                nbytes = 4.0 * (a[5] * Cin + n_out * Cout + K * Cin * Cout) + (4.0 * K * n_out if a[2] else 0.0)
+                nbytes = 4.0 * (n_in * Cin + n_out * Cout + K * Cin * Cout) + (4.0 * K * n_out if has_map else 0.0)
                 probe._cur.append((probe._pairs, 2.0 * Cin * Cout, n_out, nbytes))
         L.call = call
         self._pairs = None
@@ -294,7 +300,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = step(args.warmup + i, 'time')
+        loss = step(args.warmup + i, 'time' if i % max(args.probe_every, 1) == 0 else None)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -326,7 +332,9 @@ def main():
         }
         rl = probe.summary() if probe else None
         if rl:
-            conv_ms = rl['avg_launch_us'] * rl['launches'] / 1e3 / args.steps
+            probed_steps = len(range(0, args.steps, max(args.probe_every, 1)))
+            conv_ms = rl['avg_launch_us'] * rl['launches'] / 1e3 / probed_steps
+            rl['probed_steps'] = probed_steps
             rl['time_share_ms_per_step'] = round(conv_ms, 3)
         out['roofline'] = rl
         if world == 1 and not args.no_cpu_baseline:
