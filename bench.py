@@ -239,14 +239,24 @@ def cpu_baseline(args, model, cfg):
                        f'(ME-CPU-algorithm restatement: hash kernel maps + per-offset gather-GEMM-scatter, torch CPU fp32)')
 
 
+def count_steps(args, n_batches):
+    """number of untimed FLOP-count steps after the timed region — a function of the flags only, never of the rank"""
+    return 0 if (args.no_instrument or args.breakdown) else min(n_batches, args.steps)
+
+
 def main():
     args = parse()
+    if os.environ.get('FC_FAULT_DUMP'):           # debugging aid: dump every thread's stack after n seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['FC_FAULT_DUMP']), exit=True)
     from fcaf3d_amd import dist as D
     D.init_dist()
     rank = int(os.environ.get('RANK', '0'))
     world = D.world_size()
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (there is no CPU fallback for the product path)'
+    if os.environ.get('FC_DIST_BACKEND') == 'gloo':
+        local %= torch.cuda.device_count()       # smoke mode only: several ranks may share one GPU
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -266,10 +276,11 @@ def main():
 
     probe = None
     bd = None
+    if args.breakdown:
+        args.no_instrument = True                # on every rank: the untimed count steps below hold collectives
     if args.breakdown and rank == 0:
         bd = Breakdown()
         bd.install()
-        args.no_instrument = True
     if not args.no_instrument and rank == 0:
         probe = ConvProbe()
         probe.install()
@@ -310,9 +321,10 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
-    if probe:                                   # untimed: FLOPs of every launch, one step per distinct batch
-        for b in range(min(len(batches), args.steps)):
-            step(b, 'count')
+    # untimed: FLOPs of every launch, one step per distinct batch.  EVERY rank steps (a step holds collectives: a
+    # rank-0-only extra step deadlocks the job); only rank 0 carries the probe
+    for b in range(count_steps(args, len(batches))):
+        step(b, 'count' if probe else None)
     if bd:
         bd.report(args.steps, dt * 1e3)
     assert np.isfinite(final_loss), 'loss diverged'

@@ -21,7 +21,8 @@ def init_dist(backend=None):
     if int(os.environ.get('WORLD_SIZE', '1')) <= 1 or is_dist():
         return
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        # FC_DIST_BACKEND=gloo: multi-process smoke of the whole DP path on a box with fewer GPUs than ranks
+        backend = os.environ.get('FC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     dist.init_process_group(backend=backend)

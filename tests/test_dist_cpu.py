@@ -75,3 +75,29 @@ def test_single_process_is_identity():
     assert D.reduce_mean(t) is t and D.world_size() == 1
     avg = D.GradientAverager([torch.nn.Parameter(torch.ones(2))])
     avg.finish()                                             # no-op without a process group
+
+
+def test_bench_step_count_is_rank_independent():
+    """every rank must execute the same number of steps (each holds collectives): r1 shipped a rank-0-only
+    FLOP-count step that deadlocked N>1; the extra-step count is now a pure function of the flags"""
+    import inspect
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert list(inspect.signature(bench.count_steps).parameters) == ['args', 'n_batches']
+    src = inspect.getsource(bench.main)
+    assert 'for b in range(count_steps(args, len(batches)))' in src
+    # the loop that runs them is not nested under a rank / probe condition
+    line = [l for l in src.splitlines() if 'count_steps(args, len(batches))' in l][0]
+    assert line.startswith('    for '), 'count-step loop must sit at function level, outside any rank-dependent branch'
+    argv = sys.argv
+    try:
+        sys.argv = ['bench.py']
+        a = bench.parse()
+        assert bench.count_steps(a, 2) == 2
+        sys.argv = ['bench.py', '--no-instrument']
+        assert bench.count_steps(bench.parse(), 2) == 0
+        sys.argv = ['bench.py', '--breakdown']
+        assert bench.count_steps(bench.parse(), 2) == 0
+    finally:
+        sys.argv = argv
