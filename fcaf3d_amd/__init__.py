@@ -11,6 +11,7 @@ from .me_resnet import MEResNet3D  # noqa: F401,E402
 from .fcaf3d_neck_with_head import Fcaf3DAssigner, Fcaf3DNeckWithHead, compute_centerness  # noqa: F401,E402
 from .single_stage_sparse import SingleStageSparse3DDetector  # noqa: F401,E402
 from .boxes import DepthInstance3DBoxes, bbox3d2result  # noqa: F401,E402
+from .checkpoint import load_checkpoint, save_checkpoint  # noqa: F401,E402
 
 import os as _os
 

@@ -101,3 +101,41 @@ def test_boxes_container():
     assert float(b.volume[0]) == 48.0 and len(b) == 1
     b6 = fa.DepthInstance3DBoxes(torch.zeros(0, 6), box_dim=6, with_yaw=False, origin=(.5, .5, .5))
     assert b6.tensor.shape == (0, 7) and b6.with_yaw is False
+
+
+def test_checkpoint_roundtrip_mmcv_layout(tmp_path):
+    """mmcv-layout checkpoints ({'meta','state_dict'}, optional DDP 'module.' prefix) load into the detector;
+    mismatches are reported, not silently dropped (tools/test.py:172 flow of the reference)"""
+    import torch
+    import fcaf3d_amd as fa
+    from fcaf3d_amd.checkpoint import load_checkpoint, load_state_dict, save_checkpoint
+    cfg = fa.get_config('fcaf3d_scannet-3d-18class', voxel_size=0.02)
+    a = fa.build_detector(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+    b = fa.build_detector(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+    with torch.no_grad():
+        for p in a.parameters():
+            p.add_(torch.randn_like(p) * 0.01)
+    path = str(tmp_path / 'ck.pth')
+    ck = save_checkpoint(a, path, meta=dict(epoch=12))
+    assert set(ck) == {'meta', 'state_dict'} and ck['meta']['epoch'] == 12
+    out = load_checkpoint(b, path, map_location='cpu', strict=True)
+    assert out['meta']['epoch'] == 12
+    for (k, x), (_, y) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(x, y), k
+    # DDP-prefixed, bare state_dict, one wrong shape, one unknown key
+    sd = {'module.' + k: v.clone() for k, v in a.state_dict().items()}
+    sd['module.backbone.conv1.0.kernel'] = torch.zeros(27, 3, 32)
+    sd['module.not_a_param'] = torch.zeros(1)
+    torch.save(sd, path)
+    c = fa.build_detector(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+    msgs = []
+
+    class Log:
+        def warning(self, m):
+            msgs.append(m)
+    load_checkpoint(c, path, map_location='cpu', strict=False, logger=Log())
+    assert 'size mismatch for backbone.conv1.0.kernel' in msgs[0] and 'not_a_param' in msgs[0]
+    assert torch.equal(c.state_dict()['backbone.layer1.0.conv1.kernel'], a.state_dict()['backbone.layer1.0.conv1.kernel'])
+    import pytest
+    with pytest.raises(RuntimeError):
+        load_state_dict(c, {k[len('module.'):]: v for k, v in sd.items()}, strict=True)
