@@ -430,8 +430,8 @@ int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags)
 int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
                 int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
+  if (n_out == 0) return FC_OK;                 // nothing to write (an empty table may well be a NULL pointer)
   if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
-  if (n_out == 0) return FC_OK;
   if (out_index && !nbr) return FC_EINVAL;
   if (is_stem(nbr, K, Cin, Cout, flags) && !out_index) {
     size_t smem = (size_t)(STEM_ROWS * STEM_FWD_LDA + 96 * 64) * sizeof(float);
@@ -710,12 +710,12 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
                            float* gW, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
                            int64_t ws_bytes, hipStream_t stream) {
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
-  if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
   const int64_t elems = (int64_t)K * Cin * Cout;
   if (n_out == 0) {
     FC_HIP(hipMemsetAsync(gW, 0, elems * sizeof(float), stream));
     return FC_OK;
   }
+  if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
   int S; int64_t rps;
   wgrad_plan(n_out, K, Cin, Cout, flags, &S, &rps);
   if (ws_bytes < (int64_t)S * elems * (int64_t)sizeof(float)) return FC_EWS;

@@ -398,3 +398,49 @@ def test_head_split_matches_torch(n_reg, n_cls):
     assert not m.requires_grad
     for a, r_, what in zip(grads_g, grads_r, ('gy', 'gbias', 'gscale')):
         _close(a, r_, what='head ' + what)
+
+
+def test_empty_and_degenerate_inputs():
+    """edge cases through the C ABI: zero rows, a one-voxel map (26 of 27 offsets have no pair: the pair-list
+    paths see empty lists), empty NMS / IoU / head / sort_v calls"""
+    import fcaf3d_amd.functional as Fn
+    from fcaf3d_amd import _lib as L
+    from fcaf3d_amd.losses import sort_v
+    from fcaf3d_amd.nms import boxes_iou_bev, nms_bev, pcdet_nms_gpu
+    from fcaf3d_amd.sparse import CoordMap
+    dev = _dev()
+    # conv / wgrad with zero output rows
+    x = torch.randn(5, 64, device=dev); w = torch.randn(27, 64, 64, device=dev)
+    nbr = torch.empty((27, 0), dtype=torch.int32, device=dev)
+    out = torch.empty((0, 64), device=dev)
+    L.call('fc_conv_fwd', L.ptr(x), L.ptr(w), L.ptr(nbr), None, L.ptr(out), 5, 0, 27, 64, 64, 0, None, 0, L.stream())
+    gw = torch.full_like(w, 7.0)
+    L.call('fc_conv_wgrad', L.ptr(x), L.ptr(out), L.ptr(nbr), None, L.ptr(gw), 5, 0, 27, 64, 64, 0, None, 0, L.stream())
+    assert float(gw.abs().max()) == 0.0
+    # one voxel per scene, two scenes: only the centre offset has pairs
+    uc = np.array([[0, 4, 8, 12], [1, -4, 0, 4]], np.int32)
+    cm, _, _ = CoordMap.from_coords(torch.from_numpy(uc).to(dev), 4, 2)
+    km = cm.kernel_map(cm, 3)
+    assert km.use_pairs
+    pi, po, pos, cnt = (t.cpu().numpy() for t in km.pairs())
+    assert cnt.tolist() == [0] * 13 + [2] + [0] * 13 and po[13, :2].tolist() == [0, 1] and (pos[13] == [0, 1]).all()
+    g = torch.Generator().manual_seed(0)
+    xf = torch.randn(2, 64, generator=g); wf = torch.randn(27, 64, 128, generator=g); go = torch.randn(2, 128, generator=g)
+    xr, wr = xf.clone().requires_grad_(True), wf.clone().requires_grad_(True)
+    ref = mo.conv(xr, wr, mo.kernel_map(uc, uc, mo.kernel_offsets(3, 4)))
+    gx_r, gw_r = torch.autograd.grad(ref, [xr, wr], go)
+    xg, wg = xf.to(dev).requires_grad_(True), wf.to(dev).requires_grad_(True)
+    got = Fn.sparse_conv(xg, wg, km, 2)                       # pair mode (2 rows <= PAIR_CONV_ROWS)
+    gx_g, gw_g = torch.autograd.grad(got, [xg, wg], go.to(dev))
+    _close(got, ref, what='1-voxel conv'); _close(gx_g, gx_r, what='1-voxel dgrad'); _close(gw_g, gw_r, what='1-voxel wgrad')
+    assert float(gw_g[:13].abs().max()) == 0.0 and float(gw_g[14:].abs().max()) == 0.0
+    # empty NMS / IoU / head epilogue / sort_v
+    eb = torch.zeros((0, 7), device=dev); es = torch.zeros(0, device=dev)
+    assert nms_bev(eb, es, 0.5).numel() == 0 and pcdet_nms_gpu(eb, es, 0.5)[0].numel() == 0
+    assert boxes_iou_bev(eb, torch.rand(3, 7, device=dev)).shape == (0, 3)
+    c, b, s, m = Fn.head_split(torch.zeros((0, 64), device=dev), torch.zeros(1, 18, device=dev), torch.tensor(1.0, device=dev), 6, 18)
+    assert c.shape == (0, 1) and b.shape == (0, 6) and s.shape == (0, 18) and m.shape == (0, 1)
+    idx = sort_v(torch.zeros((1, 0, 24, 2), device=dev), torch.zeros((1, 0, 24), dtype=torch.bool, device=dev),
+                 torch.zeros((1, 0), dtype=torch.int32, device=dev))
+    assert idx.shape == (1, 0, 9)
+    torch.cuda.synchronize()
