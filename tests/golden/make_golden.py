@@ -12,6 +12,8 @@ third-party packages that are absent here — MinkowskiEngine, mmdet, mmcv):
   * mmdet3d/ops/rotated_iou/{oriented_iou_loss,box_intersection_2d}.py   cal_iou_3d
       (its un-vendored CUDA `sort_v` is replaced by an angular argsort; the polygon
        area is invariant to the start vertex)
+  * mmdet3d/core/evaluation/indoor_eval.py      indoor_eval / eval_map_recall / eval_det_cls / average_precision
+      (mmcv.print_log and terminaltables stubbed; per-box `overlaps` served by the oracle's 3D IoU)
   * oracle/_ref/pcdet_iou3d_cpu (compiled from mmdet3d/ops/pcdet_nms/src/iou3d_cpu.cpp
     by oracle/Makefile) -> boxes_iou_bev_cpu
 Only inputs + outputs are stored.
@@ -209,6 +211,92 @@ def gen_iou(aiou, riou, out):
     np.savez_compressed(out, **d)
 
 
+def gen_indoor_eval(out):
+    """mmdet3d/core/evaluation/indoor_eval.py run as it is (mmcv.print_log / terminaltables stubbed) on random
+    detections; its per-box `overlaps` is served by the oracle's 3D IoU, so the golden pins the matching / AP logic."""
+    from oracle import bev as obev
+
+    class Boxes:                                   # the slice of BaseInstance3DBoxes indoor_eval touches
+        def __init__(self, tensor, box_dim=7, with_yaw=True, origin=(0.5, 0.5, 0)):
+            t = torch.as_tensor(np.asarray(tensor), dtype=torch.float32).reshape(-1, 7).clone()
+            if tuple(origin) != (0.5, 0.5, 0):
+                t[:, 2] += t[:, 5] * (0 - origin[2])
+            self.tensor = t
+
+        def __len__(self):
+            return len(self.tensor)
+
+        def __getitem__(self, i):
+            b = Boxes.__new__(Boxes); b.tensor = self.tensor[i:i + 1]
+            return b
+
+        def new_box(self, t):
+            b = Boxes.__new__(Boxes); b.tensor = torch.as_tensor(t).reshape(-1, 7).clone()
+            return b
+
+        def convert_to(self, mode):
+            return self
+
+        @classmethod
+        def overlaps(cls, a, b):
+            return torch.from_numpy(iou3d(_grav(a.tensor), _grav(b.tensor)))
+
+    def _grav(t):
+        t = t.clone().numpy(); t[:, 2] += t[:, 5] / 2
+        return t
+
+    def iou3d(a, b):                               # pcdet_nms_utils.py:44-78 on the oracle's BEV IoU
+        iou = obev.iou_matrix(a, b, True).astype(np.float64)
+        sa, sb = (a[:, 3] * a[:, 4])[:, None], (b[:, 3] * b[:, 4])[None]
+        ov = iou * (sa + sb) / (1 + iou)
+        oh = np.clip(np.minimum(a[:, 2:3] + a[:, 5:6] / 2, (b[:, 2] + b[:, 5] / 2)[None])
+                     - np.maximum(a[:, 2:3] - a[:, 5:6] / 2, (b[:, 2] - b[:, 5] / 2)[None]), 0, None)
+        o3 = ov * oh
+        return (o3 / np.clip((a[:, 3] * a[:, 4] * a[:, 5])[:, None] + (b[:, 3] * b[:, 4] * b[:, 5])[None] - o3, 1e-6, None)).astype(np.float32)
+
+    _stub('mmcv.utils', print_log=lambda *a, **k: None)
+
+    class AsciiTable:
+        def __init__(self, data):
+            self.table = ''
+    _stub('terminaltables', AsciiTable=AsciiTable)
+    ev = _load('ref_indoor_eval', f'{REF}/mmdet3d/core/evaluation/indoor_eval.py')
+    rng = np.random.default_rng(7)
+    d = {}
+    for case, (n_scenes, n_cls, rotated) in enumerate([(6, 4, False), (5, 3, True)]):
+        gt_annos, dt_annos = [], []
+        for s in range(n_scenes):
+            m = int(rng.integers(0, 7)) if s else 5
+            gb = np.concatenate([rng.uniform(0, 6, (m, 3)), rng.uniform(0.4, 1.6, (m, 3)),
+                                 rng.uniform(-3, 3, (m, 1)) if rotated else np.zeros((m, 1))], 1).astype(np.float32)
+            gl = rng.integers(0, n_cls, m)
+            if s == 0:
+                gl[:n_cls] = np.arange(n_cls)[:m]                       # every class has a GT box somewhere
+            # detections: jittered copies of GT (some duplicated) + random false positives
+            k = int(rng.integers(0, 2 * m + 3))
+            src = rng.integers(0, max(m, 1), k)
+            db = (gb[src] if m else np.zeros((k, 7), np.float32)).copy()
+            db[:, :3] += rng.normal(0, 0.15, (k, 3)); db[:, 3:6] *= rng.uniform(0.8, 1.25, (k, 3))
+            if rotated:
+                db[:, 6] += rng.normal(0, 0.2, k)
+            dl = np.where(rng.random(k) < 0.8, gl[src] if m else 0, rng.integers(0, n_cls, k)).astype(np.int64)
+            fp = np.concatenate([rng.uniform(0, 6, (3, 3)), rng.uniform(0.4, 1.6, (3, 3)), np.zeros((3, 1))], 1).astype(np.float32)
+            db = np.concatenate([db, fp]).astype(np.float32); dl = np.concatenate([dl, rng.integers(0, n_cls, 3)])
+            ds = rng.random(len(db)).astype(np.float32)
+            gt_annos.append(dict(gt_num=m, gt_boxes_upright_depth=gb, **{'class': gl}))
+            dt_annos.append(dict(boxes_3d=Boxes(db, origin=(0.5, 0.5, 0.5)), scores_3d=torch.from_numpy(ds),
+                                 labels_3d=torch.from_numpy(dl)))
+            d[f'c{case}_gt_boxes{s}'] = gb; d[f'c{case}_gt_class{s}'] = gl
+            d[f'c{case}_dt_boxes{s}'] = db; d[f'c{case}_dt_scores{s}'] = ds; d[f'c{case}_dt_labels{s}'] = dl
+        label2cat = {i: f'cat{i}' for i in range(n_cls)}
+        ret = ev.indoor_eval(gt_annos, dt_annos, (0.25, 0.5), label2cat, box_type_3d=Boxes, box_mode_3d=None)
+        d[f'c{case}_n_scenes'] = n_scenes; d[f'c{case}_n_cls'] = n_cls
+        keys = sorted(ret)
+        d[f'c{case}_keys'] = np.array(keys); d[f'c{case}_vals'] = np.array([ret[k] for k in keys], np.float64)
+        print('indoor_eval golden case', case, {k: round(ret[k], 4) for k in keys if k.startswith('m')})
+    np.savez_compressed(out, **d)
+
+
 def gen_bev(out):
     sys.path.insert(0, os.path.join(ROOT, 'oracle', '_ref'))
     import pcdet_iou3d_cpu as ref
@@ -229,7 +317,11 @@ def gen_bev(out):
 
 
 if __name__ == '__main__':
+    if sys.argv[1:] == ['indoor_eval']:            # only this fixture (the others are unchanged)
+        gen_indoor_eval(os.path.join(HERE, 'indoor_eval.npz'))
+        sys.exit(0)
     head, utils, aiou, riou = load_reference()
+    gen_indoor_eval(os.path.join(HERE, 'indoor_eval.npz'))
     gen_assigner(head, os.path.join(HERE, 'assigner.npz'))
     gen_decode(head, os.path.join(HERE, 'decode.npz'))
     gen_iou(aiou, riou, os.path.join(HERE, 'iou3d.npz'))

@@ -451,3 +451,17 @@ def test_full_size_properties_config2():
     lhs = Fn.sparse_conv(2.0 * a + b, w, km, lvl.n)
     rhs = 2.0 * Fn.sparse_conv(a, w, km, lvl.n) + Fn.sparse_conv(b, w, km, lvl.n)
     assert _rel(lhs, rhs) < 1e-5
+
+
+def test_indoor_eval_hip_iou_vs_reference_golden():
+    """the step after the path: indoor_eval with its IoU matrices from the HIP kernel reproduces the
+    reference's mAP / mAR on the golden annotations"""
+    from fcaf3d_amd.evaluation import indoor_eval
+    from tests.test_oracle_golden import _indoor_eval_case
+    _dev()
+    d = np.load(os.path.join(G, 'indoor_eval.npz'))
+    for case in (0, 1):
+        gt_annos, dt_annos, label2cat, want = _indoor_eval_case(d, case)
+        got = indoor_eval(gt_annos, dt_annos, (0.25, 0.5), label2cat)
+        for k in want:
+            assert abs(got[k] - want[k]) < 1e-4, (case, k, got[k], want[k])

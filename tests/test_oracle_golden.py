@@ -109,3 +109,50 @@ def test_sort_v_restatement_gives_the_pinned_iou():
     a1, a2 = (b1[:, 2] * b1[:, 3]).numpy(), (b2[:, 2] * b2[:, 3]).numpy()
     assert np.abs(area / (a1 + a2 - area) - iou).max() < 1e-5
     assert (idx[20:40] >= 8).all()                       # disjoint pairs: every slot is the pad index
+
+
+def _oracle_iou3d(a, b):
+    """3D IoU of gravity-centre boxes on the oracle's BEV IoU (the IoU make_golden.py served to the reference)"""
+    import numpy as np
+    from oracle import bev as obev
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    iou = obev.iou_matrix(a, b, True).astype(np.float64)
+    sa, sb = (a[:, 3] * a[:, 4])[:, None], (b[:, 3] * b[:, 4])[None]
+    ov = iou * (sa + sb) / (1 + iou)
+    oh = np.clip(np.minimum(a[:, 2:3] + a[:, 5:6] / 2, (b[:, 2] + b[:, 5] / 2)[None])
+                 - np.maximum(a[:, 2:3] - a[:, 5:6] / 2, (b[:, 2] - b[:, 5] / 2)[None]), 0, None)
+    o3 = ov * oh
+    return (o3 / np.clip((a[:, 3] * a[:, 4] * a[:, 5])[:, None] + (b[:, 3] * b[:, 4] * b[:, 5])[None] - o3, 1e-6, None)).astype(np.float32)
+
+
+def _indoor_eval_case(d, case):
+    import numpy as np
+    import torch
+    import fcaf3d_amd as fa
+    gt_annos, dt_annos = [], []
+    for s in range(int(d[f'c{case}_n_scenes'])):
+        gb, gl = d[f'c{case}_gt_boxes{s}'], d[f'c{case}_gt_class{s}']
+        gt_annos.append({'gt_num': len(gb), 'gt_boxes_upright_depth': gb, 'class': gl})
+        dt_annos.append(dict(boxes_3d=fa.DepthInstance3DBoxes(torch.from_numpy(d[f'c{case}_dt_boxes{s}']), origin=(.5, .5, .5)),
+                             scores_3d=torch.from_numpy(d[f'c{case}_dt_scores{s}']),
+                             labels_3d=torch.from_numpy(d[f'c{case}_dt_labels{s}'])))
+    label2cat = {i: f'cat{i}' for i in range(int(d[f'c{case}_n_cls']))}
+    want = dict(zip([str(k) for k in d[f'c{case}_keys']], d[f'c{case}_vals']))
+    return gt_annos, dt_annos, label2cat, want
+
+
+def test_indoor_eval_matches_reference_golden():
+    """mAP / mAR / per-class AP + recall == the reference's indoor_eval run on the same annotations (tests/golden/
+    make_golden.py::gen_indoor_eval), axis-aligned and rotated cases, thresholds 0.25 / 0.5"""
+    import os
+    import numpy as np
+    from fcaf3d_amd.evaluation import average_precision, indoor_eval
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'indoor_eval.npz'))
+    for case in (0, 1):
+        gt_annos, dt_annos, label2cat, want = _indoor_eval_case(d, case)
+        got = indoor_eval(gt_annos, dt_annos, (0.25, 0.5), label2cat, iou_fn=_oracle_iou3d)
+        assert sorted(got) == sorted(want)
+        for k in want:
+            assert abs(got[k] - want[k]) < 1e-6, (case, k, got[k], want[k])
+    # VOC area AP on a hand-checkable curve: recall steps 0.5, 1.0 with precisions 1.0, 2/3
+    assert abs(float(average_precision(np.array([0.5, 0.5, 1.0]), np.array([1.0, 0.5, 2 / 3]))[0]) - (0.5 + 0.5 * 2 / 3)) < 1e-6
