@@ -14,6 +14,8 @@ third-party packages that are absent here — MinkowskiEngine, mmdet, mmcv):
        area is invariant to the start vertex)
   * mmdet3d/core/evaluation/indoor_eval.py      indoor_eval / eval_map_recall / eval_det_cls / average_precision
       (mmcv.print_log and terminaltables stubbed; per-box `overlaps` served by the oracle's 3D IoU)
+  * mmdet3d/core/bbox/structures/{base_box3d,depth_box3d}.py, mmdet3d/core/points/{base_points,depth_points}.py
+      rotate / flip / scale / translate of boxes + points (what RandomFlip3D, GlobalRotScaleTrans, GlobalAlignment apply)
   * oracle/_ref/pcdet_iou3d_cpu (compiled from mmdet3d/ops/pcdet_nms/src/iou3d_cpu.cpp
     by oracle/Makefile) -> boxes_iou_bev_cpu
 Only inputs + outputs are stored.
@@ -297,6 +299,59 @@ def gen_indoor_eval(out):
     np.savez_compressed(out, **d)
 
 
+def gen_pipeline(out):
+    """the reference's own DepthInstance3DBoxes / DepthPoints (depth_box3d.py, base_box3d.py, base_points.py,
+    depth_points.py; the compiled iou3d / roiaware ops they import but do not use here are stubbed) driven through
+    rotate / flip / scale / translate with fixed parameters, and GlobalAlignment's rotate+translate."""
+    _stub('mmdet3d')
+    _stub('mmdet3d.ops', points_in_boxes_batch=None)
+    _stub('mmdet3d.ops.iou3d', iou3d_cuda=None)
+    _stub('mmdet3d.core')
+    pts_pkg = types.ModuleType('mmdet3d.core.points'); pts_pkg.__path__ = [f'{REF}/mmdet3d/core/points']
+    sys.modules['mmdet3d.core.points'] = pts_pkg
+    bp = _load('mmdet3d.core.points.base_points', f'{REF}/mmdet3d/core/points/base_points.py')
+    pts_pkg.BasePoints = bp.BasePoints
+    dp = _load('mmdet3d.core.points.depth_points', f'{REF}/mmdet3d/core/points/depth_points.py')
+    pkg = types.ModuleType('refstruct'); pkg.__path__ = [f'{REF}/mmdet3d/core/bbox/structures']
+    sys.modules['refstruct'] = pkg
+    _load('refstruct.utils', f'{REF}/mmdet3d/core/bbox/structures/utils.py')
+    _load('refstruct.base_box3d', f'{REF}/mmdet3d/core/bbox/structures/base_box3d.py')
+    db = _load('refstruct.depth_box3d', f'{REF}/mmdet3d/core/bbox/structures/depth_box3d.py')
+    rng = np.random.default_rng(11)
+    d = {}
+    for case, with_yaw in enumerate([True, False]):
+        pts = np.concatenate([rng.uniform(-3, 3, (500, 3)), rng.uniform(0, 255, (500, 3))], 1).astype(np.float32)
+        m = 9
+        bx = np.concatenate([rng.uniform(-3, 3, (m, 3)), rng.uniform(0.3, 2.0, (m, 3))], 1).astype(np.float32)
+        if with_yaw:
+            bx = np.concatenate([bx, rng.uniform(-3, 3, (m, 1)).astype(np.float32)], 1)
+        angle, scale, trans = 0.0613, 1.0731, np.array([0.12, -0.07, 0.031], np.float32)
+        d[f'c{case}_points'] = pts; d[f'c{case}_boxes'] = bx
+        d[f'c{case}_params'] = np.array([angle, scale, *trans], np.float64)
+
+        def fresh():
+            b = db.DepthInstance3DBoxes(torch.from_numpy(bx.copy()), box_dim=bx.shape[1], with_yaw=with_yaw, origin=(0.5, 0.5, 0))
+            p = dp.DepthPoints(torch.from_numpy(pts.copy()), points_dim=6, attribute_dims=dict(color=[3, 4, 5]))
+            return b, p
+        for direction in ('horizontal', 'vertical'):
+            b, p = fresh()
+            p = b.flip(direction, points=p)
+            d[f'c{case}_flip_{direction}_points'] = p.tensor.numpy(); d[f'c{case}_flip_{direction}_boxes'] = b.tensor.numpy()
+        b, p = fresh()
+        p, _ = b.rotate(angle, p)                      # GlobalRotScaleTrans._rot_bbox_points
+        p.scale(scale); b.scale(scale)                 # ._scale_bbox_points
+        p.translate(trans); b.translate(trans)         # ._trans_bbox_points
+        d[f'c{case}_rst_points'] = p.tensor.numpy(); d[f'c{case}_rst_boxes'] = b.tensor.numpy()
+    # GlobalAlignment.__call__: points.rotate(rot.T) then translate
+    th = 0.4
+    A = np.eye(4, dtype=np.float32); A[:2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]; A[:3, 3] = [0.5, -1.25, 0.1]
+    p = dp.DepthPoints(torch.from_numpy(pts.copy()), points_dim=6, attribute_dims=dict(color=[3, 4, 5]))
+    p.rotate(A[:3, :3].T); p.translate(A[:3, 3])
+    d['align_matrix'] = A; d['align_points_in'] = pts; d['align_points_out'] = p.tensor.numpy()
+    np.savez_compressed(out, **d)
+    print('pipeline golden written')
+
+
 def gen_bev(out):
     sys.path.insert(0, os.path.join(ROOT, 'oracle', '_ref'))
     import pcdet_iou3d_cpu as ref
@@ -320,8 +375,12 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['indoor_eval']:            # only this fixture (the others are unchanged)
         gen_indoor_eval(os.path.join(HERE, 'indoor_eval.npz'))
         sys.exit(0)
+    if sys.argv[1:] == ['pipeline']:
+        gen_pipeline(os.path.join(HERE, 'pipeline.npz'))
+        sys.exit(0)
     head, utils, aiou, riou = load_reference()
     gen_indoor_eval(os.path.join(HERE, 'indoor_eval.npz'))
+    gen_pipeline(os.path.join(HERE, 'pipeline.npz'))
     gen_assigner(head, os.path.join(HERE, 'assigner.npz'))
     gen_decode(head, os.path.join(HERE, 'decode.npz'))
     gen_iou(aiou, riou, os.path.join(HERE, 'iou3d.npz'))

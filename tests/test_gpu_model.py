@@ -465,3 +465,35 @@ def test_indoor_eval_hip_iou_vs_reference_golden():
         got = indoor_eval(gt_annos, dt_annos, (0.25, 0.5), label2cat)
         for k in want:
             assert abs(got[k] - want[k]) < 1e-4, (case, k, got[k], want[k])
+
+
+def test_pipeline_feeds_the_detector_on_device(tmp_path):
+    """the step before the path: .bin -> LoadPointsFromFile -> GlobalAlignment -> IndoorPointSample /
+    RandomFlip3D / GlobalRotScaleTrans, all on the GPU, into forward_train; same transforms on the CPU give the same scene"""
+    from fcaf3d_amd import pipelines as pl
+    dev = _dev()
+    pts, gt, labels = make_scene(21, n_points=30000)
+    pts = pts.copy(); pts[:, 3:] *= 255.0 if pts[:, 3:].max() <= 1.0 else 1.0
+    path = str(tmp_path / 'scene.bin')
+    pts.astype(np.float32).tofile(path)
+    th = 0.3
+    A = np.eye(4, dtype=np.float32); A[:2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]; A[:3, 3] = [0.2, -0.1, 0.05]
+    boxes = fa.DepthInstance3DBoxes(torch.from_numpy(gt), origin=(.5, .5, .5)).tensor
+    aug = pl.TrainAugment(num_points=20000, with_yaw=False)
+    outs = []
+    for device in ('cpu', dev):
+        p = pl.global_alignment(pl.load_points_from_file(path, device=device), A)
+        params = dict(flip_h=True, flip_v=False, angle=0.05, scale=1.07, trans=[0.1, -0.05, 0.02])
+        q, b = pl.flip_bev(p, boxes.to(device), 'horizontal', False)
+        q, b = pl.rot_scale_trans(q, b, params['angle'], params['scale'], params['trans'], False)
+        outs.append((q.cpu(), b.cpu()))
+    assert torch.allclose(outs[0][0], outs[1][0], atol=1e-5) and torch.allclose(outs[0][1], outs[1][1], atol=1e-5)
+    g = torch.Generator(device=dev).manual_seed(5)
+    p = pl.global_alignment(pl.load_points_from_file(path, device=dev), A)
+    q, b, params = aug(p, boxes.to(dev), g)
+    assert q.shape == (20000, 6) and q.is_cuda
+    model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 2)
+    model = model.to(dev).train()
+    losses = model(return_loss=True, points=[q], gt_bboxes_3d=[fa.DepthInstance3DBoxes(b)], gt_labels_3d=[torch.from_numpy(labels).to(dev)],
+                   img_metas=[dict(box_type_3d=fa.DepthInstance3DBoxes)])
+    assert all(torch.isfinite(v) for v in losses.values())

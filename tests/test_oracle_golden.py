@@ -156,3 +156,39 @@ def test_indoor_eval_matches_reference_golden():
             assert abs(got[k] - want[k]) < 1e-6, (case, k, got[k], want[k])
     # VOC area AP on a hand-checkable curve: recall steps 0.5, 1.0 with precisions 1.0, 2/3
     assert abs(float(average_precision(np.array([0.5, 0.5, 1.0]), np.array([1.0, 0.5, 2 / 3]))[0]) - (0.5 + 0.5 * 2 / 3)) < 1e-6
+
+
+def test_pipeline_transforms_match_reference_classes():
+    """fcaf3d_amd/pipelines.py == the reference's DepthInstance3DBoxes / DepthPoints rotate / flip / scale / translate
+    and GlobalAlignment on the same inputs (tests/golden/pipeline.npz, generated by importing those classes)"""
+    import os
+    import numpy as np
+    import torch
+    from fcaf3d_amd import pipelines as pl
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pipeline.npz'))
+    for case, with_yaw in enumerate([True, False]):
+        pts = torch.from_numpy(d[f'c{case}_points'])
+        bx = torch.from_numpy(d[f'c{case}_boxes'])
+        if bx.shape[1] == 6:
+            bx = torch.cat((bx, bx.new_zeros(len(bx), 1)), 1)
+        angle, scale, *trans = d[f'c{case}_params'].tolist()
+        for direction in ('horizontal', 'vertical'):
+            p, b = pl.flip_bev(pts, bx, direction, with_yaw)
+            assert np.allclose(p.numpy(), d[f'c{case}_flip_{direction}_points'], atol=1e-6)
+            assert np.allclose(b.numpy(), d[f'c{case}_flip_{direction}_boxes'], atol=1e-6)
+        p, b = pl.rot_scale_trans(pts, bx, angle, scale, trans, with_yaw)
+        assert np.allclose(p.numpy(), d[f'c{case}_rst_points'], atol=2e-6), np.abs(p.numpy() - d[f'c{case}_rst_points']).max()
+        assert np.allclose(b.numpy(), d[f'c{case}_rst_boxes'], atol=2e-6), np.abs(b.numpy() - d[f'c{case}_rst_boxes']).max()
+    out = pl.global_alignment(torch.from_numpy(d['align_points_in']), d['align_matrix'])
+    assert np.allclose(out.numpy(), d['align_points_out'], atol=2e-6)
+    # sampling: exact row count, without replacement when possible, colours ride along
+    g = torch.Generator().manual_seed(0)
+    s, idx = pl.indoor_point_sample(torch.from_numpy(d['c0_points']), 300, g)
+    assert s.shape == (300, 6) and len(set(idx.tolist())) == 300
+    s, idx = pl.indoor_point_sample(torch.from_numpy(d['c0_points']), 800, g)
+    assert s.shape == (800, 6) and int(idx.max()) < 500
+    aug = pl.TrainAugment(num_points=400, with_yaw=True)
+    p, b, params = aug(torch.from_numpy(d['c0_points']), torch.from_numpy(d['c0_boxes']), g)
+    assert p.shape == (400, 6) and b.shape == (9, 7) and 0.9 <= params['scale'] <= 1.1
+    assert abs(params['angle']) <= 0.087266 + 1e-9
+    assert torch.allclose(b[:, 3:6], torch.from_numpy(d['c0_boxes'])[:, 3:6] * params['scale'], atol=1e-5)
