@@ -241,7 +241,7 @@ def cpu_baseline(args, model, cfg):
 
 def count_steps(args, n_batches):
     """number of untimed FLOP-count steps after the timed region — a function of the flags only, never of the rank"""
-    return 0 if (args.no_instrument or args.breakdown) else min(n_batches, args.steps)
+    return 0 if (args.no_instrument or args.breakdown) else n_batches      # every distinct batch a probed step may use
 
 
 def main():
