@@ -115,8 +115,8 @@ class Config:
         ns = {}
         with open(path) as f:
             exec(compile(f.read(), path, 'exec'), ns)
-        cfg = {k: v for k, v in ns.items() if not k.startswith('__') and not callable(v)
-               and not isinstance(v, type(os))}
+        cfg = {k: v for k, v in ns.items() if (k == '_base_' or not k.startswith('_')) and not callable(v)
+               and not isinstance(v, type(os))}          # `_name` = file-local helper value, not a config key
         bases = cfg.pop('_base_', [])
         if isinstance(bases, str):
             bases = [bases]
