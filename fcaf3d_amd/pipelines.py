@@ -148,3 +148,46 @@ class TrainAugment:
             points, boxes = flip_bev(points, boxes, 'vertical', self.with_yaw)
         points, boxes = rot_scale_trans(points, boxes, p['angle'], p['scale'], p['trans'], self.with_yaw)
         return points, boxes, p
+
+
+class IndoorInfoDataset:
+    """The annotation side of the reference's ScanNetDataset / S3DISDataset / SUNRGBDDataset
+    (mmdet3d/datasets/scannet_dataset.py:70-117, custom_3d.py): an info `.pkl` (list of per-scene dicts written by
+    tools/create_data.py) -> per scene: points file, axis-alignment matrix, GT boxes as Depth-mode bottom-centre (m,7)
+    and labels.  `load()` returns the scene on `device`, aligned, ready for TrainAugment / the detector."""
+
+    def __init__(self, data_root, ann_file, with_yaw=False, load_dim=6, use_dim=(0, 1, 2, 3, 4, 5)):
+        import pickle
+        self.data_root = data_root
+        with open(ann_file, 'rb') as f:
+            self.data_infos = pickle.load(f)
+        self.with_yaw, self.load_dim, self.use_dim = with_yaw, load_dim, tuple(use_dim)
+
+    def __len__(self):
+        return len(self.data_infos)
+
+    def get_ann_info(self, index):
+        from .boxes import DepthInstance3DBoxes
+        ann = self.data_infos[index]['annos']
+        if ann['gt_num'] != 0:
+            boxes = np.asarray(ann['gt_boxes_upright_depth'], np.float32)
+            labels = np.asarray(ann['class']).astype(np.int64)
+        else:
+            boxes = np.zeros((0, 7 if self.with_yaw else 6), np.float32)
+            labels = np.zeros((0,), np.int64)
+        gt = DepthInstance3DBoxes(torch.from_numpy(boxes), box_dim=boxes.shape[-1], with_yaw=self.with_yaw,
+                                  origin=(0.5, 0.5, 0.5))
+        align = np.asarray(ann.get('axis_align_matrix', np.eye(4)), np.float32)
+        return dict(gt_bboxes_3d=gt, gt_labels_3d=torch.from_numpy(labels), axis_align_matrix=align)
+
+    def load(self, index, device=None, points_file=None):
+        import os
+        info = self.data_infos[index]
+        path = points_file or os.path.join(self.data_root, info['pts_path'])
+        ann = self.get_ann_info(index)
+        pts = load_points_from_file(path, self.load_dim, self.use_dim, device)
+        pts = global_alignment(pts, ann['axis_align_matrix'])
+        boxes = ann['gt_bboxes_3d'].tensor
+        if device is not None:
+            boxes = boxes.to(device); ann['gt_labels_3d'] = ann['gt_labels_3d'].to(device)
+        return pts, boxes, ann['gt_labels_3d'], dict(sample_idx=info['point_cloud']['lidar_idx'], file_name=path)

@@ -192,3 +192,68 @@ def test_pipeline_transforms_match_reference_classes():
     assert p.shape == (400, 6) and b.shape == (9, 7) and 0.9 <= params['scale'] <= 1.1
     assert abs(params['angle']) <= 0.087266 + 1e-9
     assert torch.allclose(b[:, 3:6], torch.from_numpy(d['c0_boxes'])[:, 3:6] * params['scale'], atol=1e-5)
+
+
+def test_pipeline_on_the_reference_scannet_fixture():
+    """the reference's own dataset fixture (tests/data/scannet: scannet_infos.pkl + scene0000_00.bin, copied as data)
+    through load -> align -> sample -> flip H,V -> rotate, against the numbers its test holds
+    (tests/test_data/test_datasets/test_scannet_dataset.py:65-86, np.random.seed(0))"""
+    import math
+    import os
+    import numpy as np
+    import torch
+    from fcaf3d_amd import pipelines as pl
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    ds = pl.IndoorInfoDataset(G, os.path.join(G, 'scannet_infos.pkl'), with_yaw=False)
+    assert len(ds) == 1
+    pts, boxes, labels, meta = ds.load(0, points_file=os.path.join(G, 'scannet_scene0000_00.bin'))
+    assert meta['sample_idx'] == 'scene0000_00' and pts.shape == (100, 6) and boxes.shape == (27, 7)
+    expected_labels = [6, 6, 4, 9, 11, 11, 10, 0, 15, 17, 17, 17, 3, 12, 4, 4, 14, 1, 0, 0, 0, 0, 0, 0, 5, 5, 5]
+    assert labels.tolist() == expected_labels
+    # the reference's draws under np.random.seed(0): the sample indices, both flips (ratio 1.0), and the rotation whose
+    # matrix its test pins as pcd_rotation = [[0.99654, 0.08311407, 0], [-0.08311407, 0.99654, 0], [0, 0, 1]]
+    idx = np.random.RandomState(0).choice(100, 5, replace=False)
+    angle = math.asin(0.08311407)
+    p = pts[torch.from_numpy(idx)]
+    p, b = pl.flip_bev(p, boxes, 'horizontal', False)
+    p, b = pl.flip_bev(p, b, 'vertical', False)
+    p, b = pl.rot_scale_trans(p, b, angle, 1.0, [0.0, 0.0, 0.0], False)
+    expected_points = torch.tensor([[1.8339e+00, 2.1093e+00, 2.2900e+00], [3.6079e+00, 1.4592e-01, 2.0687e+00],
+                                    [4.1886e+00, 5.0614e+00, -1.0841e-01], [6.8790e+00, 1.5086e+00, -9.3154e-02],
+                                    [4.8253e+00, 2.6668e-01, 1.4917e+00]])
+    expected_boxes = torch.tensor([[-1.1835, -3.6317, 1.5704, 1.7577, 0.3761, 0.5724, 0.0000],
+                                   [-3.1832, 3.2269, 1.1911, 0.6727, 0.2251, 0.6715, 0.0000],
+                                   [-0.9598, -2.2864, 0.0093, 0.7506, 2.5709, 1.2145, 0.0000],
+                                   [-2.6988, -2.7354, 0.8288, 0.7680, 1.8877, 0.2870, 0.0000],
+                                   [3.2989, 0.2885, -0.0090, 0.7600, 3.8814, 2.1603, 0.0000]])
+    assert torch.allclose(b[:5], expected_boxes, rtol=1e-2, atol=2e-4), (b[:5] - expected_boxes).abs().max()
+    assert torch.allclose(p[:, :3], expected_points, rtol=1e-2, atol=2e-4), (p[:, :3] - expected_points).abs().max()
+
+
+def test_pipeline_on_the_reference_sunrgbd_fixture():
+    """rotated boxes (with_yaw): the reference's SUN RGB-D fixture through flip(no) -> rotate -> scale -> sample against
+    the numbers of tests/test_data/test_datasets/test_sunrgbd_dataset.py:96-126 (np.random.seed(0): the draw sequence —
+    one choice + two rand of RandomFlip3D, uniform rot, uniform scale, normal x3, then the sample — is replayed)"""
+    import os
+    import numpy as np
+    import torch
+    from fcaf3d_amd import pipelines as pl
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    ds = pl.IndoorInfoDataset(G, os.path.join(G, 'sunrgbd_infos.pkl'), with_yaw=True)
+    pts, boxes, labels, meta = ds.load(0, points_file=os.path.join(G, 'sunrgbd_000001.bin'))
+    assert labels.tolist() == [0, 7, 6] and boxes.shape == (3, 7)
+    rs = np.random.RandomState(0)
+    rs.rand(); flip_h = rs.rand() < 0.5; rs.rand()
+    angle = rs.uniform(-0.523599, 0.523599)
+    scale = rs.uniform(0.85, 1.15)
+    rs.normal(scale=[0.0, 0.0, 0.0], size=3)
+    assert not flip_h and abs(scale - 0.9770964398016714) < 1e-9 and abs(np.sin(angle) - 0.04698427) < 1e-6
+    p, b = pl.rot_scale_trans(pts, boxes, angle, scale, [0.0, 0.0, 0.0], True)
+    idx = rs.choice(p.shape[0], 5, replace=False)
+    expected_boxes = torch.tensor([[0.8308, 4.1168, -1.2035, 2.2493, 1.8444, 1.9245, 1.6486],
+                                   [2.3002, 4.8149, -1.2442, 0.5718, 0.8629, 0.9510, 1.6030],
+                                   [-1.1477, 1.8090, -1.1725, 0.6965, 1.5273, 2.0563, 0.0552]])
+    expected_points = torch.tensor([[-0.9904, 1.2596, 0.1105], [-0.9948, 1.2758, 0.0437], [-0.9866, 1.2641, 0.0504],
+                                    [-0.9915, 1.2586, 0.1265], [-0.9890, 1.2561, 0.1216]])
+    assert torch.allclose(b, expected_boxes, rtol=1e-3, atol=1e-4), (b - expected_boxes).abs().max()
+    assert torch.allclose(p[torch.from_numpy(idx), :3], expected_points, rtol=1e-2, atol=2e-4)
