@@ -12,23 +12,31 @@ import torch
 
 
 def average_precision(recalls, precisions, mode='area'):
-    """VOC AP of one precision/recall curve (indoor_eval.py:7-52): 'area' under the monotone envelope, or '11points'."""
-    r = np.asarray(recalls, np.float64).reshape(-1)
-    p = np.asarray(precisions, np.float64).reshape(-1)
-    assert r.shape == p.shape
+    """VOC AP (indoor_eval.py:7-52) of one curve (n,) or of several (num_scales, n) -> float32 (num_scales,).
+    'area': area under the monotone precision envelope; '11points': mean of the best precision at recall >= 0, .1, ... 1.
+    NB the reference divides by 11 INSIDE its loop over scales, so with S scales entry i ends up divided S - i times;
+    kept, because its own test vector (tests/test_metrics/test_indoor_eval.py:183-188) encodes it."""
+    r = np.atleast_2d(np.asarray(recalls, np.float64))
+    p = np.atleast_2d(np.asarray(precisions, np.float64))
+    assert r.shape == p.shape and r.ndim == 2
+    S = r.shape[0]
+    ap = np.zeros(S, np.float32)
     if mode == 'area':
-        mrec = np.concatenate(([0.0], r, [1.0]))
-        mpre = np.concatenate(([0.0], p, [0.0]))
-        mpre = np.maximum.accumulate(mpre[::-1])[::-1]            # envelope
-        step = np.nonzero(mrec[1:] != mrec[:-1])[0]
-        return np.array([np.sum((mrec[step + 1] - mrec[step]) * mpre[step + 1])], np.float32)
-    if mode == '11points':
-        ap = 0.0
-        for thr in np.arange(0, 1 + 1e-3, 0.1):
-            sel = p[r >= thr]
-            ap += (sel.max() if sel.size else 0.0) / 11
-        return np.array([ap], np.float32)
-    raise ValueError('Unrecognized mode, only "area" and "11points" are supported')
+        for i in range(S):
+            mrec = np.concatenate(([0.0], r[i], [1.0]))
+            mpre = np.concatenate(([0.0], p[i], [0.0]))
+            mpre = np.maximum.accumulate(mpre[::-1])[::-1]            # envelope
+            step = np.nonzero(mrec[1:] != mrec[:-1])[0]
+            ap[i] = np.sum((mrec[step + 1] - mrec[step]) * mpre[step + 1])
+    elif mode == '11points':
+        for i in range(S):
+            for thr in np.arange(0, 1 + 1e-3, 0.1):
+                sel = p[i, r[i] >= thr]
+                ap[i] += sel.max() if sel.size else 0.0
+            ap /= 11
+    else:
+        raise ValueError('Unrecognized mode, only "area" and "11points" are supported')
+    return ap
 
 
 def _gravity7(boxes):

@@ -497,3 +497,10 @@ def test_pipeline_feeds_the_detector_on_device(tmp_path):
     losses = model(return_loss=True, points=[q], gt_bboxes_3d=[fa.DepthInstance3DBoxes(b)], gt_labels_3d=[torch.from_numpy(labels).to(dev)],
                    img_metas=[dict(box_type_3d=fa.DepthInstance3DBoxes)])
     assert all(torch.isfinite(v) for v in losses.values())
+
+
+def test_indoor_eval_reference_test_vectors_hip():
+    """known-answer vectors of the reference's tests/test_metrics/test_indoor_eval.py, IoU matrices from the HIP kernel"""
+    from tests.test_oracle_golden import _check_ref_indoor_eval
+    _dev()
+    _check_ref_indoor_eval(None)
