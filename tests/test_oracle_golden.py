@@ -307,3 +307,46 @@ def test_indoor_eval_reference_test_vectors():
     _check_ref_indoor_eval(_oracle_iou3d)
     ap = average_precision(np.array([[0.25, 0.5, 0.75], [0.25, 0.5, 0.75]]), np.array([[1., 1., 1.], [1., 1., 1.]]), '11points')
     assert abs(ap[0] - 0.06611571) < 0.001
+
+
+def test_box_transforms_reference_test_vectors():
+    """known-answer vectors of the reference's tests/test_utils/test_box3d.py::test_depth_boxes3d (gravity centre, flip
+    H / V with points, rotate with yaw, rotate of yaw-less boxes) through fcaf3d_amd.boxes / fcaf3d_amd.pipelines"""
+    import torch
+    import fcaf3d_amd as fa
+    from fcaf3d_amd import pipelines as pl
+    b1 = torch.tensor([[1.4856, 2.5299, -0.5570, 0.9385, 2.1404, 0.8954, 3.0601],
+                       [2.3262, 3.3065, 0.44255, 0.8234, 0.5325, 1.0099, 2.9971]])
+    assert torch.allclose(fa.DepthInstance3DBoxes(b1).gravity_center,
+                          torch.tensor([[1.4856, 2.5299, -0.1093], [2.3262, 3.3065, 0.9475]]), atol=1e-4)
+    boxes = torch.cat([b1, torch.tensor([[2.4593, 2.5870, -0.4321, 0.8597, 0.6193, 1.0204, 3.0693],
+                                         [1.4856, 2.5299, -0.5570, 0.9385, 2.1404, 0.8954, 3.0601]])])
+    points = torch.tensor([[0.6762, 1.2559, -1.4658, 2.5359], [0.8784, 4.7814, -1.3857, 0.7167],
+                           [-0.2517, 6.7053, -0.9697, 0.5599], [0.5520, 0.6533, -0.5265, 1.0032],
+                           [-0.5358, 4.5870, -1.4741, 0.0556]])
+    p, b = pl.flip_bev(points, boxes, 'horizontal', True)
+    assert torch.allclose(b, torch.tensor([[-1.4856, 2.5299, -0.5570, 0.9385, 2.1404, 0.8954, 0.0815],
+                                           [-2.3262, 3.3065, 0.4426, 0.8234, 0.5325, 1.0099, 0.1445],
+                                           [-2.4593, 2.5870, -0.4321, 0.8597, 0.6193, 1.0204, 0.0723],
+                                           [-1.4856, 2.5299, -0.5570, 0.9385, 2.1404, 0.8954, 0.0815]]), rtol=1e-3, atol=1e-4)
+    assert torch.allclose(p[:, 0], -points[:, 0]) and torch.equal(p[:, 1:], points[:, 1:])
+    p, b = pl.flip_bev(p, b, 'vertical', True)
+    assert torch.allclose(b[:, [0, 1, 6]], torch.tensor([[-1.4856, -2.5299, -0.0815], [-2.3262, -3.3065, -0.1445],
+                                                          [-2.4593, -2.5870, -0.0723], [-1.4856, -2.5299, -0.0815]]),
+                          rtol=1e-3, atol=1e-4)
+    p, b = pl.rotate(p, b, -0.022998953275003075, True)
+    assert torch.allclose(b, torch.tensor([[-1.5434, -2.4951, -0.5570, 0.9385, 2.1404, 0.8954, -0.0585],
+                                           [-2.4016, -3.2521, 0.4426, 0.8234, 0.5325, 1.0099, -0.1215],
+                                           [-2.5181, -2.5298, -0.4321, 0.8597, 0.6193, 1.0204, -0.0493],
+                                           [-1.5434, -2.4951, -0.5570, 0.9385, 2.1404, 0.8954, -0.0585]]), rtol=1e-3, atol=1e-4)
+    assert torch.allclose(p, torch.tensor([[-0.7049, -1.2400, -1.4658, 2.5359], [-0.9881, -4.7599, -1.3857, 0.7167],
+                                           [0.0974, -6.7093, -0.9697, 0.5599], [-0.5669, -0.6404, -0.5265, 1.0032],
+                                           [0.4302, -4.5981, -1.4741, 0.0556]]), rtol=1e-3, atol=1e-4)
+    # yaw-less boxes: the rotated box is replaced by its axis-aligned extent
+    th = torch.tensor([[0.61211395, 0.8129094, 0.10563634, 1.497534, 0.16927195, 0.27956772],
+                       [1.430009, 0.49797538, 0.9382923, 0.07694054, 0.9312509, 1.8919173]])
+    b6 = fa.DepthInstance3DBoxes(th, box_dim=6, with_yaw=False).tensor
+    _, br = pl.rotate(torch.zeros((1, 3)), b6, -0.04599790655000615, False)
+    assert torch.allclose(br, torch.tensor([[0.64884546, 0.78390356, 0.10563634, 1.50373348, 0.23795205, 0.27956772, 0],
+                                            [1.45139421, 0.43169443, 0.93829232, 0.11967964, 0.93380373, 1.89191735, 0]]),
+                          atol=1e-6)
