@@ -29,7 +29,11 @@ __device__ __attribute__((aligned(16))) float g_zero_row[64];   // what an absen
 // (single LDS buffer, global-load latency hidden behind the matrix pipe).
 // gridDim.z > 1 = split over kernel offsets (offset k handled by split k % gridDim.z) for layers whose
 // row count cannot fill the chip; partial tiles go to `out` + z*n_out*Cout and are summed by k_sum_parts.
-template <int BM, int BN, int BKT, bool HAS_NBR>
+// IDXL: the neighbour rows of this workgroup's offsets, read once by the offset-mask prologue, are kept in a (dynamic) LDS
+// table [offset slot][BM]; the per-stage prefetch then takes its indices from LDS instead of re-loading them from the
+// neighbour table in front of every gather.  Used when the table is small (few offsets per workgroup: split launches,
+// pair mode), so that it does not cost a workgroup of occupancy.
+template <int BM, int BN, int BKT, bool HAS_NBR, bool IDXL = false>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
                                                    const int* __restrict__ nbr, const int* __restrict__ out_index,
                                                    const int* __restrict__ cnt,
@@ -43,6 +47,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
   __shared__ __attribute__((aligned(16))) float As[BM * LDAT];
   __shared__ __attribute__((aligned(16))) float Bs[BKT * BN];
   __shared__ unsigned int kmask_s;
+  extern __shared__ int idx_s[];                 // IDXL: [ceil(K / S)][BM]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -78,7 +83,15 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
   if (tid < BM) {
     unsigned int mk = 0u;
     int64_t row = m0 + tid;
-    if (row < n_out) {
+    if (IDXL) {
+      int slot = 0;
+      for (int k = z; k < K; k += S, ++slot) {
+        int t = -1;
+        if (row < n_out) t = HAS_NBR ? nbr[(int64_t)k * n_out + row] : (int)row;
+        idx_s[slot * BM + tid] = t;
+        if (t >= 0) mk |= 1u << k;
+      }
+    } else if (row < n_out) {
       if (HAS_NBR) {
         for (int k = z; k < K; k += S)
           if (nbr[(int64_t)k * n_out + row] >= 0) mk |= 1u << k;
@@ -106,12 +119,18 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
     auto load_stage = [&](int kk, int cc) {
       const float* Wk = W + (int64_t)kk * Cin * Cout;
       int v[AR];
+      if (IDXL) {
+        const int slot = (kk - z) / S;
 #pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        int64_t row = m0 + a_r + APASS * i;
-        int64_t rc = row < n_out ? row : n_out - 1;
-        int t = HAS_NBR ? nbr[(int64_t)kk * n_out + rc] : (int)rc;    // compile-time: no null test between the loads
-        v[i] = row < n_out ? t : -1;
+        for (int i = 0; i < AR; ++i) v[i] = idx_s[slot * BM + a_r + APASS * i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+          int64_t row = m0 + a_r + APASS * i;
+          int64_t rc = row < n_out ? row : n_out - 1;
+          int t = HAS_NBR ? nbr[(int64_t)kk * n_out + rc] : (int)rc;    // compile-time: no null test between the loads
+          v[i] = row < n_out ? t : -1;
+        }
       }
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
@@ -416,6 +435,11 @@ static inline size_t lds_pad_for_cap(int cap, size_t static_bytes) {
 }
 static inline size_t conv_static_lds(int bm, int bn, int bk) { return (size_t)(bm * (bk + 4) + bk * bn) * 4 + 64; }
 
+// LDS index table (k_conv_mfma IDXL): default OFF (flags bit23 turns it ON) until measured — see profiles/r1_conv_pmc.md
+#define IDXL_DEFAULT 0
+#define IDXL_ENABLED(flags) ((((flags) >> 23) & 1) != IDXL_DEFAULT)
+#define IDXL_MAX_BYTES 4608           // <= 9 offsets per workgroup: 35.3 KB + 4.5 KB still fits 4 workgroups per CU
+
 static inline bool is_stem(const int* nbr, int K, int Cin, int Cout, int flags) {
   return !(flags & 1) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27;
 }
@@ -451,6 +475,12 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
   const size_t pad = lds_pad_for_cap((flags >> 21) & 3, conv_static_lds(bm, bn, bk));
+  // index table in LDS when it is small enough not to cost occupancy (see IDXL); flags bit23 switches it off
+  const size_t idx_bytes = (size_t)fc_cdiv(K, S) * 128 * sizeof(int);
+  if (IDXL_ENABLED(flags) && nbr && bm == 128 && bk == 32 && idx_bytes <= IDXL_MAX_BYTES) {
+    if (bn == 128) k_conv_mfma<128, 128, 32, true, true><<<grid, 256, pad + idx_bytes, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout);
+    else k_conv_mfma<128, 64, 32, true, true><<<grid, 256, pad + idx_bytes, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout);
+  } else
   if (bm == 256) { if (nbr) k_conv_mfma<256, 64, 32, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<256, 64, 32, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
   else if (bm == 128 && bn == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 128, 64, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 64, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
   else if (bm == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 64, 64, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 64, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
@@ -485,6 +515,11 @@ int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const
   const int bn = wide ? 128 : 64;
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
   const size_t pad = lds_pad_for_cap((flags >> 21) & 3, conv_static_lds(128, bn, 32));
+  if (IDXL_ENABLED(flags)) {
+    const size_t ib = 128 * sizeof(int);
+    if (wide) k_conv_mfma<128, 128, 32, true, true><<<grid, 256, pad + ib, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
+    else k_conv_mfma<128, 64, 32, true, true><<<grid, 256, pad + ib, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
+  } else
   if (wide) k_conv_mfma<128, 128, 32, true><<<grid, 256, pad, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
   else k_conv_mfma<128, 64, 32, true><<<grid, 256, pad, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
   FC_CHECK_LAUNCH();
