@@ -36,10 +36,12 @@ int fc_voxelize(const float* points, int64_t n, int pt_stride, int batch_idx, fl
                 int nfeat, int* coords, float* feats, hipStream_t stream);
 
 /* Z-order key per voxel coordinate [b | x,y,z bit-interleaved]; sorting the collated points by it before
- * fc_hash_unique turns "order of first occurrence" into a space-filling-curve order on every pyramid level. */
+ * fc_hash_unique turns "order of first occurrence" into a space-filling-curve order on every pyramid level.
+ * No reference counterpart (optional locality aid of this implementation, off by default). */
 int fc_morton_keys(const int* coords, int64_t n, long long* keys, hipStream_t stream);
 
-/* Order-preserving compaction primitive (wave ballot + prefix sum): pos[i] = #set flags before i. */
+/* Order-preserving compaction primitive (wave ballot + prefix sum): pos[i] = #set flags before i — the row selection
+ * of ME.MinkowskiPruning (fcaf3d_neck_with_head.py:76, called at :124-125) and of the per-scene decomposition. */
 int fc_scan_flags(const unsigned char* flags, int64_t n, int* pos, int* total_dev, void* ws, int64_t ws_bytes,
                   hipStream_t stream);
 int fc_compact_rows(const unsigned char* flags, const int* pos, int64_t n, int* kept, hipStream_t stream);
@@ -54,20 +56,23 @@ int fc_hash_unique(const int* coords, int64_t n, int q, unsigned long long* tabl
                    hipStream_t stream);
 
 /* ME CoordinateManager kernel map for one (in set, out set, kernel) triple: nbr[k][o] = input row at
- * out_coords[o] + offsets[k] (every ME.MinkowskiConvolution / MinkowskiMaxPooling call). */
+ * out_coords[o] + offsets[k] — built inside every ME.MinkowskiConvolution / MinkowskiMaxPooling call
+ * (me_resnet.py:19-24, :56-62; fcaf3d_neck_with_head.py:52, :69). */
 int fc_kernel_map(const int* out_coords, int64_t n_out, const unsigned long long* table_keys, const int* table_vals,
                   int64_t cap, const int* offsets, int K, int* nbr, hipStream_t stream);
-/* per-row occupancy masks of a neighbour table, and the table permuted into a row order (mask-sorted rows). */
+/* per-row occupancy masks of a neighbour table, and the table permuted into a row order (mask-sorted rows).
+ * No reference counterpart: scheduling aid of the output-stationary kernel. */
 int fc_nbr_row_masks(const int* nbr, int64_t n_out, int K, int* masks, hipStream_t stream);
 int fc_permute_nbr(const int* nbr, const int* order, int64_t n_out, int K, int* nbr_sorted, hipStream_t stream);
 /* exact (input row, output row) pair lists per kernel offset, ascending in the output row — what ME's kernel map
- * (in_maps / out_maps per offset) holds; the weight-gradient pass reduces over them (fc_conv_wgrad_pairs).
+ * (in_maps / out_maps per offset; consumed by the convolutions of me_resnet.py:56-62) holds; the weight-gradient pass reduces over them (fc_conv_wgrad_pairs).
  * pair_in / pair_out are (K, n_out) int32 with the first cnt[k] entries of row k valid; pair_pos (nullable,
  * (K, n_out)) is the inverse: pair_pos[k][o] = j with pair_out[k][j] == o, or -1. */
 int64_t fc_kernel_map_pairs_ws_bytes(int64_t n_out, int K);
 int fc_kernel_map_pairs(const int* nbr, int64_t n_out, int K, int* pair_in, int* pair_out, int* pair_pos, int* cnt,
                         void* ws, int64_t ws_bytes, hipStream_t stream);
-/* nbr_t[k][i] = o  iff  nbr[k][o] == i  (the gather table of the backward-data pass). */
+/* nbr_t[k][i] = o  iff  nbr[k][o] == i  (the gather table of the backward-data pass: ME's convolution backward walks the
+ * same in/out maps with the roles swapped, `gin[i] += gout[o] @ W[k]^T`; reached by autograd of me_resnet.py:56-62). */
 int fc_kernel_map_transpose(const int* nbr, int64_t n_out, int64_t n_in, int K, int* nbr_t, hipStream_t stream);
 
 /* ME.MinkowskiGenerativeConvolutionTranspose(k=2,s=2) output coordinates — fcaf3d_neck_with_head.py:60-66:
@@ -102,7 +107,8 @@ int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags)
 int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
                 int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);
 
-/* the same convolution as ME itself runs it (per offset: gather -> GEMM -> scatter) over the exact pair lists:
+/* ME.MinkowskiConvolution (me_resnet.py:56-62, BasicBlock convs; fcaf3d_neck_with_head.py:52) the way ME itself runs it
+ * (per offset: gather -> GEMM -> scatter) over the exact pair lists:
  * T_k = in[pair_in[k][:cnt[k]]] @ W[k] into the workspace, then out[o] = sum_k T_k[pair_pos[k][o]] in fixed k order.
  * No MFMA work is issued for absent neighbours; pays off on the small, ~60 % occupied deep levels.  MFMA shapes only
  * (Cin % 32 == 0, Cout % 64 == 0).  For the backward-data pass pass the lists of the transposed table. */
@@ -111,17 +117,20 @@ int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const
                       float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
                       int64_t ws_bytes, hipStream_t stream);
 
-/* backward-weights: gW[k] = sum_o in[nbr[k][o]]^T (x) gout[o]; deterministic two-level reduction. */
+/* backward-weights of ME.MinkowskiConvolution (autograd of me_resnet.py:19-21, :56-62 and fcaf3d_neck_with_head.py:52,
+ * :60-69; `gW[k] += in[i]^T (x) gout[o]`): gW[k] = sum_o in[nbr[k][o]]^T (x) gout[o];
+ * deterministic two-level reduction. */
 int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);
 int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int* row_index, float* gW, int64_t n_in,
                   int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);
-/* the same over the exact pair lists of fc_kernel_map_pairs (Cin, Cout multiples of 64): the reduction skips absent
+/* the same (autograd of me_resnet.py:56-62) over the exact pair lists of fc_kernel_map_pairs (Cin, Cout multiples of 64): the reduction skips absent
  * neighbours, which is ~40 % of a 27-offset table on surface-like scenes.  Workspace as fc_conv_wgrad_ws_bytes. */
 int fc_conv_wgrad_pairs(const float* in, const float* gout, const int* pair_in, const int* pair_out, const int* pair_cnt,
                         float* gW, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
                         int64_t ws_bytes, hipStream_t stream);
 
-/* (K,Cin,Cout) -> (K,Cout,Cin) */
+/* (K,Cin,Cout) -> (K,Cout,Cin): the W[k]^T of ME's backward-data rule `gin[i] += gout[o] @ W[k]^T` (SURVEY.md Appendix A.3;
+ * autograd of me_resnet.py:56-62), so that the pass runs through fc_conv_fwd on the transposed table. */
 int fc_transpose_weight(const float* W, float* Wt, int K, int Cin, int Cout, hipStream_t stream);
 
 /* ---- normalisation / pooling / rows ------------------------------------------------------- */
@@ -135,12 +144,15 @@ int fc_col_stats(const float* x, const int* seg, int seg_stride, int64_t n, int 
 /* per-segment column sums (deterministic): the per-scene loss normalisers of fcaf3d_neck_with_head.py:178-187. */
 int fc_seg_col_sums(const float* x, const int* seg, int seg_stride, int64_t n, int C, int nseg, float* out, void* ws,
                     int64_t ws_bytes, hipStream_t stream);
-/* nn.BatchNorm1d training-mode buffer update inside ME.MinkowskiBatchNorm (momentum, unbiased variance). */
+/* nn.BatchNorm1d training-mode buffer update inside ME.MinkowskiBatchNorm (momentum, unbiased variance) —
+ * me_resnet.py:48-50, BasicBlock norm1/norm2, fcaf3d_neck_with_head.py:53, :62, :68. */
 int fc_bn_running_update(const float* mean, const float* var, const float* cnt, float momentum, int C, float* running_mean,
                          float* running_var, long long* num_batches_tracked, hipStream_t stream);
 
 /* y = act((x-mean)/sqrt(var+eps)*gamma + beta (+ residual)); act 0 none, 1 ReLU, 2 ELU —
- * MinkowskiBatchNorm/InstanceNorm + MinkowskiReLU/ELU (+ BasicBlock's `out += residual`). */
+ * ME.MinkowskiInstanceNorm + MinkowskiReLU of the stem (me_resnet.py:22-23), ME.MinkowskiBatchNorm + MinkowskiELU of the
+ * neck (fcaf3d_neck_with_head.py:53-54, :62-63, :68-70), BasicBlock's norm / `out += residual` / relu (Appendix A.6, A.7);
+ * fc_norm_act_bwd is their autograd. */
 int fc_norm_act_fwd(const float* x, const int* seg, int seg_stride, int64_t n, int C, const float* mean, const float* var,
                     float eps, const float* gamma, const float* beta, const float* residual, int act, float* y,
                     hipStream_t stream);
@@ -149,8 +161,8 @@ int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* 
                     int nseg, const float* mean, const float* var, const float* cnt, float eps, const float* gamma,
                     int act, float* gx, float* gres, float* sums, void* ws, int64_t ws_bytes, hipStream_t stream);
 
-/* Training-mode ME.MinkowskiBatchNorm (+ fused ReLU/ELU / residual) for small feature matrices in TWO launches per
- * direction: batch statistics, running-buffer update (nn.BatchNorm1d momentum / unbiased variance) and apply. */
+/* Training-mode ME.MinkowskiBatchNorm (+ fused ReLU/ELU / residual; the BasicBlock norms of me_resnet.py:3, :56-63 and the
+ * neck norms of fcaf3d_neck_with_head.py:53, :62, :68) for small feature matrices in TWO launches per direction: batch statistics, running-buffer update (nn.BatchNorm1d momentum / unbiased variance) and apply. */
 int64_t fc_bn_stats_ws_bytes(int64_t n, int C);
 int fc_bn_stats_train(const float* x, int64_t n, int C, float momentum, float* mean, float* var, float* cnt,
                       float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
@@ -169,7 +181,8 @@ int fc_maxpool_fwd(const float* in, const int* nbr, int64_t n_out, int K, int C,
                    hipStream_t stream);
 int fc_maxpool_bwd(const float* gout, const int* argrow, int64_t n_out, int C, float* gin, hipStream_t stream);
 
-/* feature rows of MinkowskiPruning / union-add / per-scene decomposition. */
+/* feature rows of MinkowskiPruning (fcaf3d_neck_with_head.py:124-125), of the sparse sum `inputs[i] + x` (:101) and of
+ * the per-scene decomposition (:266-275); fc_scatter_rows_add is the autograd of the gather. */
 int fc_gather_rows(const float* src, const int* idx, int64_t n, int C, float* dst, hipStream_t stream);
 int fc_scatter_rows_add(const float* src, const int* idx, int64_t n, int C, float* dst, hipStream_t stream);
 

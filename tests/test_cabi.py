@@ -20,3 +20,20 @@ def test_size_queries_run_without_gpu():
     assert L.query('fc_hash_unique_ws_bytes', 1000) > 0
     assert L.query('fc_conv_wgrad_ws_bytes', 100000, 27, 64, 64, 0) >= 27 * 64 * 64 * 4
     assert L.query('fc_col_stats_ws_bytes', 1000, 64, 1) > 0
+
+
+def test_every_prototype_cites_its_reference_interface():
+    """include/fcaf3d_hip.h: the comment above each declaration names the reference file:line it replaces (or says that
+    there is no reference counterpart)"""
+    import re
+    from fcaf3d_amd._lib import HEADER
+    txt = open(HEADER).read()
+    last, missing = '', []
+    for block in re.split(r'(/\*.*?\*/)', txt, flags=re.S):
+        if block.startswith('/*'):
+            last = block
+            continue
+        for m in re.finditer(r'\b(?:int64_t|int)\s+(fc_\w+)\s*\(', block):
+            if not re.search(r'\.(py|cu|cpp|cuh)\s*:\s*\d+|No reference counterpart', last):
+                missing.append(m.group(1))
+    assert not missing, missing
