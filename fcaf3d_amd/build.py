@@ -44,6 +44,37 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_tools(verbose=True):
+    """tools/nbench (native conv micro-benchmark) and, with FC_TRACE kernels, tools/nbench_trace — diagnostics only."""
+    root = os.path.dirname(HERE)
+    tools = os.path.join(root, 'tools')
+    inc = os.path.join(root, 'include')
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    build(verbose=verbose)
+    run([HIPCC, '-O2', '-std=c++17', '--offload-arch=gfx950', os.path.join(tools, 'nbench.cpp'), '-I' + inc, '-L' + HERE,
+         '-lfcaf3d_hip', '-ldl', '-Wl,-rpath,$ORIGIN/../fcaf3d_amd', '-o', os.path.join(tools, 'nbench')])
+    tdir = os.path.join(tools, 'trace')
+    os.makedirs(tdir, exist_ok=True)
+    objs = []
+    for s in _sources():
+        obj = os.path.join(tdir, s[:-4] + '.o')
+        objs.append(obj)
+        src = os.path.join(CSRC, s)
+        if _stale(obj, [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]):
+            run([HIPCC] + FLAGS + ['-DFC_TRACE', '-c', src, '-o', obj])
+    tlib = os.path.join(tdir, 'libfcaf3d_hip.so')
+    run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tlib] + objs)
+    run([HIPCC, '-O2', '-std=c++17', '--offload-arch=gfx950', os.path.join(tools, 'nbench.cpp'), '-I' + inc, '-L' + tdir, '-lfcaf3d_hip', '-ldl',
+         '-Wl,-rpath,$ORIGIN/trace', '-o', os.path.join(tools, 'nbench_trace')])
+
+
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    if '--tools' in sys.argv:
+        build_tools()
+    else:
+        build(force='--force' in sys.argv)
     print(LIB)

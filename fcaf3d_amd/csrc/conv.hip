@@ -12,8 +12,22 @@
 // Replaces MinkowskiEngine's ConvolutionForward/Backward (and ConvolutionTranspose, 1x1 mm) called
 // from me_resnet.py:19-21,56-62, BasicBlock, fcaf3d_neck_with_head.py:52,60-69,83-85,257-263.
 #include "fc_common.h"
+#include "conv_reg.h"
+#ifdef FC_TRACE
+__device__ unsigned long long* g_trace_buf_lds;
+__device__ int g_trace_cap_lds;
+extern "C" int fc_debug_trace_lds(unsigned long long* buf, int cap) {
+  FC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf_lds), &buf, sizeof(buf)));
+  FC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_cap_lds), &cap, sizeof(cap)));
+  return FC_OK;
+}
+#define TR_BUF g_trace_buf_lds
+#define TR_CAP g_trace_cap_lds
+#endif
+#include "fc_trace.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: struct float4 copies lower to memcpy and
                                                           // pin the prefetch registers in scratch (r1 finding)
 
@@ -23,20 +37,17 @@ __device__ __attribute__((aligned(16))) float g_zero_row[64];   // what an absen
 #define LDA (BK + 4)     // A row stride in floats: 16B-aligned rows, conflict-free ds_read_b128 (9r mod 16)
 
 // ------------------------------------------------------------------------------------------------
-// Pipeline per workgroup: (1) OR-reduce, over the tile's rows, which kernel offsets have any neighbour
-// (offsets without one are skipped outright); (2) walk the surviving (offset, Cin-slab) stages with the
-// NEXT stage's gathers + weight loads issued into registers before the current stage's MFMAs run
-// (single LDS buffer, global-load latency hidden behind the matrix pipe).
+// Pipeline per workgroup: (1) which kernel offsets have any neighbour among the tile's rows (offsets without one are
+// skipped outright) — from the precomputed 32-row group masks when the caller has them (gmask: fc_nbr_group_masks, 4
+// words per 128-row tile, no table scan), else OR-reduced over the tile's rows; (2) walk the surviving (offset,
+// Cin-slab) stages with the NEXT stage's gathers + weight loads issued into registers before the current stage's MFMAs
+// run (single LDS buffer, global-load latency hidden behind the matrix pipe).
 // gridDim.z > 1 = split over kernel offsets (offset k handled by split k % gridDim.z) for layers whose
 // row count cannot fill the chip; partial tiles go to `out` + z*n_out*Cout and are summed by k_sum_parts.
-// IDXL: the neighbour rows of this workgroup's offsets, read once by the offset-mask prologue, are kept in a (dynamic) LDS
-// table [offset slot][BM]; the per-stage prefetch then takes its indices from LDS instead of re-loading them from the
-// neighbour table in front of every gather.  Used when the table is small (few offsets per workgroup: split launches,
-// pair mode), so that it does not cost a workgroup of occupancy.
-template <int BM, int BN, int BKT, bool HAS_NBR, bool IDXL = false>
+template <int BM, int BN, int BKT, bool HAS_NBR>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
-                                                   const int* __restrict__ nbr, const int* __restrict__ out_index,
-                                                   const int* __restrict__ cnt,
+                                                   const int* __restrict__ nbr, const unsigned int* __restrict__ gmask,
+                                                   const int* __restrict__ out_index, const int* __restrict__ cnt,
                                                    float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout) {
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave
   constexpr int LDAT = BKT + 4;                  // (BKT+4)/4 odd -> conflict-free ds_read_b128 of the A fragments
@@ -47,7 +58,6 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
   __shared__ __attribute__((aligned(16))) float As[BM * LDAT];
   __shared__ __attribute__((aligned(16))) float Bs[BKT * BN];
   __shared__ unsigned int kmask_s;
-  extern __shared__ int idx_s[];                 // IDXL: [ceil(K / S)][BM]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -55,6 +65,10 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   int S = gridDim.z, z = blockIdx.z;
+  TR_DECL;
+  TR(0);
+  int tr_units = 0;
+  (void)tr_units;
   if (cnt) {
     // pair mode (fc_conv_fwd_pairs): grid.z = kernel offset; `nbr` row z lists the input rows of that offset's cnt[z]
     // pairs and the tile computes those compacted rows only: T_z[j] = in[pair_in[z][j]] @ W[z], written to slab z
@@ -78,33 +92,37 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // ---- (1) which of this split's offsets have a neighbour anywhere in the tile ---------------------
-  if (tid == 0) kmask_s = 0u;
-  __syncthreads();
-  if (tid < BM) {
+  unsigned int kmask;
+  if (HAS_NBR && gmask && !cnt) {
     unsigned int mk = 0u;
-    int64_t row = m0 + tid;
-    if (IDXL) {
-      int slot = 0;
-      for (int k = z; k < K; k += S, ++slot) {
-        int t = -1;
-        if (row < n_out) t = HAS_NBR ? nbr[(int64_t)k * n_out + row] : (int)row;
-        idx_s[slot * BM + tid] = t;
-        if (t >= 0) mk |= 1u << k;
+#pragma unroll
+    for (int g = 0; g < BM / 32; ++g)
+      if (m0 + g * 32 < n_out) mk |= gmask[m0 / 32 + g];
+    unsigned int zm = 0u;
+    for (int k = z; k < K; k += S) zm |= 1u << k;
+    kmask = mk & zm;
+  } else {
+    if (tid == 0) kmask_s = 0u;
+    __syncthreads();
+    if (tid < BM) {
+      unsigned int mk = 0u;
+      int64_t row = m0 + tid;
+      if (row < n_out) {
+        if (HAS_NBR) {
+          for (int k = z; k < K; k += S)
+            if (nbr[(int64_t)k * n_out + row] >= 0) mk |= 1u << k;
+        } else {
+          mk = 1u;
+        }
       }
-    } else if (row < n_out) {
-      if (HAS_NBR) {
-        for (int k = z; k < K; k += S)
-          if (nbr[(int64_t)k * n_out + row] >= 0) mk |= 1u << k;
-      } else {
-        mk = 1u;
-      }
+      // wave-level OR, one LDS atomic per wave
+      for (int off = 32; off > 0; off >>= 1) mk |= __shfl_xor(mk, off, 64);
+      if (lane == 0 && mk) atomicOr(&kmask_s, mk);
     }
-    // wave-level OR, one LDS atomic per wave
-    for (int off = 32; off > 0; off >>= 1) mk |= __shfl_xor(mk, off, 64);
-    if (lane == 0 && mk) atomicOr(&kmask_s, mk);
+    __syncthreads();
+    kmask = kmask_s;
   }
-  __syncthreads();
-  unsigned int kmask = kmask_s;
+  TR(1);
 
   // ---- (2) software-pipelined stage loop -------------------------------------------------------------
   if (kmask) {
@@ -119,18 +137,12 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
     auto load_stage = [&](int kk, int cc) {
       const float* Wk = W + (int64_t)kk * Cin * Cout;
       int v[AR];
-      if (IDXL) {
-        const int slot = (kk - z) / S;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) v[i] = idx_s[slot * BM + a_r + APASS * i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-          int64_t row = m0 + a_r + APASS * i;
-          int64_t rc = row < n_out ? row : n_out - 1;
-          int t = HAS_NBR ? nbr[(int64_t)kk * n_out + rc] : (int)rc;    // compile-time: no null test between the loads
-          v[i] = row < n_out ? t : -1;
-        }
+      for (int i = 0; i < AR; ++i) {
+        int64_t row = m0 + a_r + APASS * i;
+        int64_t rc = row < n_out ? row : n_out - 1;
+        int t = HAS_NBR ? nbr[(int64_t)kk * n_out + rc] : (int)rc;    // compile-time: no null test between the loads
+        v[i] = row < n_out ? t : -1;
       }
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
@@ -146,6 +158,10 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
     };
     load_stage(k, c0);
     while (true) {
+#ifdef FC_TRACE
+      if (tr_units == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TR(2); }
+      tr_units += BKT / 8;
+#endif
       __syncthreads();                           // previous stage fully consumed
 #pragma unroll
       for (int i = 0; i < AR; ++i)
@@ -174,10 +190,18 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
           a[i] = *reinterpret_cast<const f32x4*>(&As[(wr * (BM / 2) + i * 32 + r) * LDAT + 8 * q + 4 * h]);
+        // sub-tile j of the wave owns the INTERLEAVED columns TN*r + j of its half of the tile: one ds_read_b64 per
+        // (k, lane) instead of two ds_read_b32 (conflict-free: 32 lanes x 8 B = 64 banks), and 8-byte output stores
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) b[j][e] = Bs[(8 * q + 4 * h + e) * BN + wc * (BN / 2) + j * 32 + r];
+        for (int e = 0; e < 4; ++e) {
+          if (TN == 2) {
+            const f32x2 bb = *reinterpret_cast<const f32x2*>(&Bs[(8 * q + 4 * h + e) * BN + wc * (BN / 2) + 2 * r]);
+            b[0][e] = bb[0];
+            b[TN - 1][e] = bb[1];
+          } else {
+            b[0][e] = Bs[(8 * q + 4 * h + e) * BN + wc * (BN / 2) + r];
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -194,20 +218,33 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
     }
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float* dst = out + (int64_t)z * n_out * Cout;
+  TR(3);
+  float* dst = out + (int64_t)z * n_out * Cout + n0 + wc * (BN / 2) + TN * r;
+  int orow[TM][16];                              // looked up in one batch ahead of the stores
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      int o = -1;
+      if (row < n_out) o = out_index ? out_index[row] : (int)row;      // rows are processed in mask-sorted order
+      orow[i][e] = o;
+    }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int64_t row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        int col = n0 + wc * (BN / 2) + j * 32 + r;
-        if (row < n_out) {
-          if (out_index) row = out_index[row];           // rows are processed in mask-sorted order
-          dst[row * Cout + col] = acc[i][j][e];
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (orow[i][e] >= 0) {
+        if (TN == 2) {
+          f32x2 v = {acc[i][0][e], acc[i][TN - 1][e]};
+          *reinterpret_cast<f32x2*>(dst + (int64_t)orow[i][e] * Cout) = v;
+        } else {
+          dst[(int64_t)orow[i][e] * Cout] = acc[i][0][e];
         }
       }
+    }
+  TR(5);
+  TR_FLUSH(tr_units);
 }
 
 // out[i] = sum_z part[z][i]   (fixed order; elems % 4 == 0)
@@ -394,7 +431,16 @@ __global__ void k_conv_fma(const float* __restrict__ in, const float* __restrict
 
 extern "C" {
 
-static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* mfma, int* bm, int* bn, int* S, int* bk) {
+// flags[24:27]: register-direct kernel variant (conv_reg.h), 0 = LDS-tiled kernel; flags bit28: register-direct wgrad
+#define FC_REG_VARIANT(flags) (((flags) >> 24) & 15)
+#define FC_REG_WGRAD(flags) (((flags) >> 28) & 1)
+static inline int reg_variant_for(int flags, int Cout) {
+  int rv = FC_REG_VARIANT(flags);
+  if ((rv == FC_REG_32x128_SPLIT || rv == FC_REG_64x128_SPLIT) && Cout % 128 != 0) rv = FC_REG_64x64_SPLIT;
+  return rv;
+}
+
+static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* mfma, int* bm, int* bn, int* S) {
   *mfma = !(flags & 1) && (Cin % BK == 0) && (Cout % 64 == 0) && K <= 32;
   *bn = (Cout % 128 == 0) ? 128 : 64;
   const int64_t wg128 = fc_cdiv(n_out, 128) * (Cout / *bn);
@@ -409,50 +455,66 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   }
   // tuning overrides: flags[4:5] BM (1=64, 2=128), flags[6:7] BN (1=64, 2=128), flags[8:15] S
   int fbm = (flags >> 4) & 3, fbn = (flags >> 6) & 3, fs = (flags >> 8) & 255;
-  if (fbm) *bm = fbm == 1 ? 64 : (fbm == 2 ? 128 : 256);
-  if (*bm == 256 && *bn != 64) *bm = 128;       // the 256-row tile exists for 64-wide outputs only
+  if (fbm) *bm = fbm == 1 ? 64 : 128;
   if (fbn && (Cout % (fbn == 1 ? 64 : 128) == 0)) *bn = fbn == 1 ? 64 : 128;
   if (fbm || fbn) {
     const int64_t t2 = fc_cdiv(n_out, *bm) * (Cout / *bn);
     s = 1;
     if (*mfma && K > 1 && t2 < 512) { s = (int)fc_cdiv(1024, t2); if (s > K) s = K; }
   }
+  const int rv = FC_REG_VARIANT(flags);
+  if (*mfma && rv) {                             // register-direct kernels (conv_reg.hip): their own tile shapes
+    int rows, cols;
+    fc_reg_tile(rv, &rows, &cols);
+    if (Cout % cols != 0 && rv != FC_REG_64x64_WAVE) { fc_reg_tile(FC_REG_64x64_SPLIT, &rows, &cols); }
+    const int64_t t3 = fc_cdiv(n_out, rows) * fc_cdiv(Cout, cols);
+    s = 1;
+    if (K > 1 && t3 < 640) { s = (int)fc_cdiv(768, t3); if (s > K) s = K; }
+  }
   if (fs) s = fs > K ? K : fs;
   *S = s;
-  // 64-deep reduction slabs (half the barriers per FLOP) when the tile is 128 rows and Cin allows; flags bit16/17 force 32/64
-  *bk = 32;     // measured r1: 64-deep slabs LOSE 5-10 % on the 437k-row layers (LDS 68 KB -> 2 workgroups/CU instead of 3)
-  if (flags & (1 << 16)) *bk = 32;
-  if ((flags & (1 << 17)) && Cin % 64 == 0 && *bm == 128) *bk = 64;
 }
 
-// Workgroups-per-CU cap by LDS padding.  The dispatcher fills a CU up to its occupancy limit before it moves on, so
-// a launch with fewer workgroups than 256 CUs x occupancy leaves CUs idle while others time-share their matrix pipe;
-// asking for more (unused) dynamic LDS lowers the per-CU limit and spreads the workgroups.  cap in 1..3, 0 = off.
-static inline size_t lds_pad_for_cap(int cap, size_t static_bytes) {
-  if (cap < 2 || cap > 3) return 0;                       // cap 1 would need > 64 KB (opt-in attribute): not used
-  size_t want = 163840 / (size_t)(cap + 1) + 2048;
-  return want > static_bytes ? want - static_bytes : 0;
+// one launch of the LDS-tiled MFMA kernel (32-deep slabs; measured r1: 64-deep slabs, 256-row tiles, an LDS index table
+// and LDS-padding occupancy caps all lose or are neutral — profiles/r1_conv_pmc.md — and were removed in r2)
+static int launch_conv_mfma(int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr, const unsigned int* gmask,
+                            const int* out_index, const int* cnt, float* dst, int64_t n_rows, int K, int Cin, int Cout,
+                            hipStream_t stream) {
+#define FC_LAUNCH_MFMA(BM_, BN_)                                                                                              \
+  do {                                                                                                                        \
+    if (nbr) k_conv_mfma<BM_, BN_, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);  \
+    else k_conv_mfma<BM_, BN_, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);     \
+  } while (0)
+  if (bm == 128 && bn == 128) FC_LAUNCH_MFMA(128, 128);
+  else if (bm == 128) FC_LAUNCH_MFMA(128, 64);
+  else if (bn == 128) FC_LAUNCH_MFMA(64, 128);
+  else FC_LAUNCH_MFMA(64, 64);
+#undef FC_LAUNCH_MFMA
+  FC_CHECK_LAUNCH();
+  return FC_OK;
 }
-static inline size_t conv_static_lds(int bm, int bn, int bk) { return (size_t)(bm * (bk + 4) + bk * bn) * 4 + 64; }
-
-// LDS index table (k_conv_mfma IDXL): default OFF (flags bit23 turns it ON) until measured — see profiles/r1_conv_pmc.md
-#define IDXL_DEFAULT 0
-#define IDXL_ENABLED(flags) ((((flags) >> 23) & 1) != IDXL_DEFAULT)
-#define IDXL_MAX_BYTES 4608           // <= 9 offsets per workgroup: 35.3 KB + 4.5 KB still fits 4 workgroups per CU
 
 static inline bool is_stem(const int* nbr, int K, int Cin, int Cout, int flags) {
   return !(flags & 1) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27;
 }
 
 int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags) {
-  bool mfma; int bm, bn, S, bk;
-  conv_plan(n_out > 0 ? n_out : 1, K, Cin, Cout, flags, &mfma, &bm, &bn, &S, &bk);
+  bool mfma; int bm, bn, S;
+  conv_plan(n_out > 0 ? n_out : 1, K, Cin, Cout, flags, &mfma, &bm, &bn, &S);
   return S > 1 ? (int64_t)S * n_out * Cout * (int64_t)sizeof(float) : 0;
 }
 
-// flags: bit0 = force the generic FMA kernel.
-int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
-                int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
+static int sum_parts(const float* part, float* out, int64_t n_out, int Cout, int S, hipStream_t stream) {
+  int64_t e4 = n_out * Cout / 4;
+  k_sum_parts<<<(unsigned)fc_cdiv(e4, 256), 256, 0, stream>>>(part, out, e4, S);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+// gmask (nullable): 32-row group masks of `nbr` (fc_nbr_group_masks) — the tile's offset mask without a table scan
+static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const unsigned int* gmask, const int* out_index,
+                         float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
+                         int64_t ws_bytes, hipStream_t stream) {
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (n_out == 0) return FC_OK;                 // nothing to write (an empty table may well be a NULL pointer)
   if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
@@ -463,8 +525,8 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
-  bool mfma_ok; int bm, bn, S, bk;
-  conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S, &bk);
+  bool mfma_ok; int bm, bn, S;
+  conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S);
   if (!mfma_ok) {
     if (out_index) return FC_EINVAL;              // sorted-row tables are an MFMA-path feature
     k_conv_fma<<<(unsigned)fc_cdiv(n_out * Cout, 256), 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
@@ -473,22 +535,51 @@ int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_
   }
   if (S > 1 && ws_bytes < (int64_t)S * n_out * Cout * (int64_t)sizeof(float)) return FC_EWS;
   float* dst = S > 1 ? (float*)ws : out;
-  dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
-  const size_t pad = lds_pad_for_cap((flags >> 21) & 3, conv_static_lds(bm, bn, bk));
-  // index table in LDS when it is small enough not to cost occupancy (see IDXL); flags bit23 switches it off
-  const size_t idx_bytes = (size_t)fc_cdiv(K, S) * 128 * sizeof(int);
-  if (IDXL_ENABLED(flags) && nbr && bm == 128 && bk == 32 && idx_bytes <= IDXL_MAX_BYTES) {
-    if (bn == 128) k_conv_mfma<128, 128, 32, true, true><<<grid, 256, pad + idx_bytes, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout);
-    else k_conv_mfma<128, 64, 32, true, true><<<grid, 256, pad + idx_bytes, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout);
-  } else
-  if (bm == 256) { if (nbr) k_conv_mfma<256, 64, 32, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<256, 64, 32, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  else if (bm == 128 && bn == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 128, 64, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 64, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  else if (bm == 128 && bk == 64) { if (nbr) k_conv_mfma<128, 64, 64, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 64, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  else if (bm == 128 && bn == 128) { if (nbr) k_conv_mfma<128, 128, 32, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 128, 32, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  else if (bm == 128) { if (nbr) k_conv_mfma<128, 64, 32, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<128, 64, 32, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  else if (bn == 128) { if (nbr) k_conv_mfma<64, 128, 32, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<64, 128, 32, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  else { if (nbr) k_conv_mfma<64, 64, 32, true><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); else k_conv_mfma<64, 64, 32, false><<<grid, 256, pad, stream>>>(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout); }
-  FC_CHECK_LAUNCH();
+  int rc;
+  if (FC_REG_VARIANT(flags)) {
+    rc = fc_conv_reg_launch(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout, S, reg_variant_for(flags, Cout), stream);
+  } else {
+    dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
+    rc = launch_conv_mfma(bm, bn, grid, in, W, nbr, K <= 31 ? gmask : nullptr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream);
+  }
+  if (rc != FC_OK) return rc;
+  return S > 1 ? sum_parts(dst, out, n_out, Cout, S, stream) : FC_OK;
+}
+
+// flags: bit0 = force the generic FMA kernel.
+int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
+                int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  return conv_fwd_impl(in, W, nbr, nullptr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream);
+}
+
+// ---- streaming (persistent-wave) convolution: conv_reg.hip k_conv_stream ------------------------------------------
+int fc_nbr_group_masks(const int* nbr, int64_t n_out, int K, unsigned int* gmask, hipStream_t stream) {
+  if (n_out < 0 || !nbr || !gmask) return n_out == 0 ? FC_OK : FC_EINVAL;
+  return fc_group_masks_launch(nbr, n_out, K, gmask, stream);
+}
+
+// flags bit2: the LDS-tiled kernel of fc_conv_fwd with the group-mask prologue instead of the persistent-wave kernel
+// (the remaining flag bits then mean what they mean for fc_conv_fwd)
+int64_t fc_conv_fwd_stream_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags) {
+  if (flags & 4) return fc_conv_fwd_ws_bytes(n_out, K, Cin, Cout, flags);
+  int tm, S, items;
+  fc_conv_stream_plan(n_out > 0 ? n_out : 1, K, Cin, Cout, (flags >> 4) & 3, (flags >> 8) & 255, &tm, &S, &items);
+  return S > 1 ? (int64_t)S * n_out * Cout * (int64_t)sizeof(float) : 0;
+}
+
+int fc_conv_fwd_stream(const float* in, const float* W, const int* nbr, const unsigned int* gmask, const int* out_index,
+                       float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
+                       int64_t ws_bytes, hipStream_t stream) {
+  if (n_in < 0 || n_out < 0 || K < 1 || K > 31 || Cin < 1 || Cout < 1 || !nbr || !gmask) return FC_EINVAL;
+  if (Cin % 32 != 0 || Cout % 64 != 0) return FC_EINVAL;       // MFMA shapes only; callers use fc_conv_fwd otherwise
+  if (n_out == 0) return FC_OK;
+  if (flags & 4) return conv_fwd_impl(in, W, nbr, gmask, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream);
+  int tm, S, items;
+  fc_conv_stream_plan(n_out, K, Cin, Cout, (flags >> 4) & 3, (flags >> 8) & 255, &tm, &S, &items);
+  if (S > 1 && ws_bytes < (int64_t)S * n_out * Cout * (int64_t)sizeof(float)) return FC_EWS;
+  float* dst = S > 1 ? (float*)ws : out;
+  int rc = fc_conv_stream_launch(in, W, nbr, gmask, out_index, dst, n_out, K, Cin, Cout, tm, S, stream);
+  if (rc != FC_OK) return rc;
   if (S > 1) {
     int64_t e4 = n_out * Cout / 4;
     k_sum_parts<<<(unsigned)fc_cdiv(e4, 256), 256, 0, stream>>>(dst, out, e4, S);
@@ -511,18 +602,20 @@ int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const
   if (n_out == 0) return FC_OK;
   if (ws_bytes < fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout)) return FC_EWS;
   float* part = (float*)ws;
+  if (FC_REG_VARIANT(flags)) {
+    int rc = fc_conv_reg_launch(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, K, reg_variant_for(flags, Cout), stream);
+    if (rc != FC_OK) return rc;
+    k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);
+    FC_CHECK_LAUNCH();
+    return FC_OK;
+  }
   const bool wide = (Cout % 128 == 0) && !(((flags >> 6) & 3) == 1);
   const int bn = wide ? 128 : 64;
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
-  const size_t pad = lds_pad_for_cap((flags >> 21) & 3, conv_static_lds(128, bn, 32));
-  if (IDXL_ENABLED(flags)) {
-    const size_t ib = 128 * sizeof(int);
-    if (wide) k_conv_mfma<128, 128, 32, true, true><<<grid, 256, pad + ib, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
-    else k_conv_mfma<128, 64, 32, true, true><<<grid, 256, pad + ib, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
-  } else
-  if (wide) k_conv_mfma<128, 128, 32, true><<<grid, 256, pad, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
-  else k_conv_mfma<128, 64, 32, true><<<grid, 256, pad, stream>>>(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout);
-  FC_CHECK_LAUNCH();
+  {
+    int rc = launch_conv_mfma(128, bn, grid, in, W, pair_in, nullptr, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream);
+    if (rc != FC_OK) return rc;
+  }
   k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);
   FC_CHECK_LAUNCH();
   return FC_OK;
@@ -655,6 +748,121 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
       }
 }
 
+// Dense-table weight gradient with KO kernel offsets per workgroup sharing ONE gout chunk.  With 64 input channels the
+// one-offset kernel above moves 24 KB (8 KB gathered rows + 16 KB of gout) per 0.5 MFLOP chunk = 22 FLOP/B and sits on
+// the fabric at ~4.3 TB/s (r2 measurement: 88 TF on the 437k-row level); re-using the staged gout rows for KO = 3 offsets
+// lifts that to 39 FLOP/B.  64 x BNc tile of gW[k] per offset, 4 waves as 2 x 2, reduction over rows in natural order.
+template <int BNc, int KO>
+__global__ __launch_bounds__(256, (BNc == 128) ? 2 : 3) void k_wgrad_multi(const float* __restrict__ in, const float* __restrict__ gout,
+                                                         const int* __restrict__ nbr, float* __restrict__ part, int64_t n_out,
+                                                         int K, int Cin, int Cout, int64_t rows_per_split) {
+  constexpr int TN = BNc / 64;
+  constexpr int GR = BNc * 32 / 1024;            // float4 gout loads per thread per 32-row chunk
+  __shared__ __attribute__((aligned(16))) float As[KO][32 * 64];
+  __shared__ __attribute__((aligned(16))) float Gs[32 * BNc];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles_n = Cout / BNc, tiles_m = Cin / 64;
+  int y = blockIdx.y;
+  const int tn = y % tiles_n; y /= tiles_n;
+  const int tm = y % tiles_m; y /= tiles_m;
+  const int k0 = y * KO;
+  const int ci0 = tm * 64, co0 = tn * BNc;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_split;
+  int64_t r_end = r_begin + rows_per_split;
+  if (r_end > n_out) r_end = n_out;
+
+  f32x16 acc[KO][TN];
+#pragma unroll
+  for (int o = 0; o < KO; ++o)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[o][j][e] = 0.f;
+
+  f32x4 av[KO][2], gv[GR];
+  auto load_chunk = [&](int64_t rb) {        // branch-free, batched: indices, gout rows, gathers
+    int src[KO][2];
+#pragma unroll
+    for (int o = 0; o < KO; ++o)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rr = (tid + 256 * i) / 16;
+        const int64_t row = rb + rr;
+        const int64_t rc = row < r_end ? row : r_end - 1;
+        const int kk = k0 + o < K ? k0 + o : K - 1;
+        const int t = nbr[(int64_t)kk * n_out + rc];
+        src[o][i] = (row < r_end && k0 + o < K) ? t : -1;
+      }
+#pragma unroll
+    for (int i = 0; i < GR; ++i) {
+      const int lin = tid + 256 * i;
+      const int rr = lin / (BNc / 4), c4 = lin % (BNc / 4);
+      const int64_t row = rb + rr;
+      const float* gp = row < r_end ? gout + row * Cout + co0 + c4 * 4 : g_zero_row + (c4 & 15) * 4;
+      gv[i] = *reinterpret_cast<const f32x4*>(gp);
+    }
+#pragma unroll
+    for (int o = 0; o < KO; ++o)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c4 = (tid + 256 * i) % 16;
+        const float* ap = src[o][i] < 0 ? g_zero_row + c4 * 4 : in + (int64_t)src[o][i] * Cin + ci0 + c4 * 4;
+        av[o][i] = *reinterpret_cast<const f32x4*>(ap);
+      }
+  };
+  if (r_begin < r_end) load_chunk(r_begin);
+  for (int64_t rb = r_begin; rb < r_end; rb += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < KO; ++o)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int lin = tid + 256 * i;
+        *reinterpret_cast<f32x4*>(&As[o][(lin / 16) * 64 + (lin % 16) * 4]) = av[o][i];
+      }
+#pragma unroll
+    for (int i = 0; i < GR; ++i) {
+      const int lin = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(&Gs[(lin / (BNc / 4)) * BNc + (lin % (BNc / 4)) * 4]) = gv[i];
+    }
+    __syncthreads();
+    load_chunk(rb + 32 < r_end ? rb + 32 : rb);            // unconditional (see k_conv_mfma)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float b[TN][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j][e] = Gs[(8 * q + 4 * h + e) * BNc + wc * (BNc / 2) + j * 32 + r];
+#pragma unroll
+      for (int o = 0; o < KO; ++o) {
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = As[o][(8 * q + 4 * h + e) * 64 + wr * 32 + r];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[o][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[j][e], acc[o][j], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < KO; ++o) {
+    if (k0 + o >= K) break;
+    float* dst = part + ((int64_t)blockIdx.x * K + k0 + o) * Cin * Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = ci0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int col = co0 + wc * (BNc / 2) + j * 32 + r;
+        dst[(int64_t)row * Cout + col] = acc[o][j][e];
+      }
+  }
+}
+
 // generic wgrad: block = (row range, k); each thread owns (ci,co) pairs strided by blockDim.
 __global__ void k_wgrad_fma(const float* __restrict__ in, const float* __restrict__ gout, const int* __restrict__ nbr,
                             float* __restrict__ part, int64_t n_out, int K, int Cin, int Cout, int64_t rows_per_split) {
@@ -704,6 +912,7 @@ extern "C" {
 static void wgrad_tiles(int Cin, int Cout, int flags, int* bm, int* bn) {
   *bm = 64;                                  // measured: 64-channel Cin tiles beat 128 on every benchmark layer
   *bn = (Cout % 128 == 0) ? 128 : 64;
+  if (FC_REG_WGRAD(flags)) { *bm = 64; *bn = 64; return; }
   int fbm = (flags >> 4) & 3, fbn = (flags >> 6) & 3;      // tuning overrides
   if (fbm == 1) *bm = 64;
   if (fbm == 2 && Cin % 128 == 0) *bm = 128;
@@ -711,7 +920,14 @@ static void wgrad_tiles(int Cin, int Cout, int flags, int* bm, int* bn) {
   if (fbn == 2 && Cout % 128 == 0) *bn = 128;
 }
 
-static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, int* S, int64_t* rows_per_split) {
+// several offsets per workgroup (k_wgrad_multi): dense tables with few input channels on big maps; flags bit29 disables it
+#define WGRAD_KO 3
+static inline bool wgrad_multi_ok(int64_t n_out, int K, int Cin, int Cout, int flags, bool dense_table) {
+  return dense_table && !(flags & 1) && !(flags & (1 << 29)) && !FC_REG_WGRAD(flags) && K % WGRAD_KO == 0 && Cin == 64 &&
+         Cout % 64 == 0 && n_out >= 32768;
+}
+
+static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool dense_table, int* S, int64_t* rows_per_split) {
   if (!(flags & 1) && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27) {     // stem: 4096 rows per block
     int64_t m = n_out > 0 ? n_out : 1;
     *rows_per_split = 1024;
@@ -724,6 +940,12 @@ static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, int* 
   int64_t tiles = mfma_ok ? (int64_t)K * (Cin / tbm) * (Cout / tbn) : (int64_t)K;
   // aim for ~2048 workgroups, at least 512 rows per split, at most 256 splits
   int64_t s = fc_cdiv(2048, tiles);
+  if (wgrad_multi_ok(n_out, K, Cin, Cout, flags, dense_table)) {
+    // uniform long workgroups: exactly one resident round (3 per CU), fewer partial gradients to write and re-read
+    const bool wide = Cout % 128 == 0;
+    tiles = (int64_t)(K / WGRAD_KO) * (Cin / 64) * (Cout / (wide ? 128 : 64));
+    s = (wide ? 512 : 768) / tiles;                     // the 128-column variant holds 2 workgroups per CU (registers)
+  }
   int64_t max_by_rows = fc_cdiv(n_out > 0 ? n_out : 1, mfma_ok ? 512 : 2048);
   if (s > max_by_rows) s = max_by_rows;
   if (s > 256) s = 256;
@@ -736,8 +958,10 @@ static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, int* 
 }
 
 int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags) {
-  int S; int64_t rps;
-  wgrad_plan(n_out, K, Cin, Cout, flags, &S, &rps);
+  int S, S2; int64_t rps;
+  wgrad_plan(n_out, K, Cin, Cout, flags, false, &S, &rps);
+  wgrad_plan(n_out, K, Cin, Cout, flags, true, &S2, &rps);        // dense tables may take the multi-offset kernel
+  if (S2 > S) S = S2;
   return (int64_t)S * K * Cin * Cout * (int64_t)sizeof(float);
 }
 
@@ -752,7 +976,8 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
   }
   if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
   int S; int64_t rps;
-  wgrad_plan(n_out, K, Cin, Cout, flags, &S, &rps);
+  const bool dense_table = nbr && !cnt;
+  wgrad_plan(n_out, K, Cin, Cout, flags, dense_table, &S, &rps);
   if (ws_bytes < (int64_t)S * elems * (int64_t)sizeof(float)) return FC_EWS;
   float* part = (S == 1) ? gW : (float*)ws;
   bool mfma_ok = !(flags & 1) && (Cin % 64 == 0) && (Cout % 64 == 0);
@@ -760,6 +985,14 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
   if (!(flags & 1) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27) {
     size_t smem = (size_t)(STEM_ROWS * STEM_JP + STEM_ROWS * 64) * sizeof(float);
     k_stem_wgrad<<<(unsigned)S, 256, smem, stream>>>(in, gout, nbr, part, n_out, K, rps);
+  } else if (mfma_ok && wgrad_multi_ok(n_out, K, Cin, Cout, flags, dense_table)) {
+    const int bn = (Cout % 128 == 0) ? 128 : 64;
+    dim3 grid((unsigned)S, (unsigned)((K / WGRAD_KO) * (Cin / 64) * (Cout / bn)));
+    if (bn == 128) k_wgrad_multi<128, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
+    else k_wgrad_multi<64, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
+  } else if (mfma_ok && FC_REG_WGRAD(flags)) {
+    int rc = fc_wgrad_reg_launch(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, S, rps, stream);
+    if (rc != FC_OK) return rc;
   } else if (mfma_ok) {
     int bm, bn;
     wgrad_tiles(Cin, Cout, flags, &bm, &bn);

@@ -1,0 +1,398 @@
+// Native micro-benchmark of the sparse-convolution entry points of libfcaf3d_hip.so on benchmark-shaped kernel maps
+// (no Python, no torch: a fresh GPU box spends its minutes on kernels, not on `import torch`).
+//
+//   hipcc -O2 --offload-arch=gfx950 tools/nbench.cpp -Iinclude -Lfcaf3d_amd -lfcaf3d_hip -Wl,-rpath,'$ORIGIN/../fcaf3d_amd' -o tools/nbench
+//   tools/nbench [--batch 8] [--only L3] [--mode fwd|wgrad|all] [--reps 10] [--variants 0,1,2,...] [--check]
+//
+// Scenes follow fcaf3d_amd/synthetic.py (room 6 x 5 x 2.7 m, floor + walls + 15 cuboids, 100 000 points, 5 mm noise,
+// 2 cm voxels); coordinate sets and kernel maps are built on the HOST with ME's rules (first-occurrence row order,
+// floor-strided sets, generative 2x2x2 children) — only the convolution kernels under test run on the GPU.
+// Every case is checked against the library's generic FMA kernel (flags bit0) before it is timed.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "fcaf3d_hip.h"
+
+#define CK(x)                                                                                   \
+  do {                                                                                          \
+    hipError_t e__ = (x);                                                                       \
+    if (e__ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e__), __FILE__, __LINE__); exit(2); } \
+  } while (0)
+#define FC(x)                                                                       \
+  do {                                                                              \
+    int rc__ = (x);                                                                 \
+    if (rc__ != 0) { fprintf(stderr, "%s -> %d at %s:%d\n", #x, rc__, __FILE__, __LINE__); exit(3); } \
+  } while (0)
+
+struct V4 { int b, x, y, z; };
+static inline uint64_t pack(const V4& c) {
+  return ((uint64_t)(uint32_t)c.b << 48) | ((uint64_t)(uint32_t)(c.x + 32768) << 32) | ((uint64_t)(uint32_t)(c.y + 32768) << 16) |
+         (uint64_t)(uint32_t)(c.z + 32768);
+}
+static inline uint64_t mix(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
+
+struct Hash {                      // open addressing, key -> row
+  std::vector<uint64_t> keys; std::vector<int> vals; uint64_t mask;
+  void init(size_t n) { size_t cap = 2; while (cap < 2 * n + 2) cap *= 2; keys.assign(cap, ~0ull); vals.assign(cap, -1); mask = cap - 1; }
+  int find(uint64_t k) const { uint64_t h = mix(k) & mask; while (true) { if (keys[h] == k) return vals[h]; if (keys[h] == ~0ull) return -1; h = (h + 1) & mask; } }
+  bool insert(uint64_t k, int v) { uint64_t h = mix(k) & mask; while (true) { if (keys[h] == k) return false; if (keys[h] == ~0ull) { keys[h] = k; vals[h] = v; return true; } h = (h + 1) & mask; } }
+};
+
+struct CSet {                      // coordinate set in first-occurrence order + hash
+  std::vector<V4> c; Hash h; int stride;
+  int n() const { return (int)c.size(); }
+};
+static int fdiv(int a, int b) { int q = a / b, r = a % b; return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q; }
+
+static CSet unique_of(const std::vector<V4>& in, int q, int stride) {
+  CSet s; s.stride = stride; s.h.init(in.size());
+  for (const V4& v : in) {
+    V4 w{v.b, fdiv(v.x, q) * q, fdiv(v.y, q) * q, fdiv(v.z, q) * q};
+    if (s.h.insert(pack(w), (int)s.c.size())) s.c.push_back(w);
+  }
+  return s;
+}
+static CSet generate(const CSet& p) {   // children 8i+k, x fastest
+  CSet s; s.stride = p.stride / 2; s.h.init(p.c.size() * 8);
+  const int hs = s.stride;
+  for (const V4& v : p.c)
+    for (int k = 0; k < 8; ++k) {
+      V4 w{v.b, v.x + (k & 1) * hs, v.y + ((k >> 1) & 1) * hs, v.z + ((k >> 2) & 1) * hs};
+      s.h.insert(pack(w), (int)s.c.size()); s.c.push_back(w);
+    }
+  return s;
+}
+// nbr[k][o] = row in `in` of out.c[o] + offset_k * in.stride (k3: centred, x fastest)
+static std::vector<int> kernel_map(const CSet& in, const CSet& out, int ks) {
+  const int K = ks * ks * ks, n = out.n();
+  std::vector<int> nbr((size_t)K * n);
+  int k = 0;
+  for (int dz = 0; dz < ks; ++dz) for (int dy = 0; dy < ks; ++dy) for (int dx = 0; dx < ks; ++dx, ++k) {
+    const int ox = (dx - ks / 2) * in.stride, oy = (dy - ks / 2) * in.stride, oz = (dz - ks / 2) * in.stride;
+    for (int o = 0; o < n; ++o) {
+      const V4& v = out.c[o];
+      nbr[(size_t)k * n + o] = in.h.find(pack(V4{v.b, v.x + ox, v.y + oy, v.z + oz}));
+    }
+  }
+  return nbr;
+}
+
+static std::vector<V4> make_points(int batch, int npts, float voxel) {
+  std::vector<V4> pts; pts.reserve((size_t)batch * npts);
+  for (int b = 0; b < batch; ++b) {
+    std::mt19937_64 rng(1000 + b);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    std::normal_distribution<double> N(0.0, 0.005);
+    struct R { double o[3], u[3], v[3], area; };
+    std::vector<R> rects;
+    auto add = [&](double ox, double oy, double oz, double ux, double uy, double uz, double vx, double vy, double vz) {
+      R r{{ox, oy, oz}, {ux, uy, uz}, {vx, vy, vz}, 0};
+      double cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+      r.area = std::sqrt(cx * cx + cy * cy + cz * cz); rects.push_back(r);
+    };
+    const double X = 6.0, Y = 5.0, Z = 2.7;
+    add(0, 0, 0, X, 0, 0, 0, Y, 0); add(0, 0, 0, X, 0, 0, 0, 0, Z); add(0, Y, 0, X, 0, 0, 0, 0, Z);
+    add(0, 0, 0, 0, Y, 0, 0, 0, Z); add(X, 0, 0, 0, Y, 0, 0, 0, Z);
+    for (int i = 0; i < 15; ++i) {
+      double w = 0.4 + 1.4 * U(rng), l = 0.4 + 0.8 * U(rng), hh = 0.4 + 1.1 * U(rng);
+      double cx = w / 2 + (X - w) * U(rng), cy = l / 2 + (Y - l) * U(rng);
+      double bx = cx - w / 2, by = cy - l / 2;
+      add(bx, by, hh, w, 0, 0, 0, l, 0); add(bx, by, 0, w, 0, 0, 0, 0, hh); add(bx, by + l, 0, w, 0, 0, 0, 0, hh);
+      add(bx, by, 0, 0, l, 0, 0, 0, hh); add(bx + w, by, 0, 0, l, 0, 0, 0, hh);
+    }
+    std::vector<double> cum; double tot = 0; for (auto& r : rects) { tot += r.area; cum.push_back(tot); }
+    for (int i = 0; i < npts; ++i) {
+      double t = U(rng) * tot; size_t w = std::lower_bound(cum.begin(), cum.end(), t) - cum.begin(); if (w >= rects.size()) w = rects.size() - 1;
+      const R& r = rects[w]; double a = U(rng), bb = U(rng);
+      double p[3]; for (int d = 0; d < 3; ++d) p[d] = r.o[d] + a * r.u[d] + bb * r.v[d] + N(rng);
+      pts.push_back(V4{b, (int)std::floor((float)p[0] / voxel), (int)std::floor((float)p[1] / voxel), (int)std::floor((float)p[2] / voxel)});
+    }
+  }
+  return pts;
+}
+
+template <class T> struct Dev {
+  T* p = nullptr; size_t n = 0;
+  void alloc(size_t m) { if (m > n) { if (p) CK(hipFree(p)); CK(hipMalloc(&p, std::max<size_t>(m, 1) * sizeof(T))); n = m; } }
+  void up(const std::vector<T>& v) { alloc(v.size()); CK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); }
+  std::vector<T> down(size_t m) { std::vector<T> v(m); CK(hipMemcpy(v.data(), p, m * sizeof(T), hipMemcpyDeviceToHost)); return v; }
+};
+
+struct Case { std::string name; const CSet* in; const CSet* out; int ks, Cin, Cout; bool dense; };
+
+static double time_us(int reps, const std::function<void()>& fn) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  fn(); fn(); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a, 0));
+  for (int i = 0; i < reps; ++i) fn();
+  CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+  return ms * 1e3 / reps;
+}
+
+static double max_rel_err(const std::vector<float>& a, const std::vector<float>& ref) {
+  double mx = 0, md = 0;
+  for (size_t i = 0; i < a.size(); ++i) { mx = std::max(mx, (double)std::fabs(ref[i])); md = std::max(md, (double)std::fabs(a[i] - ref[i])); }
+  return md / (mx > 0 ? mx : 1);
+}
+
+int main(int argc, char** argv) {
+  int batch = 8, reps = 10, npts = 100000; std::string only, mode = "all", trace_file; bool check = true;
+  int trace_variant = 1, trace_tbl = 0; bool stream_sweep = false;
+  std::vector<int> variants = {0, 1, 2, 3, 4, 5};
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a == "--batch") batch = atoi(argv[++i]);
+    else if (a == "--reps") reps = atoi(argv[++i]);
+    else if (a == "--points") npts = atoi(argv[++i]);
+    else if (a == "--only") only = argv[++i];
+    else if (a == "--mode") mode = argv[++i];
+    else if (a == "--no-check") check = false;
+    else if (a == "--stream-sweep") stream_sweep = true;
+    else if (a == "--trace") trace_file = argv[++i];            // needs the FC_TRACE build (tools/nbench_trace)
+    else if (a == "--trace-variant") trace_variant = atoi(argv[++i]);
+    else if (a == "--trace-tbl") trace_tbl = atoi(argv[++i]);
+    else if (a == "--variants") { variants.clear(); char* s = argv[++i]; for (char* t = strtok(s, ","); t; t = strtok(nullptr, ",")) variants.push_back(atoi(t)); }
+  }
+  // ---- coordinate pyramid ------------------------------------------------------------------------------
+  std::vector<V4> pts = make_points(batch, npts, 0.02f);
+  CSet s1 = unique_of(pts, 1, 1);
+  CSet s2 = unique_of(s1.c, 2, 2), s4 = unique_of(s2.c, 4, 4);
+  CSet l1 = unique_of(s4.c, 8, 8), l2 = unique_of(l1.c, 16, 16), l3 = unique_of(l2.c, 32, 32), l4 = unique_of(l3.c, 64, 64);
+  CSet n2 = generate(l4), n1 = generate(n2), n0 = generate(n1);       // backbone level is a subset of the generated set (floor rule)
+  printf("# batch %d: N0 %d | conv1 %d | pool %d | L1 %d L2 %d L3 %d L4 %d | neck %d %d %d\n", batch, s1.n(), s2.n(), s4.n(), l1.n(), l2.n(),
+         l3.n(), l4.n(), n2.n(), n1.n(), n0.n());
+  std::vector<Case> cases = {
+      {"L1 k3s1 64->64", &l1, &l1, 3, 64, 64, false},     {"L2 k3s1 128->128", &l2, &l2, 3, 128, 128, false},
+      {"L3 k3s1 256->256", &l3, &l3, 3, 256, 256, false},  {"L4 k3s1 512->512", &l4, &l4, 3, 512, 512, false},
+      {"L4 out 512->128", &l4, &l4, 3, 512, 128, false},   {"L1 k3s2 64->64", &s4, &l1, 3, 64, 64, false},
+      {"L2 k3s2 64->128", &l1, &l2, 3, 64, 128, false},    {"L3 k3s2 128->256", &l2, &l3, 3, 128, 256, false},
+      {"N2 k3s1 256->256", &n2, &n2, 3, 256, 256, true},   {"N2 out 256->128", &n2, &n2, 3, 256, 128, true},
+      {"N1 k3s1 128->128", &n1, &n1, 3, 128, 128, true},   {"N0 k3s1 64->64", &n0, &n0, 3, 64, 64, true},
+      {"N0 out 64->128", &n0, &n0, 3, 64, 128, true},      {"N0 dgrad 128->64", &n0, &n0, 3, 128, 64, true},
+  };
+  if (mode == "density") {            // host only: MFMA work issued by a dense table at G-row skip granularity / exact pair work
+    for (const Case& cs : cases) {
+      if (!only.empty() && cs.name.find(only) == std::string::npos) continue;
+      const int K = 27, n = cs.out->n();
+      std::vector<int> nbr = kernel_map(*cs.in, *cs.out, cs.ks);
+      std::vector<unsigned> masks(n, 0u); int64_t P = 0;
+      for (int k = 0; k < K; ++k) for (int o = 0; o < n; ++o) if (nbr[(size_t)k * n + o] >= 0) { masks[o] |= 1u << k; ++P; }
+      printf("%-18s n %7d occupancy %.2f | issued/useful at G =", cs.name.c_str(), n, (double)P / (27.0 * n));
+      for (int sortmode = 0; sortmode < 3; ++sortmode) {
+        std::vector<int> order(n); for (int i = 0; i < n; ++i) order[i] = i;
+        if (sortmode == 1) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return masks[a] < masks[b]; });
+        if (sortmode == 2) std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+          int pa = __builtin_popcount(masks[a]), pb = __builtin_popcount(masks[b]); return pa != pb ? pa > pb : masks[a] < masks[b]; });
+        printf("  [%s]", sortmode == 0 ? "natural" : sortmode == 1 ? "mask" : "popc,mask");
+        for (int G : {16, 32, 64, 128}) {
+          int64_t issued = 0;
+          for (int g0 = 0; g0 < n; g0 += G) { unsigned m = 0; for (int i = g0; i < std::min(n, g0 + G); ++i) m |= masks[order[i]]; issued += (int64_t)__builtin_popcount(m) * G; }
+          printf(" %d:%.2f", G, (double)issued / P);
+        }
+      }
+      printf("\n");
+    }
+    return 0;
+  }
+  if (mode == "gemm") {       // bounds: the LDS-tiled kernel as a plain dense GEMM, and as a conv whose neighbour is the row itself
+    Dev<float> a, w, o; Dev<int> idt; Dev<unsigned char> wsb;
+    const int n = n0.n();
+    for (int Cout : {64, 128}) {
+      const int Cin = 1728;
+      a.alloc((size_t)n * Cin); w.alloc((size_t)27 * 64 * Cout); o.alloc((size_t)n * Cout);
+      CK(hipMemset(a.p, 0x3c, (size_t)n * Cin * 4)); CK(hipMemset(w.p, 0x3c, (size_t)27 * 64 * Cout * 4));
+      const double gf = 2.0 * n * Cin * Cout / 1e9;
+      double us = time_us(reps, [&]() { FC(fc_conv_fwd(a.p, w.p, nullptr, nullptr, o.p, n, n, 1, Cin, Cout, 0, nullptr, 0, 0)); });
+      printf("dense GEMM  %d x %d x %d          %9.1f us %7.1f TF\n", n, Cin, Cout, us, gf / us * 1e3);
+      std::vector<int> same((size_t)27 * n);
+      for (int k = 0; k < 27; ++k) for (int i = 0; i < n; ++i) same[(size_t)k * n + i] = i;
+      idt.up(same);
+      const double gf2 = 2.0 * 27 * n * 64.0 * Cout / 1e9;
+      us = time_us(reps, [&]() { FC(fc_conv_fwd(a.p, w.p, idt.p, nullptr, o.p, n, n, 27, 64, Cout, 0, nullptr, 0, 0)); });
+      printf("conv K=27, neighbour = own row, 64 -> %d  %9.1f us %7.1f TF\n", Cout, us, gf2 / us * 1e3);
+      for (int k = 0; k < 27; ++k) for (int i = 0; i < n; ++i) same[(size_t)k * n + i] = (int)(((int64_t)i * 7919 + k * 104729) % n);
+      idt.up(same);
+      us = time_us(reps, [&]() { FC(fc_conv_fwd(a.p, w.p, idt.p, nullptr, o.p, n, n, 27, 64, Cout, 0, nullptr, 0, 0)); });
+      printf("conv K=27, neighbour = scattered row, 64 -> %d  %9.1f us %7.1f TF\n", Cout, us, gf2 / us * 1e3);
+    }
+    return 0;
+  }
+  Dev<float> d_in, d_w, d_out, d_ref, d_gout, d_gw, d_gwref; Dev<int> d_nbr, d_sorted, d_oidx, d_pi, d_po, d_pos, d_cnt, d_masks;
+  Dev<unsigned char> d_ws;
+  std::mt19937 rng(7);
+  std::normal_distribution<float> Nf(0.f, 1.f);
+  for (const Case& cs : cases) {
+    if (!only.empty() && cs.name.find(only) == std::string::npos) continue;
+    const int K = cs.ks * cs.ks * cs.ks, n_in = cs.in->n(), n_out = cs.out->n(), Cin = cs.Cin, Cout = cs.Cout;
+    std::vector<int> nbr = kernel_map(*cs.in, *cs.out, cs.ks);
+    int64_t P = 0; for (int v : nbr) P += v >= 0;
+    const double gflop = 2.0 * P * Cin * Cout / 1e9;
+    std::vector<float> hin((size_t)n_in * Cin), hw((size_t)K * Cin * Cout), hg((size_t)n_out * Cout);
+    for (auto& v : hin) v = Nf(rng); for (auto& v : hw) v = Nf(rng) * 0.05f; for (auto& v : hg) v = Nf(rng);
+    d_in.up(hin); d_w.up(hw); d_gout.up(hg); d_nbr.up(nbr);
+    d_out.alloc((size_t)n_out * Cout); d_ref.alloc((size_t)n_out * Cout); d_gw.alloc(hw.size()); d_gwref.alloc(hw.size());
+    // derived tables (library kernels): mask-sorted rows, pair lists
+    d_masks.alloc(n_out); d_sorted.alloc(nbr.size()); d_oidx.alloc(n_out);
+    FC(fc_nbr_row_masks(d_nbr.p, n_out, K, d_masks.p, 0));
+    std::vector<int> masks = d_masks.down(n_out), order(n_out);
+    for (int i = 0; i < n_out; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return masks[a] < masks[b]; });
+    d_oidx.up(order);
+    FC(fc_permute_nbr(d_nbr.p, d_oidx.p, n_out, K, d_sorted.p, 0));
+    d_pi.alloc(nbr.size()); d_po.alloc(nbr.size()); d_pos.alloc(nbr.size()); d_cnt.alloc(K);
+    { int64_t wb = fc_kernel_map_pairs_ws_bytes(n_out, K); d_ws.alloc(wb); FC(fc_kernel_map_pairs(d_nbr.p, n_out, K, d_pi.p, d_po.p, d_pos.p, d_cnt.p, d_ws.p, wb, 0)); }
+    CK(hipDeviceSynchronize());
+    printf("%-18s n_in %7d n_out %7d P %9lld %7.1f GF (occupancy %.2f)\n", cs.name.c_str(), n_in, n_out, (long long)P, gflop, (double)P / ((double)K * n_out));
+    auto ws_for = [&](int64_t b) { d_ws.alloc((size_t)std::max<int64_t>(b, 16)); return b; };
+
+    if (mode == "all" || mode == "fwd") {
+      // reference: generic FMA kernel
+      std::vector<float> ref;
+      if (check) {
+        FC(fc_conv_fwd(d_in.p, d_w.p, d_nbr.p, nullptr, d_ref.p, n_in, n_out, K, Cin, Cout, 1, nullptr, 0, 0));
+        ref = d_ref.down((size_t)n_out * Cout);
+      }
+      struct Run { const char* what; int flags; int tbl; };     // tbl: 0 plain table, 1 mask-sorted, 2 pair lists
+      std::vector<Run> runs;
+      for (int v : variants) {
+        runs.push_back({"plain ", v << 24, 0});
+        if (!cs.dense) { runs.push_back({"sorted", v << 24, 1}); runs.push_back({"pairs ", v << 24, 2}); }
+      }
+      // streaming kernel: plain and mask-sorted tables, 32- and 64-row tiles, a few split counts
+      {
+        Dev<unsigned int> d_gm_plain, d_gm_sorted; d_gm_plain.alloc((n_out + 31) / 32 + 1); d_gm_sorted.alloc((n_out + 31) / 32 + 1);
+        FC(fc_nbr_group_masks(d_nbr.p, n_out, K, d_gm_plain.p, 0));
+        FC(fc_nbr_group_masks(d_sorted.p, n_out, K, d_gm_sorted.p, 0));
+        // LDS-tiled kernel with the group-mask prologue (flags bit2)
+        for (int tbl = 0; tbl < 2; ++tbl) {
+          const int fl = 4;
+          int64_t wb = ws_for(fc_conv_fwd_stream_ws_bytes(n_out, K, Cin, Cout, fl));
+          const int* tab = tbl ? d_sorted.p : d_nbr.p; const int* oi = tbl ? d_oidx.p : nullptr;
+          const unsigned int* gm = tbl ? d_gm_sorted.p : d_gm_plain.p;
+          std::function<void()> fn = [&, wb, fl, tab, oi, gm]() { FC(fc_conv_fwd_stream(d_in.p, d_w.p, tab, gm, oi, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
+          CK(hipMemset(d_out.p, 0xff, (size_t)n_out * Cout * 4));
+          fn(); CK(hipDeviceSynchronize());
+          double err = -1;
+          if (check) err = max_rel_err(d_out.down((size_t)n_out * Cout), ref);
+          double us = time_us(reps, fn);
+          printf("   fwd  lds+gmask %s          %9.1f us %7.1f TF  err %.2e%s\n", tbl ? "sorted" : "plain ", us, gflop / us * 1e3, err, (check && !(err < 1e-4)) ? "  <-- MISMATCH" : "");
+        }
+        if (stream_sweep)
+        for (int tbl = (cs.dense ? 0 : 1); tbl < 2; ++tbl)
+          for (int tile = 1; tile <= 2; ++tile)
+            for (int fs : {0, 1, 2, 4, 8}) {
+              const int fl = (tile << 4) | (fs << 8);
+              int64_t wb = ws_for(fc_conv_fwd_stream_ws_bytes(n_out, K, Cin, Cout, fl));
+              if (fs > 1 && (int64_t)fs * n_out * Cout * 4 > (int64_t)1 << 31) continue;
+              const int* tab = tbl ? d_sorted.p : d_nbr.p; const int* oi = tbl ? d_oidx.p : nullptr;
+              const unsigned int* gm = tbl ? d_gm_sorted.p : d_gm_plain.p;
+              std::function<void()> fn = [&, wb, fl, tab, oi, gm]() { FC(fc_conv_fwd_stream(d_in.p, d_w.p, tab, gm, oi, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
+              CK(hipMemset(d_out.p, 0xff, (size_t)n_out * Cout * 4));
+              fn(); CK(hipDeviceSynchronize());
+              double err = -1;
+              if (check) err = max_rel_err(d_out.down((size_t)n_out * Cout), ref);
+              double us = time_us(reps, fn);
+              printf("   fwd  stream %s tile %d S %d %9.1f us %7.1f TF  err %.2e%s\n", tbl ? "sorted" : "plain ", tile * 32, fs, us, gflop / us * 1e3, err,
+                     (check && !(err < 1e-4)) ? "  <-- MISMATCH" : "");
+              fflush(stdout);
+            }
+      }
+      for (const Run& r : runs) {
+        const int fl = r.flags;
+        std::function<void()> fn;
+        if (r.tbl == 2) {
+          int64_t wb = ws_for(fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout));
+          fn = [&, wb, fl]() { FC(fc_conv_fwd_pairs(d_in.p, d_w.p, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
+        } else {
+          int64_t wb = ws_for(fc_conv_fwd_ws_bytes(n_out, K, Cin, Cout, fl));
+          const int* tab = r.tbl ? d_sorted.p : d_nbr.p; const int* oi = r.tbl ? d_oidx.p : nullptr;
+          fn = [&, wb, fl, tab, oi]() { FC(fc_conv_fwd(d_in.p, d_w.p, tab, oi, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
+        }
+        CK(hipMemset(d_out.p, 0xff, (size_t)n_out * Cout * 4));
+        fn(); CK(hipDeviceSynchronize());
+        double err = -1;
+        if (check) err = max_rel_err(d_out.down((size_t)n_out * Cout), ref);
+        double us = time_us(reps, fn);
+        printf("   fwd  variant %d %s %9.1f us %7.1f TF  err %.2e%s\n", fl >> 24, r.what, us, gflop / us * 1e3, err, (check && !(err < 1e-4)) ? "  <-- MISMATCH" : "");
+        fflush(stdout);
+      }
+    }
+    if (!trace_file.empty()) {
+      typedef int (*trace_fn)(unsigned long long*, int);
+      typedef int (*count_fn)(int*);
+      trace_fn set = (trace_fn)dlsym(RTLD_DEFAULT, trace_variant ? "fc_debug_trace" : "fc_debug_trace_lds");
+      count_fn cntf = nullptr;
+      if (!set) { fprintf(stderr, "--trace needs tools/nbench_trace (FC_TRACE build)\n"); return 4; }
+      const int cap = 1 << 18;
+      Dev<unsigned long long> d_tr; d_tr.alloc((size_t)cap * 8);
+      const int fl = trace_variant << 24;
+      std::function<void()> fn;
+      Dev<unsigned int> d_gmt; d_gmt.alloc((n_out + 31) / 32 + 2);
+      if (trace_variant >= 100) {       // stream kernel: variant = 100 + flags (tile<<4 | S<<8)
+        const int sfl = trace_variant - 100;
+        const int* tab = trace_tbl ? d_sorted.p : d_nbr.p; const int* oi = trace_tbl ? d_oidx.p : nullptr;
+        FC(fc_nbr_group_masks(tab, n_out, K, d_gmt.p, 0));
+        int64_t wb = ws_for(fc_conv_fwd_stream_ws_bytes(n_out, K, Cin, Cout, sfl));
+        fn = [&, wb, sfl, tab, oi]() { FC(fc_conv_fwd_stream(d_in.p, d_w.p, tab, d_gmt.p, oi, d_out.p, n_in, n_out, K, Cin, Cout, sfl, d_ws.p, wb, 0)); };
+      } else if (trace_tbl == 2) {
+        int64_t wb = ws_for(fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout));
+        fn = [&, wb, fl]() { FC(fc_conv_fwd_pairs(d_in.p, d_w.p, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
+      } else {
+        int64_t wb = ws_for(fc_conv_fwd_ws_bytes(n_out, K, Cin, Cout, fl));
+        const int* tab = trace_tbl ? d_sorted.p : d_nbr.p; const int* oi = trace_tbl ? d_oidx.p : nullptr;
+        fn = [&, wb, fl, tab, oi]() { FC(fc_conv_fwd(d_in.p, d_w.p, tab, oi, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
+      }
+      int wrate = 0; CK(hipDeviceGetAttribute(&wrate, hipDeviceAttributeWallClockRate, 0));
+      double us_off = time_us(reps, fn);
+      FC(set(d_tr.p, cap));
+      double us_on = time_us(reps, fn);
+      printf("   trace build: %.1f us per call with tracing off, %.1f us on; wall clock rate %d kHz\n", us_off, us_on, wrate);
+      CK(hipMemset(d_tr.p, 0, (size_t)cap * 64));
+      FC(set(d_tr.p, cap));
+      fn(); CK(hipDeviceSynchronize());
+      FC(set(nullptr, 0));
+      std::vector<unsigned long long> all = d_tr.down((size_t)cap * 8), rec;
+      for (int i = 0; i < cap; ++i) if (all[(size_t)i * 8 + 2]) rec.insert(rec.end(), all.begin() + (size_t)i * 8, all.begin() + (size_t)i * 8 + 8);
+      int nrec = (int)(rec.size() / 8); (void)cntf;
+      std::string fnm = trace_file + "." + cs.name.substr(0, cs.name.find(' ')) + ".v" + std::to_string(trace_variant) + "t" + std::to_string(trace_tbl) + ".bin";
+      FILE* f = fopen(fnm.c_str(), "wb"); fwrite(rec.data(), 8, rec.size(), f); fclose(f);
+      printf("   trace: %d wave records -> %s\n", nrec, fnm.c_str());
+    }
+    if (mode == "all" || mode == "wgrad") {
+      std::vector<float> ref;
+      if (check) {
+        int64_t wb = ws_for(fc_conv_wgrad_ws_bytes(n_out, K, Cin, Cout, 1));
+        FC(fc_conv_wgrad(d_in.p, d_gout.p, d_nbr.p, nullptr, d_gwref.p, n_in, n_out, K, Cin, Cout, 1, d_ws.p, wb, 0));
+        ref = d_gwref.down(hw.size());
+      }
+      for (int reg = 0; reg < 2; ++reg)
+        for (int pairs = 0; pairs < (cs.dense ? 1 : 2); ++pairs) {
+          const int fl = reg << 28;
+          int64_t wb = ws_for(fc_conv_wgrad_ws_bytes(n_out, K, Cin, Cout, fl));
+          std::function<void()> fn;
+          if (pairs) fn = [&, wb, fl]() { FC(fc_conv_wgrad_pairs(d_in.p, d_gout.p, d_pi.p, d_po.p, d_cnt.p, d_gw.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
+          else fn = [&, wb, fl]() { FC(fc_conv_wgrad(d_in.p, d_gout.p, d_nbr.p, nullptr, d_gw.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
+          CK(hipMemset(d_gw.p, 0xff, hw.size() * 4));
+          fn(); CK(hipDeviceSynchronize());
+          double err = -1;
+          if (check) err = max_rel_err(d_gw.down(hw.size()), ref);
+          double us = time_us(reps, fn);
+          printf("   wgrad %s %s %9.1f us %7.1f TF  err %.2e%s\n", reg ? "reg " : "lds ", pairs ? "pairs" : "table", us, gflop / us * 1e3, err, (check && !(err < 2e-4)) ? "  <-- MISMATCH" : "");
+          fflush(stdout);
+        }
+    }
+  }
+  return 0;
+}
