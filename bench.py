@@ -7,8 +7,11 @@ One step = forward_train + loss.backward() + gradient all-reduce (N>1) + grad-cl
 batch of `--batch` synthetic ScanNet-shaped scenes per GPU (100 000 points, 2 cm voxels, 18 classes,
 fcaf3d_scannet-3d-18class topology: MEResNet3D-34, 4 levels).  Scenes are resident in HBM before the
 timed region.  Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     — the dominant kernel (MFMA gather-GEMM sparse conv), algorithmic FLOPs / HIP-event time
-  cpu_baseline — the CPU oracle (ME-CPU-algorithm restatement, oracle/model_oracle.py) on this host.
+  roofline     — the dominant kernel (MFMA gather-GEMM sparse conv), algorithmic FLOPs / HIP-event time, and
+                 `hbm_kernels`: GB/s of every bandwidth-bound kernel (compulsory bytes / HIP-event time) vs the 8 TB/s peak
+  cpu_baseline — MinkowskiEngine's CPU algorithm restated in C/OpenMP (oracle/conv_oracle.c) on this host's cores,
+                 with the Python/torch oracle's whole-step number beside it
+  config.{fwd_bwd_only, config4_global_batch_16, inference, data_parallel} — measured outside the timed region.
 """
 import argparse
 import json
@@ -40,7 +43,10 @@ def parse():
     ap.add_argument('--probe-every', type=int, default=4, help='HIP events bracket the conv launches of every n-th timed step '
                     '(each event pair is a pipeline bubble: sampling keeps the probe from slowing the thing it measures)')
     ap.add_argument('--spatial-sort', action='store_true', help='Z-order sort of the collated points (measured: no gain, r1)')
-    ap.add_argument('--wgrad-overlap', action='store_true', help='weight-gradient kernels on a second stream (measured r1: no gain, the GPU is already full)')
+    ap.add_argument('--no-wgrad-overlap', action='store_true', help='keep the weight-gradient kernels on the main stream (default: a second '
+                    'stream, so that they overlap the backward-data chain: +3 % measured r2)')
+    ap.add_argument('--infer-steps', type=int, default=4, help='untimed-region extra: simple_test batches for the inference scenes/s line (0 = skip)')
+    ap.add_argument('--cpu-reps', type=int, default=5, help='repetitions of the C/OpenMP cpu_baseline (median)')
     ap.add_argument('--breakdown', action='store_true', help='diagnostic: HIP-event time per C-ABI entry point and per conv shape (stderr)')
     return ap.parse_args()
 
@@ -120,6 +126,38 @@ class Breakdown:
                 print(f'{key:44s} calls/step {c / steps:6.1f}  ms/step {t / steps:8.3f}  us/call {t / c * 1e3:9.1f}', file=sys.stderr)
 
 
+# Compulsory HBM bytes (every operand tensor touched once) of the bandwidth-bound entry points, from their C-ABI arguments
+# (include/fcaf3d_hip.h).  `a` = positional arguments, `pr` = the probe (carries sizes the ABI call does not).
+def _stem(a):                   # fc_conv_fwd / fc_conv_wgrad with Cin == 3: (.., n_in, n_out, K, Cin, Cout, ..) at 5..9
+    return a[8] == 3
+
+
+HBM_BYTES = {
+    'fc_conv_fwd': lambda a, pr: (4.0 * (a[5] * 3 + a[6] * a[9] + a[7] * 3 * a[9]) + 4.0 * a[7] * a[6]) if _stem(a) else None,
+    'fc_conv_wgrad': lambda a, pr: (4.0 * (a[5] * 3 + a[6] * a[9]) + 4.0 * a[7] * a[6]) if _stem(a) else None,
+    # (in, nbr, n_out, K, C, out, argrow): every input row read once (k2s2: each voxel has one parent), out + argmax written
+    'fc_maxpool_fwd': lambda a, pr: 4.0 * a[4] * (pr.pool_n_in + 2 * a[2]) + 4.0 * a[3] * a[2],
+    'fc_maxpool_bwd': lambda a, pr: 4.0 * a[3] * 3 * a[2],
+    # (x, seg, seg_stride, n, C, mean, var, eps, gamma, beta, residual, act, y)
+    'fc_norm_act_fwd': lambda a, pr: 4.0 * a[3] * a[4] * (2 + (1 if a[10] else 0)),
+    # (x, y, gy, seg, seg_stride, n, C, nseg, mean, var, cnt, eps, gamma, act, gx, gres, ..): x, y, gy read; gx (gres) written
+    'fc_norm_act_bwd': lambda a, pr: 4.0 * a[5] * a[6] * (4 + (1 if a[15] else 0)),
+    'fc_col_stats': lambda a, pr: 4.0 * a[3] * a[4],
+    'fc_bn_stats_train': lambda a, pr: 4.0 * a[1] * a[2],
+    # (x, n, C, eps, gamma, beta, residual, act, ..): x read, y written (+ residual)
+    'fc_bn_act_train_fwd': lambda a, pr: 4.0 * a[1] * a[2] * (2 + (1 if a[6] else 0)),
+    # (x, y, gy, n, C, mean, var, eps, gamma, act, gx, gres, ..)
+    'fc_bn_act_train_bwd': lambda a, pr: 4.0 * a[3] * a[4] * (4 + (1 if a[11] else 0)),
+    # (coords, n, q, keys, vals, cap, out_coords, ..): 16 B coordinate read + 16 B key/value insert per row
+    'fc_hash_unique': lambda a, pr: 32.0 * a[1],
+    # (out_coords, n_out, keys, vals, cap, offsets, K, nbr): 16 B coordinate + K x (12 B probe + 4 B write) per row
+    'fc_kernel_map': lambda a, pr: a[1] * (16.0 + 16.0 * a[6]),
+    'fc_gather_rows': lambda a, pr: 4.0 * a[2] * (2 * a[3] + 1),
+    'fc_scatter_rows_add': lambda a, pr: 4.0 * a[2] * (3 * a[3] + 1),
+}
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable on a float4 copy)
+
+
 class ConvProbe:
     """HIP-event bracket around every MFMA sparse-conv launch (forward + backward-data) of the timed steps.
     The launches' algorithmic FLOPs (2 * valid pairs * Cin * Cout, pairs counted on the device from the map
@@ -127,6 +165,8 @@ class ConvProbe:
     step is deterministic — so that nothing but the two event records sits inside the timed region."""
 
     def __init__(self):
+        self.hbm = []          # (kernel, compulsory bytes, start, end) of the bandwidth-bound launches of the probed steps
+        self.pool_n_in = 0
         self.timed = {}        # batch index -> list of per-step lists of (start, end)
         self.counted = {}      # batch index -> list of (pairs_dev | None, flops_per_pair, n_out, bytes)
         self.mode = None
@@ -146,6 +186,19 @@ class ConvProbe:
         orig = L.call
 
         def call(name, *a):
+            if probe.mode == 'time' and name in HBM_BYTES:
+                try:
+                    nbytes = HBM_BYTES[name](a, probe)
+                except Exception:
+                    nbytes = None
+                if nbytes:
+                    s = torch.cuda.Event(enable_timing=True)
+                    e = torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    orig(name, *a)
+                    e.record()
+                    probe.hbm.append((name if not (name.startswith('fc_conv') and a[8] == 3) else name + '(stem)', nbytes, s, e))
+                    return
             if name not in ('fc_conv_fwd', 'fc_conv_fwd_pairs') or probe.mode is None:
                 return orig(name, *a)
             if name == 'fc_conv_fwd':
@@ -188,6 +241,28 @@ class ConvProbe:
             return bwd0(ctx, gout)
         Fn._SparseConv.forward = staticmethod(fwd)
         Fn._SparseConv.backward = staticmethod(bwd)
+        pool0 = Fn._MaxPool.forward
+
+        def pool(ctx, feats, kmap):
+            probe.pool_n_in = feats.shape[0]
+            return pool0(ctx, feats, kmap)
+        Fn._MaxPool.forward = staticmethod(pool)
+
+    def hbm_summary(self):
+        """per bandwidth-bound kernel: compulsory bytes / HIP-event time over the probed steps"""
+        torch.cuda.synchronize()
+        agg = {}
+        for name, nbytes, s, e in self.hbm:
+            d = agg.setdefault(name, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += nbytes
+            d[2] += s.elapsed_time(e)
+        rows = []
+        for name, (n, b, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+            gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            rows.append(dict(kernel=name, launches=n, algorithmic_MB_per_launch=round(b / n / 1e6, 3),
+                             avg_us=round(ms * 1e3 / n, 2), GBps=round(gbs, 1), frac_of_hbm_peak=round(gbs / PEAK_HBM_GBS, 4)))
+        return rows
 
     def summary(self):
         if not self.timed:
@@ -219,29 +294,103 @@ class ConvProbe:
                     time_share_ms_per_step=None)
 
 
+def physical_cores():
+    """(physical cores, logical CPUs, model name) of this host, from lscpu / /proc/cpuinfo"""
+    import subprocess
+    info = {}
+    try:
+        for line in subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if ':' in line:
+                k, v = line.split(':', 1)
+                info[k.strip()] = v.strip()
+        cores = int(info.get('Core(s) per socket', '0')) * int(info.get('Socket(s)', '1'))
+    except Exception:
+        cores = 0
+    return cores or (os.cpu_count() or 1), os.cpu_count() or 1, info.get('Model name', 'unknown')
+
+
 def cpu_baseline(args, model, cfg):
-    """The oracle (ME-CPU-algorithm restatement) forward+backward on ONE scene of the same workload."""
+    """MinkowskiEngine's CPU algorithm restated (the reference's CPU backend itself is not installable here) on ONE scene
+    of the same workload, on this host's cores:
+      (1) C / OpenMP (oracle/conv_oracle.c): every sparse convolution of the network — forward, backward-data, backward-weights
+          — per offset gather -> GEMM -> scatter-add over the scene's real kernel maps; median of `--cpu-reps` runs.
+          These convolutions are >= 97 % of the step's FLOPs; normalisation / loss / map construction are not in this number.
+      (2) the Python/torch oracle (oracle/model_oracle.py), whole forward_train + backward once — the number r1 reported."""
     from fcaf3d_amd.synthetic import WORKLOADS, make_scene
-    from oracle import model_oracle as MO
+    from oracle import conv_c, me_oracle as mo, model_oracle as MO
     kw = dict(WORKLOADS[args.workload]['scene'])
     if args.cpu_points:
         kw['n_points'] = args.cpu_points
-    cores = min(os.cpu_count() or 1, 64)
-    torch.set_num_threads(cores)
+    phys, logical, cpu_name = physical_cores()
+    torch.set_num_threads(min(phys, 64))
     P = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
     p, g, l = make_scene(999, **kw)
-    t0 = time.time()
-    losses = MO.forward_train(P, cfg.model, [p], [g], [l])
-    sum(losses.values()).backward()
-    dt = time.time() - t0
-    return dict(value=round(1.0 / dt, 5), unit='scenes/s', cores=cores, kind='port',
-                sample=f'1 scene of {kw["n_points"]} pts, fwd+bwd once ({dt:.1f} s), oracle/model_oracle.py '
-                       f'(ME-CPU-algorithm restatement: hash kernel maps + per-offset gather-GEMM-scatter, torch CPU fp32)')
+    # record every sparse convolution (map + shapes) while the Python oracle runs its timed forward + backward
+    layers = []
+    conv0 = mo.conv
+
+    def rec(feats, weight, nbr):
+        layers.append((nbr, feats.shape[0], weight.shape[1], weight.shape[2]))
+        return conv0(feats, weight, nbr)
+    mo.conv = rec
+    try:
+        t0 = time.time()
+        losses = MO.forward_train(P, cfg.model, [p], [g], [l])
+        sum(losses.values()).backward()
+        dt_py = time.time() - t0
+    finally:
+        mo.conv = conv0
+    rng = np.random.default_rng(0)
+    os.environ.setdefault('OMP_NUM_THREADS', str(phys))
+    data, flops = [], 0.0
+    for nbr, n_in, Cin, Cout in layers:
+        if Cin < 8:
+            continue                                        # the 3-channel stem: bandwidth, not GEMM
+        K, n_out = nbr.shape
+        data.append((nbr, n_in, Cin, Cout, rng.standard_normal((n_in, Cin), dtype=np.float32),
+                     rng.standard_normal((K, Cin, Cout), dtype=np.float32) * 0.05, rng.standard_normal((n_out, Cout), dtype=np.float32)))
+        flops += 3 * 2.0 * float((nbr >= 0).sum()) * Cin * Cout
+    times = []
+    for _ in range(max(args.cpu_reps, 1)):
+        t0 = time.time()
+        for nbr, n_in, Cin, Cout, x, w, go in data:
+            conv_c.conv_fwd(x, w, nbr)
+            conv_c.conv_dgrad(go, w, nbr, n_in)
+            conv_c.conv_wgrad(x, go, nbr, Cin, Cout)
+        times.append(time.time() - t0)
+    dt_c = float(np.median(times))
+    return dict(value=round(1.0 / dt_c, 5), unit='scenes/s', cores=conv_c.num_threads(), physical_cores=phys, logical_cpus=logical,
+                cpu=cpu_name, kind='port', gflops=round(flops / dt_c / 1e9, 1),
+                sample=f'1 scene of {kw["n_points"]} pts: the {len(data)} sparse convolutions of the network (fwd + dgrad + wgrad, '
+                       f'{flops / 1e9:.0f} GFLOP) in C/OpenMP (oracle/conv_oracle.c: MinkowskiEngine CPU algorithm restated, per offset '
+                       f'gather-GEMM-scatter), median of {len(times)} runs = {dt_c:.2f} s; norms / loss / map construction excluded',
+                python_oracle=dict(value=round(1.0 / dt_py, 5), unit='scenes/s', threads=torch.get_num_threads(),
+                                   sample=f'whole forward_train + backward once ({dt_py:.1f} s), oracle/model_oracle.py (torch CPU fp32)'))
 
 
 def count_steps(args, n_batches):
     """number of untimed FLOP-count steps after the timed region — a function of the flags only, never of the rank"""
     return 0 if (args.no_instrument or args.breakdown) else n_batches      # every distinct batch a probed step may use
+
+
+def timed_region(fn, n, world, dev):
+    """barrier + synchronize | n calls | synchronize + barrier; returns the MAX over ranks of the elapsed seconds"""
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(n):
+        last = fn(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, last
 
 
 def main():
@@ -250,6 +399,7 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['FC_FAULT_DUMP']), exit=True)
     from fcaf3d_amd import dist as D
+    from fcaf3d_amd.runner import TrainStep
     D.init_dist()
     rank = int(os.environ.get('RANK', '0'))
     world = D.world_size()
@@ -265,13 +415,12 @@ def main():
     model.async_maps = True           # scenes are resident in HBM: coordinate work may run on its side stream
     model.spatial_sort = args.spatial_sort
     import fcaf3d_amd.functional as Fn
-    Fn.WGRAD_ASYNC = args.wgrad_overlap
+    Fn.WGRAD_ASYNC = not args.no_wgrad_overlap
     if world > 1:
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)
-    averager = D.GradientAverager(model.parameters())
-    opt = torch.optim.AdamW(model.parameters(), lr=cfg.optimizer.lr, weight_decay=cfg.optimizer.weight_decay, fused=True)
-    max_norm = cfg.optimizer_config.grad_clip.max_norm
+    # the reference's recipe (configs/fcaf3d/fcaf3d.py:30-33): AdamW 1e-3 / 1e-4, grad-clip 10, step LR — fcaf3d_amd/runner.py
+    trainer = TrainStep.from_config(model, cfg)
     batches = make_batches(args, rank, dev)
 
     probe = None
@@ -285,20 +434,15 @@ def main():
         probe = ConvProbe()
         probe.install()
 
-    def step(i, probe_mode=None):
-        batch = batches[i % len(batches)]
+    def step(i, probe_mode=None, which=None):
+        src = which if which is not None else batches
+        batch = src[i % len(src)]
         if probe:
             if probe_mode:
-                probe.begin_step(i % len(batches), probe_mode)
+                probe.begin_step(i % len(src), probe_mode)
             else:
                 probe.mode = None
-        opt.zero_grad(set_to_none=True)
-        losses = model(return_loss=True, **batch)
-        loss = losses['loss_centerness'] + losses['loss_bbox'] + losses['loss_cls']
-        loss.backward()
-        averager.finish()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
-        opt.step()
+        loss, _ = trainer(batch)
         return loss
 
     for i in range(args.warmup):
@@ -307,27 +451,60 @@ def main():
         torch.cuda.synchronize()
         bd.rec.clear()
     if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i, 'time' if i % max(args.probe_every, 1) == 0 else None)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        trainer.averager.log = []                # host-side launch times of the gradient buckets of the timed steps
+    dt, loss = timed_region(lambda i: step(args.warmup + i, 'time' if i % max(args.probe_every, 1) == 0 else None),
+                            args.steps, world, dev)
     final_loss = float(loss.item())
+    dp_log = getattr(trainer.averager, 'log', None)
+    trainer.averager.log = None
     # untimed: FLOPs of every launch, one step per distinct batch.  EVERY rank steps (a step holds collectives: a
     # rank-0-only extra step deadlocks the job); only rank 0 carries the probe
     for b in range(count_steps(args, len(batches))):
         step(b, 'count' if probe else None)
+    if probe:
+        probe.mode = None
     if bd:
         bd.report(args.steps, dt * 1e3)
     assert np.isfinite(final_loss), 'loss diverged'
+
+    # ---- extras, all OUTSIDE the timed region above (every rank runs them: they hold collectives) ------------------
+    # (a) SURVEY 8(d) protocol: forward_train + backward only, synchronised around every iteration, median
+    fb = []
+    for i in range(5):
+        batch = batches[i % len(batches)]
+        trainer.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses = model(return_loss=True, **batch)
+        (losses['loss_centerness'] + losses['loss_bbox'] + losses['loss_cls']).backward()
+        trainer.averager.finish()
+        torch.cuda.synchronize()
+        fb.append(time.perf_counter() - t0)
+    fb_med = float(np.median(fb))
+    # (b) BASELINE config 4: global batch 16 split over the ranks (2 scenes per GPU on 8), same step
+    cfg4 = None
+    if world > 1 and 16 % world == 0 and args.workload == 'scannet-100k':
+        per = 16 // world
+        small = [{k: v[:per] for k, v in b.items()} for b in batches] if per <= args.batch else None
+        if small is not None:
+            for i in range(2):
+                step(i, which=small)
+            dt4, _ = timed_region(lambda i: step(i, which=small), 6, world, dev)
+            cfg4 = dict(global_batch=16, scenes_per_gpu_per_step=per, steps=6, ms_per_step=round(dt4 / 6 * 1e3, 3),
+                        value=round(16 * 6 / dt4, 3), unit='scenes/s')
+    # (c) inference: simple_test (eval-mode BatchNorm, decode, multi-class BEV NMS on the device) — the only quantity the
+    #     reference publishes a speed for (README.md:91-93, scenes/s on one GPU)
+    infer = None
+    if args.infer_steps > 0:
+        model.eval()
+        test_batches = [dict(points=b['points'], img_metas=b['img_metas']) for b in batches]
+        with torch.no_grad():
+            model(return_loss=False, **test_batches[0])
+            dti, _ = timed_region(lambda i: model(return_loss=False, **test_batches[i % len(test_batches)]), args.infer_steps,
+                                  world, dev)
+        model.train()
+        infer = dict(value=round(args.batch * world * args.infer_steps / dti, 3), unit='scenes/s', steps=args.infer_steps,
+                     ms_per_batch=round(dti / args.infer_steps * 1e3, 3), what='simple_test: extract_feat + get_bboxes + multi-class BEV NMS')
 
     if rank == 0:
         scenes = args.batch * world * args.steps
@@ -339,8 +516,11 @@ def main():
             'config': {'workload': f'{args.workload} synthetic, {CONFIG_OF[args.workload]}.py topology '
                                    f'(MEResNet3D-34, {args.levels} levels), voxel {args.voxel_size} m',
                        'scenes_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
-                       'step': 'forward_train + backward + grad all-reduce + grad-clip + AdamW',
-                       'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4)},
+                       'step': 'forward_train + backward + grad all-reduce + grad-clip + AdamW (fcaf3d_amd/runner.py TrainStep)',
+                       'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
+                       'fwd_bwd_only': {'protocol': 'SURVEY 8(d): forward_train + backward (+ all-reduce), synchronised per iteration, median of 5',
+                                        'ms': round(fb_med * 1e3, 3), 'scenes_per_s': round(args.batch * world / fb_med, 3)},
+                       'config4_global_batch_16': cfg4, 'inference': infer},
         }
         rl = probe.summary() if probe else None
         if rl:
@@ -348,7 +528,10 @@ def main():
             conv_ms = rl['avg_launch_us'] * rl['launches'] / 1e3 / probed_steps
             rl['probed_steps'] = probed_steps
             rl['time_share_ms_per_step'] = round(conv_ms, 3)
+            rl['hbm_kernels'] = probe.hbm_summary()
         out['roofline'] = rl
+        if world > 1 and dp_log:
+            out['config']['data_parallel'] = D.summarize_bucket_log(trainer.averager, dp_log)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, model, cfg)
         else:

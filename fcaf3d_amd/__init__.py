@@ -12,6 +12,7 @@ from .fcaf3d_neck_with_head import Fcaf3DAssigner, Fcaf3DNeckWithHead, compute_c
 from .single_stage_sparse import SingleStageSparse3DDetector  # noqa: F401,E402
 from .boxes import DepthInstance3DBoxes, bbox3d2result  # noqa: F401,E402
 from .checkpoint import load_checkpoint, save_checkpoint  # noqa: F401,E402
+from . import runner  # noqa: F401,E402
 
 import os as _os
 

@@ -200,11 +200,16 @@ __device__ static inline int4 quantize(int4 c, int q) {
   return c;
 }
 
+// `bad` (nullable): set when a coordinate does not fit fc_pack's 16 bits per axis (with room for the largest kernel
+// offset) or the batch index its 16 bits — e.g. an inf / far-outlier point: such a key would alias another voxel.
 __global__ void k_hash_insert(const int4* __restrict__ coords, int64_t n, int q, unsigned long long* keys, int* vals,
-                              unsigned long long mask, int* __restrict__ slot) {
+                              unsigned long long mask, int* __restrict__ slot, int* __restrict__ bad) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int4 c = quantize(coords[i], q);
+  if (bad && (c.x < 0 || c.x > 32767 || c.y < -FC_COORD_LIMIT || c.y > FC_COORD_LIMIT || c.z < -FC_COORD_LIMIT ||
+              c.z > FC_COORD_LIMIT || c.w < -FC_COORD_LIMIT || c.w > FC_COORD_LIMIT))
+    *bad = 1;
   unsigned long long key = fc_pack(c.x, c.y, c.z, c.w);
   unsigned long long h = fc_mix(key) & mask;
   while (true) {
@@ -216,6 +221,10 @@ __global__ void k_hash_insert(const int4* __restrict__ coords, int64_t n, int q,
     }
     h = (h + 1) & mask;
   }
+}
+
+__global__ void k_flag_bad_count(const int* __restrict__ bad, int* __restrict__ n_out_dev) {
+  if (*bad) *n_out_dev = -1;
 }
 
 __global__ void k_winner_flags(const int* __restrict__ slot, const int* __restrict__ vals, int64_t n,
@@ -243,7 +252,7 @@ __global__ void k_unique_inverse(const int* __restrict__ slot, const int* __rest
 
 int64_t fc_hash_unique_ws_bytes(int64_t n) {
   int64_t m = n > 0 ? n : 1;
-  return fc_align(4 * m, 256) /*slot*/ + fc_align(m, 256) /*flags*/ + fc_align(4 * m, 256) /*pos*/ +
+  return fc_align(4 * m, 256) /*slot*/ + fc_align(m, 256) /*flags*/ + fc_align(4 * m, 256) /*pos*/ + 256 /*range flag*/ +
          fc_align(4 * fc_cdiv(m, 1024), 256) /*blocksums*/;
 }
 
@@ -265,9 +274,11 @@ int fc_hash_unique(const int* coords, int64_t n, int q, unsigned long long* tabl
   int* slot = (int*)w;               w += fc_align(4 * n, 256);
   unsigned char* flags = (unsigned char*)w;  w += fc_align(n, 256);
   int* pos = (int*)w;                w += fc_align(4 * n, 256);
+  int* bad = (int*)w;                w += 256;
   int* blocksums = (int*)w;
   unsigned g = (unsigned)fc_cdiv(n, 256);
-  k_hash_insert<<<g, 256, 0, stream>>>((const int4*)coords, n, q, table_keys, table_vals, (unsigned long long)(cap - 1), slot);
+  FC_HIP(hipMemsetAsync(bad, 0, sizeof(int), stream));
+  k_hash_insert<<<g, 256, 0, stream>>>((const int4*)coords, n, q, table_keys, table_vals, (unsigned long long)(cap - 1), slot, bad);
   FC_CHECK_LAUNCH();
   k_winner_flags<<<g, 256, 0, stream>>>(slot, table_vals, n, flags);
   FC_CHECK_LAUNCH();
@@ -279,6 +290,8 @@ int fc_hash_unique(const int* coords, int64_t n, int q, unsigned long long* tabl
     k_unique_inverse<<<g, 256, 0, stream>>>(slot, table_vals, n, inverse);
     FC_CHECK_LAUNCH();
   }
+  k_flag_bad_count<<<1, 1, 0, stream>>>(bad, n_out_dev);      // *n_out_dev = -1: the caller's count read-back raises
+  FC_CHECK_LAUNCH();
   return FC_OK;
 }
 

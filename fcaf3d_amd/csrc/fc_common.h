@@ -24,7 +24,11 @@ static inline int64_t fc_align(int64_t a, int64_t b) { return fc_cdiv(a, b) * b;
 
 #define FC_EMPTY_KEY ((unsigned long long)0xFFFFFFFFFFFFFFFFull)
 
-// (b,x,y,z) -> 64-bit key, lexicographic; 16 bits per spatial axis with a 2^15 bias.
+// (b,x,y,z) -> 64-bit key, lexicographic; 16 bits per spatial axis with a 2^15 bias, 16 bits of batch index.
+// Valid voxel coordinates are therefore |c| <= FC_COORD_LIMIT (the margin covers the largest kernel offset of the
+// pyramid, 64 voxels, twice) — +-326 m at 1 cm voxels; fc_hash_unique reports anything else through its count (-1)
+// instead of letting the key alias a neighbouring axis / scene (MinkowskiEngine keeps full int32 coordinates).
+#define FC_COORD_LIMIT 32639
 __host__ __device__ static inline unsigned long long fc_pack(int b, int x, int y, int z) {
   return ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)(unsigned)(x + 32768) << 32) |
          ((unsigned long long)(unsigned)(y + 32768) << 16) | (unsigned long long)(unsigned)(z + 32768);

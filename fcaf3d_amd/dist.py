@@ -82,15 +82,33 @@ class GradientAverager:
     def _reset(self):
         self._pending = [len(b) for b in self.buckets]
         self._handles = []
+        self._next = 0                         # buckets are reduced strictly in index order (see _hook)
+        self._t0 = None
 
     def _hook(self, p):
+        if self.log is not None and self._t0 is None:
+            import time
+            self._t0 = time.perf_counter()     # first gradient of the step: backward is under way
+        # Collectives must be issued in the SAME order on every rank.  A bucket becomes ready when its last gradient
+        # arrives, which — if some parameter gets a gradient on one rank only — need not happen in the same order
+        # everywhere; so a ready bucket is launched only once every bucket before it has been (torch DDP's rule), and
+        # finish() flushes the rest in order.
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
+
+    log = None          # list: when set (bench.py, N > 1), (bucket, seconds since the step's first hook) per launch + waits
 
     def _launch(self, bi):
         from . import functional as Fn
+        if self.log is not None:
+            import time
+            now = time.perf_counter()
+            if self._t0 is None:
+                self._t0 = now
+            self.log.append(('launch', bi, now - self._t0))
         if Fn.WGRAD_ASYNC:
             Fn.join_wgrad_stream()            # weight gradients may still be in flight on their side stream
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.buckets[bi]]
@@ -107,9 +125,13 @@ class GradientAverager:
         """Call after backward: flush buckets whose hooks did not all fire, wait, scatter back."""
         if world_size() == 1:
             return
-        for bi, pend in enumerate(self._pending):
-            if pend > 0:
-                self._launch(bi)
+        while self._next < len(self.buckets):          # buckets some hook never completed (unused parameters), in order
+            self._launch(self._next)
+            self._next += 1
+        if self.log is not None and self._t0 is not None:
+            import time
+            t_f = time.perf_counter()
+            self.log.append(('finish_enter', -1, t_f - self._t0))
         for bi, h in self._handles:
             h.wait()
             params = self.buckets[bi]
@@ -118,3 +140,22 @@ class GradientAverager:
                     p.grad = torch.empty_like(p)
             torch._foreach_copy_([p.grad for p in params], self._views[bi])
         self._reset()
+
+
+def summarize_bucket_log(averager, log):
+    """bench.py (N > 1): when, on the host clock and relative to the first gradient hook of a step, each gradient bucket's
+    all-reduce was ENQUEUED, and when backward returned (finish() entered) — buckets enqueued well before that point are
+    the ones RCCL can overlap with the rest of backward."""
+    steps, cur = [], []
+    for kind, bi, t in log:
+        cur.append((kind, bi, t))
+        if kind == 'finish_enter':
+            steps.append(cur)
+            cur = []
+    if not steps:
+        return None
+    last = steps[-1]
+    return dict(buckets=len(averager.buckets), bucket_MB=[round(f.numel() * 4 / 2 ** 20, 1) for f in averager._flat],
+                last_step_launch_ms_after_first_grad=[round(t * 1e3, 2) for k, b, t in last if k == 'launch'],
+                last_step_backward_end_ms=round([t for k, b, t in last if k == 'finish_enter'][0] * 1e3, 2),
+                backend=dist.get_backend())

@@ -17,7 +17,7 @@ from . import _lib as L
 from . import functional as Fn
 from . import nn as MEnn
 from .dist import reduce_mean
-from .nms import nms_bev
+from .nms import nms_bev, nms_bev_multiclass
 from .registry import BBOX_ASSIGNERS, HEADS, build_assigner, build_loss
 from .sparse import SparseTensor
 
@@ -169,9 +169,18 @@ class Fcaf3DNeckWithHead(nn.Module):
         if pad:
             w = torch.cat((w, w.new_zeros(w.shape[0], pad)), dim=1)
         y = Fn.sparse_conv(x.F, w.unsqueeze(0), None, x.F.shape[0])
-        # centerness | exp(scale * reg[:, :6]), reg[:, 6:] | cls + bias, and the max class logit `_prune` interpolates:
-        # one fused pass forward, one backward (csrc/head.hip)
-        centerness, bbox_pred, cls_score, cls_max = Fn.head_split(y, self.cls_conv.bias, scale.scale, n_r, n_c)
+        if w.shape[1] <= 64:
+            # centerness | exp(scale * reg[:, :6]), reg[:, 6:] | cls + bias, and the max class logit `_prune` interpolates:
+            # one fused pass forward, one backward (csrc/head.hip)
+            centerness, bbox_pred, cls_score, cls_max = Fn.head_split(y, self.cls_conv.bias, scale.scale, n_r, n_c)
+        else:
+            # more than 64 fused columns (> 55 classes, e.g. ScanNet200): the fused epilogue kernel holds one 64-column row
+            # per wave, so split with plain tensor ops — same values, the reference's own formulation (:264-270)
+            centerness = y[:, :1]
+            reg = y[:, 1:1 + n_r]
+            bbox_pred = torch.cat((torch.exp(scale.scale * reg[:, :6]), reg[:, 6:]), dim=1)
+            cls_score = y[:, 1 + n_r:1 + n_r + n_c] + self.cls_conv.bias
+            cls_max = cls_score.detach().max(dim=1, keepdim=True).values
         prune_scores = SparseTensor(cls_max, coordinate_map_key=x.cmap)
 
         points = x.C[:, 1:].float() * self.voxel_size          # voxel corner, as the reference (:276-277)
@@ -299,6 +308,30 @@ class Fcaf3DNeckWithHead(nn.Module):
         return torch.cat((centre, torch.stack((w, w * q, d[:, 5] + d[:, 4], alpha), dim=-1)), -1)
 
     def _nms(self, bboxes, scores, img_meta):
+        """Per-class score threshold + BEV NMS + re-wrap (:332-374).  All classes of the scene go through ONE sort and one
+        pair of kernel launches (nms.nms_bev_multiclass: class segments, greedy scan on the device, a single read-back
+        of the survivor count); the survivors come out in the order of the reference's per-class loop (class-major,
+        descending score) — `_nms_per_class` is that loop, kept as the cross-check of the parity tests."""
+        yaw_flag = bboxes.shape[1] == 7
+        boxes7 = bboxes if yaw_flag else torch.cat((bboxes, torch.zeros_like(bboxes[:, :1])), dim=1)
+        if boxes7.shape[0]:
+            idx, cls = nms_bev_multiclass(boxes7, scores, self.test_cfg.score_thr, self.test_cfg.iou_thr, rotated=yaw_flag)
+            nms_bboxes = boxes7[idx]
+            nms_scores = scores[idx, cls]
+            nms_labels = cls.to(torch.long)
+        else:
+            nms_bboxes = bboxes.new_zeros((0, 7))
+            nms_scores = bboxes.new_zeros((0,))
+            nms_labels = bboxes.new_zeros((0,), dtype=torch.long)
+        if yaw_flag:
+            box_dim, with_yaw = 7, True
+        else:
+            box_dim, with_yaw = 6, False
+            nms_bboxes = nms_bboxes[:, :6]
+        nms_bboxes = img_meta['box_type_3d'](nms_bboxes, box_dim=box_dim, with_yaw=with_yaw, origin=(.5, .5, .5))
+        return nms_bboxes, nms_scores, nms_labels
+
+    def _nms_per_class(self, bboxes, scores, img_meta):
         n_classes = scores.shape[1]
         yaw_flag = bboxes.shape[1] == 7
         nms_bboxes, nms_scores, nms_labels = [], [], []

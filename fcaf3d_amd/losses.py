@@ -109,7 +109,11 @@ class _AlignedIoUFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dpred, = ctx.saved_tensors
-        return g[:, None] * dpred, None
+        # rows that do not reach the loss (zero weight => g == 0) must give an exact zero even when their own
+        # derivative is not finite (a background row whose predicted sizes overflow): 0 * NaN would poison every
+        # gradient upstream
+        g = g[:, None]
+        return torch.where(g != 0, g * dpred, torch.zeros_like(dpred)), None
 
 
 def axis_aligned_iou_3d(pred, target):
@@ -136,7 +140,8 @@ class _RotatedIoUFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dpred, = ctx.saved_tensors
-        return g[:, None] * dpred, None, None
+        g = g[:, None]
+        return torch.where(g != 0, g * dpred, torch.zeros_like(dpred)), None, None
 
 
 def rotated_iou_3d(pred, target, weight=None):

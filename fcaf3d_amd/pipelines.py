@@ -147,6 +147,9 @@ class TrainAugment:
         if p['flip_v']:
             points, boxes = flip_bev(points, boxes, 'vertical', self.with_yaw)
         points, boxes = rot_scale_trans(points, boxes, p['angle'], p['scale'], p['trans'], self.with_yaw)
+        if points.is_cuda:
+            from .sparse import mark_inputs_ready
+            mark_inputs_ready(points.device)      # the detector's coordinate side stream must not read them earlier
         return points, boxes, p
 
 

@@ -30,14 +30,32 @@ def map_stream(device):
     return _side[key]
 
 
+_inputs_ready = {}
+
+
+def mark_inputs_ready(device=None):
+    """Call on the stream that PRODUCED the points of the next batch (e.g. the on-device input pipeline) once they are
+    written: the coordinate side stream waits for this event before it reads them.  Without a mark the inputs are
+    taken to be resident already (bench / tests), and the side stream does not wait for the main stream at all —
+    that is what lets the coordinate work of step i+1 overlap the backward pass of step i."""
+    dev = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    _inputs_ready[dev] = ev
+
+
 class on_map_stream:
     """with on_map_stream(dev): ...   -> coordinate kernels go to the side stream; main waits on exit."""
 
     def __init__(self, device):
         self.side = map_stream(device)
+        self.dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
 
     def __enter__(self):
         global _record_to
+        ev = _inputs_ready.pop(self.dev, None)
+        if ev is not None:
+            self.side.wait_event(ev)           # the producer of the points has finished writing them
         self.main = torch.cuda.current_stream()
         self.prev = _record_to
         _record_to = self.main
@@ -229,6 +247,9 @@ class CoordMap:
         L.call('fc_hash_unique', L.ptr(coords), n, q, L.ptr(keys), L.ptr(vals), cap, L.ptr(out), L.ptr(first),
                L.ptr(inv), L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
         m = int(cnt.item()) if expect_n is None else expect_n     # the one host read-back of this op
+        if m < 0:
+            raise ValueError('voxel coordinate outside [-32639, 32639] (or batch index outside [0, 32767]): the 64-bit voxel '
+                             'hash keys hold 16 bits per field — check the input for outliers / non-finite points')
         cm = CoordMap(out[:m] if m != n else out, stride, keys, vals, batch_size)
         _rec(first, inv)
         return cm, (first[:m] if want_first else None), inv

@@ -49,7 +49,9 @@ int fc_compact_rows(const unsigned char* flags, const int* pos, int64_t n, int* 
 /* ME.SparseTensor(coordinates, features) de-duplication (single_stage_sparse.py:37) and the strided
  * output coordinate set of MinkowskiConvolution/MaxPooling(stride=2) (me_resnet.py:19-24,56-62):
  * unique rows of floor(coords/q)*q in order of first occurrence; builds the voxel hash of the
- * result (key -> row).  first_idx / inverse may be NULL. */
+ * result (key -> row).  first_idx / inverse may be NULL.  Coordinates must lie in [-32639, 32639] per axis and the
+ * batch index in [0, 32767] (64-bit packed hash keys, 16 bits per field): if any row does not — a stray outlier, an
+ * inf coordinate — *n_out_dev is set to -1 and the set must not be used. */
 int64_t fc_hash_unique_ws_bytes(int64_t n);
 int fc_hash_unique(const int* coords, int64_t n, int q, unsigned long long* table_keys, int* table_vals, int64_t cap,
                    int* out_coords, int* first_idx, int* inverse, int* n_out_dev, void* ws, int64_t ws_bytes,

@@ -50,6 +50,22 @@ def _worker(rank, world, port, out):
         for p, lst in zip(model.parameters(), gathered):
             assert torch.allclose(p.grad, sum(lst) / world, atol=1e-6)
         assert torch.equal(unused.grad, torch.zeros(5))
+    # a parameter that receives a gradient on ONE rank only: its bucket completes at different times on the two ranks;
+    # the collectives must still be issued in the same (index) order everywhere (wrong sums / a hang before)
+    torch.manual_seed(1)
+    a, b, c = (torch.nn.Parameter(torch.randn(6)) for _ in range(3))
+    avg2 = D.GradientAverager([a, b, c], bucket_mb=1e-5)             # one bucket per parameter, order c, b, a
+    assert len(avg2.buckets) == 3
+    for step in range(2):
+        for p in (a, b, c):
+            p.grad = None
+        loss = (a * (rank + 1)).sum() + (c * 3.0).sum()
+        if rank == 0:
+            loss = loss + (b * 5.0).sum()                              # b: gradient on rank 0 only
+        loss.backward()
+        avg2.finish()
+        assert torch.allclose(a.grad, torch.full((6,), 1.5)) and torch.allclose(c.grad, torch.full((6,), 3.0))
+        assert torch.allclose(b.grad, torch.full((6,), 2.5)), b.grad
     if rank == 0:
         out.put('ok')
     dist.barrier()

@@ -59,10 +59,15 @@ def _oracle_params(model):
             for k, v in model.state_dict().items()}
 
 
+SUNRGBD_KW = dict(rotated=True, single_view=True, rgb_unit=True, n_boxes=6, n_classes=10)
+
+
 @pytest.mark.parametrize('name,levels,B,n_points,kw', [
     ('fcaf3d_scannet-3d-18class', 1, 1, 20000, {}),                       # BASELINE config 1 (plumbing)
     ('fcaf3d_scannet-3d-18class', 4, 2, 30000, {}),                       # 4 levels, 2 scenes
     ('fcaf3d_sunrgbd-3d-10class', 2, 1, 20000, dict(rotated=True, n_boxes=6, n_classes=10)),   # rotated IoU loss
+    ('fcaf3d_scannet-3d-18class', 4, 1, 100000, {}),                      # BASELINE config 2 at FULL size
+    ('fcaf3d_sunrgbd-3d-10class', 4, 1, 100000, SUNRGBD_KW),              # BASELINE config 3 at FULL size (4 levels, rotated)
 ])
 def test_forward_train_parity(name, levels, B, n_points, kw):
     dev = _dev()
@@ -93,12 +98,15 @@ def test_forward_train_parity(name, levels, B, n_points, kw):
     # the fp64 oracle; the HIP path may be at most 2x as far from it as the fp32 oracle is (+1e-3 floor).
     P64 = {k: (v.detach().double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in P.items()}
     sum(MO.forward_train(P64, m, pts, gts, labs).values()).backward()
-    worst = 0.0
+    worst = worst_o = 0.0
     for k, p in model.named_parameters():
         e_gpu, e_o32 = _rel(p.grad, P64[k].grad), _rel(P[k].grad, P64[k].grad)
-        worst = max(worst, e_gpu)
+        worst, worst_o = max(worst, e_gpu), max(worst_o, e_o32)
         assert e_gpu < 2 * e_o32 + 1e-3, (k, e_gpu, e_o32)
-    print(f'{name} L={levels} B={B}: worst grad rel err vs fp64 oracle {worst:.2e}')
+        # ... and an ABSOLUTE bound on the distance to the fp64 oracle (max-norm relative to the tensor's largest entry):
+        # fp32 round-off through ~40 normalised layers, measured <= 1.5e-2 on every config (r2 log below)
+        assert e_gpu < 3e-2, (k, e_gpu)
+    print(f'{name} L={levels} B={B} n={n_points}: worst gradient error vs the fp64 oracle: HIP {worst:.2e}, fp32 oracle {worst_o:.2e}')
 
 
 def test_async_map_stream_is_bitwise_equivalent():
@@ -357,6 +365,184 @@ def test_pruning_path_bites():
             so, sg = np.lexsort(po.T[::-1]), np.lexsort(pg.T[::-1])
             assert np.array_equal(po[so], pg[sg])
             assert _rel(out_g[2][l][b][torch.from_numpy(sg).to(dev)], out_o[2][l][b][torch.from_numpy(so)]) < 1e-4
+
+
+def test_full_size_config5_s3dis_pruning_live():
+    """BASELINE config 5 (S3DIS-shape: 500 000 points, 12 x 10 m room, 5 classes) at FULL size with the config's real
+    pts_threshold: the finest neck level exceeds it, so interpolation + per-scene top-k + MinkowskiPruning run for real.
+    extract_feat against the oracle: kept coordinate sets exact (canonical order: top-k ties are order-dependent),
+    head outputs 1e-4."""
+    from fcaf3d_amd.synthetic import WORKLOADS
+    dev = _dev()
+    model, m = _build('fcaf3d_s3dis-3d-5class', 0.02, 4)
+    with torch.no_grad():                                     # spread the scores so that top-k has no near-ties
+        model.neck_with_head.cls_conv.kernel.normal_(0, 0.5)
+    P = _oracle_params(model)
+    model = model.to(dev).train()
+    pts, gts, labs = _scenes([51], **WORKLOADS['s3dis-500k']['scene'])
+    assert pts[0].shape[0] == 500000
+    with torch.no_grad():
+        out_o = MO.extract_feat({k: v.detach() for k, v in P.items()}, m, pts)
+        out_g = [list(x) for x in model.extract_feat([torch.from_numpy(p).to(dev) for p in pts], None)]
+    thr = m.neck_with_head['pts_threshold']
+    assert len(out_o[3][0][0]) == thr, 'the finest level must have been pruned to pts_threshold'
+    for l in range(4):
+        po, pg = out_o[3][l][0].numpy(), out_g[3][l][0].cpu().numpy()
+        assert len(po) == len(pg), (l, len(po), len(pg))
+        so, sg = np.lexsort(po.T[::-1]), np.lexsort(pg.T[::-1])
+        assert np.array_equal(po[so], pg[sg]), f'level {l}: kept coordinate sets differ'
+        for kind in range(3):
+            assert _rel(out_g[kind][l][0][torch.from_numpy(sg).to(dev)], out_o[kind][l][0][torch.from_numpy(so)]) < 1e-4, (kind, l)
+
+
+def test_out_of_range_coordinates_raise():
+    """a stray far-away / non-finite point must not silently alias another voxel through the 16-bit fields of
+    the packed hash key: the voxelisation reports it."""
+    dev = _dev()
+    model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 1)
+    model = model.to(dev).train()
+    pts, _, _ = _scenes([3], n_points=5000)
+    for bad in (5.0e4, float('inf')):                          # 50 km at 2 cm voxels = 2.5 M voxels; and inf
+        p = pts[0].copy()
+        p[17, 0] = bad
+        with pytest.raises(ValueError, match='voxel coordinate outside'):
+            model.extract_feat([torch.from_numpy(p).to(dev)], None)
+    model.extract_feat([torch.from_numpy(pts[0]).to(dev)], None)        # the clean cloud still goes through
+
+
+def test_iou_loss_zero_weight_rows_cannot_poison_gradients():
+    """a zero-weight (background) row whose own IoU derivative is not finite must contribute an exact zero."""
+    dev = _dev()
+    for with_yaw, d in ((False, 6), (True, 7)):
+        loss_fn = fa.build_loss(dict(type='IoU3DLoss', with_yaw=with_yaw, loss_weight=1.0))
+        pred = torch.tensor([[0.0, 0, 0, 1, 1, 1, 0.1][:d], [0.0, 0, 0, 3e19, 3e19, 3e19, 0.0][:d]], device=dev, requires_grad=True)
+        tgt = torch.tensor([[0.1, 0, 0, 1, 1, 1, 0.0][:d], [0.0, 0, 0, 1, 1, 1, 0.0][:d]], device=dev)
+        w = torch.tensor([1.0, 0.0], device=dev)
+        loss = loss_fn(pred, tgt, weight=w, avg_factor=1.0)
+        loss.backward()
+        assert torch.isfinite(loss) and torch.isfinite(pred.grad).all(), (with_yaw, loss, pred.grad)
+        assert float(pred.grad[1].abs().max()) == 0.0 and float(pred.grad[0].abs().max()) > 0.0
+
+
+def test_head_with_more_than_55_classes():
+    """1 + n_reg + n_classes > 64 fused head columns (e.g. ScanNet200) takes the unfused split — same maths."""
+    dev = _dev()
+    model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 2, n_classes=70)
+    P = _oracle_params(model)
+    model = model.to(dev).train()
+    pts, gts, labs = _scenes([61], n_points=12000, n_classes=70)
+    out_o = MO.extract_feat(P, m, pts)
+    out_g = [list(x) for x in model.extract_feat([torch.from_numpy(p).to(dev) for p in pts], None)]
+    for kind in range(3):
+        for l in range(2):
+            assert _rel(out_g[kind][l][0], out_o[kind][l][0]) < 1e-4, (kind, l)
+    assert out_g[2][0][0].shape[1] == 70
+    losses_g = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
+    losses_o = MO.forward_train(P, m, pts, gts, labs)
+    for k in losses_o:
+        assert _rel(losses_g[k], losses_o[k]) < 1e-4, k
+    sum(losses_g.values()).backward()
+    assert torch.isfinite(model.neck_with_head.cls_conv.kernel.grad).all()
+
+
+def test_mmcv_layout_checkpoint_reproduces_detections_on_gpu(tmp_path):
+    """weights travel through a checkpoint in mmcv's on-disk layout ({'meta', 'state_dict'} with DDP's
+    `module.` prefix, as the released .pth files and tools/test.py:172 use it) and give the same detections on the GPU as
+    the model that wrote them, and as the CPU oracle running on the checkpoint's own tensors."""
+    from collections import OrderedDict
+    dev = _dev()
+    src, m = _build('fcaf3d_scannet-3d-18class', 0.02, 2, seed=5)
+    with torch.no_grad():
+        src.neck_with_head.cls_conv.bias.fill_(0.0)
+        src.neck_with_head.cls_conv.kernel.normal_(0, 0.3)
+        for mod in src.modules():                                   # non-trivial running statistics, as after training
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.normal_(0, 0.05)
+                mod.running_var.uniform_(0.5, 1.5)
+    path = str(tmp_path / 'epoch_12.pth')
+    ckpt = dict(meta=dict(epoch=12, iter=1812, mmdet3d_version='0.8.0'),
+                state_dict=OrderedDict(('module.' + k, v.clone()) for k, v in src.state_dict().items()), optimizer=dict())
+    torch.save(ckpt, path)
+    dst, _ = _build('fcaf3d_scannet-3d-18class', 0.02, 2, seed=6)      # different random weights
+    loaded = fa.load_checkpoint(dst, path, map_location='cpu', strict=True)
+    assert loaded['meta']['epoch'] == 12
+    pts, _, _ = _scenes([81, 82], n_points=20000)
+    gp = [torch.from_numpy(p).to(dev) for p in pts]
+    metas = [dict(box_type_3d=fa.DepthInstance3DBoxes)] * 2
+    with torch.no_grad():
+        r_src = src.to(dev).eval()(return_loss=False, points=gp, img_metas=metas)
+        r_dst = dst.to(dev).eval()(return_loss=False, points=gp, img_metas=metas)
+    P = {k[len('module.'):]: v for k, v in torch.load(path, weights_only=False)['state_dict'].items()}
+    MO.TRAINING = False
+    try:
+        res_o = MO.simple_test(P, m, pts)
+    finally:
+        MO.TRAINING = True
+    for a, b, (bo, so, lo_) in zip(r_src, r_dst, res_o):
+        assert len(a['scores_3d']) > 5
+        assert torch.equal(a['scores_3d'], b['scores_3d']) and torch.equal(a['labels_3d'], b['labels_3d'])
+        assert torch.equal(a['boxes_3d'].tensor, b['boxes_3d'].tensor)
+        assert len(so) == len(b['scores_3d']) and torch.equal(b['labels_3d'], lo_) and _rel(b['scores_3d'], so) < 1e-4
+    # save_checkpoint writes the same layout back (weights on the CPU, prefix stripped)
+    out = str(tmp_path / 'resaved.pth')
+    fa.save_checkpoint(dst, out, meta=dict(epoch=12))
+    again = torch.load(out, weights_only=False)
+    assert set(again) >= {'meta', 'state_dict'} and all(not v.is_cuda for v in again['state_dict'].values())
+    assert all(torch.equal(again['state_dict'][k], v.cpu()) for k, v in dst.state_dict().items())
+
+
+def test_three_step_training_trajectory_vs_oracle():
+    """three optimisation steps of the reference's recipe (AdamW 1e-3 / 1e-4, grad-clip 10 —
+    fcaf3d_amd/runner.py TrainStep) on the HIP path against the same three steps on the CPU oracle with torch's own
+    (unfused) AdamW: the loss trajectories agree."""
+    from fcaf3d_amd.runner import TrainStep
+    dev = _dev()
+    model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 2, seed=3)
+    cfg = fa.get_config('fcaf3d_scannet-3d-18class', voxel_size=0.02)
+    P = _oracle_params(model)
+    model = model.to(dev).train()
+    tr = TrainStep.from_config(model, cfg)
+    leaves = [v for v in P.values() if v.requires_grad]
+    opt = torch.optim.AdamW(leaves, lr=cfg.optimizer.lr, weight_decay=cfg.optimizer.weight_decay)
+    traj_g, traj_o = [], []
+    for step in range(3):
+        pts, gts, labs = _scenes([90 + step], n_points=12000)
+        loss, _ = tr(_to_gpu_batch(pts, gts, labs, dev))
+        traj_g.append(float(loss))
+        opt.zero_grad()
+        lo_ = sum(MO.forward_train(P, m, pts, gts, labs).values())
+        lo_.backward()
+        torch.nn.utils.clip_grad_norm_(leaves, cfg.optimizer_config.grad_clip.max_norm)
+        opt.step()
+        traj_o.append(float(lo_))
+    print('loss trajectory HIP', traj_g, 'oracle', traj_o)
+    assert abs(traj_g[0] - traj_o[0]) <= 1e-4 * abs(traj_o[0])
+    for a, b in zip(traj_g[1:], traj_o[1:]):
+        assert abs(a - b) <= 2e-2 * abs(b), (traj_g, traj_o)
+
+
+def test_multiclass_nms_route_equals_per_class_loop():
+    """`_nms` (all classes in one sort + one pair of launches) returns exactly what the reference's per-class loop
+    (`_nms_per_class`, fcaf3d_neck_with_head.py:332-374) returns: boxes, scores, labels, order."""
+    dev = _dev()
+    rng = np.random.default_rng(3)
+    for name, rotated in (('fcaf3d_scannet-3d-18class', False), ('fcaf3d_sunrgbd-3d-10class', True)):
+        model, m = _build(name, 0.02, 2)
+        head = model.neck_with_head
+        n, C = 3000, head.n_classes
+        centre = rng.uniform(0, 4, (n, 3))
+        size = rng.uniform(0.2, 1.5, (n, 3))
+        cols = [centre, size] + ([rng.uniform(-3.14, 3.14, (n, 1))] if rotated else [])
+        boxes = torch.from_numpy(np.concatenate(cols, 1).astype(np.float32)).to(dev)
+        scores = torch.from_numpy(rng.uniform(0, 1, (n, C)).astype(np.float32) ** 4).to(dev)
+        meta = dict(box_type_3d=fa.DepthInstance3DBoxes)
+        b1, s1, l1 = head._nms(boxes, scores, meta)
+        b2, s2, l2 = head._nms_per_class(boxes, scores, meta)
+        assert len(s1) == len(s2) and len(s1) > 50
+        assert torch.equal(l1, l2) and torch.equal(s1, s2) and torch.equal(b1.tensor, b2.tensor)
+        # nothing above the threshold: empty result of the right types
+        b0, s0, l0 = head._nms(boxes, torch.zeros_like(scores), meta)
+        assert len(s0) == 0 and l0.dtype == torch.long and b0.tensor.shape[0] == 0
 
 
 def test_eval_mode_inference_and_running_stats():
