@@ -442,6 +442,9 @@ def main():
                 probe.begin_step(i % len(src), probe_mode)
             else:
                 probe.mode = None
+        # probed steps keep every kernel on the main stream: a HIP-event bracket is only a kernel's own duration when
+        # nothing else shares the GPU (the overlapped weight-gradient stream would inflate every bracket it touches)
+        Fn.WGRAD_ASYNC = (not args.no_wgrad_overlap) and probe_mode != 'time'
         loss, _ = trainer(batch)
         return loss
 

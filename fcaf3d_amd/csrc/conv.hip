@@ -44,12 +44,16 @@ __device__ __attribute__((aligned(16))) float g_zero_row[64];   // what an absen
 // run (single LDS buffer, global-load latency hidden behind the matrix pipe).
 // gridDim.z > 1 = split over kernel offsets (offset k handled by split k % gridDim.z) for layers whose
 // row count cannot fill the chip; partial tiles go to `out` + z*n_out*Cout and are summed by k_sum_parts.
-template <int BM, int BN, int BKT, bool HAS_NBR>
-__global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
+// WM = waves along the rows (2: 2 x 2 waves; 4: 4 x 1 — the 256 x 64 tile for 64-wide outputs: every wave still owns a
+// 64 x 64 quadrant, i.e. the operand re-use of the 128 x 128 tile, where a 128 x 64 tile halves it).
+template <int BM, int BN, int BKT, bool HAS_NBR, int WM = 2>
+__global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (WM == 4 ? 3 : 2)) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
                                                    const int* __restrict__ nbr, const unsigned int* __restrict__ gmask,
                                                    const int* __restrict__ out_index, const int* __restrict__ cnt,
                                                    float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout) {
-  constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 MFMA tiles per wave
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);      // 32x32 MFMA tiles per wave
+  constexpr int RW = BM / WM, CW = BN / WN;      // rows / columns of a wave's part of the tile
   constexpr int LDAT = BKT + 4;                  // (BKT+4)/4 odd -> conflict-free ds_read_b128 of the A fragments
   constexpr int A4 = BKT / 4;                    // float4 per gathered row slab
   constexpr int APASS = 256 / A4;                // rows staged per pass
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
   __shared__ unsigned int kmask_s;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = WM == 4 ? wave : wave >> 1, wc = WM == 4 ? 0 : wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
@@ -189,17 +193,17 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
         float b[TN][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          a[i] = *reinterpret_cast<const f32x4*>(&As[(wr * (BM / 2) + i * 32 + r) * LDAT + 8 * q + 4 * h]);
+          a[i] = *reinterpret_cast<const f32x4*>(&As[(wr * RW + i * 32 + r) * LDAT + 8 * q + 4 * h]);
         // sub-tile j of the wave owns the INTERLEAVED columns TN*r + j of its half of the tile: one ds_read_b64 per
         // (k, lane) instead of two ds_read_b32 (conflict-free: 32 lanes x 8 B = 64 banks), and 8-byte output stores
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (TN == 2) {
-            const f32x2 bb = *reinterpret_cast<const f32x2*>(&Bs[(8 * q + 4 * h + e) * BN + wc * (BN / 2) + 2 * r]);
+            const f32x2 bb = *reinterpret_cast<const f32x2*>(&Bs[(8 * q + 4 * h + e) * BN + wc * CW + 2 * r]);
             b[0][e] = bb[0];
             b[TN - 1][e] = bb[1];
           } else {
-            b[0][e] = Bs[(8 * q + 4 * h + e) * BN + wc * (BN / 2) + r];
+            b[0][e] = Bs[(8 * q + 4 * h + e) * BN + wc * CW + r];
           }
         }
 #pragma unroll
@@ -219,13 +223,13 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : 2)
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   TR(3);
-  float* dst = out + (int64_t)z * n_out * Cout + n0 + wc * (BN / 2) + TN * r;
+  float* dst = out + (int64_t)z * n_out * Cout + n0 + wc * CW + TN * r;
   int orow[TM][16];                              // looked up in one batch ahead of the stores
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int64_t row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int64_t row = m0 + wr * RW + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
       int o = -1;
       if (row < n_out) o = out_index ? out_index[row] : (int)row;      // rows are processed in mask-sorted order
       orow[i][e] = o;
@@ -447,6 +451,8 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   // measured on the benchmark's layers (tools/convbench.py): 128-row tiles win at every size once the grid
   // is topped up to ~1024 workgroups by splitting over kernel offsets
   *bm = (n_out > 64 && wg128 >= 4) ? 128 : 64;
+  // 64-wide outputs on big maps: 256 x 64 tiles, 4 waves along the rows (r2: +6 % on the 441k-row level, 88 / 95 TF)
+  if (*bn == 64 && Cout == 64 && fc_cdiv(n_out, 256) >= 1024) *bm = 256;
   const int64_t tiles = fc_cdiv(n_out, *bm) * (Cout / *bn);
   int s = 1;
   if (*mfma && K > 1 && tiles < 768) {           // split over kernel offsets until ~1024 workgroups
@@ -455,8 +461,9 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   }
   // tuning overrides: flags[4:5] BM (1=64, 2=128), flags[6:7] BN (1=64, 2=128), flags[8:15] S
   int fbm = (flags >> 4) & 3, fbn = (flags >> 6) & 3, fs = (flags >> 8) & 255;
-  if (fbm) *bm = fbm == 1 ? 64 : 128;
+  if (fbm) *bm = fbm == 1 ? 64 : (fbm == 2 ? 128 : 256);
   if (fbn && (Cout % (fbn == 1 ? 64 : 128) == 0)) *bn = fbn == 1 ? 64 : 128;
+  if (*bm == 256) *bn = 64;                      // the 4 x 1 wave arrangement: 256 x 64 tiles
   if (fbm || fbn) {
     const int64_t t2 = fc_cdiv(n_out, *bm) * (Cout / *bn);
     s = 1;
@@ -485,7 +492,10 @@ static int launch_conv_mfma(int bm, int bn, dim3 grid, const float* in, const fl
     if (nbr) k_conv_mfma<BM_, BN_, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);  \
     else k_conv_mfma<BM_, BN_, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);     \
   } while (0)
-  if (bm == 128 && bn == 128) FC_LAUNCH_MFMA(128, 128);
+  if (bm == 256) {
+    if (nbr) k_conv_mfma<256, 64, 32, true, 4><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
+    else k_conv_mfma<256, 64, 32, false, 4><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
+  } else if (bm == 128 && bn == 128) FC_LAUNCH_MFMA(128, 128);
   else if (bm == 128) FC_LAUNCH_MFMA(128, 64);
   else if (bn == 128) FC_LAUNCH_MFMA(64, 128);
   else FC_LAUNCH_MFMA(64, 64);

@@ -182,6 +182,8 @@ int main(int argc, char** argv) {
       {"N1 k3s1 128->128", &n1, &n1, 3, 128, 128, true},   {"N0 k3s1 64->64", &n0, &n0, 3, 64, 64, true},
       {"N0 out 64->128", &n0, &n0, 3, 64, 128, true},      {"N0 dgrad 128->64", &n0, &n0, 3, 128, 64, true},
   };
+  std::mt19937 rng(7);
+  std::normal_distribution<float> Nf(0.f, 1.f);
   if (mode == "density") {            // host only: MFMA work issued by a dense table at G-row skip granularity / exact pair work
     for (const Case& cs : cases) {
       if (!only.empty() && cs.name.find(only) == std::string::npos) continue;
@@ -203,6 +205,68 @@ int main(int argc, char** argv) {
         }
       }
       printf("\n");
+    }
+    return 0;
+  }
+  if (mode == "hbm") {        // the bandwidth-bound kernels on benchmark-sized tensors: compulsory bytes / time vs the 8 TB/s peak
+    Dev<float> x, y, gy, gx, gres, res, mean, var, cnt, gamma, beta, sums, rm, rv; Dev<long long> nbt; Dev<unsigned char> wsb; Dev<int> seg;
+    struct T { const char* name; int64_t n; int C; bool segd; };
+    std::vector<T> ts = {{"N0 64", n0.n(), 64, false}, {"N0 128", n0.n(), 128, false}, {"N1 128", n1.n(), 128, false},
+                         {"stem IN 64 (8 scenes)", s2.n(), 64, true}, {"L1 64", l1.n(), 64, false}, {"L3 256", l3.n(), 256, false}};
+    for (const T& t : ts) {
+      const size_t e = (size_t)t.n * t.C;
+      x.alloc(e); y.alloc(e); gy.alloc(e); gx.alloc(e); gres.alloc(e); res.alloc(e);
+      std::vector<float> hx(e); for (auto& v : hx) v = Nf(rng);
+      x.up(hx); gy.up(hx); res.up(hx);
+      const int nseg = t.segd ? batch : 1;
+      mean.alloc((size_t)nseg * t.C); var.alloc((size_t)nseg * t.C); cnt.alloc(nseg); gamma.alloc(t.C); beta.alloc(t.C); sums.alloc((size_t)nseg * 2 * t.C);
+      rm.alloc(t.C); rv.alloc(t.C); nbt.alloc(1);
+      CK(hipMemset(gamma.p, 0x3c, t.C * 4)); CK(hipMemset(beta.p, 0, t.C * 4));
+      const int* segp = nullptr;
+      if (t.segd) { std::vector<int> c4((size_t)t.n * 4); for (int64_t i = 0; i < t.n; ++i) { c4[i * 4] = s2.c[i].b; } seg.up(c4); segp = seg.p; }
+      int64_t w1 = fc_col_stats_ws_bytes(t.n, t.C, nseg), w2 = fc_norm_act_bwd_ws_bytes(t.n, t.C, nseg), w3 = fc_bn_stats_ws_bytes(t.n, t.C);
+      wsb.alloc((size_t)std::max(std::max(w1, w2), w3) + 256);
+      const double mb = e * 4.0 / 1e6;
+      auto report = [&](const char* k, double bytes_mb, double us) { printf("%-24s %-22s %8.1f MB %8.1f us %7.1f GB/s (%.3f of 8 TB/s)\n", t.name, k, bytes_mb, us, bytes_mb / us * 1e3, bytes_mb / us * 1e3 / 8000.0); };
+      double us;
+      us = time_us(reps, [&]() { FC(fc_col_stats(x.p, segp, 4, t.n, t.C, nseg, mean.p, var.p, cnt.p, wsb.p, w1, 0)); });
+      report("fc_col_stats", mb, us);
+      if (!t.segd) {
+        us = time_us(reps, [&]() { FC(fc_bn_stats_train(x.p, t.n, t.C, 0.1f, mean.p, var.p, cnt.p, rm.p, rv.p, nbt.p, wsb.p, w3, 0)); });
+        report("fc_bn_stats_train", mb, us);
+      }
+      us = time_us(reps, [&]() { FC(fc_norm_act_fwd(x.p, segp, 4, t.n, t.C, mean.p, var.p, 1e-5f, gamma.p, beta.p, nullptr, 2, y.p, 0)); });
+      report("fc_norm_act_fwd", 2 * mb, us);
+      us = time_us(reps, [&]() { FC(fc_norm_act_fwd(x.p, segp, 4, t.n, t.C, mean.p, var.p, 1e-5f, gamma.p, beta.p, res.p, 1, y.p, 0)); });
+      report("fc_norm_act_fwd +res", 3 * mb, us);
+      us = time_us(reps, [&]() { FC(fc_norm_act_bwd(x.p, y.p, gy.p, segp, 4, t.n, t.C, nseg, mean.p, var.p, cnt.p, 1e-5f, gamma.p, 2, gx.p, nullptr, sums.p, wsb.p, w2, 0)); });
+      report("fc_norm_act_bwd", 4 * mb, us);
+      us = time_us(reps, [&]() { FC(fc_norm_act_bwd(x.p, y.p, gy.p, segp, 4, t.n, t.C, nseg, mean.p, var.p, cnt.p, 1e-5f, gamma.p, 1, gx.p, gres.p, sums.p, wsb.p, w2, 0)); });
+      report("fc_norm_act_bwd +gres", 5 * mb, us);
+    }
+    {   // stem conv (3 -> 64, k3s2), max-pool k2s2
+      std::vector<int> nb = kernel_map(s1, s2, 3);
+      Dev<int> dn; dn.up(nb);
+      Dev<float> in3, w3, o64, g64, gw; in3.alloc((size_t)s1.n() * 3); w3.alloc(27 * 3 * 64); o64.alloc((size_t)s2.n() * 64); g64.alloc((size_t)s2.n() * 64); gw.alloc(27 * 3 * 64);
+      CK(hipMemset(in3.p, 0x3c, (size_t)s1.n() * 12)); CK(hipMemset(w3.p, 0x3c, 27 * 3 * 64 * 4)); CK(hipMemset(g64.p, 0x3c, (size_t)s2.n() * 256));
+      double bytes = 4.0 * ((double)s1.n() * 3 + (double)s2.n() * 64) + 4.0 * 27 * s2.n();
+      double us = time_us(reps, [&]() { FC(fc_conv_fwd(in3.p, w3.p, dn.p, nullptr, o64.p, s1.n(), s2.n(), 27, 3, 64, 0, nullptr, 0, 0)); });
+      printf("%-24s %-22s %8.1f MB %8.1f us %7.1f GB/s (%.3f of 8 TB/s)\n", "stem 3->64", "fc_conv_fwd", bytes / 1e6, us, bytes / us / 1e3, bytes / us / 1e3 / 8000);
+      int64_t wb = fc_conv_wgrad_ws_bytes(s2.n(), 27, 3, 64, 0); wsb.alloc(wb + 256);
+      us = time_us(reps, [&]() { FC(fc_conv_wgrad(in3.p, g64.p, dn.p, nullptr, gw.p, s1.n(), s2.n(), 27, 3, 64, 0, wsb.p, wb, 0)); });
+      printf("%-24s %-22s %8.1f MB %8.1f us %7.1f GB/s (%.3f of 8 TB/s)\n", "stem 3->64", "fc_conv_wgrad", bytes / 1e6, us, bytes / us / 1e3, bytes / us / 1e3 / 8000);
+      std::vector<int> nbp = kernel_map(s2, s4, 2);
+      // k2s2 offsets are {0,1}^3 * stride: kernel_map() centres odd kernels only, ks = 2 gives offsets (d - 1): shift by +1
+      {
+        const int n = s4.n(); nbp.assign((size_t)8 * n, -1); int k = 0;
+        for (int dz = 0; dz < 2; ++dz) for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx, ++k)
+          for (int o = 0; o < n; ++o) { const V4& v = s4.c[o]; nbp[(size_t)k * n + o] = s2.h.find(pack(V4{v.b, v.x + dx * 2, v.y + dy * 2, v.z + dz * 2})); }
+      }
+      Dev<int> dp, arg; dp.up(nbp); arg.alloc((size_t)s4.n() * 64);
+      Dev<float> po; po.alloc((size_t)s4.n() * 64);
+      bytes = 4.0 * 64 * ((double)s2.n() + 2.0 * s4.n()) + 4.0 * 8 * s4.n();
+      us = time_us(reps, [&]() { FC(fc_maxpool_fwd(o64.p, dp.p, s4.n(), 8, 64, po.p, arg.p, 0)); });
+      printf("%-24s %-22s %8.1f MB %8.1f us %7.1f GB/s (%.3f of 8 TB/s)\n", "maxpool k2s2 64", "fc_maxpool_fwd", bytes / 1e6, us, bytes / us / 1e3, bytes / us / 1e3 / 8000);
     }
     return 0;
   }
@@ -231,8 +295,6 @@ int main(int argc, char** argv) {
   }
   Dev<float> d_in, d_w, d_out, d_ref, d_gout, d_gw, d_gwref; Dev<int> d_nbr, d_sorted, d_oidx, d_pi, d_po, d_pos, d_cnt, d_masks;
   Dev<unsigned char> d_ws;
-  std::mt19937 rng(7);
-  std::normal_distribution<float> Nf(0.f, 1.f);
   for (const Case& cs : cases) {
     if (!only.empty() && cs.name.find(only) == std::string::npos) continue;
     const int K = cs.ks * cs.ks * cs.ks, n_in = cs.in->n(), n_out = cs.out->n(), Cin = cs.Cin, Cout = cs.Cout;
@@ -309,6 +371,7 @@ int main(int argc, char** argv) {
               fflush(stdout);
             }
       }
+      if (Cout == 64) { runs.push_back({"256x64", 3 << 4, 0}); if (!cs.dense) runs.push_back({"256x64s", 3 << 4, 1}); }
       for (const Run& r : runs) {
         const int fl = r.flags;
         std::function<void()> fn;
