@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ in, 
     int i = nbr[(int64_t)k * n_out + oc];
     if (o >= n_out) i = -1;
     const float* src = i < 0 ? g_zero_row : in + (int64_t)i * 3;
-    float a = src[0], b = src[1], c = src[2];
+    float a = src[0], b = src[1], c = src[2];       // (r2: one 12-byte load instead of three dwords is no faster)
     in_s[row * SLD + k * 3] = a; in_s[row * SLD + k * 3 + 1] = b; in_s[row * SLD + k * 3 + 2] = c;
   }
   for (int t = tid; t < 96 * 16; t += 256) {
@@ -358,25 +358,51 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ in
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // register-prefetch pipeline (as k_conv_mfma): the 27 x 3 gathered inputs and the gout rows of chunk t+1 are in flight
+  // while chunk t is multiplied (r2: without it the index -> gather chain of every 64-row chunk was exposed: 0.6 TB/s)
+  constexpr int NG = (STEM_ROWS * 27 + 255) / 256;          // gathers per thread per chunk (K <= 27)
+  float pa[NG][3];
+  f32x4 pg[4];
+  auto load_chunk = [&](int64_t rb) {
+    int idx[NG];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int t = tid + 256 * u;
+      const int k = t / STEM_ROWS, row = t % STEM_ROWS;
+      const int64_t o = rb + row;
+      const int64_t oc = o < r_end ? o : r_end - 1;
+      const int kk = k < K ? k : K - 1;
+      int i = nbr[(int64_t)kk * n_out + oc];
+      idx[u] = (o < r_end && k < K) ? i : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = tid + 256 * u;
+      const int64_t o = rb + (t >> 4);
+      const float* gp = o < r_end ? gout + o * 64 + (t & 15) * 4 : g_zero_row;
+      pg[u] = *reinterpret_cast<const f32x4*>(gp);
+    }
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const float* src = idx[u] < 0 ? g_zero_row : in + (int64_t)idx[u] * 3;
+      pa[u][0] = src[0]; pa[u][1] = src[1]; pa[u][2] = src[2];
+    }
+  };
+  if (r_begin < r_end) load_chunk(r_begin);
   for (int64_t rb = r_begin; rb < r_end; rb += STEM_ROWS) {
     __syncthreads();
-    for (int t = tid; t < STEM_ROWS * K; t += 256) {
-      int k = t / STEM_ROWS, row = t % STEM_ROWS;
-      int64_t o = rb + row;
-      int64_t oc = o < r_end ? o : r_end - 1;
-      int i = nbr[(int64_t)k * n_out + oc];
-      if (o >= r_end) i = -1;
-      const float* src = i < 0 ? g_zero_row : in + (int64_t)i * 3;
-      float a = src[0], b = src[1], c = src[2];
-      in_s[row * STEM_JP + k * 3] = a; in_s[row * STEM_JP + k * 3 + 1] = b; in_s[row * STEM_JP + k * 3 + 2] = c;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int t = tid + 256 * u;
+      const int k = t / STEM_ROWS, row = t % STEM_ROWS;
+      if (k < K) {
+        in_s[row * STEM_JP + k * 3] = pa[u][0]; in_s[row * STEM_JP + k * 3 + 1] = pa[u][1]; in_s[row * STEM_JP + k * 3 + 2] = pa[u][2];
+      }
     }
-    for (int t = tid; t < STEM_ROWS * 16; t += 256) {
-      int row = t >> 4;
-      int64_t o = rb + row;
-      const float* gp = o < r_end ? gout + o * 64 + (t & 15) * 4 : g_zero_row;
-      reinterpret_cast<f32x4*>(g_s)[t] = *reinterpret_cast<const f32x4*>(gp);
-    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) reinterpret_cast<f32x4*>(g_s)[tid + 256 * u] = pg[u];
     __syncthreads();
+    load_chunk(rb + STEM_ROWS < r_end ? rb + STEM_ROWS : rb);          // unconditional (see k_conv_mfma)
 #pragma unroll
     for (int sidx = 0; sidx < 8; ++sidx) {
       const int row = wave * 16 + 2 * sidx + h;
@@ -940,7 +966,7 @@ static inline bool wgrad_multi_ok(int64_t n_out, int K, int Cin, int Cout, int f
 static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool dense_table, int* S, int64_t* rows_per_split) {
   if (!(flags & 1) && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27) {     // stem: 4096 rows per block
     int64_t m = n_out > 0 ? n_out : 1;
-    *rows_per_split = 1024;
+    *rows_per_split = 1024;                      // (r2: 512 rows per block is slower — more partial tiles to write and reduce)
     *S = (int)fc_cdiv(m, 1024);
     return;
   }
