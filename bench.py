@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--spatial-sort', action='store_true', help='Z-order sort of the collated points (measured: no gain, r1)')
     ap.add_argument('--no-wgrad-overlap', action='store_true', help='keep the weight-gradient kernels on the main stream (default: a second '
                     'stream, so that they overlap the backward-data chain: +3 % measured r2)')
+    ap.add_argument('--priority-stream', action='store_true', help='run the main chain on a high-priority HIP stream')
     ap.add_argument('--infer-steps', type=int, default=4, help='untimed-region extra: simple_test batches for the inference scenes/s line (0 = skip)')
     ap.add_argument('--cpu-reps', type=int, default=5, help='repetitions of the C/OpenMP cpu_baseline (median)')
     ap.add_argument('--breakdown', action='store_true', help='diagnostic: HIP-event time per C-ABI entry point and per conv shape (stderr)')
@@ -199,13 +200,13 @@ class ConvProbe:
                     e.record()
                     probe.hbm.append((name if not (name.startswith('fc_conv') and a[8] == 3) else name + '(stem)', nbytes, s, e))
                     return
-            if name not in ('fc_conv_fwd', 'fc_conv_fwd_pairs') or probe.mode is None:
+            if name not in ('fc_conv_fwd', 'fc_conv_fwd_pairs', 'fc_conv_fwd_pairs_tiles') or probe.mode is None:
                 return orig(name, *a)
             if name == 'fc_conv_fwd':
                 # (in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream)
                 n_in, n_out, K, Cin, Cout, has_map = a[5], a[6], a[7], a[8], a[9], bool(a[2])
             else:
-                # (in, W, pair_in, pair_cnt, pair_pos, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream)
+                # (in, W, pair_in, pair_cnt, pair_pos, out, n_in, n_out, K, Cin, Cout, [live_tiles,] flags, ws, ws_bytes, stream)
                 n_in, n_out, K, Cin, Cout, has_map = a[6], a[7], a[8], a[9], a[10], True
             if Cin % 32 or Cout % 64:
                 return orig(name, *a)          # generic FMA / stem path: not the kernel under the probe
@@ -410,6 +411,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
+    if args.priority_stream:
+        # the step's dependent chain runs on a HIGH-priority HIP stream; the overlapped weight-gradient stream and the
+        # coordinate stream keep the default (lower) priority, so they fill idle CUs instead of competing for them
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     model, cfg = build_model(args)
     model = model.to(dev).train()
     model.async_maps = True           # scenes are resident in HBM: coordinate work may run on its side stream

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (W
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = WM == 4 ? wave : wave >> 1, wc = WM == 4 ? 0 : wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  int64_t bx = blockIdx.x;
   const int n0 = blockIdx.y * BN;
   int S = gridDim.z, z = blockIdx.z;
   TR_DECL;
@@ -74,17 +74,30 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (W
   int tr_units = 0;
   (void)tr_units;
   if (cnt) {
-    // pair mode (fc_conv_fwd_pairs): grid.z = kernel offset; `nbr` row z lists the input rows of that offset's cnt[z]
-    // pairs and the tile computes those compacted rows only: T_z[j] = in[pair_in[z][j]] @ W[z], written to slab z
-    // of the workspace.  From here on it is a one-offset convolution over cnt[z] rows.
+    // pair mode (fc_conv_fwd_pairs): `nbr` row z lists the input rows of offset z's cnt[z] pairs and the tile computes
+    // those compacted rows only: T_z[j] = in[pair_in[z][j]] @ W[z], written to slab z of the workspace.  From here on
+    // it is a one-offset convolution over cnt[z] rows.  Two grid shapes: (row tiles, column tiles, K) with the workgroups
+    // beyond cnt[z] exiting at once, or — gridDim.z == 1, the caller knows sum_k ceil(cnt[k] / BM) — a LINEAR list of the
+    // live tiles only, offset-major (r2: the dead workgroups of the 3-D grid skew the round-robin placement, a few
+    // shader engines overflow and their last workgroups start a whole round late: 115 -> 88 us on the 3.5k-row level).
+    if (gridDim.z == 1 && K > 1) {
+      int k = 0;
+      for (; k < K - 1; ++k) {
+        const int64_t t = ((int64_t)cnt[k] + BM - 1) / BM;
+        if (bx < t) break;
+        bx -= t;
+      }
+      z = k;
+    }
     const int64_t stride = n_out;
     n_out = cnt[z];
-    if ((int64_t)blockIdx.x * BM >= n_out) return;
+    if (bx * BM >= n_out) return;
     nbr += (int64_t)z * stride;
     W += (int64_t)z * Cin * Cout;
     out += (int64_t)z * stride * Cout;
     K = 1; S = 1; z = 0;
   }
+  const int64_t m0 = bx * BM;
   const int a_c4 = tid % A4, a_r = tid / A4;     // A staging: A4 float4 per row, APASS rows per pass
 
   f32x16 acc[TM][TN];
@@ -481,9 +494,14 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   if (*bn == 64 && Cout == 64 && fc_cdiv(n_out, 256) >= 1024) *bm = 256;
   const int64_t tiles = fc_cdiv(n_out, *bm) * (Cout / *bn);
   int s = 1;
-  if (*mfma && K > 1 && tiles < 768) {           // split over kernel offsets until ~1024 workgroups
-    s = (int)fc_cdiv(1024, tiles);
+  // split over kernel offsets: the LARGEST split that still fits one resident round (1024 workgroup slots) — one workgroup
+  // over (r1 rounded up) starts a second, nearly empty round (r2 sweep: 256->256 on 6.9k rows 275 us at S = 10 -> 238 at
+  // S = 9); from ~400 tiles on the unsplit launch wins (64->64 on 64k rows: 159 us at S = 2 -> 144 at S = 1, and no
+  // partial tiles to write and sum)
+  if (*mfma && K > 1 && tiles < 384) {
+    s = (int)(1024 / tiles);
     if (s > K) s = K;
+    if (s < 1) s = 1;
   }
   // tuning overrides: flags[4:5] BM (1=64, 2=128), flags[6:7] BN (1=64, 2=128), flags[8:15] S
   int fbm = (flags >> 4) & 3, fbn = (flags >> 6) & 3, fs = (flags >> 8) & 255;
@@ -493,7 +511,7 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   if (fbm || fbn) {
     const int64_t t2 = fc_cdiv(n_out, *bm) * (Cout / *bn);
     s = 1;
-    if (*mfma && K > 1 && t2 < 512) { s = (int)fc_cdiv(1024, t2); if (s > K) s = K; }
+    if (*mfma && K > 1 && t2 < 384) { s = (int)(1024 / t2); if (s > K) s = K; if (s < 1) s = 1; }
   }
   const int rv = FC_REG_VARIANT(flags);
   if (*mfma && rv) {                             // register-direct kernels (conv_reg.hip): their own tile shapes
@@ -629,9 +647,9 @@ int64_t fc_conv_fwd_pairs_ws_bytes(int64_t n_out, int K, int Cout) {
 }
 
 // Convolution over the exact pair lists: per offset a compacted gather-GEMM into the workspace, then a gather-sum.
-int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
-                      float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
-                      int64_t ws_bytes, hipStream_t stream) {
+int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
+                            float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
+                            void* ws, int64_t ws_bytes, hipStream_t stream) {
   if (n_in < 0 || n_out < 0 || K < 1 || K > 65535 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (!pair_in || !pair_cnt || !pair_pos) return FC_EINVAL;
   if (Cin % 32 != 0 || Cout % 64 != 0) return FC_EINVAL;       // MFMA shapes only; callers use fc_conv_fwd otherwise
@@ -648,6 +666,7 @@ int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const
   const bool wide = (Cout % 128 == 0) && !(((flags >> 6) & 3) == 1);
   const int bn = wide ? 128 : 64;
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
+  if (live_tiles > 0) grid = dim3((unsigned)live_tiles, Cout / bn, 1);       // linear list of the live (offset, tile) pairs
   {
     int rc = launch_conv_mfma(128, bn, grid, in, W, pair_in, nullptr, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream);
     if (rc != FC_OK) return rc;
@@ -655,6 +674,12 @@ int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const
   k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);
   FC_CHECK_LAUNCH();
   return FC_OK;
+}
+
+int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
+                      float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
+                      int64_t ws_bytes, hipStream_t stream) {
+  return fc_conv_fwd_pairs_tiles(in, W, pair_in, pair_cnt, pair_pos, out, n_in, n_out, K, Cin, Cout, 0, flags, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

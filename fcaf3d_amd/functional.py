@@ -85,11 +85,11 @@ def _pair_conv(kmap, n_rows, Cin, Cout):
             and Cin % 32 == 0 and Cout % 64 == 0)
 
 
-def _conv_pairs(x, w, lists, out, n_in, n_out, K, Cin, Cout):
+def _conv_pairs(x, w, lists, out, n_in, n_out, K, Cin, Cout, live_tiles=0):
     pi, _, pos, cnt = lists
     ws = L.workspace(L.query('fc_conv_fwd_pairs_ws_bytes', n_out, K, Cout), x.device)
-    L.call('fc_conv_fwd_pairs', L.ptr(x), L.ptr(w), L.ptr(pi), L.ptr(cnt), L.ptr(pos), L.ptr(out), n_in, n_out, K, Cin, Cout,
-           FLAGS, L.ptr(ws), ws.numel(), L.stream())
+    L.call('fc_conv_fwd_pairs_tiles', L.ptr(x), L.ptr(w), L.ptr(pi), L.ptr(cnt), L.ptr(pos), L.ptr(out), n_in, n_out, K, Cin,
+           Cout, live_tiles, FLAGS, L.ptr(ws), ws.numel(), L.stream())
 
 
 def _conv_fwd(x, w, nbr, out, n_in, n_out, K, Cin, Cout, out_index=None):
@@ -112,7 +112,7 @@ class _SparseConv(torch.autograd.Function):
         n_in = feats.shape[0]
         out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
         if _pair_conv(kmap, n_out, Cin, Cout):
-            _conv_pairs(feats, weight, kmap.pairs(), out, n_in, n_out, K, Cin, Cout)
+            _conv_pairs(feats, weight, kmap.pairs(), out, n_in, n_out, K, Cin, Cout, kmap.pair_tiles())
         else:
             nbr, oidx = ((kmap.sorted_fwd() if _mfma_shape(Cin, Cout) else (kmap.nbr, None))
                          if kmap is not None else (None, None))
@@ -135,7 +135,7 @@ class _SparseConv(torch.autograd.Function):
             L.call('fc_transpose_weight', L.ptr(weight), L.ptr(wt), K, Cin, Cout, L.stream())
             gin = torch.empty((n_in, Cin), dtype=torch.float32, device=dev)
             if _pair_conv(kmap, n_in, Cout, Cin):
-                _conv_pairs(gout, wt, kmap.pairs_t(), gin, n_out, n_in, K, Cout, Cin)
+                _conv_pairs(gout, wt, kmap.pairs_t(), gin, n_out, n_in, K, Cout, Cin, kmap.pair_tiles(transposed=True))
             else:
                 nbr_t, tidx = ((kmap.sorted_bwd() if _mfma_shape(Cout, Cin) else (kmap.nbr_t, None))
                                if kmap is not None else (None, None))

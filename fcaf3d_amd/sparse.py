@@ -160,12 +160,28 @@ class KernelMap:
                L.ptr(ws), ws.numel(), L.stream())
         return _rec(pi, po, pos, cnt)
 
+    @staticmethod
+    def _live_tiles(cnt):
+        """sum_k ceil(cnt[k] / 128): the non-empty (offset, 128-row tile) workgroups of the per-offset convolution.  One small
+        read-back per map, on the coordinate stream (where the other data-dependent sizes are read too): the launch then
+        holds live workgroups only (fc_conv_fwd_pairs_tiles; +20...35 % on the deep levels, r2)."""
+        return int(((cnt.to(torch.int64) + 127) // 128).sum().item())
+
     def pairs(self):
         """(pair_in, pair_out, pair_pos, cnt): per offset, the (input row, output row) pairs in ascending output row,
         and where each output row sits in each list (ME's in_maps / out_maps)."""
         if self._pairs is None:
             self._pairs = self._pair_lists(self.nbr, self.n_out, self.K)
         return self._pairs
+
+    def pair_tiles(self, transposed=False):
+        """live tile count of pairs() / pairs_t() for the per-offset convolution (lazy, cached)"""
+        key = '_tiles_t' if transposed else '_tiles'
+        v = getattr(self, key, None)
+        if v is None:
+            v = self._live_tiles((self.pairs_t() if transposed else self.pairs())[3])
+            setattr(self, key, v)
+        return v
 
     def pairs_t(self):
         """the same for the transposed table (backward-data pass): lists ascending in the INPUT row."""
@@ -180,7 +196,7 @@ class KernelMap:
         if self.K != 27:
             return
         if self.use_pairs and self.n_out <= PAIR_CONV_ROWS:
-            self.pairs()
+            self.pair_tiles()
         else:
             self.sorted_fwd()
         if backward:
@@ -188,7 +204,7 @@ class KernelMap:
             if self.use_pairs:
                 self.pairs()
             if self.use_pairs and self.n_in <= PAIR_CONV_ROWS:
-                self.pairs_t()
+                self.pair_tiles(transposed=True)
             else:
                 self.sorted_bwd()
 

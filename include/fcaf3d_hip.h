@@ -131,6 +131,13 @@ int fc_conv_fwd_stream(const float* in, const float* W, const int* nbr, const un
                        float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
                        int64_t ws_bytes, hipStream_t stream);
 
+/* The same (ME.MinkowskiConvolution per offset over its in/out maps, me_resnet.py:56-62) for a caller that has read the pair
+ * counts back: live_tiles = sum_k ceil(pair_cnt[k] / 128) launches exactly the non-empty (offset, 128-row tile) workgroups
+ * as one linear list (no workgroup exits on arrival; evenly filled shader engines).  live_tiles <= 0: as fc_conv_fwd_pairs. */
+int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
+                            float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
+                            void* ws, int64_t ws_bytes, hipStream_t stream);
+
 /* backward-weights of ME.MinkowskiConvolution (autograd of me_resnet.py:19-21, :56-62 and fcaf3d_neck_with_head.py:52,
  * :60-69; `gW[k] += in[i]^T (x) gout[o]`): gW[k] = sum_o in[nbr[k][o]]^T (x) gout[o];
  * deterministic two-level reduction. */

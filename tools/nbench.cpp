@@ -149,7 +149,7 @@ static double max_rel_err(const std::vector<float>& a, const std::vector<float>&
 
 int main(int argc, char** argv) {
   int batch = 8, reps = 10, npts = 100000; std::string only, mode = "all", trace_file; bool check = true;
-  int trace_variant = 1, trace_tbl = 0; bool stream_sweep = false;
+  int trace_variant = 1, trace_tbl = 0; bool stream_sweep = false, popc_sort = false, s_sweep = false;
   std::vector<int> variants = {0, 1, 2, 3, 4, 5};
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -160,6 +160,8 @@ int main(int argc, char** argv) {
     else if (a == "--mode") mode = argv[++i];
     else if (a == "--no-check") check = false;
     else if (a == "--stream-sweep") stream_sweep = true;
+    else if (a == "--popc-sort") popc_sort = true;
+    else if (a == "--s-sweep") s_sweep = true;
     else if (a == "--trace") trace_file = argv[++i];            // needs the FC_TRACE build (tools/nbench_trace)
     else if (a == "--trace-variant") trace_variant = atoi(argv[++i]);
     else if (a == "--trace-tbl") trace_tbl = atoi(argv[++i]);
@@ -310,7 +312,9 @@ int main(int argc, char** argv) {
     FC(fc_nbr_row_masks(d_nbr.p, n_out, K, d_masks.p, 0));
     std::vector<int> masks = d_masks.down(n_out), order(n_out);
     for (int i = 0; i < n_out; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return masks[a] < masks[b]; });
+    if (popc_sort) std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      int pa = __builtin_popcount((unsigned)masks[a]), pb = __builtin_popcount((unsigned)masks[b]); return pa != pb ? pa > pb : masks[a] < masks[b]; });
+    else std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return masks[a] < masks[b]; });
     d_oidx.up(order);
     FC(fc_permute_nbr(d_nbr.p, d_oidx.p, n_out, K, d_sorted.p, 0));
     d_pi.alloc(nbr.size()); d_po.alloc(nbr.size()); d_pos.alloc(nbr.size()); d_cnt.alloc(K);
@@ -330,7 +334,7 @@ int main(int argc, char** argv) {
       std::vector<Run> runs;
       for (int v : variants) {
         runs.push_back({"plain ", v << 24, 0});
-        if (!cs.dense) { runs.push_back({"sorted", v << 24, 1}); runs.push_back({"pairs ", v << 24, 2}); }
+        if (!cs.dense) { runs.push_back({"sorted", v << 24, 1}); runs.push_back({"pairs ", v << 24, 2}); if (v == 0) runs.push_back({"pairsL", 0, 3}); }
       }
       // streaming kernel: plain and mask-sorted tables, 32- and 64-row tiles, a few split counts
       {
@@ -372,10 +376,17 @@ int main(int argc, char** argv) {
             }
       }
       if (Cout == 64) { runs.push_back({"256x64", 3 << 4, 0}); if (!cs.dense) runs.push_back({"256x64s", 3 << 4, 1}); }
+      static const char* snames[] = {"S=1", "S=2", "S=3", "S=4", "S=5", "S=6", "S=7", "S=8", "S=9", "S=10", "S=12", "S=14"};
+      static const int svals[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14};
+      if (s_sweep) for (int q = 0; q < 12; ++q) runs.push_back({snames[q], svals[q] << 8, cs.dense ? 0 : 1});
       for (const Run& r : runs) {
         const int fl = r.flags;
         std::function<void()> fn;
-        if (r.tbl == 2) {
+        if (r.tbl == 3) {
+          int64_t wb = ws_for(fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout));
+          std::vector<int> hc = d_cnt.down(K); int64_t live = 0; for (int v : hc) live += (v + 127) / 128;
+          fn = [&, wb, fl, live]() { FC(fc_conv_fwd_pairs_tiles(d_in.p, d_w.p, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, live, fl, d_ws.p, wb, 0)); };
+        } else if (r.tbl == 2) {
           int64_t wb = ws_for(fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout));
           fn = [&, wb, fl]() { FC(fc_conv_fwd_pairs(d_in.p, d_w.p, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
         } else {
