@@ -87,6 +87,7 @@ def _next_pow2(n):
 
 SORT_ROWS = True      # process conv rows in occupancy-mask order on sparse 27-offset maps
 SORT_MIN_ROWS = int(os.environ.get('FC_SORT_MIN_ROWS', '8192'))
+SORT_DENSE = os.environ.get('FC_SORT_DENSE', '0') != '0'     # mask-sorted rows also on the generated / union (neck) maps
 WGRAD_PAIRS = os.environ.get('FC_WGRAD_PAIRS', '1') != '0'    # weight gradients reduce over exact pair lists there
 # ... and with at most this many result rows the convolution itself runs per offset over the pair lists
 PAIR_CONV_ROWS = int(os.environ.get('FC_PAIR_CONV_ROWS', '16384'))
@@ -305,8 +306,12 @@ class CoordMap:
             km._out_map = out_map            # keep alive so id() stays unique
             # generated / union sets are ~94 % dense (2x2x2 blocks): nothing to skip there
             # ... and below ~8k rows the masks do not group well enough to pay for themselves (tools/convbench.py)
+            # (r2: the generated / union sets are 77 % / 88 % / 94 % occupied; mask order would issue 1.10x / 1.02x / 1.00x the
+            # useful MFMA work instead of 1.30x / 1.14x / 1.07x and the isolated kernels gain 3...10 %, but in the full step
+            # the extra argsort + permuted tables + scattered output rows cancel it exactly: 233.5 vs 233.5 scenes/s on the
+            # same box.  FC_SORT_DENSE=1 turns it on.)
             km.sort_rows = (SORT_ROWS and K == 27 and out_map.n >= SORT_MIN_ROWS
-                            and not (self.dense_hint and out_map.dense_hint))
+                            and (SORT_DENSE or not (self.dense_hint and out_map.dense_hint)))
             km.use_pairs = WGRAD_PAIRS and K == 27 and not (self.dense_hint and out_map.dense_hint)
             self._kmaps[key] = km
         return km
