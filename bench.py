@@ -283,10 +283,10 @@ class ConvProbe:
                     n += 1
         achieved = flops / (ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
+        tj = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
         if os.path.exists(tj):          # PMC passes cannot run inside the timed region: committed rocprofv3 result
             t = json.load(open(tj))
-            traffic, traffic_src = t['hbm_bytes_per_launch'], 'profiles/r1_traffic.json (' + t['method'] + ')'
+            traffic, traffic_src = t['hbm_bytes_per_launch'], 'profiles/r2_traffic.json (' + t['method'] + ')'
         return dict(bound='mfma', kernel='k_conv_mfma (sparse conv fwd + dgrad, dense GEMMs of convT/heads)',
                     achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_unit='B/launch',
