@@ -264,6 +264,250 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (W
   TR_FLUSH(tr_units);
 }
 
+// Deeper-pipelined variant of k_conv_mfma (same tiles, same LDS layout, same results) at 3 waves per SIMD (168 VGPRs):
+//  * the neighbour rows of the NEXT kernel offset are requested one offset ahead (vnxt), so that a stage's gathers are
+//    issued at once instead of behind an exposed index round trip (r2 ISA reading of k_conv_mfma: index loads ->
+//    s_waitcnt vmcnt(0) -> gathers in front of every stage's MFMA block; the 128-VGPR budget of 4 waves/SIMD had no
+//    room for the look-ahead — r1 dead end);
+//  * the MFMA fragments of 8-channel step q+1 are read from LDS while step q multiplies (double-buffered fragment
+//    registers) instead of read -> s_waitcnt lgkmcnt(0) -> multiply.
+template <int BM, int BN, int BKT, bool HAS_NBR, int WM = 2>
+__global__ __launch_bounds__(256, 3) void k_conv_mfma_p(const float* __restrict__ in, const float* __restrict__ W,
+                                                   const int* __restrict__ nbr, const unsigned int* __restrict__ gmask,
+                                                   const int* __restrict__ out_index, const int* __restrict__ cnt,
+                                                   float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout) {
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);      // 32x32 MFMA tiles per wave
+  constexpr int RW = BM / WM, CW = BN / WN;      // rows / columns of a wave's part of the tile
+  constexpr int LDAT = BKT + 4;                  // (BKT+4)/4 odd -> conflict-free ds_read_b128 of the A fragments
+  constexpr int A4 = BKT / 4;                    // float4 per gathered row slab
+  constexpr int APASS = 256 / A4;                // rows staged per pass
+  constexpr int AR = BM / APASS;                 // float4 gathers per thread per stage
+  constexpr int BR = BKT * BN / 1024;            // float4 weight loads per thread per stage
+  __shared__ __attribute__((aligned(16))) float As[BM * LDAT];
+  __shared__ __attribute__((aligned(16))) float Bs[BKT * BN];
+  __shared__ unsigned int kmask_s;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = WM == 4 ? wave : wave >> 1, wc = WM == 4 ? 0 : wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int64_t bx = blockIdx.x;
+  const int n0 = blockIdx.y * BN;
+  int S = gridDim.z, z = blockIdx.z;
+  TR_DECL;
+  TR(0);
+  int tr_units = 0;
+  (void)tr_units;
+  if (cnt) {
+    // pair mode (fc_conv_fwd_pairs): `nbr` row z lists the input rows of offset z's cnt[z] pairs and the tile computes
+    // those compacted rows only: T_z[j] = in[pair_in[z][j]] @ W[z], written to slab z of the workspace.  From here on
+    // it is a one-offset convolution over cnt[z] rows.  Two grid shapes: (row tiles, column tiles, K) with the workgroups
+    // beyond cnt[z] exiting at once, or — gridDim.z == 1, the caller knows sum_k ceil(cnt[k] / BM) — a LINEAR list of the
+    // live tiles only, offset-major (r2: the dead workgroups of the 3-D grid skew the round-robin placement, a few
+    // shader engines overflow and their last workgroups start a whole round late: 115 -> 88 us on the 3.5k-row level).
+    if (gridDim.z == 1 && K > 1) {
+      int k = 0;
+      for (; k < K - 1; ++k) {
+        const int64_t t = ((int64_t)cnt[k] + BM - 1) / BM;
+        if (bx < t) break;
+        bx -= t;
+      }
+      z = k;
+    }
+    const int64_t stride = n_out;
+    n_out = cnt[z];
+    if (bx * BM >= n_out) return;
+    nbr += (int64_t)z * stride;
+    W += (int64_t)z * Cin * Cout;
+    out += (int64_t)z * stride * Cout;
+    K = 1; S = 1; z = 0;
+  }
+  const int64_t m0 = bx * BM;
+  const int a_c4 = tid % A4, a_r = tid / A4;     // A staging: A4 float4 per row, APASS rows per pass
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- (1) which of this split's offsets have a neighbour anywhere in the tile ---------------------
+  unsigned int kmask;
+  if (HAS_NBR && gmask && !cnt) {
+    unsigned int mk = 0u;
+#pragma unroll
+    for (int g = 0; g < BM / 32; ++g)
+      if (m0 + g * 32 < n_out) mk |= gmask[m0 / 32 + g];
+    unsigned int zm = 0u;
+    for (int k = z; k < K; k += S) zm |= 1u << k;
+    kmask = mk & zm;
+  } else {
+    if (tid == 0) kmask_s = 0u;
+    __syncthreads();
+    if (tid < BM) {
+      unsigned int mk = 0u;
+      int64_t row = m0 + tid;
+      if (row < n_out) {
+        if (HAS_NBR) {
+          for (int k = z; k < K; k += S)
+            if (nbr[(int64_t)k * n_out + row] >= 0) mk |= 1u << k;
+        } else {
+          mk = 1u;
+        }
+      }
+      // wave-level OR, one LDS atomic per wave
+      for (int off = 32; off > 0; off >>= 1) mk |= __shfl_xor(mk, off, 64);
+      if (lane == 0 && mk) atomicOr(&kmask_s, mk);
+    }
+    __syncthreads();
+    kmask = kmask_s;
+  }
+  TR(1);
+
+  // ---- (2) software-pipelined stage loop -------------------------------------------------------------
+  if (kmask) {
+    const int nst = __popc(kmask) * (Cin / BKT);         // stages of this tile
+    unsigned int rem = kmask;
+    int lk = __ffs(rem) - 1;                              // load cursor: offset / channel slab of the stage requested next
+    rem &= rem - 1;
+    int lnk = rem ? __ffs(rem) - 1 : lk;                  // ... and the offset after it (its rows are already on their way)
+    if (rem) rem &= rem - 1;
+    int lc0 = 0;
+    bool sw = false;                                      // the cursor has left lk: switch to lnk at the next request
+    f32x4 av[AR], bv[BR];
+    int vcur[AR], vnxt[AR];
+    int64_t arow[AR];
+    bool aok[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int64_t row = m0 + a_r + APASS * i;
+      aok[i] = row < n_out;
+      arow[i] = aok[i] ? row : n_out - 1;
+    }
+    // raw table entries only: nothing touches a requested index until the stage that uses it
+    auto fetch_idx = [&](int kk, int (&v)[AR]) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) v[i] = HAS_NBR ? nbr[(int64_t)kk * n_out + arow[i]] : (int)arow[i];
+    };
+    fetch_idx(lk, vcur);
+    fetch_idx(lnk, vnxt);
+    auto load_stage = [&]() {
+      if (sw) {                                           // first slab of a new offset: its rows were requested an offset ago
+        sw = false;
+        lk = lnk;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) vcur[i] = vnxt[i];
+        if (rem) {
+          lnk = __ffs(rem) - 1;
+          rem &= rem - 1;
+        }
+        fetch_idx(lnk, vnxt);
+      }
+      const float* Wk = W + (int64_t)lk * Cin * Cout;
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        int lin = tid + 256 * i;
+        int kr = lin / (BN / 4), c4 = lin % (BN / 4);
+        bv[i] = *reinterpret_cast<const f32x4*>(Wk + (int64_t)(lc0 + kr) * Cout + n0 + c4 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const float* src = (vcur[i] < 0 || !aok[i]) ? g_zero_row + a_c4 * 4 : in + (int64_t)vcur[i] * Cin + lc0 + a_c4 * 4;
+        av[i] = *reinterpret_cast<const f32x4*>(src);
+      }
+    };
+    load_stage();
+    for (int st = 0; st < nst; ++st) {
+#ifdef FC_TRACE
+      if (tr_units == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TR(2); }
+      tr_units += BKT / 8;
+#endif
+      __syncthreads();                           // previous stage fully consumed
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        *reinterpret_cast<f32x4*>(&As[(a_r + APASS * i) * LDAT + a_c4 * 4]) = av[i];
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        int lin = tid + 256 * i;
+        int kr = lin / (BN / 4), c4 = lin % (BN / 4);
+        *reinterpret_cast<f32x4*>(&Bs[kr * BN + c4 * 4]) = bv[i];
+      }
+      __syncthreads();
+      // request the next stage before multiplying this one (the last iteration re-reads its own stage: a conditionally
+      // assigned staging array lands in scratch)
+      if (st + 1 < nst) {
+        lc0 += BKT;
+        if (lc0 >= Cin) {
+          lc0 = 0;
+          sw = true;
+        }
+      }
+      load_stage();
+      f32x4 fa[2][TM];
+      float fb[2][TN][4];
+      auto read_frag = [&](int q, int u) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[u][i] = *reinterpret_cast<const f32x4*>(&As[(wr * RW + i * 32 + r) * LDAT + 8 * q + 4 * h]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (TN == 2) {
+            const f32x2 bb = *reinterpret_cast<const f32x2*>(&Bs[(8 * q + 4 * h + e) * BN + wc * CW + 2 * r]);
+            fb[u][0][e] = bb[0];
+            fb[u][TN - 1][e] = bb[1];
+          } else {
+            fb[u][0][e] = Bs[(8 * q + 4 * h + e) * BN + wc * CW + r];
+          }
+        }
+      };
+      read_frag(0, 0);
+#pragma unroll
+      for (int q = 0; q < BKT / 8; ++q) {
+        if (q + 1 < BKT / 8) read_frag(q + 1, (q + 1) & 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float ae = fa[q & 1][i][e];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, fb[q & 1][j][e], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  TR(3);
+  float* dst = out + (int64_t)z * n_out * Cout + n0 + wc * CW + TN * r;
+  int orow[TM][16];                              // looked up in one batch ahead of the stores
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = m0 + wr * RW + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      int o = -1;
+      if (row < n_out) o = out_index ? out_index[row] : (int)row;      // rows are processed in mask-sorted order
+      orow[i][e] = o;
+    }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (orow[i][e] >= 0) {
+        if (TN == 2) {
+          f32x2 v = {acc[i][0][e], acc[i][TN - 1][e]};
+          *reinterpret_cast<f32x2*>(dst + (int64_t)orow[i][e] * Cout) = v;
+        } else {
+          dst[(int64_t)orow[i][e] * Cout] = acc[i][0][e];
+        }
+      }
+    }
+  TR(5);
+  TR_FLUSH(tr_units);
+}
+
 // out[i] = sum_z part[z][i]   (fixed order; elems % 4 == 0)
 __global__ void k_sum_parts(const float* __restrict__ part, float* __restrict__ out, int64_t elems4, int S) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -477,6 +721,16 @@ extern "C" {
 // flags[24:27]: register-direct kernel variant (conv_reg.h), 0 = LDS-tiled kernel; flags bit28: register-direct wgrad
 #define FC_REG_VARIANT(flags) (((flags) >> 24) & 15)
 #define FC_REG_WGRAD(flags) (((flags) >> 28) & 1)
+// The deeper-pipelined LDS kernel (k_conv_mfma_p) holds 3 workgroups per CU (768 slots) where k_conv_mfma holds 4 (1024): it
+// wins on launches of many rounds and on launches that fit 768 slots anyway, and loses a round in between (r2: +5.5 / +7 %
+// on the 441k / 55k-row levels, +5 % on the 862-row pair mode, -12 % on the 3.5k-row pair mode with its 972 workgroups).
+// flags bit18 forces it on, bit17 off.
+static inline bool conv_pipe(int flags, dim3 grid) {
+  if (flags & (1 << 18)) return true;
+  if (flags & (1 << 17)) return false;
+  const int64_t wgs = (int64_t)grid.x * grid.y * grid.z;
+  return wgs >= 1536 || wgs <= 768;
+}
 static inline int reg_variant_for(int flags, int Cout) {
   int rv = FC_REG_VARIANT(flags);
   if ((rv == FC_REG_32x128_SPLIT || rv == FC_REG_64x128_SPLIT) && Cout % 128 != 0) rv = FC_REG_64x64_SPLIT;
@@ -528,7 +782,7 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
 
 // one launch of the LDS-tiled MFMA kernel (32-deep slabs; measured r1: 64-deep slabs, 256-row tiles, an LDS index table
 // and LDS-padding occupancy caps all lose or are neutral — profiles/r1_conv_pmc.md — and were removed in r2)
-static int launch_conv_mfma(int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr, const unsigned int* gmask,
+static int launch_conv_mfma(bool pipe, int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr, const unsigned int* gmask,
                             const int* out_index, const int* cnt, float* dst, int64_t n_rows, int K, int Cin, int Cout,
                             hipStream_t stream) {
 #define FC_LAUNCH_MFMA(BM_, BN_)                                                                                              \
@@ -536,7 +790,16 @@ static int launch_conv_mfma(int bm, int bn, dim3 grid, const float* in, const fl
     if (nbr) k_conv_mfma<BM_, BN_, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);  \
     else k_conv_mfma<BM_, BN_, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);     \
   } while (0)
-  if (bm == 256) {
+  if (pipe && bm == 256) {
+    if (nbr) k_conv_mfma_p<256, 64, 32, true, 4><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
+    else k_conv_mfma_p<256, 64, 32, false, 4><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
+  } else if (pipe && bm == 128 && bn == 128) {
+    if (nbr) k_conv_mfma_p<128, 128, 32, true, 2><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
+    else k_conv_mfma_p<128, 128, 32, false, 2><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
+  } else if (pipe && bm == 128 && bn == 64) {
+    if (nbr) k_conv_mfma_p<128, 64, 32, true, 2><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
+    else k_conv_mfma_p<128, 64, 32, false, 2><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
+  } else if (bm == 256) {
     if (nbr) k_conv_mfma<256, 64, 32, true, 4><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
     else k_conv_mfma<256, 64, 32, false, 4><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
   } else if (bm == 128 && bn == 128) FC_LAUNCH_MFMA(128, 128);
@@ -594,7 +857,7 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
     rc = fc_conv_reg_launch(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout, S, reg_variant_for(flags, Cout), stream);
   } else {
     dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
-    rc = launch_conv_mfma(bm, bn, grid, in, W, nbr, K <= 31 ? gmask : nullptr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream);
+    rc = launch_conv_mfma(conv_pipe(flags, grid), bm, bn, grid, in, W, nbr, K <= 31 ? gmask : nullptr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream);
   }
   if (rc != FC_OK) return rc;
   return S > 1 ? sum_parts(dst, out, n_out, Cout, S, stream) : FC_OK;
@@ -668,7 +931,7 @@ int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in,
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
   if (live_tiles > 0) grid = dim3((unsigned)live_tiles, Cout / bn, 1);       // linear list of the live (offset, tile) pairs
   {
-    int rc = launch_conv_mfma(128, bn, grid, in, W, pair_in, nullptr, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream);
+    int rc = launch_conv_mfma(live_tiles > 0 ? conv_pipe(flags, grid) : (flags & (1 << 18)) != 0, 128, bn, grid, in, W, pair_in, nullptr, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream);
     if (rc != FC_OK) return rc;
   }
   k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);

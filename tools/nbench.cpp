@@ -375,6 +375,8 @@ int main(int argc, char** argv) {
               fflush(stdout);
             }
       }
+      runs.push_back({"pipe  ", 1 << 18, 0});
+      if (!cs.dense) { runs.push_back({"pipeS ", 1 << 18, 1}); runs.push_back({"pipeL ", 1 << 18, 3}); }
       if (Cout == 64) { runs.push_back({"256x64", 3 << 4, 0}); if (!cs.dense) runs.push_back({"256x64s", 3 << 4, 1}); }
       static const char* snames[] = {"S=1", "S=2", "S=3", "S=4", "S=5", "S=6", "S=7", "S=8", "S=9", "S=10", "S=12", "S=14"};
       static const int svals[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14};
