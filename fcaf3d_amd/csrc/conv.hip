@@ -1072,6 +1072,137 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const float* __restrict__
       }
 }
 
+// Deeper-pipelined weight gradient (64-channel Cin tile x BNc, 32-row chunks; same partial layout and results as
+// k_wgrad_mfma).  r2 ISA reading of the pair-list path of k_wgrad_mfma: every gout row of a chunk went through its own
+// `row index load -> s_waitcnt vmcnt(0) -> row load` chain (a bounds branch per load) — five exposed round trips in front of
+// 2 048 MFMA cycles.  Here the (input row, output row) indices of chunk t+2 are requested while chunk t+1's rows are
+// (branch-free: out-of-range rows read the zero row), and the MFMA fragments of 8-row step q+1 are read from LDS while step
+// q multiplies.  3 waves per SIMD.
+template <int BNc, bool HAS_NBR, bool PAIRS>
+__global__ __launch_bounds__(256, 3) void k_wgrad_mfma_p(const float* __restrict__ in, const float* __restrict__ gout,
+                                                          const int* __restrict__ nbr, const int* __restrict__ row_index,
+                                                          const int* __restrict__ cnt, float* __restrict__ part,
+                                                          int64_t n_out, int K, int Cin, int Cout, int64_t rows_per_split) {
+  constexpr int BMc = 64, BKR = 32;
+  constexpr int TN = BNc / 64;
+  constexpr int AR = 2, GR = BNc * BKR / 1024;   // float4 loads per thread per chunk
+  __shared__ __attribute__((aligned(16))) float As[BKR * BMc];
+  __shared__ __attribute__((aligned(16))) float Gs[BKR * BNc];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles_n = Cout / BNc, tiles_m = Cin / BMc;
+  int y = blockIdx.y;
+  const int tn = y % tiles_n; y /= tiles_n;
+  const int tm = y % tiles_m; y /= tiles_m;
+  const int k = y;
+  const int ci0 = tm * BMc, co0 = tn * BNc;
+  int64_t total = n_out;
+  if (PAIRS) {
+    total = cnt[k];
+    rows_per_split = ((total + gridDim.x - 1) / gridDim.x + BKR - 1) / BKR * BKR;
+  }
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_split;
+  int64_t r_end = r_begin + rows_per_split;
+  if (r_end > total) r_end = total;
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  if (r_begin < r_end) {
+    const int* tab_in = HAS_NBR ? nbr + (int64_t)k * n_out : nullptr;
+    const int* tab_out = PAIRS ? row_index + (int64_t)k * n_out : nullptr;
+    const int a_rr[AR] = {tid / 16, (tid + 256) / 16};
+    const int a_c4 = tid % 16;
+    int g_rr[GR];
+#pragma unroll
+    for (int i = 0; i < GR; ++i) g_rr[i] = (tid + 256 * i) / (BNc / 4);
+    const int g_c4 = tid % (BNc / 4);
+    // indices of a chunk (raw table entries; rows beyond the range are clamped here and zeroed at the row load)
+    int ia[AR], ig[GR], ian[AR], ign[GR];
+    auto fetch_idx = [&](int64_t rb, int (&va)[AR], int (&vg)[GR]) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        int64_t row = rb + a_rr[i];
+        if (row >= r_end) row = r_end - 1;
+        va[i] = HAS_NBR ? tab_in[row] : (int)row;
+      }
+#pragma unroll
+      for (int i = 0; i < GR; ++i) {
+        int64_t row = rb + g_rr[i];
+        if (row >= r_end) row = r_end - 1;
+        vg[i] = PAIRS ? tab_out[row] : (int)row;
+      }
+    };
+    f32x4 av[AR], gv[GR];
+    auto load_rows = [&](int64_t rb) {          // rows of chunk rb from the indices in ia / ig
+#pragma unroll
+      for (int i = 0; i < GR; ++i) {
+        const bool ok = rb + g_rr[i] < r_end;
+        const float* gp = ok ? gout + (int64_t)ig[i] * Cout + co0 + g_c4 * 4 : g_zero_row + (g_c4 & 15) * 4;
+        gv[i] = *reinterpret_cast<const f32x4*>(gp);
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const bool ok = rb + a_rr[i] < r_end && ia[i] >= 0;
+        const float* ap = ok ? in + (int64_t)ia[i] * Cin + ci0 + a_c4 * 4 : g_zero_row + a_c4 * 4;
+        av[i] = *reinterpret_cast<const f32x4*>(ap);
+      }
+    };
+    fetch_idx(r_begin, ia, ig);
+    fetch_idx(r_begin + BKR < r_end ? r_begin + BKR : r_begin, ian, ign);
+    load_rows(r_begin);
+    for (int64_t rb = r_begin; rb < r_end; rb += BKR) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(&As[a_rr[i] * BMc + a_c4 * 4]) = av[i];
+#pragma unroll
+      for (int i = 0; i < GR; ++i) *reinterpret_cast<f32x4*>(&Gs[g_rr[i] * BNc + g_c4 * 4]) = gv[i];
+      __syncthreads();
+      // chunk t+1: its indices arrived a chunk ago; request chunk t+2's indices, then t+1's rows (unconditional: past the
+      // end the last chunk is re-read and never used)
+      const int64_t nb = rb + BKR < r_end ? rb + BKR : rb;
+      const int64_t nnb = nb + BKR < r_end ? nb + BKR : nb;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) ia[i] = ian[i];
+#pragma unroll
+      for (int i = 0; i < GR; ++i) ig[i] = ign[i];
+      fetch_idx(nnb, ian, ign);
+      load_rows(nb);
+      float fa[2][4], fb[2][TN][4];
+      auto read_frag = [&](int q, int u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          fa[u][e] = As[(8 * q + 4 * h + e) * BMc + wr * 32 + r];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[u][j][e] = Gs[(8 * q + 4 * h + e) * BNc + wc * (BNc / 2) + j * 32 + r];
+        }
+      };
+      read_frag(0, 0);
+#pragma unroll
+      for (int q = 0; q < BKR / 8; ++q) {
+        if (q + 1 < BKR / 8) read_frag(q + 1, (q + 1) & 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][e], fb[q & 1][j][e], acc[j], 0, 0, 0);
+      }
+    }
+  }
+  float* dst = part + ((int64_t)blockIdx.x * K + k) * Cin * Cout;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = ci0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int col = co0 + wc * (BNc / 2) + j * 32 + r;
+      dst[(int64_t)row * Cout + col] = acc[j][e];
+    }
+}
+
 // Dense-table weight gradient with KO kernel offsets per workgroup sharing ONE gout chunk.  With 64 input channels the
 // one-offset kernel above moves 24 KB (8 KB gathered rows + 16 KB of gout) per 0.5 MFLOP chunk = 22 FLOP/B and sits on
 // the fabric at ~4.3 TB/s (r2 measurement: 88 TF on the 437k-row level); re-using the staged gout rows for KO = 3 offsets
@@ -1324,6 +1455,17 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     if (cnt) bm = 64;
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
     const bool deep = (flags & (1 << 19)) && bm == 64 && nbr;          // 64-row chunks (tuning flag)
+    const bool wpipe = !(flags & (1 << 16)) && bm == 64 && !(flags & (1 << 19));      // bit16: the r1 kernel (A/B switch)
+    if (wpipe && cnt) {
+      if (bn == 128) k_wgrad_mfma_p<128, true, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
+      else k_wgrad_mfma_p<64, true, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
+    } else if (wpipe && nbr) {
+      if (bn == 128) k_wgrad_mfma_p<128, true, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
+      else k_wgrad_mfma_p<64, true, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
+    } else if (wpipe) {
+      if (bn == 128) k_wgrad_mfma_p<128, false, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
+      else k_wgrad_mfma_p<64, false, false><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
+    } else
     if (cnt) {
       if (bn == 128) k_wgrad_mfma<64, 128, true, 32, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
       else k_wgrad_mfma<64, 64, true, 32, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);

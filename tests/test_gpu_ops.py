@@ -175,7 +175,12 @@ def test_conv_mfma_large_tiles(Cin, Cout):
                                         (2 << 24, 'register-direct 64x64, one tile per wave'),
                                         (3 << 24, 'register-direct 32x128'), (4 << 24, 'register-direct 64x128'),
                                         (5 << 24, 'register-direct 32x64'), (1 << 28, 'register-direct weight gradient'),
-                                        (3 << 4, '256x64 LDS tile (4x1 waves)'), (1 << 29, 'one-offset dense weight gradient')])
+                                        (3 << 4, '256x64 LDS tile (4x1 waves)'), (1 << 29, 'one-offset dense weight gradient'),
+                                        (1 << 18, 'deeper-pipelined LDS kernel forced on'),
+                                        ((1 << 18) | (2 << 4), 'deeper-pipelined LDS kernel, 128-row tiles'),
+                                        ((1 << 18) | (3 << 4), 'deeper-pipelined LDS kernel, 256x64 tiles'),
+                                        (1 << 17, 'r1 LDS kernel forced'), (1 << 16, 'r1 weight-gradient kernel'),
+                                        ((1 << 16) | (1 << 29), 'r1 weight-gradient kernel, one offset per workgroup')])
 def test_conv_kernel_variants_behind_flags(flags, what):
     """every flag-selected kernel variant (conv.hip / conv_reg.hip; the defaults are chosen by measurement) against the oracle,
     forward + backward-data + backward-weights, on a strided and an unstrided map"""
