@@ -1455,7 +1455,9 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     if (cnt) bm = 64;
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
     const bool deep = (flags & (1 << 19)) && bm == 64 && nbr;          // 64-row chunks (tuning flag)
-    const bool wpipe = !(flags & (1 << 16)) && bm == 64 && !(flags & (1 << 19));      // bit16: the r1 kernel (A/B switch)
+    // k_wgrad_mfma_p where it measured ahead (r2 nbench, same box: pair lists with 128-wide gout tiles +3..7 %; 64-wide
+    // tiles -5 %, dense tables -7..13 %).  bit16: never, bit20: wherever it applies (tests / A-B).
+    const bool wpipe = bm == 64 && !(flags & (1 << 19)) && !(flags & (1 << 16)) && ((flags & (1 << 20)) || (cnt && bn == 128));
     if (wpipe && cnt) {
       if (bn == 128) k_wgrad_mfma_p<128, true, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
       else k_wgrad_mfma_p<64, true, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
