@@ -508,6 +508,237 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_p(const float* __restrict_
   TR_FLUSH(tr_units);
 }
 
+// LDS-DMA variant (r2; VERDICT r1 item 1a — double-buffered LDS, one barrier per stage): the gathered rows and the weight slab go
+// from global memory STRAIGHT into LDS (`global_load_lds_dwordx4`, 1 KiB per wave instruction: 8 gathered rows x 128 B, or
+// 1 KiB of a weight slab), no staging registers and no ds_write pass, into one of TWO stage buffers; a stage is
+//     wait for my own DMAs -> barrier -> issue stage s+1's DMAs into the other buffer -> multiply stage s.
+// The DMA's LDS image is lane-linear (wave-uniform base + lane x 16 B: MI355X guide), so the A tile cannot be padded; its
+// rows are XOR-swizzled instead ON THE SOURCE SIDE: the lane that fills 16-byte slot p of row j fetches the row's slot
+// p ^ ((j >> 1) & 7), and the MFMA fragment read of slot c of row j addresses slot c ^ ((j >> 1) & 7) — conflict-free for
+// ds_read_b128's 16-lane groups.  Same tiles, prologue, epilogue, grid shapes and results as k_conv_mfma / _p.
+template <int BM, int BN, bool HAS_NBR, int WM = 2>
+__global__ __launch_bounds__(256, 2) void k_conv_glds(const float* __restrict__ in, const float* __restrict__ W,
+                                                      const int* __restrict__ nbr, const unsigned int* __restrict__ gmask,
+                                                      const int* __restrict__ out_index, const int* __restrict__ cnt,
+                                                      float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout) {
+  constexpr int BKT = 32;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int RW = BM / WM, CW = BN / WN;
+  constexpr int AR = BM / 32;                    // row DMAs per thread per stage (8 rows per wave instruction)
+  constexpr int BR = BN / 32;                    // weight DMAs per thread per stage
+  constexpr int BRPI = 256 / BN;                 // weight-slab rows per wave instruction
+  constexpr int STAGE = BM * BKT + BKT * BN;     // floats per stage buffer
+  __shared__ __attribute__((aligned(1024))) float smem[2 * STAGE];         // ONE array (a second one costs vmcnt(0)s: guide §5)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = WM == 4 ? wave : wave >> 1, wc = WM == 4 ? 0 : wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int64_t bx = blockIdx.x;
+  const int n0 = blockIdx.y * BN;
+  int S = gridDim.z, z = blockIdx.z;
+  if (cnt) {                                     // pair mode: see k_conv_mfma_p
+    if (gridDim.z == 1 && K > 1) {
+      int k = 0;
+      for (; k < K - 1; ++k) {
+        const int64_t t = ((int64_t)cnt[k] + BM - 1) / BM;
+        if (bx < t) break;
+        bx -= t;
+      }
+      z = k;
+    }
+    const int64_t stride = n_out;
+    n_out = cnt[z];
+    if (bx * BM >= n_out) return;
+    nbr += (int64_t)z * stride;
+    W += (int64_t)z * Cin * Cout;
+    out += (int64_t)z * stride * Cout;
+    K = 1; S = 1; z = 0;
+  }
+  const int64_t m0 = bx * BM;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  unsigned int kmask;
+  if (HAS_NBR && gmask && !cnt) {
+    unsigned int mk = 0u;
+#pragma unroll
+    for (int g = 0; g < BM / 32; ++g)
+      if (m0 + g * 32 < n_out) mk |= gmask[m0 / 32 + g];
+    unsigned int zm = 0u;
+    for (int k = z; k < K; k += S) zm |= 1u << k;
+    kmask = mk & zm;
+  } else {
+    // the tile-mask word lives in stage buffer 1: nothing is written there before every wave has passed stage 0's barrier
+    unsigned int* kmask_s = reinterpret_cast<unsigned int*>(&smem[STAGE]);
+    if (tid == 0) *kmask_s = 0u;
+    __syncthreads();
+    if (tid < BM) {
+      unsigned int mk = 0u;
+      int64_t row = m0 + tid;
+      if (row < n_out) {
+        if (HAS_NBR) {
+          for (int k = z; k < K; k += S)
+            if (nbr[(int64_t)k * n_out + row] >= 0) mk |= 1u << k;
+        } else {
+          mk = 1u;
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) mk |= __shfl_xor(mk, off, 64);
+      if (lane == 0 && mk) atomicOr(kmask_s, mk);
+    }
+    __syncthreads();
+    kmask = *kmask_s;
+  }
+
+  if (kmask) {
+    const int nst = __popc(kmask) * (Cin / BKT);
+    unsigned int rem = kmask;
+    int lk = __ffs(rem) - 1;
+    rem &= rem - 1;
+    int lnk = rem ? __ffs(rem) - 1 : lk;
+    if (rem) rem &= rem - 1;
+    int lc0 = 0;
+    bool sw = false;
+    // this lane's part of a row DMA: row (i*4 + wave)*8 + lane/8 of the tile, LDS slot lane%8, source slot swizzled
+    const int a_j = lane >> 3;
+    int vcur[AR], vnxt[AR], a_src4[AR];
+    int64_t arow[AR];
+    bool aok[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int lrow = (i * 4 + wave) * 8 + a_j;
+      const int64_t row = m0 + lrow;
+      aok[i] = row < n_out;
+      arow[i] = aok[i] ? row : n_out - 1;
+      a_src4[i] = (((lane & 7) ^ ((lrow >> 1) & 7))) * 4;
+    }
+    auto fetch_idx = [&](int kk, int (&v)[AR]) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) v[i] = HAS_NBR ? nbr[(int64_t)kk * n_out + arow[i]] : (int)arow[i];
+    };
+    fetch_idx(lk, vcur);
+    fetch_idx(lnk, vnxt);
+    const int b_kr = lane / (BN / 4), b_c4 = lane % (BN / 4);
+    auto issue_stage = [&](int buf) {
+      if (sw) {
+        sw = false;
+        lk = lnk;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) vcur[i] = vnxt[i];
+        if (rem) {
+          lnk = __ffs(rem) - 1;
+          rem &= rem - 1;
+        }
+        fetch_idx(lnk, vnxt);
+      }
+      float* As = smem + buf * STAGE;
+      float* Bs = As + BM * BKT;
+      const float* Wk = W + (int64_t)lk * Cin * Cout;
+      // every source address first (this consumes the index registers: hipcc waits vmcnt(0) at the first use of an ordinary
+      // load's result while a DMA is in flight — here nothing is, the loop-top wait has just drained the queue), then the
+      // DMAs back to back
+      const float* asrc[AR];
+      const float* bsrc[BR];
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const bool ok = vcur[i] >= 0 && aok[i];
+        const int64_t off = ok ? (int64_t)vcur[i] * Cin + lc0 : 0;
+        asrc[i] = (ok ? in : g_zero_row) + off + a_src4[i];
+      }
+#pragma unroll
+      for (int i = 0; i < BR; ++i) bsrc[i] = Wk + (int64_t)(lc0 + (i * 4 + wave) * BRPI + b_kr) * Cout + n0 + b_c4 * 4;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < BR; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bsrc[i],
+                                         (__attribute__((address_space(3))) void*)(Bs + (i * 4 + wave) * BRPI * BN), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)asrc[i],
+                                         (__attribute__((address_space(3))) void*)(As + (i * 4 + wave) * 8 * BKT), 16, 0, 0);
+    };
+    issue_stage(0);
+    const int fsw = (r >> 1) & 7;                // the fragment rows' swizzle (tile row = 32-aligned base + r)
+    for (int st = 0; st < nst; ++st) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my DMAs of stage st have landed ...
+      __syncthreads();                                      // ... and everyone's; stage st-1 is fully consumed
+      if (st + 1 < nst) {
+        lc0 += BKT;
+        if (lc0 >= Cin) {
+          lc0 = 0;
+          sw = true;
+        }
+        issue_stage((st + 1) & 1);
+      }
+      const float* As = smem + (st & 1) * STAGE;
+      const float* Bs = As + BM * BKT;
+      f32x4 fa[2][TM];
+      float fb[2][TN][4];
+      auto read_frag = [&](int q, int u) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[u][i] = *reinterpret_cast<const f32x4*>(&As[(wr * RW + i * 32 + r) * BKT + 4 * ((2 * q + h) ^ fsw)]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (TN == 2) {
+            const f32x2 bb = *reinterpret_cast<const f32x2*>(&Bs[(8 * q + 4 * h + e) * BN + wc * CW + 2 * r]);
+            fb[u][0][e] = bb[0];
+            fb[u][TN - 1][e] = bb[1];
+          } else {
+            fb[u][0][e] = Bs[(8 * q + 4 * h + e) * BN + wc * CW + r];
+          }
+        }
+      };
+      read_frag(0, 0);
+#pragma unroll
+      for (int q = 0; q < BKT / 8; ++q) {
+        if (q + 1 < BKT / 8) read_frag(q + 1, (q + 1) & 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float ae = fa[q & 1][i][e];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, fb[q & 1][j][e], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  float* dst = out + (int64_t)z * n_out * Cout + n0 + wc * CW + TN * r;
+  int orow[TM][16];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = m0 + wr * RW + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      int o = -1;
+      if (row < n_out) o = out_index ? out_index[row] : (int)row;
+      orow[i][e] = o;
+    }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (orow[i][e] >= 0) {
+        if (TN == 2) {
+          f32x2 v = {acc[i][0][e], acc[i][TN - 1][e]};
+          *reinterpret_cast<f32x2*>(dst + (int64_t)orow[i][e] * Cout) = v;
+        } else {
+          dst[(int64_t)orow[i][e] * Cout] = acc[i][0][e];
+        }
+      }
+    }
+}
+
 // out[i] = sum_z part[z][i]   (fixed order; elems % 4 == 0)
 __global__ void k_sum_parts(const float* __restrict__ part, float* __restrict__ out, int64_t elems4, int S) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -725,11 +956,16 @@ extern "C" {
 // wins on launches of many rounds and on launches that fit 768 slots anyway, and loses a round in between (r2: +5.5 / +7 %
 // on the 441k / 55k-row levels, +5 % on the 862-row pair mode, -12 % on the 3.5k-row pair mode with its 972 workgroups).
 // flags bit18 forces it on, bit17 off.
-static inline bool conv_pipe(int flags, dim3 grid) {
-  if (flags & (1 << 18)) return true;
-  if (flags & (1 << 17)) return false;
+// flags bit21: the LDS-DMA kernel (k_conv_glds, 2 workgroups per CU) instead.  Returns 0 / 1 / 2 = k_conv_mfma / _p / k_conv_glds.
+static inline int conv_pipe(int flags, dim3 grid) {
+  if (flags & (1 << 21)) return 2;
+  if (flags & (1 << 18)) return 1;
+  if (flags & (1 << 17)) return 0;
   const int64_t wgs = (int64_t)grid.x * grid.y * grid.z;
-  return wgs >= 1536 || wgs <= 768;
+  if (wgs >= 1536 || wgs <= 768) return 1;
+  // in between: offset-split launches of a dense table go to the LDS-DMA kernel (r2 nbench, same box: 6.9k rows 256->256
+  // 251 -> 232 us, 256->128 139 -> 128 us, 14.9k rows 128->128 163 -> 146 us; unsplit and pair-list launches: neutral)
+  return (grid.z > 1 && !(flags & (1 << 22))) ? 2 : 0;
 }
 static inline int reg_variant_for(int flags, int Cout) {
   int rv = FC_REG_VARIANT(flags);
@@ -782,7 +1018,7 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
 
 // one launch of the LDS-tiled MFMA kernel (32-deep slabs; measured r1: 64-deep slabs, 256-row tiles, an LDS index table
 // and LDS-padding occupancy caps all lose or are neutral — profiles/r1_conv_pmc.md — and were removed in r2)
-static int launch_conv_mfma(bool pipe, int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr, const unsigned int* gmask,
+static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr, const unsigned int* gmask,
                             const int* out_index, const int* cnt, float* dst, int64_t n_rows, int K, int Cin, int Cout,
                             hipStream_t stream) {
 #define FC_LAUNCH_MFMA(BM_, BN_)                                                                                              \
@@ -790,7 +1026,17 @@ static int launch_conv_mfma(bool pipe, int bm, int bn, dim3 grid, const float* i
     if (nbr) k_conv_mfma<BM_, BN_, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);  \
     else k_conv_mfma<BM_, BN_, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);     \
   } while (0)
-  if (pipe && bm == 256) {
+  if (pipe == 2 && bm >= 128) {
+#define FC_LAUNCH_GLDS(BM_, BN_, WM_)                                                                                         \
+  do {                                                                                                                        \
+    if (nbr) k_conv_glds<BM_, BN_, true, WM_><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);  \
+    else k_conv_glds<BM_, BN_, false, WM_><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);     \
+  } while (0)
+    if (bm == 256) FC_LAUNCH_GLDS(256, 64, 4);
+    else if (bn == 128) FC_LAUNCH_GLDS(128, 128, 2);
+    else FC_LAUNCH_GLDS(128, 64, 2);
+#undef FC_LAUNCH_GLDS
+  } else if (pipe && bm == 256) {
     if (nbr) k_conv_mfma_p<256, 64, 32, true, 4><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
     else k_conv_mfma_p<256, 64, 32, false, 4><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
   } else if (pipe && bm == 128 && bn == 128) {
@@ -931,7 +1177,7 @@ int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in,
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
   if (live_tiles > 0) grid = dim3((unsigned)live_tiles, Cout / bn, 1);       // linear list of the live (offset, tile) pairs
   {
-    int rc = launch_conv_mfma(live_tiles > 0 ? conv_pipe(flags, grid) : (flags & (1 << 18)) != 0, 128, bn, grid, in, W, pair_in, nullptr, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream);
+    int rc = launch_conv_mfma(live_tiles > 0 ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream);
     if (rc != FC_OK) return rc;
   }
   k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);

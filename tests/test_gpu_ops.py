@@ -179,6 +179,8 @@ def test_conv_mfma_large_tiles(Cin, Cout):
                                         (1 << 18, 'deeper-pipelined LDS kernel forced on'),
                                         ((1 << 18) | (2 << 4), 'deeper-pipelined LDS kernel, 128-row tiles'),
                                         ((1 << 18) | (3 << 4), 'deeper-pipelined LDS kernel, 256x64 tiles'),
+                                        (1 << 21, 'LDS-DMA kernel (global_load_lds, two stage buffers)'),
+                                        ((1 << 21) | (3 << 4), 'LDS-DMA kernel, 256x64 tiles'),
                                         (1 << 17, 'r1 LDS kernel forced'), (1 << 16, 'r1 weight-gradient kernel'),
                                         (1 << 20, 'pipelined weight-gradient kernel wherever it applies'),
                                         ((1 << 16) | (1 << 29), 'r1 weight-gradient kernel, one offset per workgroup')])

@@ -378,6 +378,9 @@ int main(int argc, char** argv) {
       runs.push_back({"pipe  ", 1 << 18, 0});
       if (!cs.dense) { runs.push_back({"pipeS ", 1 << 18, 1}); runs.push_back({"pipeL ", 1 << 18, 3}); }
       if (Cout == 64) { runs.push_back({"256x64", 3 << 4, 0}); if (!cs.dense) runs.push_back({"256x64s", 3 << 4, 1}); }
+      runs.push_back({"glds  ", 1 << 21, 0});
+      if (!cs.dense) { runs.push_back({"gldsS ", 1 << 21, 1}); runs.push_back({"gldsL ", 1 << 21, 3}); }
+      if (Cout == 64) { runs.push_back({"glds256", (1 << 21) | (3 << 4), 0}); runs.push_back({"glds128", (1 << 21) | (2 << 4), 0}); }
       static const char* snames[] = {"S=1", "S=2", "S=3", "S=4", "S=5", "S=6", "S=7", "S=8", "S=9", "S=10", "S=12", "S=14"};
       static const int svals[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14};
       if (s_sweep) for (int q = 0; q < 12; ++q) runs.push_back({snames[q], svals[q] << 8, cs.dense ? 0 : 1});
