@@ -57,6 +57,8 @@ def lib():
             fn.restype = ret
             fn.argtypes = [t for _, t in args]
         _lib = l
+        if os.environ.get('FC_PRIO_OFF'):        # A/B switch of the MFMA-block wave priority (conv.hip: g_fc_prio); tuning only
+            l.fc_debug_set_prio(-1)
     return _lib
 
 

@@ -33,6 +33,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: str
 
 __device__ __attribute__((aligned(16))) float g_zero_row[64];   // what an absent neighbour gathers from (BKT <= 64 floats)
 
+// Wave priority around the MFMA block of a stage (s_setprio 1 ... 0): a wave that is multiplying goes ahead of the waves
+// that are staging, so the resident waves of a SIMD drift apart instead of all meeting their barriers together.  r2,
+// same box, instruction-identical otherwise: +2.4...3.4 % on the 441k-row launches, +3 % on the 64k-row level, +4 % on
+// the 3.5k-row pair mode, +1...4 % on k_wgrad_multi; the one-offset weight-gradient kernels LOSE 2...7 % and the LDS-DMA
+// kernel up to 9 %, so those stay at priority 0.  Static per-workgroup priorities (by block index, by hardware wave slot):
+// +1 % or -10 %.  g_fc_prio = -1 switches it off (A/B: tools/nbench --prio -1, FC_PRIO_OFF=1; not a C-ABI entry point).
+__device__ int g_fc_prio;
+extern "C" int fc_debug_set_prio(int mode) {
+  FC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fc_prio), &mode, sizeof(mode)));
+  return FC_OK;
+}
+
 #define BK 32            // reduction slab (input channels per stage / rows per stage for wgrad)
 #define LDA (BK + 4)     // A row stride in floats: 16B-aligned rows, conflict-free ds_read_b128 (9r mod 16)
 
@@ -174,6 +186,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (W
       }
     };
     load_stage(k, c0);
+    const bool prio = g_fc_prio >= 0;             // see g_fc_prio
     while (true) {
 #ifdef FC_TRACE
       if (tr_units == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TR(2); }
@@ -200,6 +213,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (W
       // unconditional (the last iteration re-reads its own stage): a conditionally assigned float4 array is not
       // promoted to registers by the compiler and lands in scratch
       load_stage(nk >= 0 ? nk : k, nk >= 0 ? nc0 : c0);
+      if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int q = 0; q < BKT / 8; ++q) {
         f32x4 a[TM];
@@ -229,6 +243,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (W
           }
         }
       }
+      if (prio) __builtin_amdgcn_s_setprio(0);
       if (nk < 0) break;
       k = nk;
       c0 = nc0;
@@ -419,6 +434,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_p(const float* __restrict_
       }
     };
     load_stage();
+    const bool prio = g_fc_prio >= 0;
     for (int st = 0; st < nst; ++st) {
 #ifdef FC_TRACE
       if (tr_units == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TR(2); }
@@ -463,6 +479,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_p(const float* __restrict_
         }
       };
       read_frag(0, 0);
+      if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int q = 0; q < BKT / 8; ++q) {
         if (q + 1 < BKT / 8) read_frag(q + 1, (q + 1) & 1);
@@ -476,6 +493,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_p(const float* __restrict_
           }
         }
       }
+      if (prio) __builtin_amdgcn_s_setprio(0);
     }
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -1514,6 +1532,7 @@ __global__ __launch_bounds__(256, (BNc == 128) ? 2 : 3) void k_wgrad_multi(const
       }
   };
   if (r_begin < r_end) load_chunk(r_begin);
+  const bool prio = g_fc_prio >= 0;               // see g_fc_prio
   for (int64_t rb = r_begin; rb < r_end; rb += 32) {
     __syncthreads();
 #pragma unroll
@@ -1530,6 +1549,7 @@ __global__ __launch_bounds__(256, (BNc == 128) ? 2 : 3) void k_wgrad_multi(const
     }
     __syncthreads();
     load_chunk(rb + 32 < r_end ? rb + 32 : rb);            // unconditional (see k_conv_mfma)
+    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float b[TN][4];
@@ -1548,6 +1568,7 @@ __global__ __launch_bounds__(256, (BNc == 128) ? 2 : 3) void k_wgrad_multi(const
           for (int j = 0; j < TN; ++j) acc[o][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[j][e], acc[o][j], 0, 0, 0);
       }
     }
+    if (prio) __builtin_amdgcn_s_setprio(0);
   }
 #pragma unroll
   for (int o = 0; o < KO; ++o) {

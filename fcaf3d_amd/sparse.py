@@ -9,6 +9,7 @@ oracle's, so parity is checked row for row.
 import itertools
 import os
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -166,7 +167,7 @@ class KernelMap:
         """sum_k ceil(cnt[k] / 128): the non-empty (offset, 128-row tile) workgroups of the per-offset convolution.  One small
         read-back per map, on the coordinate stream (where the other data-dependent sizes are read too): the launch then
         holds live workgroups only (fc_conv_fwd_pairs_tiles; +20...35 % on the deep levels, r2)."""
-        return int(((cnt.to(torch.int64) + 127) // 128).sum().item())
+        return int(((cnt.cpu().numpy().astype(np.int64) + 127) // 128).sum())      # ONE device op: the 27-int read-back
 
     def pairs(self):
         """(pair_in, pair_out, pair_pos, cnt): per offset, the (input row, output row) pairs in ascending output row,

@@ -147,7 +147,9 @@ static double max_rel_err(const std::vector<float>& a, const std::vector<float>&
   return md / (mx > 0 ? mx : 1);
 }
 
+extern "C" int fc_debug_set_prio(int mode);
 int main(int argc, char** argv) {
+  int prio = 0;
   int batch = 8, reps = 10, npts = 100000; std::string only, mode = "all", trace_file; bool check = true;
   int trace_variant = 1, trace_tbl = 0; bool stream_sweep = false, popc_sort = false, s_sweep = false;
   std::vector<int> variants = {0, 1, 2, 3, 4, 5};
@@ -159,6 +161,7 @@ int main(int argc, char** argv) {
     else if (a == "--only") only = argv[++i];
     else if (a == "--mode") mode = argv[++i];
     else if (a == "--no-check") check = false;
+    else if (a == "--prio") prio = atoi(argv[++i]);
     else if (a == "--stream-sweep") stream_sweep = true;
     else if (a == "--popc-sort") popc_sort = true;
     else if (a == "--s-sweep") s_sweep = true;
@@ -186,6 +189,7 @@ int main(int argc, char** argv) {
   };
   std::mt19937 rng(7);
   std::normal_distribution<float> Nf(0.f, 1.f);
+  if (prio) { FC(fc_debug_set_prio(prio)); printf("# wave-priority experiment mode %d\n", prio); }
   if (mode == "density") {            // host only: MFMA work issued by a dense table at G-row skip granularity / exact pair work
     for (const Case& cs : cases) {
       if (!only.empty() && cs.name.find(only) == std::string::npos) continue;
