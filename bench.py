@@ -31,8 +31,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step (reference samples_per_gpu=8)')
     ap.add_argument('--workload', default='scannet-100k', choices=['plumbing-20k', 'scannet-100k', 'sunrgbd-100k', 's3dis-500k'])
     ap.add_argument('--voxel-size', type=float, default=0.02)
@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-points', type=int, default=0, help='points of the cpu_baseline sample scene (0 = same as workload)')
     ap.add_argument('--no-instrument', action='store_true', help='skip per-kernel HIP events (roofline = null)')
-    ap.add_argument('--probe-every', type=int, default=4, help='HIP events bracket the conv launches of every n-th timed step '
+    ap.add_argument('--probe-every', type=int, default=11, help='HIP events bracket the conv launches of every n-th timed step '
                     '(each event pair is a pipeline bubble: sampling keeps the probe from slowing the thing it measures)')
     ap.add_argument('--spatial-sort', action='store_true', help='Z-order sort of the collated points (measured: no gain, r1)')
     ap.add_argument('--no-wgrad-overlap', action='store_true', help='keep the weight-gradient kernels on the main stream (default: a second '

@@ -58,7 +58,11 @@ extern "C" int fc_debug_set_prio(int mode) {
 // row count cannot fill the chip; partial tiles go to `out` + z*n_out*Cout and are summed by k_sum_parts.
 // WM = waves along the rows (2: 2 x 2 waves; 4: 4 x 1 — the 256 x 64 tile for 64-wide outputs: every wave still owns a
 // 64 x 64 quadrant, i.e. the operand re-use of the 128 x 128 tile, where a 128 x 64 tile halves it).
-template <int BM, int BN, int BKT, bool HAS_NBR, int WM = 2>
+// WT: the weights are given TRANSPOSED, W[k] as (Cout, Cin) row-major — the backward-data pass reads the layer's own
+// (K, Cin, Cout) kernel as the (Cout -> Cin) operator it needs, no per-step transpose launch.  Only the staging differs:
+// a thread loads 4 reduction-consecutive floats of one output column and stores them as 4 ds_write_b32 (conflict-free:
+// consecutive lanes = consecutive columns); the LDS image, the fragment reads and the results are the same.
+template <int BM, int BN, int BKT, bool HAS_NBR, int WM = 2, bool WT = false>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (WM == 4 ? 3 : 2)) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
                                                    const int* __restrict__ nbr, const unsigned int* __restrict__ gmask,
                                                    const int* __restrict__ out_index, const int* __restrict__ cnt,
@@ -176,8 +180,12 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (W
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         int lin = tid + 256 * i;
-        int kr = lin / (BN / 4), c4 = lin % (BN / 4);
-        bv[i] = *reinterpret_cast<const f32x4*>(Wk + (int64_t)(cc + kr) * Cout + n0 + c4 * 4);
+        if (WT) {
+          bv[i] = *reinterpret_cast<const f32x4*>(Wk + (int64_t)(n0 + lin % BN) * Cin + cc + (lin / BN) * 4);
+        } else {
+          int kr = lin / (BN / 4), c4 = lin % (BN / 4);
+          bv[i] = *reinterpret_cast<const f32x4*>(Wk + (int64_t)(cc + kr) * Cout + n0 + c4 * 4);
+        }
       }
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
@@ -199,8 +207,13 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (W
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         int lin = tid + 256 * i;
-        int kr = lin / (BN / 4), c4 = lin % (BN / 4);
-        *reinterpret_cast<f32x4*>(&Bs[kr * BN + c4 * 4]) = bv[i];
+        if (WT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Bs[((lin / BN) * 4 + e) * BN + lin % BN] = bv[i][e];
+        } else {
+          int kr = lin / (BN / 4), c4 = lin % (BN / 4);
+          *reinterpret_cast<f32x4*>(&Bs[kr * BN + c4 * 4]) = bv[i];
+        }
       }
       __syncthreads();
       // issue the next stage's global loads before computing this one
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (W
 //    room for the look-ahead — r1 dead end);
 //  * the MFMA fragments of 8-channel step q+1 are read from LDS while step q multiplies (double-buffered fragment
 //    registers) instead of read -> s_waitcnt lgkmcnt(0) -> multiply.
-template <int BM, int BN, int BKT, bool HAS_NBR, int WM = 2>
+template <int BM, int BN, int BKT, bool HAS_NBR, int WM = 2, bool WT = false>
 __global__ __launch_bounds__(256, 3) void k_conv_mfma_p(const float* __restrict__ in, const float* __restrict__ W,
                                                    const int* __restrict__ nbr, const unsigned int* __restrict__ gmask,
                                                    const int* __restrict__ out_index, const int* __restrict__ cnt,
@@ -424,8 +437,12 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_p(const float* __restrict_
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         int lin = tid + 256 * i;
-        int kr = lin / (BN / 4), c4 = lin % (BN / 4);
-        bv[i] = *reinterpret_cast<const f32x4*>(Wk + (int64_t)(lc0 + kr) * Cout + n0 + c4 * 4);
+        if (WT) {
+          bv[i] = *reinterpret_cast<const f32x4*>(Wk + (int64_t)(n0 + lin % BN) * Cin + lc0 + (lin / BN) * 4);
+        } else {
+          int kr = lin / (BN / 4), c4 = lin % (BN / 4);
+          bv[i] = *reinterpret_cast<const f32x4*>(Wk + (int64_t)(lc0 + kr) * Cout + n0 + c4 * 4);
+        }
       }
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
@@ -447,8 +464,13 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_p(const float* __restrict_
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         int lin = tid + 256 * i;
-        int kr = lin / (BN / 4), c4 = lin % (BN / 4);
-        *reinterpret_cast<f32x4*>(&Bs[kr * BN + c4 * 4]) = bv[i];
+        if (WT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Bs[((lin / BN) * 4 + e) * BN + lin % BN] = bv[i][e];
+        } else {
+          int kr = lin / (BN / 4), c4 = lin % (BN / 4);
+          *reinterpret_cast<f32x4*>(&Bs[kr * BN + c4 * 4]) = bv[i];
+        }
       }
       __syncthreads();
       // request the next stage before multiplying this one (the last iteration re-reads its own stage: a conditionally
@@ -949,7 +971,7 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ in
 // generic fallback (any Cin/Cout): one thread per (row, cout).  Used for the Cin=3 stem and as the
 // cross-check path of the parity tests (flags & 1).
 __global__ void k_conv_fma(const float* __restrict__ in, const float* __restrict__ W, const int* __restrict__ nbr,
-                           float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout) {
+                           float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout, int wt) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_out * Cout) return;
   int64_t o = t / Cout;
@@ -959,8 +981,9 @@ __global__ void k_conv_fma(const float* __restrict__ in, const float* __restrict
     int i = nbr ? nbr[(int64_t)k * n_out + o] : (int)o;
     if (i < 0) continue;
     const float* x = in + (int64_t)i * Cin;
-    const float* w = W + (int64_t)k * Cin * Cout + co;
-    for (int ci = 0; ci < Cin; ++ci) acc = fmaf(x[ci], w[(int64_t)ci * Cout], acc);
+    const float* w = W + (int64_t)k * Cin * Cout + (wt ? (int64_t)co * Cin : co);
+    const int64_t ws = wt ? 1 : Cout;             // wt: W[k] stored (Cout, Cin)
+    for (int ci = 0; ci < Cin; ++ci) acc = fmaf(x[ci], w[ci * ws], acc);
   }
   out[t] = acc;
 }
@@ -968,6 +991,7 @@ __global__ void k_conv_fma(const float* __restrict__ in, const float* __restrict
 extern "C" {
 
 // flags[24:27]: register-direct kernel variant (conv_reg.h), 0 = LDS-tiled kernel; flags bit28: register-direct wgrad
+#define FC_CONV_WT (1 << 23)   // fc_conv_fwd / fc_conv_fwd_pairs(_tiles): W[k] is stored transposed, (Cout, Cin) row-major
 #define FC_REG_VARIANT(flags) (((flags) >> 24) & 15)
 #define FC_REG_WGRAD(flags) (((flags) >> 28) & 1)
 // The deeper-pipelined LDS kernel (k_conv_mfma_p) holds 3 workgroups per CU (768 slots) where k_conv_mfma holds 4 (1024): it
@@ -1038,45 +1062,42 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
 // and LDS-padding occupancy caps all lose or are neutral — profiles/r1_conv_pmc.md — and were removed in r2)
 static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr, const unsigned int* gmask,
                             const int* out_index, const int* cnt, float* dst, int64_t n_rows, int K, int Cin, int Cout,
-                            hipStream_t stream) {
-#define FC_LAUNCH_MFMA(BM_, BN_)                                                                                              \
-  do {                                                                                                                        \
-    if (nbr) k_conv_mfma<BM_, BN_, 32, true><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);  \
-    else k_conv_mfma<BM_, BN_, 32, false><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);     \
+                            hipStream_t stream, bool wt = false) {
+#define FC_ARGS <<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout)
+#define FC_LAUNCH_MFMA(KERNEL, BM_, BN_, WM_)                                    \
+  do {                                                                           \
+    if (wt) KERNEL<BM_, BN_, 32, true, WM_, true> FC_ARGS;                        \
+    else if (nbr) KERNEL<BM_, BN_, 32, true, WM_> FC_ARGS;                        \
+    else KERNEL<BM_, BN_, 32, false, WM_> FC_ARGS;                                \
   } while (0)
+#define FC_LAUNCH_GLDS(BM_, BN_, WM_)                                            \
+  do {                                                                           \
+    if (nbr) k_conv_glds<BM_, BN_, true, WM_> FC_ARGS;                            \
+    else k_conv_glds<BM_, BN_, false, WM_> FC_ARGS;                               \
+  } while (0)
+  if (wt && !nbr) return FC_EINVAL;              // transposed weights: neighbour-table / pair-list launches only
+  if (wt && pipe == 2) pipe = 0;                 // the LDS-DMA image cannot be transposed in flight
   if (pipe == 2 && bm >= 128) {
-#define FC_LAUNCH_GLDS(BM_, BN_, WM_)                                                                                         \
-  do {                                                                                                                        \
-    if (nbr) k_conv_glds<BM_, BN_, true, WM_><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);  \
-    else k_conv_glds<BM_, BN_, false, WM_><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);     \
-  } while (0)
     if (bm == 256) FC_LAUNCH_GLDS(256, 64, 4);
     else if (bn == 128) FC_LAUNCH_GLDS(128, 128, 2);
     else FC_LAUNCH_GLDS(128, 64, 2);
+  } else if (pipe && bm == 256) FC_LAUNCH_MFMA(k_conv_mfma_p, 256, 64, 4);
+  else if (pipe && bm == 128 && bn == 128) FC_LAUNCH_MFMA(k_conv_mfma_p, 128, 128, 2);
+  else if (pipe && bm == 128 && bn == 64) FC_LAUNCH_MFMA(k_conv_mfma_p, 128, 64, 2);
+  else if (bm == 256) FC_LAUNCH_MFMA(k_conv_mfma, 256, 64, 4);
+  else if (bm == 128 && bn == 128) FC_LAUNCH_MFMA(k_conv_mfma, 128, 128, 2);
+  else if (bm == 128) FC_LAUNCH_MFMA(k_conv_mfma, 128, 64, 2);
+  else if (bn == 128) FC_LAUNCH_MFMA(k_conv_mfma, 64, 128, 2);
+  else FC_LAUNCH_MFMA(k_conv_mfma, 64, 64, 2);
 #undef FC_LAUNCH_GLDS
-  } else if (pipe && bm == 256) {
-    if (nbr) k_conv_mfma_p<256, 64, 32, true, 4><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
-    else k_conv_mfma_p<256, 64, 32, false, 4><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
-  } else if (pipe && bm == 128 && bn == 128) {
-    if (nbr) k_conv_mfma_p<128, 128, 32, true, 2><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
-    else k_conv_mfma_p<128, 128, 32, false, 2><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
-  } else if (pipe && bm == 128 && bn == 64) {
-    if (nbr) k_conv_mfma_p<128, 64, 32, true, 2><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
-    else k_conv_mfma_p<128, 64, 32, false, 2><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
-  } else if (bm == 256) {
-    if (nbr) k_conv_mfma<256, 64, 32, true, 4><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
-    else k_conv_mfma<256, 64, 32, false, 4><<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout);
-  } else if (bm == 128 && bn == 128) FC_LAUNCH_MFMA(128, 128);
-  else if (bm == 128) FC_LAUNCH_MFMA(128, 64);
-  else if (bn == 128) FC_LAUNCH_MFMA(64, 128);
-  else FC_LAUNCH_MFMA(64, 64);
 #undef FC_LAUNCH_MFMA
+#undef FC_ARGS
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
 
 static inline bool is_stem(const int* nbr, int K, int Cin, int Cout, int flags) {
-  return !(flags & 1) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27;
+  return !(flags & 1) && !(flags & FC_CONV_WT) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27;
 }
 
 int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags) {
@@ -1106,11 +1127,13 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
+  const bool wt = (flags & FC_CONV_WT) != 0;    // W[k] given as (Cout, Cin): the backward-data pass on the layer's own kernel
+  if (wt && (!nbr || FC_REG_VARIANT(flags))) return FC_EINVAL;
   bool mfma_ok; int bm, bn, S;
   conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S);
   if (!mfma_ok) {
     if (out_index) return FC_EINVAL;              // sorted-row tables are an MFMA-path feature
-    k_conv_fma<<<(unsigned)fc_cdiv(n_out * Cout, 256), 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout);
+    k_conv_fma<<<(unsigned)fc_cdiv(n_out * Cout, 256), 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout, wt ? 1 : 0);
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
@@ -1121,7 +1144,7 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
     rc = fc_conv_reg_launch(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout, S, reg_variant_for(flags, Cout), stream);
   } else {
     dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
-    rc = launch_conv_mfma(conv_pipe(flags, grid), bm, bn, grid, in, W, nbr, K <= 31 ? gmask : nullptr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream);
+    rc = launch_conv_mfma(conv_pipe(flags, grid), bm, bn, grid, in, W, nbr, K <= 31 ? gmask : nullptr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream, wt);
   }
   if (rc != FC_OK) return rc;
   return S > 1 ? sum_parts(dst, out, n_out, Cout, S, stream) : FC_OK;
@@ -1183,6 +1206,8 @@ int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in,
   if (n_out == 0) return FC_OK;
   if (ws_bytes < fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout)) return FC_EWS;
   float* part = (float*)ws;
+  const bool wt = (flags & FC_CONV_WT) != 0;
+  if (wt && FC_REG_VARIANT(flags)) return FC_EINVAL;
   if (FC_REG_VARIANT(flags)) {
     int rc = fc_conv_reg_launch(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, K, reg_variant_for(flags, Cout), stream);
     if (rc != FC_OK) return rc;
@@ -1195,7 +1220,7 @@ int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in,
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
   if (live_tiles > 0) grid = dim3((unsigned)live_tiles, Cout / bn, 1);       // linear list of the live (offset, tile) pairs
   {
-    int rc = launch_conv_mfma(live_tiles > 0 ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream);
+    int rc = launch_conv_mfma(live_tiles > 0 ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt);
     if (rc != FC_OK) return rc;
   }
   k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);

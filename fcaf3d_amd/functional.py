@@ -85,17 +85,23 @@ def _pair_conv(kmap, n_rows, Cin, Cout):
             and Cin % 32 == 0 and Cout % 64 == 0)
 
 
-def _conv_pairs(x, w, lists, out, n_in, n_out, K, Cin, Cout, live_tiles=0):
+CONV_WT = 1 << 23          # flags bit of fc_conv_fwd / fc_conv_fwd_pairs_tiles: W[k] is stored (Cout, Cin) — see conv.hip
+DGRAD_WT = os.environ.get('FC_DGRAD_TRANSPOSE', '0') != '1'      # backward-data reads the layer's own kernel (no transpose launch)
+
+
+def _conv_pairs(x, w, lists, out, n_in, n_out, K, Cin, Cout, live_tiles=0, flags=None):
     pi, _, pos, cnt = lists
+    flags = FLAGS if flags is None else flags
     ws = L.workspace(L.query('fc_conv_fwd_pairs_ws_bytes', n_out, K, Cout), x.device)
     L.call('fc_conv_fwd_pairs_tiles', L.ptr(x), L.ptr(w), L.ptr(pi), L.ptr(cnt), L.ptr(pos), L.ptr(out), n_in, n_out, K, Cin,
-           Cout, live_tiles, FLAGS, L.ptr(ws), ws.numel(), L.stream())
+           Cout, live_tiles, flags, L.ptr(ws), ws.numel(), L.stream())
 
 
-def _conv_fwd(x, w, nbr, out, n_in, n_out, K, Cin, Cout, out_index=None):
-    wsb = L.query('fc_conv_fwd_ws_bytes', n_out, K, Cin, Cout, FLAGS)
+def _conv_fwd(x, w, nbr, out, n_in, n_out, K, Cin, Cout, out_index=None, flags=None):
+    flags = FLAGS if flags is None else flags
+    wsb = L.query('fc_conv_fwd_ws_bytes', n_out, K, Cin, Cout, flags)
     ws = L.workspace(wsb, x.device) if wsb else None
-    L.call('fc_conv_fwd', L.ptr(x), L.ptr(w), L.ptr(nbr), L.ptr(out_index), L.ptr(out), n_in, n_out, K, Cin, Cout, FLAGS,
+    L.call('fc_conv_fwd', L.ptr(x), L.ptr(w), L.ptr(nbr), L.ptr(out_index), L.ptr(out), n_in, n_out, K, Cin, Cout, flags,
            L.ptr(ws), ws.numel() if ws is not None else 0, L.stream())
 
 
@@ -131,15 +137,21 @@ class _SparseConv(torch.autograd.Function):
         dev = feats.device
         gin = gw = None
         if ctx.needs_input_grad[0]:
-            wt = torch.empty((K, Cout, Cin), dtype=torch.float32, device=dev)
-            L.call('fc_transpose_weight', L.ptr(weight), L.ptr(wt), K, Cin, Cout, L.stream())
+            # the (Cout -> Cin) operator of the backward-data pass: the kernels read the layer's own (K, Cin, Cout) kernel as
+            # its transpose (flags CONV_WT; r2: 50 transpose launches and 0.34 ms per step gone); identity maps (dense GEMMs)
+            # and the register-direct tuning variants still take a transposed copy
+            if DGRAD_WT and kmap is not None and not ((FLAGS >> 24) & 15):
+                wt, fl = weight, FLAGS | CONV_WT
+            else:
+                wt, fl = torch.empty((K, Cout, Cin), dtype=torch.float32, device=dev), FLAGS
+                L.call('fc_transpose_weight', L.ptr(weight), L.ptr(wt), K, Cin, Cout, L.stream())
             gin = torch.empty((n_in, Cin), dtype=torch.float32, device=dev)
             if _pair_conv(kmap, n_in, Cout, Cin):
-                _conv_pairs(gout, wt, kmap.pairs_t(), gin, n_out, n_in, K, Cout, Cin, kmap.pair_tiles(transposed=True))
+                _conv_pairs(gout, wt, kmap.pairs_t(), gin, n_out, n_in, K, Cout, Cin, kmap.pair_tiles(transposed=True), flags=fl)
             else:
                 nbr_t, tidx = ((kmap.sorted_bwd() if _mfma_shape(Cout, Cin) else (kmap.nbr_t, None))
                                if kmap is not None else (None, None))
-                _conv_fwd(gout, wt, nbr_t, gin, n_out, n_in, K, Cout, Cin, tidx)
+                _conv_fwd(gout, wt, nbr_t, gin, n_out, n_in, K, Cout, Cin, tidx, flags=fl)
         if ctx.needs_input_grad[1]:
             nbr, ridx = (kmap.nbr if kmap is not None else None), None      # wgrad walks rows in natural order (see conv.hip)
 

@@ -101,7 +101,9 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
  * its backward-data pass (call with the transposed table and fc_transpose_weight'ed kernel), and with
  * nbr == NULL (K = 1, identity) the dense GEMMs of MinkowskiGenerativeConvolutionTranspose (:60-66)
  * and of the 1x1 head convolutions (:83-85, :257-263).  out[o] = sum_k in[nbr[k][o]] @ W[k].
- * flags bit0: force the generic FMA kernel instead of the MFMA kernel.  Layers with too few rows to fill
+ * flags bit0: force the generic FMA kernel instead of the MFMA kernel.  flags bit23 (also fc_conv_fwd_pairs /
+ * _pairs_tiles; needs nbr != NULL): W[k] is stored TRANSPOSED, (Cout, Cin) row-major — the backward-data pass run on the
+ * layer's own (K, Cin, Cout) kernel without a transposed copy.  Layers with too few rows to fill
  * the chip are split over kernel offsets into `ws` and summed in a fixed order (deterministic).
  * out_index (nullable): `nbr` is a table permuted into occupancy-mask order (fc_permute_nbr) and tile row t
  * belongs to output row out_index[t] — tiles of similar rows skip the offsets none of them has. */

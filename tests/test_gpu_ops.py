@@ -160,6 +160,20 @@ def test_conv_mfma_small_tiles(Cin, Cout):
     _conv_case(_dev(), 6000, Cin, Cout, 3, 1, 0, level_q=4)
 
 
+def test_conv_backward_data_with_a_transposed_weight_copy():
+    """default: the backward-data pass reads the layer's own kernel as its transpose (flags bit23, every other conv test
+    here); this is the other route — fc_transpose_weight + the plain operand — on a dense-table and a pair-list map"""
+    import fcaf3d_amd.functional as Fn
+    assert Fn.DGRAD_WT
+    Fn.DGRAD_WT = False
+    try:
+        _conv_case(_dev(), 6000, 64, 128, 3, 1, 0, level_q=4)
+        _conv_case(_dev(), 100000, 128, 64, 3, 1, 0, B=1)
+        _conv_case(_dev(), 8000, 64, 128, 3, 2, 0, level_q=2)
+    finally:
+        Fn.DGRAD_WT = True
+
+
 def test_conv_mfma_k3s2_and_k1s2():
     _conv_case(_dev(), 8000, 64, 128, 3, 2, 0, level_q=2)
     _conv_case(_dev(), 8000, 64, 64, 1, 2, 0, level_q=2)
