@@ -57,8 +57,8 @@ def lib():
             fn.restype = ret
             fn.argtypes = [t for _, t in args]
         _lib = l
-        if os.environ.get('FC_PRIO_OFF'):        # A/B switch of the MFMA-block wave priority (conv.hip: g_fc_prio); tuning only
-            l.fc_debug_set_prio(-1)
+        if os.environ.get('FC_PRIO_OFF') or os.environ.get('FC_PRIO_MODE'):     # A/B switches of the MFMA-block wave priority
+            l.fc_debug_set_prio(-1 if os.environ.get('FC_PRIO_OFF') else int(os.environ['FC_PRIO_MODE']))      # (conv.hip: g_fc_prio)
     return _lib
 
 

@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(256, (BNc == 128) ? 2 : 3) void k_wgrad_multi(const
       }
   };
   if (r_begin < r_end) load_chunk(r_begin);
-  const bool prio = g_fc_prio >= 0;               // see g_fc_prio
+  const bool prio = g_fc_prio == 0;               // see g_fc_prio (mode 1: forward / backward-data kernels only)
   for (int64_t rb = r_begin; rb < r_end; rb += 32) {
     __syncthreads();
 #pragma unroll
