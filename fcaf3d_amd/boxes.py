@@ -53,3 +53,22 @@ class DepthInstance3DBoxes:
 
 def bbox3d2result(bboxes, scores, labels):
     return dict(boxes_3d=bboxes.to('cpu'), scores_3d=scores.cpu(), labels_3d=labels.cpu())
+
+
+def bbox3d2result_batch(bbox_list):
+    """bbox3d2result for every scene of a batch with THREE device->host copies instead of three per scene
+    (mmdet3d/core/bbox/transforms.py bbox3d2result semantics: boxes / scores / labels on the CPU)."""
+    if not bbox_list:
+        return []
+    sizes = [len(s) for _, s, _ in bbox_list]
+    boxes = torch.cat([b.tensor for b, _, _ in bbox_list]).cpu()
+    scores = torch.cat([s for _, s, _ in bbox_list]).cpu()
+    labels = torch.cat([l for _, _, l in bbox_list]).cpu()
+    out, o = [], 0
+    for (b, _, _), n in zip(bbox_list, sizes):
+        cb = b.__class__.__new__(b.__class__)
+        cb.tensor = boxes[o:o + n]
+        cb.box_dim, cb.with_yaw = b.box_dim, b.with_yaw
+        out.append(dict(boxes_3d=cb, scores_3d=scores[o:o + n], labels_3d=labels[o:o + n]))
+        o += n
+    return out

@@ -18,6 +18,7 @@ from . import _lib as L
 from . import functional as Fn
 from . import nn as MEnn
 from .dist import reduce_mean
+from .nms import _run as _nms_run
 from .nms import nms_bev, nms_bev_multiclass
 from .registry import BBOX_ASSIGNERS, HEADS, build_assigner, build_loss
 from .sparse import SparseTensor
@@ -267,11 +268,80 @@ class Fcaf3DNeckWithHead(nn.Module):
     # ---- inference (reference :205-253, :332-374) --------------------------------------------------
     def get_bboxes(self, centernesses, bbox_preds, cls_scores, points, img_metas, rescale=False):
         assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) == len(points[0]) == len(img_metas)
+        if self.batched_decode and self.test_cfg.nms_pre > 0 and all(
+                isinstance(v, SceneList) for group in (centernesses, bbox_preds, cls_scores, points) for v in group):
+            return self._get_bboxes_batched(centernesses, bbox_preds, cls_scores, points, img_metas)
         results = []
         for i in range(len(img_metas)):
             results.append(self._get_bboxes_single(
                 centernesses=[x[i] for x in centernesses], bbox_preds=[x[i] for x in bbox_preds],
                 cls_scores=[x[i] for x in cls_scores], points=[x[i] for x in points], img_meta=img_metas[i]))
+        return results
+
+    batched_decode = True      # False: the reference's per-scene loop (_get_bboxes_single), kept as the cross-check
+
+    def _get_bboxes_batched(self, centernesses, bbox_preds, cls_scores, points, img_metas):
+        """get_bboxes for ALL scenes at once (r2: the per-scene, per-level loop of the reference issued ~1 500 tiny launches
+        and 8 read-backs per batch of 8 scenes, 8.9 ms): scores, decode and the per-(scene, level) top-`nms_pre` selection run
+        on the whole batch (one segmented sort), then every (scene, class) segment goes through ONE pair of NMS launches and
+        one read-back of the survivor counts.  Candidates reach the NMS in the order of the per-scene loop (scene, level,
+        then descending max score where top-k bites, row order where it does not), all sorts are stable: same results."""
+        B, Lv = len(img_metas), len(centernesses)
+        cfg = self.test_cfg
+        dev = centernesses[0].full.device
+        sc_l, mx_l, bx_l, sg_l = [], [], [], []
+        for l in range(Lv):
+            cm = centernesses[l].cmap
+            sc = cls_scores[l].full.sigmoid() * centernesses[l].full.sigmoid()
+            sc_l.append(sc)
+            mx_l.append(sc.max(dim=1).values)
+            bx_l.append(self._bbox_pred_to_bbox(points[l].full, bbox_preds[l].full))
+            sg_l.append(cm.coords[:, 0].to(torch.int64) * Lv + l)
+        scores, maxs, boxes, seg = torch.cat(sc_l), torch.cat(mx_l), torch.cat(bx_l), torch.cat(sg_l)
+        N, C = scores.shape
+        yaw_flag = boxes.shape[1] == 7
+        boxes7 = boxes if yaw_flag else torch.cat((boxes, torch.zeros_like(boxes[:, :1])), dim=1)
+        # ---- top-nms_pre per (scene, level): one stable sort of (segment, rank key) ----------------------------------
+        counts = torch.bincount(seg, minlength=B * Lv)
+        big = counts > cfg.nms_pre
+        row = torch.arange(N, device=dev)
+        frac = torch.where(big[seg], 1.0 - maxs.double(), row.double() / (N + 1))       # descending score | row order
+        order = torch.sort(seg.double() * 2.0 + frac, stable=True).indices
+        seg_o = seg[order]
+        starts = torch.cumsum(counts, 0) - counts
+        keep = (row - starts[seg_o]) < cfg.nms_pre
+        sel = order[keep]                                   # (scene, level, rank) order == the per-scene loop's cat order
+        scene = seg[sel] // Lv
+        per_scene = torch.bincount(scene, minlength=B)
+        pos = torch.arange(sel.numel(), device=dev) - (torch.cumsum(per_scene, 0) - per_scene)[scene]
+        n_max = min(Lv * cfg.nms_pre, N)                    # static bound: no read-back
+        P = scores.new_full((B, n_max, C), -1.0)
+        P[scene, pos] = scores[sel]
+        PB = boxes7.new_zeros((B, n_max, 7))
+        PB[scene, pos] = boxes7[sel]
+        # ---- every (scene, class) segment through one NMS ---------------------------------------------------------------
+        masked = torch.where(P > cfg.score_thr, P, P.new_full((1,), -1.0)).permute(0, 2, 1).reshape(B * C, n_max)
+        sorted_scores, ordr = masked.sort(dim=1, descending=True, stable=True)
+        cnts = (sorted_scores > cfg.score_thr).sum(dim=1).to(torch.int32)
+        seg_boxes = PB[:, None].expand(B, C, n_max, 7).gather(2, ordr.view(B, C, n_max, 1).expand(B, C, n_max, 7))
+        kept, kcount = _nms_run(seg_boxes.reshape(B * C, n_max, 7).contiguous(), cnts, cfg.iou_thr, yaw_flag)
+        valid = torch.arange(n_max, device=dev)[None, :] < kcount[:, None]
+        sc_seg, p = torch.nonzero(valid, as_tuple=True)     # (scene, class)-major, ascending position = descending score
+        idx = ordr[sc_seg, kept[sc_seg, p].long()]
+        out_scene, out_cls = sc_seg // C, sc_seg % C
+        out_boxes = PB[out_scene, idx]
+        out_scores = P[out_scene, idx, out_cls]
+        sizes = torch.bincount(out_scene, minlength=B).tolist()          # the one read-back
+        results, o = [], 0
+        for i, n in enumerate(sizes):
+            b = out_boxes[o:o + n]
+            if yaw_flag:
+                box_dim, with_yaw = 7, True
+            else:
+                box_dim, with_yaw, b = 6, False, b[:, :6]
+            results.append((img_metas[i]['box_type_3d'](b, box_dim=box_dim, with_yaw=with_yaw, origin=(.5, .5, .5)),
+                            out_scores[o:o + n], out_cls[o:o + n]))
+            o += n
         return results
 
     def _get_bboxes_single(self, centernesses, bbox_preds, cls_scores, points, img_meta):

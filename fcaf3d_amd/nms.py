@@ -40,7 +40,7 @@ def nms_bev_multiclass(boxes, scores, score_thr, iou_thr, rotated):
     n, C = scores.shape
     dev = boxes.device
     masked = torch.where(scores > score_thr, scores, scores.new_full((1,), -1.0)).t().contiguous()   # (C,N)
-    sorted_scores, order = masked.sort(dim=1, descending=True)
+    sorted_scores, order = masked.sort(dim=1, descending=True, stable=True)      # stable: ties keep candidate order (as the batched route)
     counts = (sorted_scores > score_thr).sum(dim=1).to(torch.int32)
     seg_boxes = boxes[order.reshape(-1)].reshape(C, n, 7).contiguous()
     keep, kcount = _run(seg_boxes, counts, iou_thr, rotated)

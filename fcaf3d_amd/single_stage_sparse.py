@@ -4,7 +4,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .boxes import bbox3d2result
+from .boxes import bbox3d2result, bbox3d2result_batch
 from .registry import DETECTORS, build_backbone, build_head
 from .sparse import SparseTensor, _rec, on_map_stream
 
@@ -109,7 +109,7 @@ class SingleStageSparse3DDetector(nn.Module):
     def simple_test(self, points, img_metas, imgs=None, rescale=False):
         x = self.extract_feat(points, img_metas)
         bbox_list = self.neck_with_head.get_bboxes(*x, img_metas, rescale=rescale)
-        return [bbox3d2result(bboxes, scores, labels) for bboxes, scores, labels in bbox_list]
+        return bbox3d2result_batch(bbox_list)
 
     def aug_test(self, points, img_metas, imgs=None, rescale=False):
         pass

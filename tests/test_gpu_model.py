@@ -547,6 +547,35 @@ def test_multiclass_nms_route_equals_per_class_loop():
         assert len(s0) == 0 and l0.dtype == torch.long and b0.tensor.shape[0] == 0
 
 
+def test_batched_get_bboxes_equals_per_scene_loop():
+    """get_bboxes over the whole batch (one segmented top-k sort, one NMS over every (scene, class) segment, one read-back)
+    returns exactly what the reference's per-scene / per-level loop returns (fcaf3d_neck_with_head.py:205-253)."""
+    dev = _dev()
+    for name, seeds, npts in (('fcaf3d_scannet-3d-18class', [31, 32, 33], 30000), ('fcaf3d_sunrgbd-3d-10class', [34, 35], 20000)):
+        model, m = _build(name, 0.02, 3)
+        with torch.no_grad():
+            model.neck_with_head.cls_conv.bias.fill_(0.0)
+            model.neck_with_head.cls_conv.kernel.normal_(0, 0.3)
+        model = model.to(dev).train()
+        pts, _, _ = _scenes(seeds, n_points=npts)
+        kw = dict(points=[torch.from_numpy(p).to(dev) for p in pts], img_metas=[dict(box_type_3d=fa.DepthInstance3DBoxes)] * len(pts))
+        head = model.neck_with_head
+        assert head.batched_decode
+        with torch.no_grad():
+            res_b = model(return_loss=False, **kw)
+            head.batched_decode = False
+            try:
+                res_s = model(return_loss=False, **kw)
+            finally:
+                head.batched_decode = True
+        for rb, rs in zip(res_b, res_s):
+            assert len(rs['scores_3d']) > 10 and len(rb['scores_3d']) == len(rs['scores_3d'])
+            assert torch.equal(rb['labels_3d'], rs['labels_3d'])
+            assert torch.equal(rb['scores_3d'], rs['scores_3d'])
+            assert torch.equal(rb['boxes_3d'].tensor, rs['boxes_3d'].tensor)
+            assert rb['boxes_3d'].box_dim == rs['boxes_3d'].box_dim and rb['boxes_3d'].with_yaw == rs['boxes_3d'].with_yaw
+
+
 def test_eval_mode_inference_and_running_stats():
     """model.eval(): BatchNorm runs on the running statistics that training steps accumulated
     (nn.BatchNorm1d semantics inside ME.MinkowskiBatchNorm): the buffers, and the detections, match the oracle."""
