@@ -136,6 +136,10 @@ def _stem(a):                   # fc_conv_fwd / fc_conv_wgrad with Cin == 3: (..
 HBM_BYTES = {
     'fc_conv_fwd': lambda a, pr: (4.0 * (a[5] * 3 + a[6] * a[9] + a[7] * 3 * a[9]) + 4.0 * a[7] * a[6]) if _stem(a) else None,
     'fc_conv_wgrad': lambda a, pr: (4.0 * (a[5] * 3 + a[6] * a[9]) + 4.0 * a[7] * a[6]) if _stem(a) else None,
+    # (in, W, nbr, out, col, n_in, n_out, K): inputs + table read, out + col (84 floats per row) written
+    'fc_stem_conv_fwd': lambda a, pr: 4.0 * (a[5] * 3 + a[6] * 64 + a[7] * 3 * 64 + (a[6] * 84 if a[4] else 0)) + 4.0 * a[7] * a[6],
+    # (col, gout, gW, n_out, K, ..): col and gout streamed once
+    'fc_stem_conv_wgrad': lambda a, pr: 4.0 * a[3] * (84 + 64),
     # (in, nbr, n_out, K, C, out, argrow): every input row read once (k2s2: each voxel has one parent), out + argmax written
     'fc_maxpool_fwd': lambda a, pr: 4.0 * a[4] * (pr.pool_n_in + 2 * a[2]) + 4.0 * a[3] * a[2],
     'fc_maxpool_bwd': lambda a, pr: 4.0 * a[3] * 3 * a[2],
@@ -198,7 +202,7 @@ class ConvProbe:
                     s.record()
                     orig(name, *a)
                     e.record()
-                    probe.hbm.append((name if not (name.startswith('fc_conv') and a[8] == 3) else name + '(stem)', nbytes, s, e))
+                    probe.hbm.append((name if not (name in ('fc_conv_fwd', 'fc_conv_wgrad') and a[8] == 3) else name + '(stem)', nbytes, s, e))
                     return
             if name not in ('fc_conv_fwd', 'fc_conv_fwd_pairs', 'fc_conv_fwd_pairs_tiles') or probe.mode is None:
                 return orig(name, *a)

@@ -815,8 +815,10 @@ __global__ void k_sum_pairs(const float* __restrict__ part, const int* __restric
 #define STEM_COUT 64
 #define STEM_ROWS 64
 #define STEM_FWD_LDA 97
+#define STEM_COL_LD 84      // row stride of the saved gathered inputs: 27 x 3 = 81 floats, padded to 21 float4
 __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ in, const float* __restrict__ W,
-                                                  const int* __restrict__ nbr, float* __restrict__ out, int64_t n_out, int K) {
+                                                  const int* __restrict__ nbr, float* __restrict__ out,
+                                                  float* __restrict__ col, int64_t n_out, int K) {
   // out[64 rows][64] = A[64][81 -> 96] x W[96][64] on the matrix cores: one 32x32 tile per wave, 48 MFMA steps.
   extern __shared__ float sm[];
   constexpr int SLD = STEM_FWD_LDA;          // odd row stride -> conflict-free column reads of A
@@ -846,6 +848,19 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ in, 
     reinterpret_cast<f32x4*>(W_s)[t] = v;
   }
   __syncthreads();
+  if (col) {
+    // training: the gathered inputs of the tile go out as rows of `col` (n_out, 84) — the weight gradient then streams them
+    // instead of repeating 27 scattered 12-byte reads per output row (r2: 390 -> ~100 us; the forward pays one 195 MB write)
+    for (int t = tid; t < STEM_ROWS * (STEM_COL_LD / 4); t += 256) {
+      const int row = t / (STEM_COL_LD / 4), c = (t % (STEM_COL_LD / 4)) * 4;
+      const int64_t o = m0 + row;
+      if (o < n_out) {
+        const float* sp = in_s + row * SLD + c;
+        f32x4 v = {sp[0], sp[1], sp[2], sp[3]};
+        *reinterpret_cast<f32x4*>(col + o * STEM_COL_LD + c) = v;
+      }
+    }
+  }
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -926,6 +941,96 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ in
       if (k < K) {
         in_s[row * STEM_JP + k * 3] = pa[u][0]; in_s[row * STEM_JP + k * 3 + 1] = pa[u][1]; in_s[row * STEM_JP + k * 3 + 2] = pa[u][2];
       }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) reinterpret_cast<f32x4*>(g_s)[tid + 256 * u] = pg[u];
+    __syncthreads();
+    load_chunk(rb + STEM_ROWS < r_end ? rb + STEM_ROWS : rb);          // unconditional (see k_conv_mfma)
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) {
+      const int row = wave * 16 + 2 * sidx + h;
+      float a[3], b[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a[i] = in_s[row * STEM_JP + i * 32 + r];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = g_s[row * 64 + j * 32 + r];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // cross-wave sum in wave order through LDS ([96][64] floats = 24 KB, reusing the staging area)
+  __syncthreads();
+  float* red = sm;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            int jj = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, co = j * 32 + r;
+            float v = acc[i][j][e];
+            if (w > 0) v += red[jj * 64 + co];
+            red[jj * 64 + co] = v;
+          }
+    }
+    __syncthreads();
+  }
+  float* dst = part + (int64_t)blockIdx.x * KC * 64;
+  for (int t = tid; t < KC * 64; t += 256) dst[t] = red[t];
+}
+
+// The same reduction with the gathered inputs read back from `col` (k_stem_fwd) — no neighbour table, no gathers.
+__global__ __launch_bounds__(256) void k_stem_wgrad_col(const float* __restrict__ col, const float* __restrict__ gout,
+                                                        float* __restrict__ part, int64_t n_out, int K, int64_t rows_per_block) {
+  extern __shared__ float sm[];
+  const int KC = K * STEM_CIN;
+  float* in_s = sm;                          // [STEM_ROWS][STEM_JP]   (columns >= KC stay zero)
+  float* g_s = sm + STEM_ROWS * STEM_JP;     // [STEM_ROWS][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r_end = r_begin + rows_per_block;
+  if (r_end > n_out) r_end = n_out;
+  for (int t = tid; t < STEM_ROWS * STEM_JP; t += 256) in_s[t] = 0.f;
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // the gathered inputs come as rows of `col` (saved by k_stem_fwd): two coalesced streams, prefetched one chunk ahead
+  constexpr int NC = (STEM_ROWS * (STEM_COL_LD / 4) + 255) / 256;      // float4 per thread per chunk
+  f32x4 pc[NC], pg[4];
+  auto load_chunk = [&](int64_t rb) {
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      const int t = tid + 256 * u;
+      const int row = t / (STEM_COL_LD / 4), c = (t % (STEM_COL_LD / 4)) * 4;
+      const int64_t o = rb + row;
+      const float* cp = (o < r_end && row < STEM_ROWS) ? col + o * STEM_COL_LD + c : g_zero_row;
+      pc[u] = *reinterpret_cast<const f32x4*>(cp);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = tid + 256 * u;
+      const int64_t o = rb + (t >> 4);
+      const float* gp = o < r_end ? gout + o * 64 + (t & 15) * 4 : g_zero_row;
+      pg[u] = *reinterpret_cast<const f32x4*>(gp);
+    }
+  };
+  if (r_begin < r_end) load_chunk(r_begin);
+  for (int64_t rb = r_begin; rb < r_end; rb += STEM_ROWS) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      const int t = tid + 256 * u;
+      const int row = t / (STEM_COL_LD / 4), c = (t % (STEM_COL_LD / 4)) * 4;
+      if (row < STEM_ROWS) *reinterpret_cast<f32x4*>(&in_s[row * STEM_JP + c]) = pc[u];      // columns 84..95 stay zero
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) reinterpret_cast<f32x4*>(g_s)[tid + 256 * u] = pg[u];
@@ -1123,7 +1228,7 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
   if (out_index && !nbr) return FC_EINVAL;
   if (is_stem(nbr, K, Cin, Cout, flags) && !out_index) {
     size_t smem = (size_t)(STEM_ROWS * STEM_FWD_LDA + 96 * 64) * sizeof(float);
-    k_stem_fwd<<<(unsigned)fc_cdiv(n_out, STEM_ROWS), 256, smem, stream>>>(in, W, nbr, out, n_out, K);
+    k_stem_fwd<<<(unsigned)fc_cdiv(n_out, STEM_ROWS), 256, smem, stream>>>(in, W, nbr, out, nullptr, n_out, K);
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
@@ -1703,6 +1808,45 @@ static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool 
   s = fc_cdiv(n_out > 0 ? n_out : 1, rps);
   *S = (int)s;
   *rows_per_split = rps;
+}
+
+// ---- stem convolution with saved gathered inputs (training): forward writes col (n_out, 84), the weight gradient streams it ----
+int fc_stem_conv_fwd(const float* in, const float* W, const int* nbr, float* out, float* col, int64_t n_in, int64_t n_out,
+                     int K, hipStream_t stream) {
+  if (n_in < 0 || n_out < 0 || K < 1 || K > 27 || !nbr) return FC_EINVAL;
+  if (n_out == 0) return FC_OK;
+  size_t smem = (size_t)(STEM_ROWS * STEM_FWD_LDA + 96 * 64) * sizeof(float);
+  k_stem_fwd<<<(unsigned)fc_cdiv(n_out, STEM_ROWS), 256, smem, stream>>>(in, W, nbr, out, col, n_out, K);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+int64_t fc_stem_conv_wgrad_ws_bytes(int64_t n_out, int K) {
+  int S; int64_t rps;
+  wgrad_plan(n_out > 0 ? n_out : 1, K, STEM_CIN, STEM_COUT, 0, true, &S, &rps);
+  return (int64_t)S * K * STEM_CIN * STEM_COUT * (int64_t)sizeof(float);
+}
+
+int fc_stem_conv_wgrad(const float* col, const float* gout, float* gW, int64_t n_out, int K, void* ws, int64_t ws_bytes,
+                       hipStream_t stream) {
+  if (n_out < 0 || K < 1 || K > 27) return FC_EINVAL;
+  const int64_t elems = (int64_t)K * STEM_CIN * STEM_COUT;
+  if (n_out == 0) {
+    FC_HIP(hipMemsetAsync(gW, 0, elems * sizeof(float), stream));
+    return FC_OK;
+  }
+  int S; int64_t rps;
+  wgrad_plan(n_out, K, STEM_CIN, STEM_COUT, 0, true, &S, &rps);
+  if (ws_bytes < (int64_t)S * elems * (int64_t)sizeof(float)) return FC_EWS;
+  float* part = (S == 1) ? gW : (float*)ws;
+  size_t smem = (size_t)(STEM_ROWS * STEM_JP + STEM_ROWS * 64) * sizeof(float);
+  k_stem_wgrad_col<<<(unsigned)S, 256, smem, stream>>>(col, gout, part, n_out, K, rps);
+  FC_CHECK_LAUNCH();
+  if (S > 1) {
+    k_wgrad_reduce<<<(unsigned)fc_cdiv(elems, 256), 256, 0, stream>>>(part, gW, elems, S);
+    FC_CHECK_LAUNCH();
+  }
+  return FC_OK;
 }
 
 int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags) {

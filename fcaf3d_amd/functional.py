@@ -85,6 +85,7 @@ def _pair_conv(kmap, n_rows, Cin, Cout):
             and Cin % 32 == 0 and Cout % 64 == 0)
 
 
+STEM_COL = os.environ.get('FC_STEM_COL', '1') != '0'      # stem: save the gathered inputs in forward, stream them in the weight gradient
 CONV_WT = 1 << 23          # flags bit of fc_conv_fwd / fc_conv_fwd_pairs_tiles: W[k] is stored (Cout, Cin) — see conv.hip
 DGRAD_WT = os.environ.get('FC_DGRAD_TRANSPOSE', '0') != '1'      # backward-data reads the layer's own kernel (no transpose launch)
 
@@ -117,7 +118,13 @@ class _SparseConv(torch.autograd.Function):
         K, Cin, Cout = weight.shape
         n_in = feats.shape[0]
         out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
-        if _pair_conv(kmap, n_out, Cin, Cout):
+        ctx.col = None
+        if STEM_COL and kmap is not None and Cin == 3 and Cout == 64 and K <= 27 and not (FLAGS & 1) and ctx.needs_input_grad[1]:
+            # stem in training: keep the gathered inputs (n_out, 84) for the weight gradient (conv.hip: k_stem_fwd / k_stem_wgrad_col)
+            ctx.col = torch.empty((n_out, 84), dtype=torch.float32, device=feats.device)
+            L.call('fc_stem_conv_fwd', L.ptr(feats), L.ptr(weight), L.ptr(kmap.nbr), L.ptr(out), L.ptr(ctx.col), n_in, n_out, K,
+                   L.stream())
+        elif _pair_conv(kmap, n_out, Cin, Cout):
             _conv_pairs(feats, weight, kmap.pairs(), out, n_in, n_out, K, Cin, Cout, kmap.pair_tiles())
         else:
             nbr, oidx = ((kmap.sorted_fwd() if _mfma_shape(Cin, Cout) else (kmap.nbr, None))
@@ -155,8 +162,14 @@ class _SparseConv(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             nbr, ridx = (kmap.nbr if kmap is not None else None), None      # wgrad walks rows in natural order (see conv.hip)
 
+            col = ctx.col
+
             def launch():
                 g = torch.empty_like(weight)
+                if col is not None:
+                    ws = L.workspace(L.query('fc_stem_conv_wgrad_ws_bytes', n_out, K), dev)
+                    L.call('fc_stem_conv_wgrad', L.ptr(col), L.ptr(gout), L.ptr(g), n_out, K, L.ptr(ws), ws.numel(), L.stream())
+                    return g
                 wsb = L.query('fc_conv_wgrad_ws_bytes', n_out, K, Cin, Cout, FLAGS)
                 ws = L.workspace(wsb, dev)
                 if kmap is not None and kmap.use_pairs and not (FLAGS & 1) and Cin % 64 == 0 and Cout % 64 == 0:
@@ -174,7 +187,7 @@ class _SparseConv(torch.autograd.Function):
                 side.wait_stream(main)                      # gout / activations are ready on the main stream
                 with torch.cuda.stream(side):
                     gw = launch()
-                for t in (feats, gout, nbr):
+                for t in (feats, gout, nbr, col):
                     if t is not None:
                         t.record_stream(side)              # keep their memory until the side stream has read it
                 gw.record_stream(main)

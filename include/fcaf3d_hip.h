@@ -152,6 +152,16 @@ int fc_conv_wgrad_pairs(const float* in, const float* gout, const int* pair_in, 
                         float* gW, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
                         int64_t ws_bytes, hipStream_t stream);
 
+/* The stem convolution in training (me_resnet.py:19-21: `conv1` = ME.MinkowskiConvolution(3, 64, kernel_size=3, stride=2), K <= 27
+ * offsets; its autograd for the weight): the forward additionally saves the gathered inputs of every output row as
+ * col (n_out, 84) (27 x 3 floats, zero-padded), and the weight gradient gW (K,3,64) = col^T @ gout streams col and gout
+ * instead of repeating 27 scattered 12-byte reads per output row.  col == NULL: plain forward (= fc_conv_fwd). */
+int fc_stem_conv_fwd(const float* in, const float* W, const int* nbr, float* out, float* col, int64_t n_in, int64_t n_out,
+                     int K, hipStream_t stream);
+int64_t fc_stem_conv_wgrad_ws_bytes(int64_t n_out, int K);
+int fc_stem_conv_wgrad(const float* col, const float* gout, float* gW, int64_t n_out, int K, void* ws, int64_t ws_bytes,
+                       hipStream_t stream);
+
 /* (K,Cin,Cout) -> (K,Cout,Cin): the W[k]^T of ME's backward-data rule `gin[i] += gout[o] @ W[k]^T` (SURVEY.md Appendix A.3;
  * autograd of me_resnet.py:56-62), so that the pass runs through fc_conv_fwd on the transposed table. */
 int fc_transpose_weight(const float* W, float* Wt, int K, int Cin, int Cout, hipStream_t stream);

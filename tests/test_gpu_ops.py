@@ -253,6 +253,21 @@ def test_streaming_and_group_mask_convolution_entry_points():
             _close(out, ref.cpu(), what=f'pair conv live_tiles={live}')
 
 
+@pytest.mark.parametrize('n_points,B', [(5000, 2), (150000, 1)])
+def test_stem_convolution_both_weight_gradient_routes(n_points, B):
+    """the 3 -> 64 k3s2 stem on the matrix cores (k_stem_fwd): default = the forward saves the gathered inputs (col) and the
+    weight gradient streams them (fc_stem_conv_fwd / fc_stem_conv_wgrad); FC_STEM_COL=0 = gathers in both passes
+    (fc_conv_fwd / fc_conv_wgrad).  Both against the oracle, one split and one many-split launch."""
+    import fcaf3d_amd.functional as Fn
+    assert Fn.STEM_COL
+    _conv_case(_dev(), n_points, 3, 64, 3, 2, 0, B=B)
+    Fn.STEM_COL = False
+    try:
+        _conv_case(_dev(), n_points, 3, 64, 3, 2, 0, B=B)
+    finally:
+        Fn.STEM_COL = True
+
+
 @pytest.mark.parametrize('Cin,Cout,ks,s', [(3, 64, 3, 2), (64, 64, 3, 1), (16, 24, 3, 1)])
 def test_conv_generic_fma(Cin, Cout, ks, s):
     _conv_case(_dev(), 4000, Cin, Cout, ks, s, 1, level_q=2)
