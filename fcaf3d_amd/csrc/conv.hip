@@ -514,6 +514,20 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_p(const float* __restrict_
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, fb[q & 1][j][e], acc[i][j], 0, 0, 0);
           }
         }
+#ifdef FC_SGB
+        // experiment (-DFC_SGB=4, r2): pin "the LDS reads of step q+1 go out FIRST, interleaved with the head of step q's
+        // MFMAs" (the compiler otherwise sinks them behind the 16 MFMAs and waits for them on the spot; with the pin the
+        // waits become counted lgkmcnt(2/4)).  Measured: +-1 % on 50 of 58 launch shapes, 441k rows 64->128 +1.3 %,
+        // 128->64 -3.2 %, 64->64 (256 x 64 tile, at its VGPR limit) -10.5 %: the fragment reads are not what the loop waits for.
+        if (q + 1 < BKT / 8) {
+#pragma unroll
+          for (int g = 0; g < FC_SGB; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * 4 - 2 * FC_SGB, 0);
+        }
+#endif
       }
       if (prio) __builtin_amdgcn_s_setprio(0);
     }
