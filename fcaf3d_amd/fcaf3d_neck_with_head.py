@@ -472,13 +472,13 @@ class Fcaf3DAssigner:
         if sum(lens):
             allb = torch.cat([g.tensor.to(dev) for g in gt_bboxes if len(g)])
             alll = torch.cat([l.to(dev) for g, l in zip(gt_bboxes, gt_labels) if len(g)])
-            slot = torch.from_numpy(np.concatenate([i * M + np.arange(n) for i, n in enumerate(lens) if n])).pin_memory().to(dev, non_blocking=True)
+            slot = L.upload(np.concatenate([i * M + np.arange(n) for i, n in enumerate(lens) if n]), dev)
             packed = allb.clone()
             packed[:, 2] += allb[:, 5] * 0.5                     # gravity centre (DepthInstance3DBoxes.gravity_center)
             boxes.view(B * M, 7)[slot] = packed                  # (.,7): DepthInstance3DBoxes pads yaw-less boxes with a zero yaw
             labels.view(B * M)[slot] = alll.to(torch.int64)
         # pinned + non_blocking: a pageable host->device copy would block the host until the whole forward has drained
-        box_count = torch.tensor([len(g) for g in gt_bboxes], dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+        box_count = L.upload(np.asarray(lens, dtype=np.int32), dev)
         order, counts, off = [], [], 0
         for cm in cmaps:
             cm._decompose()
