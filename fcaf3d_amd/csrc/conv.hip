@@ -1835,9 +1835,18 @@ int fc_stem_conv_fwd(const float* in, const float* W, const int* nbr, float* out
   return FC_OK;
 }
 
+// ~192 row ranges (multiples of 64 rows): every range ends with a 24 KB cross-wave LDS sum, a 20 KB partial and a pass of
+// k_wgrad_reduce over all partials, so FEWER, longer ranges win until the chip runs dry (r2, 580k rows, forward + weight
+// gradient: 1 024-row ranges 436 us, 2 048: 365, 3 072: 353, 4 096: 378, 8 192: 512; the gather kernel: 493)
+static void stem_col_plan(int64_t n_out, int* S, int64_t* rps) {
+  int64_t r = fc_cdiv(fc_cdiv(n_out > 0 ? n_out : 1, 192), STEM_ROWS) * STEM_ROWS;
+  *rps = r;
+  *S = (int)fc_cdiv(n_out > 0 ? n_out : 1, r);
+}
+
 int64_t fc_stem_conv_wgrad_ws_bytes(int64_t n_out, int K) {
   int S; int64_t rps;
-  wgrad_plan(n_out > 0 ? n_out : 1, K, STEM_CIN, STEM_COUT, 0, true, &S, &rps);
+  stem_col_plan(n_out, &S, &rps);
   return (int64_t)S * K * STEM_CIN * STEM_COUT * (int64_t)sizeof(float);
 }
 
@@ -1850,7 +1859,7 @@ int fc_stem_conv_wgrad(const float* col, const float* gout, float* gW, int64_t n
     return FC_OK;
   }
   int S; int64_t rps;
-  wgrad_plan(n_out, K, STEM_CIN, STEM_COUT, 0, true, &S, &rps);
+  stem_col_plan(n_out, &S, &rps);
   if (ws_bytes < (int64_t)S * elems * (int64_t)sizeof(float)) return FC_EWS;
   float* part = (S == 1) ? gW : (float*)ws;
   size_t smem = (size_t)(STEM_ROWS * STEM_JP + STEM_ROWS * 64) * sizeof(float);
