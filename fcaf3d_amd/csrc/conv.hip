@@ -1786,11 +1786,13 @@ static void wgrad_tiles(int Cin, int Cout, int flags, int* bm, int* bn) {
   if (fbn == 2 && Cout % 128 == 0) *bn = 128;
 }
 
-// several offsets per workgroup (k_wgrad_multi): dense tables with few input channels on big maps; flags bit29 disables it
+// several offsets per workgroup (k_wgrad_multi): every dense table with >= 4096 rows (r2 nbench, one-offset kernel -> multi:
+// 55k rows 128->128 504 -> 446 us, 6.9k rows 256->256 278 -> 247, 256->128 148 -> 135, 441k rows 128->64 2121 -> 2003, 64->64
+// 1086 -> 1051); flags bit29 disables it, bit30 restricts it to its first rule (Cin = 64, >= 32768 rows)
 #define WGRAD_KO 3
 static inline bool wgrad_multi_ok(int64_t n_out, int K, int Cin, int Cout, int flags, bool dense_table) {
-  return dense_table && !(flags & 1) && !(flags & (1 << 29)) && !FC_REG_WGRAD(flags) && K % WGRAD_KO == 0 && Cin == 64 &&
-         Cout % 64 == 0 && n_out >= 32768;
+  return dense_table && !(flags & 1) && !(flags & (1 << 29)) && !FC_REG_WGRAD(flags) && K % WGRAD_KO == 0 &&
+         Cin % 64 == 0 && Cout % 64 == 0 && n_out >= 4096 && (!(flags & (1 << 30)) || (Cin == 64 && n_out >= 32768));
 }
 
 static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool dense_table, int* S, int64_t* rows_per_split) {

@@ -253,6 +253,35 @@ def test_streaming_and_group_mask_convolution_entry_points():
             _close(out, ref.cpu(), what=f'pair conv live_tiles={live}')
 
 
+@pytest.mark.parametrize('Cin,Cout', [(64, 64), (128, 128), (256, 128), (128, 64)])
+def test_dense_table_weight_gradient_kernels(Cin, Cout):
+    """fc_conv_wgrad over a dense neighbour table: the multi-offset kernel (default from 4096 rows), the one-offset kernels
+    (flags bit29, and bit29 + bit16) and the row-range split override == the generic FMA kernel (flags bit0)."""
+    from fcaf3d_amd import _lib as L
+    from fcaf3d_amd.sparse import CoordMap
+    dev = _dev()
+    _, c_ref, _ = _scene_coords(23, n_points=30000, B=2)
+    c_ref = c_ref.copy(); c_ref[:, 1:] = np.floor_divide(c_ref[:, 1:], 2) * 2
+    uc, _, _ = mo.unique_first(c_ref)
+    cm, _, _ = CoordMap.from_coords(torch.from_numpy(uc).to(dev), 2, 2)
+    km = cm.kernel_map(cm, 3)
+    n, K = cm.n, 27
+    assert n >= 4096
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, Cin, generator=g).to(dev)
+    go = torch.randn(n, Cout, generator=g).to(dev)
+
+    def run(flags):
+        gw = torch.full((K, Cin, Cout), float('nan'), device=dev)
+        ws = L.workspace(max(L.query('fc_conv_wgrad_ws_bytes', n, K, Cin, Cout, flags), 16), dev)
+        L.call('fc_conv_wgrad', L.ptr(x), L.ptr(go), L.ptr(km.nbr), None, L.ptr(gw), n, n, K, Cin, Cout, flags, L.ptr(ws), ws.numel(),
+               L.stream())
+        return gw.cpu()
+    ref = run(1)
+    for fl in (0, 1 << 29, (1 << 29) | (1 << 16), 1 << 30, 3 << 8, (5 << 8) | (1 << 29)):
+        _close(run(fl), ref, what=f'dense-table wgrad {Cin}->{Cout} flags={fl:#x}')
+
+
 @pytest.mark.parametrize('n_points,B', [(5000, 2), (150000, 1)])
 def test_stem_convolution_both_weight_gradient_routes(n_points, B):
     """the 3 -> 64 k3s2 stem on the matrix cores (k_stem_fwd): default = the forward saves the gathered inputs (col) and the
