@@ -103,6 +103,29 @@ def test_boxes_container():
     assert b6.tensor.shape == (0, 7) and b6.with_yaw is False
 
 
+def test_bbox3d2result_batch_equals_per_scene_conversion():
+    """simple_test's batched result conversion (three copies for the whole batch) == bbox3d2result per scene
+    (mmdet3d/core/bbox/transforms.py bbox3d2result: boxes / scores / labels on the CPU), empty scenes included"""
+    from fcaf3d_amd.boxes import bbox3d2result, bbox3d2result_batch
+    g = torch.Generator().manual_seed(0)
+    lst = []
+    for n, dim in ((5, 7), (0, 7), (3, 7)):
+        b = fa.DepthInstance3DBoxes(torch.rand(n, dim, generator=g), box_dim=dim, with_yaw=True, origin=(.5, .5, .5))
+        lst.append((b, torch.rand(n, generator=g), torch.randint(0, 18, (n,), generator=g)))
+    got = bbox3d2result_batch(lst)
+    assert len(got) == 3 and bbox3d2result_batch([]) == []
+    for (b, s, l), r in zip(lst, got):
+        ref = bbox3d2result(b, s, l)
+        assert torch.equal(r['boxes_3d'].tensor, ref['boxes_3d'].tensor) and type(r['boxes_3d']) is type(ref['boxes_3d'])
+        assert r['boxes_3d'].box_dim == ref['boxes_3d'].box_dim and r['boxes_3d'].with_yaw == ref['boxes_3d'].with_yaw
+        assert torch.equal(r['scores_3d'], ref['scores_3d']) and torch.equal(r['labels_3d'], ref['labels_3d'])
+        assert torch.equal(r['boxes_3d'].gravity_center, ref['boxes_3d'].gravity_center)
+    # 6-dim (yaw-less) boxes keep their flags
+    b6 = fa.DepthInstance3DBoxes(torch.rand(4, 6, generator=g), box_dim=6, with_yaw=False, origin=(.5, .5, .5))
+    r6 = bbox3d2result_batch([(b6, torch.rand(4, generator=g), torch.zeros(4, dtype=torch.long))])[0]
+    assert r6['boxes_3d'].with_yaw is False and r6['boxes_3d'].box_dim == b6.box_dim
+
+
 def test_checkpoint_roundtrip_mmcv_layout(tmp_path):
     """mmcv-layout checkpoints ({'meta','state_dict'}, optional DDP 'module.' prefix) load into the detector;
     mismatches are reported, not silently dropped (tools/test.py:172 flow of the reference)"""
