@@ -301,16 +301,7 @@ class Fcaf3DNeckWithHead(nn.Module):
         N, C = scores.shape
         yaw_flag = boxes.shape[1] == 7
         boxes7 = boxes if yaw_flag else torch.cat((boxes, torch.zeros_like(boxes[:, :1])), dim=1)
-        # ---- top-nms_pre per (scene, level): one stable sort of (segment, rank key) ----------------------------------
-        counts = torch.bincount(seg, minlength=B * Lv)
-        big = counts > cfg.nms_pre
-        row = torch.arange(N, device=dev)
-        frac = torch.where(big[seg], 1.0 - maxs.double(), row.double() / (N + 1))       # descending score | row order
-        order = torch.sort(seg.double() * 2.0 + frac, stable=True).indices
-        seg_o = seg[order]
-        starts = torch.cumsum(counts, 0) - counts
-        keep = (row - starts[seg_o]) < cfg.nms_pre
-        sel = order[keep]                                   # (scene, level, rank) order == the per-scene loop's cat order
+        sel = segmented_topk(seg, maxs, B * Lv, cfg.nms_pre)   # (scene, level, rank) order == the per-scene loop's cat order
         scene = seg[sel] // Lv
         per_scene = torch.bincount(scene, minlength=B)
         pos = torch.arange(sel.numel(), device=dev) - (torch.cumsum(per_scene, 0) - per_scene)[scene]
@@ -432,6 +423,22 @@ class Fcaf3DNeckWithHead(nn.Module):
             nms_bboxes = nms_bboxes[:, :6]
         nms_bboxes = img_meta['box_type_3d'](nms_bboxes, box_dim=box_dim, with_yaw=with_yaw, origin=(.5, .5, .5))
         return nms_bboxes, nms_scores, nms_labels
+
+
+def segmented_topk(seg, score, n_seg, k):
+    """Indices of the rows the reference's per-(scene, level) loop keeps (fcaf3d_neck_with_head.py:238-243: `if len(scores) >
+    nms_pre: topk(nms_pre)`), for every segment at once: segments in ascending id; inside a segment with more than k rows the k
+    best by descending score (ties: row order), inside a smaller one ALL rows in row order.  One stable sort of a float64 key
+    (segment id, then 1 - score | row / (N + 1)); seg (N,) int64 in [0, n_seg), score (N,) in [0, 1]."""
+    N = seg.numel()
+    counts = torch.bincount(seg, minlength=n_seg)
+    big = counts > k
+    row = torch.arange(N, device=seg.device)
+    frac = torch.where(big[seg], 1.0 - score.double(), row.double() / (N + 1))
+    order = torch.sort(seg.double() * 2.0 + frac, stable=True).indices
+    starts = torch.cumsum(counts, 0) - counts
+    keep = (row - starts[seg[order]]) < k
+    return order[keep]
 
 
 def compute_centerness(bbox_targets):

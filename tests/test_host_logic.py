@@ -103,6 +103,30 @@ def test_boxes_container():
     assert b6.tensor.shape == (0, 7) and b6.with_yaw is False
 
 
+def test_segmented_topk_equals_the_per_segment_loop():
+    """the batched candidate selection of get_bboxes == the reference's loop (`if len(scores) > nms_pre: topk(nms_pre)` per
+    scene and level, fcaf3d_neck_with_head.py:238-243): same rows, same order; segments interleaved in memory, empty and
+    exactly-k segments, tied scores"""
+    from fcaf3d_amd.fcaf3d_neck_with_head import segmented_topk
+    g = torch.Generator().manual_seed(1)
+    n_seg, k = 7, 50
+    sizes = [0, 1, 49, 50, 51, 400, 1300]
+    seg = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(sizes)])
+    seg = seg[torch.randperm(seg.numel(), generator=g)]                     # rows of a segment are not contiguous
+    score = torch.rand(seg.numel(), generator=g)
+    score[::7] = score[3]                                                    # ties
+    sel = segmented_topk(seg, score, n_seg, k)
+    want = []
+    for s_ in range(n_seg):
+        rows = torch.nonzero(seg == s_).flatten()
+        if len(rows) > k:
+            sc = score[rows]
+            idx = torch.sort(-sc.double(), stable=True).indices[:k]          # descending score, ties in row order
+            rows = rows[idx]
+        want.append(rows)
+    assert torch.equal(sel, torch.cat(want))
+
+
 def test_bbox3d2result_batch_equals_per_scene_conversion():
     """simple_test's batched result conversion (three copies for the whole batch) == bbox3d2result per scene
     (mmdet3d/core/bbox/transforms.py bbox3d2result: boxes / scores / labels on the CPU), empty scenes included"""
