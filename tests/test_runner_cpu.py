@@ -54,6 +54,58 @@ def test_train_step_equals_the_recipe_written_out():
     tr.load_state_dict(sd)
 
 
+def _dp_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from fcaf3d_amd import dist as D
+    D.init_dist(backend='gloo')
+    cfg = fa.get_config('fcaf3d_scannet-3d-18class')
+    model = _Toy()
+    tr = R.TrainStep.from_config(model, cfg, bucket_mb=1e-4)          # several tiny buckets: hooks + ordered launches + flush
+    assert len(tr.averager.buckets) >= 2
+    g = torch.Generator().manual_seed(7)
+    for step in range(3):
+        x, y = torch.randn(16, 6, generator=g), torch.randn(16, 3, generator=g)      # the GLOBAL batch, same on both ranks
+        half = slice(rank * 8, rank * 8 + 8)
+        tr(dict(x=x[half], y=y[half]))
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    torch.distributed.all_gather(gathered, flat)
+    if rank == 0:
+        q.put([t.numpy() for t in gathered])
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_train_step_data_parallel_world2_equals_global_batch():
+    """TrainStep under a 2-rank gloo group (one process per rank, gradients averaged bucket by bucket from the autograd hooks,
+    then clip + AdamW on every rank): after 3 steps both ranks hold the SAME parameters, equal to one process stepping on the
+    whole batch — the losses are means over samples, so the average of the two half-batch gradients is the global gradient
+    (what MMDistributedDataParallel gives the reference, tools/dist_train.sh:7-9)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(got[0], got[1])                      # identical replicas
+    cfg = fa.get_config('fcaf3d_scannet-3d-18class')
+    model = _Toy()
+    tr = R.TrainStep.from_config(model, cfg)
+    g = torch.Generator().manual_seed(7)
+    for step in range(3):
+        x, y = torch.randn(16, 6, generator=g), torch.randn(16, 3, generator=g)
+        tr(dict(x=x, y=y))
+    ref = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()
+    assert np.allclose(got[0], ref, atol=2e-6), np.abs(got[0] - ref).max()
+
+
 def test_c_openmp_conv_oracle_matches_numpy_oracle():
     from oracle import conv_c, me_oracle as mo
     rng = np.random.default_rng(0)
