@@ -12,7 +12,6 @@
 // Replaces MinkowskiEngine's ConvolutionForward/Backward (and ConvolutionTranspose, 1x1 mm) called
 // from me_resnet.py:19-21,56-62, BasicBlock, fcaf3d_neck_with_head.py:52,60-69,83-85,257-263.
 #include "fc_common.h"
-#include "conv_reg.h"
 #ifdef FC_TRACE
 __device__ unsigned long long* g_trace_buf_lds;
 __device__ int g_trace_cap_lds;
@@ -50,8 +49,7 @@ extern "C" int fc_debug_set_prio(int mode) {
 
 // ------------------------------------------------------------------------------------------------
 // Pipeline per workgroup: (1) which kernel offsets have any neighbour among the tile's rows (offsets without one are
-// skipped outright) — from the precomputed 32-row group masks when the caller has them (gmask: fc_nbr_group_masks, 4
-// words per 128-row tile, no table scan), else OR-reduced over the tile's rows; (2) walk the surviving (offset,
+// skipped outright), OR-reduced over the tile's rows; (2) walk the surviving (offset,
 // Cin-slab) stages with the NEXT stage's gathers + weight loads issued into registers before the current stage's MFMAs
 // run (single LDS buffer, global-load latency hidden behind the matrix pipe).
 // gridDim.z > 1 = split over kernel offsets (offset k handled by split k % gridDim.z) for layers whose
@@ -64,7 +62,7 @@ extern "C" int fc_debug_set_prio(int mode) {
 // consecutive lanes = consecutive columns); the LDS image, the fragment reads and the results are the same.
 template <int BM, int BN, int BKT, bool HAS_NBR, int WM = 2, bool WT = false>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (WM == 4 ? 3 : 2)) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ W,
-                                                   const int* __restrict__ nbr, const unsigned int* __restrict__ gmask,
+                                                   const int* __restrict__ nbr,
                                                    const int* __restrict__ out_index, const int* __restrict__ cnt,
                                                    float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout) {
   constexpr int WN = 4 / WM;
@@ -126,15 +124,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (W
 
   // ---- (1) which of this split's offsets have a neighbour anywhere in the tile ---------------------
   unsigned int kmask;
-  if (HAS_NBR && gmask && !cnt) {
-    unsigned int mk = 0u;
-#pragma unroll
-    for (int g = 0; g < BM / 32; ++g)
-      if (m0 + g * 32 < n_out) mk |= gmask[m0 / 32 + g];
-    unsigned int zm = 0u;
-    for (int k = z; k < K; k += S) zm |= 1u << k;
-    kmask = mk & zm;
-  } else {
+  {
     if (tid == 0) kmask_s = 0u;
     __syncthreads();
     if (tid < BM) {
@@ -301,7 +291,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128 && BKT == 32) ? 4 : (W
 //    registers) instead of read -> s_waitcnt lgkmcnt(0) -> multiply.
 template <int BM, int BN, int BKT, bool HAS_NBR, int WM = 2, bool WT = false>
 __global__ __launch_bounds__(256, 3) void k_conv_mfma_p(const float* __restrict__ in, const float* __restrict__ W,
-                                                   const int* __restrict__ nbr, const unsigned int* __restrict__ gmask,
+                                                   const int* __restrict__ nbr,
                                                    const int* __restrict__ out_index, const int* __restrict__ cnt,
                                                    float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout) {
   constexpr int WN = 4 / WM;
@@ -363,15 +353,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_p(const float* __restrict_
 
   // ---- (1) which of this split's offsets have a neighbour anywhere in the tile ---------------------
   unsigned int kmask;
-  if (HAS_NBR && gmask && !cnt) {
-    unsigned int mk = 0u;
-#pragma unroll
-    for (int g = 0; g < BM / 32; ++g)
-      if (m0 + g * 32 < n_out) mk |= gmask[m0 / 32 + g];
-    unsigned int zm = 0u;
-    for (int k = z; k < K; k += S) zm |= 1u << k;
-    kmask = mk & zm;
-  } else {
+  {
     if (tid == 0) kmask_s = 0u;
     __syncthreads();
     if (tid < BM) {
@@ -572,7 +554,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_p(const float* __restrict_
 // ds_read_b128's 16-lane groups.  Same tiles, prologue, epilogue, grid shapes and results as k_conv_mfma / _p.
 template <int BM, int BN, bool HAS_NBR, int WM = 2>
 __global__ __launch_bounds__(256, 2) void k_conv_glds(const float* __restrict__ in, const float* __restrict__ W,
-                                                      const int* __restrict__ nbr, const unsigned int* __restrict__ gmask,
+                                                      const int* __restrict__ nbr,
                                                       const int* __restrict__ out_index, const int* __restrict__ cnt,
                                                       float* __restrict__ out, int64_t n_out, int K, int Cin, int Cout) {
   constexpr int BKT = 32;
@@ -621,15 +603,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_glds(const float* __restrict__ 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   unsigned int kmask;
-  if (HAS_NBR && gmask && !cnt) {
-    unsigned int mk = 0u;
-#pragma unroll
-    for (int g = 0; g < BM / 32; ++g)
-      if (m0 + g * 32 < n_out) mk |= gmask[m0 / 32 + g];
-    unsigned int zm = 0u;
-    for (int k = z; k < K; k += S) zm |= 1u << k;
-    kmask = mk & zm;
-  } else {
+  {
     // the tile-mask word lives in stage buffer 1: nothing is written there before every wave has passed stage 0's barrier
     unsigned int* kmask_s = reinterpret_cast<unsigned int*>(&smem[STAGE]);
     if (tid == 0) *kmask_s = 0u;
@@ -1109,10 +1083,7 @@ __global__ void k_conv_fma(const float* __restrict__ in, const float* __restrict
 
 extern "C" {
 
-// flags[24:27]: register-direct kernel variant (conv_reg.h), 0 = LDS-tiled kernel; flags bit28: register-direct wgrad
 #define FC_CONV_WT (1 << 23)   // fc_conv_fwd / fc_conv_fwd_pairs(_tiles): W[k] is stored transposed, (Cout, Cin) row-major
-#define FC_REG_VARIANT(flags) (((flags) >> 24) & 15)
-#define FC_REG_WGRAD(flags) (((flags) >> 28) & 1)
 // The deeper-pipelined LDS kernel (k_conv_mfma_p) holds 3 workgroups per CU (768 slots) where k_conv_mfma holds 4 (1024): it
 // wins on launches of many rounds and on launches that fit 768 slots anyway, and loses a round in between (r2: +5.5 / +7 %
 // on the 441k / 55k-row levels, +5 % on the 862-row pair mode, -12 % on the 3.5k-row pair mode with its 972 workgroups).
@@ -1127,11 +1098,6 @@ static inline int conv_pipe(int flags, dim3 grid) {
   // in between: offset-split launches of a dense table go to the LDS-DMA kernel (r2 nbench, same box: 6.9k rows 256->256
   // 251 -> 232 us, 256->128 139 -> 128 us, 14.9k rows 128->128 163 -> 146 us; unsplit and pair-list launches: neutral)
   return (grid.z > 1 && !(flags & (1 << 22))) ? 2 : 0;
-}
-static inline int reg_variant_for(int flags, int Cout) {
-  int rv = FC_REG_VARIANT(flags);
-  if ((rv == FC_REG_32x128_SPLIT || rv == FC_REG_64x128_SPLIT) && Cout % 128 != 0) rv = FC_REG_64x64_SPLIT;
-  return rv;
 }
 
 static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* mfma, int* bm, int* bn, int* S) {
@@ -1164,25 +1130,16 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
     s = 1;
     if (*mfma && K > 1 && t2 < 384) { s = (int)(1024 / t2); if (s > K) s = K; if (s < 1) s = 1; }
   }
-  const int rv = FC_REG_VARIANT(flags);
-  if (*mfma && rv) {                             // register-direct kernels (conv_reg.hip): their own tile shapes
-    int rows, cols;
-    fc_reg_tile(rv, &rows, &cols);
-    if (Cout % cols != 0 && rv != FC_REG_64x64_WAVE) { fc_reg_tile(FC_REG_64x64_SPLIT, &rows, &cols); }
-    const int64_t t3 = fc_cdiv(n_out, rows) * fc_cdiv(Cout, cols);
-    s = 1;
-    if (K > 1 && t3 < 640) { s = (int)fc_cdiv(768, t3); if (s > K) s = K; }
-  }
   if (fs) s = fs > K ? K : fs;
   *S = s;
 }
 
 // one launch of the LDS-tiled MFMA kernel (32-deep slabs; measured r1: 64-deep slabs, 256-row tiles, an LDS index table
 // and LDS-padding occupancy caps all lose or are neutral — profiles/r1_conv_pmc.md — and were removed in r2)
-static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr, const unsigned int* gmask,
+static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr,
                             const int* out_index, const int* cnt, float* dst, int64_t n_rows, int K, int Cin, int Cout,
                             hipStream_t stream, bool wt = false) {
-#define FC_ARGS <<<grid, 256, 0, stream>>>(in, W, nbr, gmask, out_index, cnt, dst, n_rows, K, Cin, Cout)
+#define FC_ARGS <<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout)
 #define FC_LAUNCH_MFMA(KERNEL, BM_, BN_, WM_)                                    \
   do {                                                                           \
     if (wt) KERNEL<BM_, BN_, 32, true, WM_, true> FC_ARGS;                        \
@@ -1232,8 +1189,7 @@ static int sum_parts(const float* part, float* out, int64_t n_out, int Cout, int
   return FC_OK;
 }
 
-// gmask (nullable): 32-row group masks of `nbr` (fc_nbr_group_masks) — the tile's offset mask without a table scan
-static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const unsigned int* gmask, const int* out_index,
+static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const int* out_index,
                          float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
                          int64_t ws_bytes, hipStream_t stream) {
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
@@ -1247,7 +1203,7 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
     return FC_OK;
   }
   const bool wt = (flags & FC_CONV_WT) != 0;    // W[k] given as (Cout, Cin): the backward-data pass on the layer's own kernel
-  if (wt && (!nbr || FC_REG_VARIANT(flags))) return FC_EINVAL;
+  if (wt && !nbr) return FC_EINVAL;
   bool mfma_ok; int bm, bn, S;
   conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S);
   if (!mfma_ok) {
@@ -1258,13 +1214,8 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
   }
   if (S > 1 && ws_bytes < (int64_t)S * n_out * Cout * (int64_t)sizeof(float)) return FC_EWS;
   float* dst = S > 1 ? (float*)ws : out;
-  int rc;
-  if (FC_REG_VARIANT(flags)) {
-    rc = fc_conv_reg_launch(in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout, S, reg_variant_for(flags, Cout), stream);
-  } else {
-    dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
-    rc = launch_conv_mfma(conv_pipe(flags, grid), bm, bn, grid, in, W, nbr, K <= 31 ? gmask : nullptr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream, wt);
-  }
+  dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
+  int rc = launch_conv_mfma(conv_pipe(flags, grid), bm, bn, grid, in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream, wt);
   if (rc != FC_OK) return rc;
   return S > 1 ? sum_parts(dst, out, n_out, Cout, S, stream) : FC_OK;
 }
@@ -1272,43 +1223,7 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
 // flags: bit0 = force the generic FMA kernel.
 int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
                 int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
-  return conv_fwd_impl(in, W, nbr, nullptr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream);
-}
-
-// ---- streaming (persistent-wave) convolution: conv_reg.hip k_conv_stream ------------------------------------------
-int fc_nbr_group_masks(const int* nbr, int64_t n_out, int K, unsigned int* gmask, hipStream_t stream) {
-  if (n_out < 0 || !nbr || !gmask) return n_out == 0 ? FC_OK : FC_EINVAL;
-  return fc_group_masks_launch(nbr, n_out, K, gmask, stream);
-}
-
-// flags bit2: the LDS-tiled kernel of fc_conv_fwd with the group-mask prologue instead of the persistent-wave kernel
-// (the remaining flag bits then mean what they mean for fc_conv_fwd)
-int64_t fc_conv_fwd_stream_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags) {
-  if (flags & 4) return fc_conv_fwd_ws_bytes(n_out, K, Cin, Cout, flags);
-  int tm, S, items;
-  fc_conv_stream_plan(n_out > 0 ? n_out : 1, K, Cin, Cout, (flags >> 4) & 3, (flags >> 8) & 255, &tm, &S, &items);
-  return S > 1 ? (int64_t)S * n_out * Cout * (int64_t)sizeof(float) : 0;
-}
-
-int fc_conv_fwd_stream(const float* in, const float* W, const int* nbr, const unsigned int* gmask, const int* out_index,
-                       float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
-                       int64_t ws_bytes, hipStream_t stream) {
-  if (n_in < 0 || n_out < 0 || K < 1 || K > 31 || Cin < 1 || Cout < 1 || !nbr || !gmask) return FC_EINVAL;
-  if (Cin % 32 != 0 || Cout % 64 != 0) return FC_EINVAL;       // MFMA shapes only; callers use fc_conv_fwd otherwise
-  if (n_out == 0) return FC_OK;
-  if (flags & 4) return conv_fwd_impl(in, W, nbr, gmask, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream);
-  int tm, S, items;
-  fc_conv_stream_plan(n_out, K, Cin, Cout, (flags >> 4) & 3, (flags >> 8) & 255, &tm, &S, &items);
-  if (S > 1 && ws_bytes < (int64_t)S * n_out * Cout * (int64_t)sizeof(float)) return FC_EWS;
-  float* dst = S > 1 ? (float*)ws : out;
-  int rc = fc_conv_stream_launch(in, W, nbr, gmask, out_index, dst, n_out, K, Cin, Cout, tm, S, stream);
-  if (rc != FC_OK) return rc;
-  if (S > 1) {
-    int64_t e4 = n_out * Cout / 4;
-    k_sum_parts<<<(unsigned)fc_cdiv(e4, 256), 256, 0, stream>>>(dst, out, e4, S);
-    FC_CHECK_LAUNCH();
-  }
-  return FC_OK;
+  return conv_fwd_impl(in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream);
 }
 
 int64_t fc_conv_fwd_pairs_ws_bytes(int64_t n_out, int K, int Cout) {
@@ -1326,20 +1241,12 @@ int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in,
   if (ws_bytes < fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout)) return FC_EWS;
   float* part = (float*)ws;
   const bool wt = (flags & FC_CONV_WT) != 0;
-  if (wt && FC_REG_VARIANT(flags)) return FC_EINVAL;
-  if (FC_REG_VARIANT(flags)) {
-    int rc = fc_conv_reg_launch(in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, K, reg_variant_for(flags, Cout), stream);
-    if (rc != FC_OK) return rc;
-    k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);
-    FC_CHECK_LAUNCH();
-    return FC_OK;
-  }
   const bool wide = (Cout % 128 == 0) && !(((flags >> 6) & 3) == 1);
   const int bn = wide ? 128 : 64;
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
   if (live_tiles > 0) grid = dim3((unsigned)live_tiles, Cout / bn, 1);       // linear list of the live (offset, tile) pairs
   {
-    int rc = launch_conv_mfma(live_tiles > 0 ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt);
+    int rc = launch_conv_mfma(live_tiles > 0 ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt);
     if (rc != FC_OK) return rc;
   }
   k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);
@@ -1778,7 +1685,6 @@ extern "C" {
 static void wgrad_tiles(int Cin, int Cout, int flags, int* bm, int* bn) {
   *bm = 64;                                  // measured: 64-channel Cin tiles beat 128 on every benchmark layer
   *bn = (Cout % 128 == 0) ? 128 : 64;
-  if (FC_REG_WGRAD(flags)) { *bm = 64; *bn = 64; return; }
   int fbm = (flags >> 4) & 3, fbn = (flags >> 6) & 3;      // tuning overrides
   if (fbm == 1) *bm = 64;
   if (fbm == 2 && Cin % 128 == 0) *bm = 128;
@@ -1791,7 +1697,7 @@ static void wgrad_tiles(int Cin, int Cout, int flags, int* bm, int* bn) {
 // 1086 -> 1051); flags bit29 disables it, bit30 restricts it to its first rule (Cin = 64, >= 32768 rows)
 #define WGRAD_KO 3
 static inline bool wgrad_multi_ok(int64_t n_out, int K, int Cin, int Cout, int flags, bool dense_table) {
-  return dense_table && !(flags & 1) && !(flags & (1 << 29)) && !FC_REG_WGRAD(flags) && K % WGRAD_KO == 0 &&
+  return dense_table && !(flags & 1) && !(flags & (1 << 29)) && K % WGRAD_KO == 0 &&
          Cin % 64 == 0 && Cout % 64 == 0 && n_out >= 4096 && (!(flags & (1 << 30)) || (Cin == 64 && n_out >= 32768));
 }
 
@@ -1907,9 +1813,6 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     dim3 grid((unsigned)S, (unsigned)((K / WGRAD_KO) * (Cin / 64) * (Cout / bn)));
     if (bn == 128) k_wgrad_multi<128, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
     else k_wgrad_multi<64, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
-  } else if (mfma_ok && FC_REG_WGRAD(flags)) {
-    int rc = fc_wgrad_reg_launch(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, S, rps, stream);
-    if (rc != FC_OK) return rc;
   } else if (mfma_ok) {
     int bm, bn;
     wgrad_tiles(Cin, Cout, flags, &bm, &bn);

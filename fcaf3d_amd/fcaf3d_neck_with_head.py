@@ -9,6 +9,7 @@ the HIP operators of this package).  Differences that do not change results:
     ONE all-reduce — numerically identical.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -129,29 +130,65 @@ class Fcaf3DNeckWithHead(nn.Module):
         nn.init.constant_(self.cls_conv.bias, bias_init_with_prob(.01))
 
     # ---- forward (reference :94-108) ---------------------------------------------------------------
+    # out_block_i + forward_single(i) of every level but the finest depend only on that level's neck tensor, while the
+    # neck itself goes on to the next finer level: they run on a second HIP stream (r3), so that the ramp / tail of one
+    # branch's launches is filled by the other's.  autograd replays each node on the stream of its forward, so the
+    # backward pass overlaps the same way.  Results are identical (same kernels, same inputs).
+    head_overlap = os.environ.get('FC_HEAD_OVERLAP', '1') != '0'
+    _head_streams = {}
+
+    def _head_stream(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if idx not in self._head_streams:
+            self._head_streams[idx] = torch.cuda.Stream(device=idx)
+        return self._head_streams[idx]
+
     def forward(self, x):
         outs = []
         inputs = x
         x = inputs[-1]
         scores = None
+        dev = x.F.device
+        side = self._head_stream(dev) if (self.head_overlap and dev.type == 'cuda' and len(inputs) > 1) else None
+        main = torch.cuda.current_stream(dev) if side is not None else None
+        self._side_busy = False
+        wk = self._packed_head_kernel()
         for i in range(len(inputs) - 1, -1, -1):
             if i < len(inputs) - 1:
                 x = MEnn.run_sequential(getattr(self, f'up_block_{i + 1}'), x)
                 x = inputs[i] + x
-                x = self._prune(x, scores)
-            out = MEnn.run_sequential(getattr(self, f'out_block_{i}'), x)
-            out = self.forward_single(out, self.scales[i])
+                x = self._prune(x, scores, (main, side))
+            if side is not None and i > 0:
+                side.wait_stream(main)                       # x is complete on the main stream
+                x.F.record_stream(side)
+                with torch.cuda.stream(side):
+                    out = MEnn.run_sequential(getattr(self, f'out_block_{i}'), x)
+                    out = self.forward_single(out, self.scales[i], wk)
+                self._side_busy = True
+            else:
+                out = MEnn.run_sequential(getattr(self, f'out_block_{i}'), x)
+                out = self.forward_single(out, self.scales[i], wk)
             scores = out[-1]
             outs.append(out[:-1])
+        if side is not None and self._side_busy:
+            main.wait_stream(side)
+            for o in outs[:-1]:
+                for v in o:
+                    v.full.record_stream(main)               # allocated under the side stream, consumed by the loss on main
+            self._side_busy = False
         return zip(*outs[::-1])
 
-    def _prune(self, x, scores):
+    def _prune(self, x, scores, streams=(None, None)):
         """Keep, per scene, the pts_threshold voxels with the largest interpolated parent score (:110-126)."""
         if self.pts_threshold < 0:
             return x
         perms = x.decomposition_permutations
         if all(len(p) <= self.pts_threshold for p in perms):
             return x                        # top-k of everything keeps everything
+        main, side = streams
+        if side is not None and getattr(self, '_side_busy', False):
+            main.wait_stream(side)          # the parent level's scores come from the head branch
+            scores.F.record_stream(main)
         with torch.no_grad():
             interpolated = scores.features_at_coordinates(x.C).squeeze(1)
             mask = torch.zeros(len(interpolated), dtype=torch.bool, device=interpolated.device)
@@ -161,15 +198,20 @@ class Fcaf3DNeckWithHead(nn.Module):
                 mask[perm[ids]] = True
         return self.pruning(x, mask)
 
-    def forward_single(self, x, scale):
-        """Three 1x1 convs as ONE 128 -> (1 + n_reg + n_cls) GEMM, padded to a multiple of 64 columns for
-        the MFMA tile (reference :256-279)."""
-        n_c, n_r = self.n_classes, self.n_reg_outs
-        w = torch.cat((self.centerness_conv.kernel, self.reg_conv.kernel, self.cls_conv.kernel), dim=1)
-        used = w.shape[1]
-        pad = (-used) % 64
+    def _packed_head_kernel(self):
+        """[centerness | reg | cls] kernels side by side, zero-padded to a multiple of 64 columns (the MFMA tile)."""
+        ws = [self.centerness_conv.kernel, self.reg_conv.kernel, self.cls_conv.kernel]
+        pad = (-sum(w.shape[1] for w in ws)) % 64
         if pad:
-            w = torch.cat((w, w.new_zeros(w.shape[0], pad)), dim=1)
+            ws.append(ws[0].new_zeros(ws[0].shape[0], pad))
+        return torch.cat(ws, dim=1).unsqueeze(0)
+
+    def forward_single(self, x, scale, packed_kernel=None):
+        """Three 1x1 convs as ONE 128 -> (1 + n_reg + n_cls) GEMM, padded to a multiple of 64 columns for
+        the MFMA tile (reference :256-279).  `packed_kernel`: the packed operator, built once per forward pass by
+        `forward` for all levels (r3: it used to be rebuilt per level — 3 launches forward and 2 backward each)."""
+        n_c, n_r = self.n_classes, self.n_reg_outs
+        w = (packed_kernel if packed_kernel is not None else self._packed_head_kernel())[0]
         y = Fn.sparse_conv(x.F, w.unsqueeze(0), None, x.F.shape[0])
         if w.shape[1] <= 64:
             # centerness | exp(scale * reg[:, :6]), reg[:, 6:] | cls + bias, and the max class logit `_prune` interpolates:

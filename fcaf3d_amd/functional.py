@@ -15,6 +15,7 @@ FLAGS = int(os.environ.get('FC_FLAGS', '0'), 0)   # bit0: force the generic FMA 
 WGRAD_ASYNC = False
 _wg_streams = {}
 _join_queued = False
+_pending_gw = []          # weight gradients produced on the side stream since the last join
 
 
 def wgrad_stream(device):
@@ -30,6 +31,9 @@ def join_wgrad_stream():
     _join_queued = False
     for s in _wg_streams.values():
         torch.cuda.current_stream(s.device).wait_stream(s)
+    for g in _pending_gw:                               # their consumer (optimizer / all-reduce) runs on the joining stream
+        g.record_stream(torch.cuda.current_stream(g.device))
+    _pending_gw.clear()
 
 
 def _chk(*ts):
@@ -146,8 +150,8 @@ class _SparseConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # the (Cout -> Cin) operator of the backward-data pass: the kernels read the layer's own (K, Cin, Cout) kernel as
             # its transpose (flags CONV_WT; r2: 50 transpose launches and 0.34 ms per step gone); identity maps (dense GEMMs)
-            # and the register-direct tuning variants still take a transposed copy
-            if DGRAD_WT and kmap is not None and not ((FLAGS >> 24) & 15):
+            # still take a transposed copy
+            if DGRAD_WT and kmap is not None:
                 wt, fl = weight, FLAGS | CONV_WT
             else:
                 wt, fl = torch.empty((K, Cout, Cin), dtype=torch.float32, device=dev), FLAGS
@@ -191,6 +195,7 @@ class _SparseConv(torch.autograd.Function):
                     if t is not None:
                         t.record_stream(side)              # keep their memory until the side stream has read it
                 gw.record_stream(main)
+                _pending_gw.append(gw)
                 if not _join_queued:
                     _join_queued = True
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)

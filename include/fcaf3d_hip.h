@@ -121,18 +121,6 @@ int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const
                       float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
                       int64_t ws_bytes, hipStream_t stream);
 
-/* The same convolution (ME.MinkowskiConvolution forward / backward-data: me_resnet.py:56-62, BasicBlock convs,
- * fcaf3d_neck_with_head.py:52, :69) on PERSISTENT wavefronts: every wave walks a static list of (offset split, row tile,
- * column tile) items as one uninterrupted operand stream, skips the MFMAs of a 32-row group at offsets none of its rows
- * has (gmask: one word per 32 rows of `nbr`, bit k = offset k present; fc_nbr_group_masks), and writes each tile once.
- * `nbr` is normally the mask-sorted table of fc_permute_nbr with its `out_index`.  MFMA shapes only (Cin % 32 == 0,
- * Cout % 64 == 0, K <= 31).  flags[4:5]: tile rows (1 = 32, 2 = 64, 0 = auto), flags[8:15]: offset splits (0 = auto). */
-int fc_nbr_group_masks(const int* nbr, int64_t n_out, int K, unsigned int* gmask, hipStream_t stream);
-int64_t fc_conv_fwd_stream_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);
-int fc_conv_fwd_stream(const float* in, const float* W, const int* nbr, const unsigned int* gmask, const int* out_index,
-                       float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
-                       int64_t ws_bytes, hipStream_t stream);
-
 /* The same (ME.MinkowskiConvolution per offset over its in/out maps, me_resnet.py:56-62) for a caller that has read the pair
  * counts back: live_tiles = sum_k ceil(pair_cnt[k] / 128) launches exactly the non-empty (offset, 128-row tile) workgroups
  * as one linear list (no workgroup exits on arrival; evenly filled shader engines).  live_tiles <= 0: as fc_conv_fwd_pairs. */

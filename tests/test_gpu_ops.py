@@ -185,11 +185,7 @@ def test_conv_mfma_large_tiles(Cin, Cout):
     _conv_case(_dev(), 100000, Cin, Cout, 3, 1, 0, B=1)
 
 
-@pytest.mark.parametrize('flags,what', [(1 << 24, 'register-direct 64x64, waves split the reduction'),
-                                        (2 << 24, 'register-direct 64x64, one tile per wave'),
-                                        (3 << 24, 'register-direct 32x128'), (4 << 24, 'register-direct 64x128'),
-                                        (5 << 24, 'register-direct 32x64'), (1 << 28, 'register-direct weight gradient'),
-                                        (3 << 4, '256x64 LDS tile (4x1 waves)'), (1 << 29, 'one-offset dense weight gradient'),
+@pytest.mark.parametrize('flags,what', [(3 << 4, '256x64 LDS tile (4x1 waves)'), (1 << 29, 'one-offset dense weight gradient'),
                                         (1 << 18, 'deeper-pipelined LDS kernel forced on'),
                                         ((1 << 18) | (2 << 4), 'deeper-pipelined LDS kernel, 128-row tiles'),
                                         ((1 << 18) | (3 << 4), 'deeper-pipelined LDS kernel, 256x64 tiles'),
@@ -199,16 +195,15 @@ def test_conv_mfma_large_tiles(Cin, Cout):
                                         (1 << 20, 'pipelined weight-gradient kernel wherever it applies'),
                                         ((1 << 16) | (1 << 29), 'r1 weight-gradient kernel, one offset per workgroup')])
 def test_conv_kernel_variants_behind_flags(flags, what):
-    """every flag-selected kernel variant (conv.hip / conv_reg.hip; the defaults are chosen by measurement) against the oracle,
+    """every flag-selected kernel variant (conv.hip; the defaults are chosen by measurement) against the oracle,
     forward + backward-data + backward-weights, on a strided and an unstrided map"""
     _conv_case(_dev(), 9000, 64, 128, 3, 1, flags, level_q=4)
     _conv_case(_dev(), 9000, 64, 64, 3, 2, flags, level_q=2)
 
 
-def test_streaming_and_group_mask_convolution_entry_points():
-    """fc_nbr_group_masks + fc_conv_fwd_stream (persistent-wave kernel, and with flags bit2 the LDS-tiled kernel on the
-    group-mask prologue) and fc_conv_fwd_pairs_tiles (linear live-tile launch) == the generic FMA kernel, on plain and
-    on mask-sorted tables, with and without offset splits."""
+def test_pair_list_convolution_linear_live_tile_launch():
+    """fc_conv_fwd_pairs_tiles (3-D grid and the linear list of live (offset, tile) workgroups) == the generic FMA kernel
+    (flags bit0; itself checked against the oracle by the tests above — a transitive check, stated here on purpose)."""
     from fcaf3d_amd import _lib as L
     from fcaf3d_amd.sparse import CoordMap
     dev = _dev()
@@ -217,7 +212,6 @@ def test_streaming_and_group_mask_convolution_entry_points():
     uc, _, _ = mo.unique_first(c_ref)
     cm, _, _ = CoordMap.from_coords(torch.from_numpy(uc).to(dev), 4, 2)
     km = cm.kernel_map(cm, 3)
-    km.sort_rows = True
     n, K = cm.n, 27
     for Cin, Cout in ((64, 128), (128, 64)):
         g = torch.Generator().manual_seed(1)
@@ -225,25 +219,6 @@ def test_streaming_and_group_mask_convolution_entry_points():
         w = (torch.randn(K, Cin, Cout, generator=g) / np.sqrt(Cin * K)).to(dev)
         ref = torch.empty(n, Cout, device=dev)
         L.call('fc_conv_fwd', L.ptr(x), L.ptr(w), L.ptr(km.nbr), None, L.ptr(ref), n, n, K, Cin, Cout, 1, None, 0, L.stream())
-        for tab, oidx in ((km.nbr, None), km.sorted_fwd()):
-            gm = torch.zeros(2 * ((n + 63) // 64) + 2, dtype=torch.int32, device=dev)
-            L.call('fc_nbr_group_masks', L.ptr(tab), n, K, L.ptr(gm), L.stream())
-            # group masks == OR over 32 rows of the per-row occupancy
-            occ = (tab >= 0).to(torch.int64) * (1 << torch.arange(K, device=dev))[:, None]
-            rows = occ.sum(0)
-            pad = (-n) % 32
-            want = torch.nn.functional.pad(rows, (0, pad)).reshape(-1, 32)
-            acc = want[:, 0].clone()
-            for j in range(1, 32):
-                acc |= want[:, j]
-            assert torch.equal(gm[:acc.numel()].to(torch.int64), acc)
-            for fl in (0, 1 << 4, 2 << 4, (2 << 4) | (3 << 8), (1 << 4) | (5 << 8), 4, 4 | (5 << 8)):
-                out = torch.full((n, Cout), float('nan'), device=dev)
-                wsb = L.query('fc_conv_fwd_stream_ws_bytes', n, K, Cin, Cout, fl)
-                ws = L.workspace(max(wsb, 16), dev)
-                L.call('fc_conv_fwd_stream', L.ptr(x), L.ptr(w), L.ptr(tab), L.ptr(gm), L.ptr(oidx), L.ptr(out), n, n, K, Cin, Cout,
-                       fl, L.ptr(ws), ws.numel(), L.stream())
-                _close(out, ref.cpu(), what=f'stream conv {Cin}->{Cout} flags={fl} sorted={oidx is not None}')
         pi, _, pos, cnt = km.pairs()
         for live in (0, km.pair_tiles()):
             out = torch.full((n, Cout), float('nan'), device=dev)

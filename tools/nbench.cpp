@@ -2,7 +2,7 @@
 // (no Python, no torch: a fresh GPU box spends its minutes on kernels, not on `import torch`).
 //
 //   hipcc -O2 --offload-arch=gfx950 tools/nbench.cpp -Iinclude -Lfcaf3d_amd -lfcaf3d_hip -Wl,-rpath,'$ORIGIN/../fcaf3d_amd' -o tools/nbench
-//   tools/nbench [--batch 8] [--only L3] [--mode fwd|wgrad|all] [--reps 10] [--variants 0,1,2,...] [--check]
+//   tools/nbench [--batch 8] [--only L3] [--mode fwd|wgrad|all] [--reps 10] [--s-sweep] [--no-check]
 //
 // Scenes follow fcaf3d_amd/synthetic.py (room 6 x 5 x 2.7 m, floor + walls + 15 cuboids, 100 000 points, 5 mm noise,
 // 2 cm voxels); coordinate sets and kernel maps are built on the HOST with ME's rules (first-occurrence row order,
@@ -151,8 +151,7 @@ extern "C" int fc_debug_set_prio(int mode);
 int main(int argc, char** argv) {
   int prio = 0;
   int batch = 8, reps = 10, npts = 100000; std::string only, mode = "all", trace_file; bool check = true;
-  int trace_variant = 1, trace_tbl = 0; bool stream_sweep = false, popc_sort = false, s_sweep = false;
-  std::vector<int> variants = {0, 1, 2, 3, 4, 5};
+  int trace_variant = 0, trace_tbl = 0; bool popc_sort = false, s_sweep = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "--batch") batch = atoi(argv[++i]);
@@ -162,13 +161,11 @@ int main(int argc, char** argv) {
     else if (a == "--mode") mode = argv[++i];
     else if (a == "--no-check") check = false;
     else if (a == "--prio") prio = atoi(argv[++i]);
-    else if (a == "--stream-sweep") stream_sweep = true;
     else if (a == "--popc-sort") popc_sort = true;
     else if (a == "--s-sweep") s_sweep = true;
     else if (a == "--trace") trace_file = argv[++i];            // needs the FC_TRACE build (tools/nbench_trace)
     else if (a == "--trace-variant") trace_variant = atoi(argv[++i]);
     else if (a == "--trace-tbl") trace_tbl = atoi(argv[++i]);
-    else if (a == "--variants") { variants.clear(); char* s = argv[++i]; for (char* t = strtok(s, ","); t; t = strtok(nullptr, ",")) variants.push_back(atoi(t)); }
   }
   // ---- coordinate pyramid ------------------------------------------------------------------------------
   std::vector<V4> pts = make_points(batch, npts, 0.02f);
@@ -336,49 +333,8 @@ int main(int argc, char** argv) {
       }
       struct Run { const char* what; int flags; int tbl; };     // tbl: 0 plain table, 1 mask-sorted, 2 pair lists
       std::vector<Run> runs;
-      for (int v : variants) {
-        runs.push_back({"plain ", v << 24, 0});
-        if (!cs.dense) { runs.push_back({"sorted", v << 24, 1}); runs.push_back({"pairs ", v << 24, 2}); if (v == 0) runs.push_back({"pairsL", 0, 3}); }
-      }
-      // streaming kernel: plain and mask-sorted tables, 32- and 64-row tiles, a few split counts
-      {
-        Dev<unsigned int> d_gm_plain, d_gm_sorted; d_gm_plain.alloc((n_out + 31) / 32 + 1); d_gm_sorted.alloc((n_out + 31) / 32 + 1);
-        FC(fc_nbr_group_masks(d_nbr.p, n_out, K, d_gm_plain.p, 0));
-        FC(fc_nbr_group_masks(d_sorted.p, n_out, K, d_gm_sorted.p, 0));
-        // LDS-tiled kernel with the group-mask prologue (flags bit2)
-        for (int tbl = 0; tbl < 2; ++tbl) {
-          const int fl = 4;
-          int64_t wb = ws_for(fc_conv_fwd_stream_ws_bytes(n_out, K, Cin, Cout, fl));
-          const int* tab = tbl ? d_sorted.p : d_nbr.p; const int* oi = tbl ? d_oidx.p : nullptr;
-          const unsigned int* gm = tbl ? d_gm_sorted.p : d_gm_plain.p;
-          std::function<void()> fn = [&, wb, fl, tab, oi, gm]() { FC(fc_conv_fwd_stream(d_in.p, d_w.p, tab, gm, oi, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
-          CK(hipMemset(d_out.p, 0xff, (size_t)n_out * Cout * 4));
-          fn(); CK(hipDeviceSynchronize());
-          double err = -1;
-          if (check) err = max_rel_err(d_out.down((size_t)n_out * Cout), ref);
-          double us = time_us(reps, fn);
-          printf("   fwd  lds+gmask %s          %9.1f us %7.1f TF  err %.2e%s\n", tbl ? "sorted" : "plain ", us, gflop / us * 1e3, err, (check && !(err < 1e-4)) ? "  <-- MISMATCH" : "");
-        }
-        if (stream_sweep)
-        for (int tbl = (cs.dense ? 0 : 1); tbl < 2; ++tbl)
-          for (int tile = 1; tile <= 2; ++tile)
-            for (int fs : {0, 1, 2, 4, 8}) {
-              const int fl = (tile << 4) | (fs << 8);
-              int64_t wb = ws_for(fc_conv_fwd_stream_ws_bytes(n_out, K, Cin, Cout, fl));
-              if (fs > 1 && (int64_t)fs * n_out * Cout * 4 > (int64_t)1 << 31) continue;
-              const int* tab = tbl ? d_sorted.p : d_nbr.p; const int* oi = tbl ? d_oidx.p : nullptr;
-              const unsigned int* gm = tbl ? d_gm_sorted.p : d_gm_plain.p;
-              std::function<void()> fn = [&, wb, fl, tab, oi, gm]() { FC(fc_conv_fwd_stream(d_in.p, d_w.p, tab, gm, oi, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
-              CK(hipMemset(d_out.p, 0xff, (size_t)n_out * Cout * 4));
-              fn(); CK(hipDeviceSynchronize());
-              double err = -1;
-              if (check) err = max_rel_err(d_out.down((size_t)n_out * Cout), ref);
-              double us = time_us(reps, fn);
-              printf("   fwd  stream %s tile %d S %d %9.1f us %7.1f TF  err %.2e%s\n", tbl ? "sorted" : "plain ", tile * 32, fs, us, gflop / us * 1e3, err,
-                     (check && !(err < 1e-4)) ? "  <-- MISMATCH" : "");
-              fflush(stdout);
-            }
-      }
+      runs.push_back({"plain ", 0, 0});
+      if (!cs.dense) { runs.push_back({"sorted", 0, 1}); runs.push_back({"pairs ", 0, 2}); runs.push_back({"pairsL", 0, 3}); }
       runs.push_back({"pipe  ", 1 << 18, 0});
       if (!cs.dense) { runs.push_back({"pipeS ", 1 << 18, 1}); runs.push_back({"pipeL ", 1 << 18, 3}); }
       if (Cout == 64) { runs.push_back({"256x64", 3 << 4, 0}); if (!cs.dense) runs.push_back({"256x64s", 3 << 4, 1}); }
@@ -408,28 +364,21 @@ int main(int argc, char** argv) {
         double err = -1;
         if (check) err = max_rel_err(d_out.down((size_t)n_out * Cout), ref);
         double us = time_us(reps, fn);
-        printf("   fwd  variant %d %s %9.1f us %7.1f TF  err %.2e%s\n", fl >> 24, r.what, us, gflop / us * 1e3, err, (check && !(err < 1e-4)) ? "  <-- MISMATCH" : "");
+        printf("   fwd  flags %#x %s %9.1f us %7.1f TF  err %.2e%s\n", fl, r.what, us, gflop / us * 1e3, err, (check && !(err < 1e-4)) ? "  <-- MISMATCH" : "");
         fflush(stdout);
       }
     }
     if (!trace_file.empty()) {
       typedef int (*trace_fn)(unsigned long long*, int);
       typedef int (*count_fn)(int*);
-      trace_fn set = (trace_fn)dlsym(RTLD_DEFAULT, trace_variant ? "fc_debug_trace" : "fc_debug_trace_lds");
+      trace_fn set = (trace_fn)dlsym(RTLD_DEFAULT, "fc_debug_trace_lds");
       count_fn cntf = nullptr;
       if (!set) { fprintf(stderr, "--trace needs tools/nbench_trace (FC_TRACE build)\n"); return 4; }
       const int cap = 1 << 18;
       Dev<unsigned long long> d_tr; d_tr.alloc((size_t)cap * 8);
-      const int fl = trace_variant << 24;
+      const int fl = trace_variant;      // flags of the traced launch
       std::function<void()> fn;
-      Dev<unsigned int> d_gmt; d_gmt.alloc((n_out + 31) / 32 + 2);
-      if (trace_variant >= 100) {       // stream kernel: variant = 100 + flags (tile<<4 | S<<8)
-        const int sfl = trace_variant - 100;
-        const int* tab = trace_tbl ? d_sorted.p : d_nbr.p; const int* oi = trace_tbl ? d_oidx.p : nullptr;
-        FC(fc_nbr_group_masks(tab, n_out, K, d_gmt.p, 0));
-        int64_t wb = ws_for(fc_conv_fwd_stream_ws_bytes(n_out, K, Cin, Cout, sfl));
-        fn = [&, wb, sfl, tab, oi]() { FC(fc_conv_fwd_stream(d_in.p, d_w.p, tab, d_gmt.p, oi, d_out.p, n_in, n_out, K, Cin, Cout, sfl, d_ws.p, wb, 0)); };
-      } else if (trace_tbl == 2) {
+      if (trace_tbl == 2) {
         int64_t wb = ws_for(fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout));
         fn = [&, wb, fl]() { FC(fc_conv_fwd_pairs(d_in.p, d_w.p, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
       } else {
@@ -463,10 +412,10 @@ int main(int argc, char** argv) {
       std::vector<int> wg_s = {0};
       if (s_sweep) wg_s = {0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32};
       for (int fsw : wg_s)
-      for (int reg = 0; reg < (s_sweep ? 1 : 4); ++reg)          // 0: default (pipelined LDS kernel), 1: register kernel, 2: r1 LDS kernel, 3: multi-offset kernel only under its first rule (Cin = 64, >= 32768 rows)
+      for (int reg = 0; reg < (s_sweep ? 1 : 4); ++reg)          // 0: default, 1: separate reduce launch (no in-launch combine), 2: r1 LDS kernel, 3: multi-offset kernel only under its first rule (Cin = 64, >= 32768 rows)
         for (int pairs = (s_sweep && !cs.dense ? 1 : 0); pairs < (cs.dense ? 1 : 2); ++pairs) {
           if (reg == 3 && pairs) continue;
-          const int fl = ((reg == 1) << 28) | ((reg == 2) << 16) | ((reg == 3) << 30) | (fsw << 8);
+          const int fl = ((reg == 1) << 1) | ((reg == 2) << 16) | ((reg == 3) << 30) | (fsw << 8);
           int64_t wb = ws_for(fc_conv_wgrad_ws_bytes(n_out, K, Cin, Cout, fl));
           std::function<void()> fn;
           if (pairs) fn = [&, wb, fl]() { FC(fc_conv_wgrad_pairs(d_in.p, d_gout.p, d_pi.p, d_po.p, d_cnt.p, d_gw.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
@@ -476,7 +425,7 @@ int main(int argc, char** argv) {
           double err = -1;
           if (check) err = max_rel_err(d_gw.down(hw.size()), ref);
           double us = time_us(reps, fn);
-          printf("   wgrad %s %s S=%-2d %9.1f us %7.1f TF  err %.2e%s\n", reg == 1 ? "reg " : reg == 2 ? "ldsr1" : reg == 3 ? "m-r1 " : "lds ", pairs ? "pairs" : "table", fsw, us, gflop / us * 1e3, err, (check && !(err < 2e-4)) ? "  <-- MISMATCH" : "");
+          printf("   wgrad %s %s S=%-2d %9.1f us %7.1f TF  err %.2e%s\n", reg == 1 ? "2pass" : reg == 2 ? "ldsr1" : reg == 3 ? "m-r1 " : "lds ", pairs ? "pairs" : "table", fsw, us, gflop / us * 1e3, err, (check && !(err < 2e-4)) ? "  <-- MISMATCH" : "");
           fflush(stdout);
         }
     }
