@@ -425,6 +425,7 @@ def main():
     model.spatial_sort = args.spatial_sort
     import fcaf3d_amd.functional as Fn
     Fn.WGRAD_ASYNC = not args.no_wgrad_overlap
+    head_overlap = model.neck_with_head.head_overlap and not args.no_wgrad_overlap
     if world > 1:
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)
@@ -454,6 +455,7 @@ def main():
         # probed steps keep every kernel on the main stream: a HIP-event bracket is only a kernel's own duration when
         # nothing else shares the GPU (the overlapped weight-gradient stream would inflate every bracket it touches)
         Fn.WGRAD_ASYNC = (not args.no_wgrad_overlap) and probe_mode != 'time'
+        model.neck_with_head.head_overlap = head_overlap and probe_mode != 'time'      # ... nor the head branch's stream
         loss, _ = trainer(batch)
         return loss
 

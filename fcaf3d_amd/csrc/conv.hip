@@ -1663,6 +1663,44 @@ __global__ void k_wgrad_reduce(const float* __restrict__ part, float* __restrict
   gW[i] = acc;
 }
 
+// The same for elems % 4 == 0 with 16-byte accesses and G slab groups per output (256 threads = 256 / G float4 columns x G
+// groups): group g sums slabs [g * ceil(S / G), ...) in slab order with four loads in flight, the G group sums are added in
+// group order through LDS — a fixed order, whatever the grid (r3: the stem's 192 x 20 KB slabs went through 5 184 threads
+// with one dependent 4-byte load each).  Measured and dropped (r3, profiles/r3_notes.md): combining the partial tiles INSIDE
+// the weight-gradient launch (last-arriving workgroup per tile, agent-scope release / ticket / acquire) — the release's
+// buffer_wbl2 in each of the ~1 500 workgroups of a launch writes back everything the concurrently running main-stream
+// kernels have dirtied in that L2: 32.4 -> 34.3 ms per step.
+template <int G>
+__global__ __launch_bounds__(256) void k_wgrad_reduce4(const float* __restrict__ part, float* __restrict__ gW, int64_t elems4, int S) {
+  __shared__ f32x4 red[256];
+  constexpr int COLS = 256 / G;
+  const int col = threadIdx.x % COLS, g = threadIdx.x / COLS;
+  const int64_t i = (int64_t)blockIdx.x * COLS + col;
+  const int per = (S + G - 1) / G;
+  const int s0 = g * per, s1 = (s0 + per < S) ? s0 + per : S;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (i < elems4) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(part) + i;
+    int sl = s0;
+    for (; sl + 4 <= s1; sl += 4) {
+      const f32x4 v0 = src[(int64_t)sl * elems4], v1 = src[(int64_t)(sl + 1) * elems4];
+      const f32x4 v2 = src[(int64_t)(sl + 2) * elems4], v3 = src[(int64_t)(sl + 3) * elems4];
+      a += v0; a += v1; a += v2; a += v3;
+    }
+    for (; sl < s1; ++sl) a += src[(int64_t)sl * elems4];
+  }
+  if (G == 1) {
+    if (i < elems4) reinterpret_cast<f32x4*>(gW)[i] = a;
+    return;
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (g == 0 && i < elems4) {
+    for (int q = 1; q < G; ++q) a += red[q * COLS + col];
+    reinterpret_cast<f32x4*>(gW)[i] = a;
+  }
+}
+
 // (K,Cin,Cout) -> (K,Cout,Cin)
 __global__ void k_transpose_w(const float* __restrict__ W, float* __restrict__ Wt, int K, int Cin, int Cout) {
   __shared__ float tile[32][33];
@@ -1732,6 +1770,20 @@ static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool 
   *rows_per_split = rps;
 }
 
+// gW = sum of the S partial slabs, fixed order
+static int wgrad_reduce(const float* part, float* gW, int64_t elems, int S, hipStream_t stream) {
+  if (elems % 4 == 0) {
+    const int64_t e4 = elems / 4;
+    if (S >= 64) k_wgrad_reduce4<16><<<(unsigned)fc_cdiv(e4, 16), 256, 0, stream>>>(part, gW, e4, S);
+    else if (S >= 16) k_wgrad_reduce4<4><<<(unsigned)fc_cdiv(e4, 64), 256, 0, stream>>>(part, gW, e4, S);
+    else k_wgrad_reduce4<1><<<(unsigned)fc_cdiv(e4, 256), 256, 0, stream>>>(part, gW, e4, S);
+  } else {
+    k_wgrad_reduce<<<(unsigned)fc_cdiv(elems, 256), 256, 0, stream>>>(part, gW, elems, S);
+  }
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
 // ---- stem convolution with saved gathered inputs (training): forward writes col (n_out, 84), the weight gradient streams it ----
 int fc_stem_conv_fwd(const float* in, const float* W, const int* nbr, float* out, float* col, int64_t n_in, int64_t n_out,
                      int K, hipStream_t stream) {
@@ -1773,10 +1825,7 @@ int fc_stem_conv_wgrad(const float* col, const float* gout, float* gW, int64_t n
   size_t smem = (size_t)(STEM_ROWS * STEM_JP + STEM_ROWS * 64) * sizeof(float);
   k_stem_wgrad_col<<<(unsigned)S, 256, smem, stream>>>(col, gout, part, n_out, K, rps);
   FC_CHECK_LAUNCH();
-  if (S > 1) {
-    k_wgrad_reduce<<<(unsigned)fc_cdiv(elems, 256), 256, 0, stream>>>(part, gW, elems, S);
-    FC_CHECK_LAUNCH();
-  }
+  if (S > 1) return wgrad_reduce(part, gW, elems, S, stream);
   return FC_OK;
 }
 
@@ -1849,10 +1898,7 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     k_wgrad_fma<<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
   }
   FC_CHECK_LAUNCH();
-  if (S > 1) {
-    k_wgrad_reduce<<<(unsigned)fc_cdiv(elems, 256), 256, 0, stream>>>(part, gW, elems, S);
-    FC_CHECK_LAUNCH();
-  }
+  if (S > 1) return wgrad_reduce(part, gW, elems, S, stream);
   return FC_OK;
 }
 

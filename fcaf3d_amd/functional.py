@@ -15,7 +15,6 @@ FLAGS = int(os.environ.get('FC_FLAGS', '0'), 0)   # bit0: force the generic FMA 
 WGRAD_ASYNC = False
 _wg_streams = {}
 _join_queued = False
-_pending_gw = []          # weight gradients produced on the side stream since the last join
 
 
 def wgrad_stream(device):
@@ -31,9 +30,6 @@ def join_wgrad_stream():
     _join_queued = False
     for s in _wg_streams.values():
         torch.cuda.current_stream(s.device).wait_stream(s)
-    for g in _pending_gw:                               # their consumer (optimizer / all-reduce) runs on the joining stream
-        g.record_stream(torch.cuda.current_stream(g.device))
-    _pending_gw.clear()
 
 
 def _chk(*ts):
@@ -194,8 +190,9 @@ class _SparseConv(torch.autograd.Function):
                 for t in (feats, gout, nbr, col):
                     if t is not None:
                         t.record_stream(side)              # keep their memory until the side stream has read it
+                # no second reference to gw may be kept here: AccumulateGrad only STEALS a gradient it holds the sole
+                # reference to — otherwise it clones it on the spot, on the main stream, before the side stream has written it
                 gw.record_stream(main)
-                _pending_gw.append(gw)
                 if not _join_queued:
                     _join_queued = True
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)

@@ -270,6 +270,22 @@ int fc_nms_bev(const float* boxes, const int* counts_dev, int nseg, int stride, 
 int fc_boxes_iou_bev(const float* boxes_a, int n, const float* boxes_b, int m, int rotated, float* out,
                      hipStream_t stream);
 
+/* ---- optimizer (the reference's recipe, configs/fcaf3d/fcaf3d.py:30-31) --------------------------------- */
+
+/* mmcv OptimizerHook grad_clip = dict(max_norm=10, norm_type=2) (configs/fcaf3d/fcaf3d.py:31; torch.nn.utils.clip_grad_norm_)
+ * over ONE flat gradient buffer of n floats (n % 4 == 0; padding zero): out[0] = the global 2-norm, out[1] = the clip
+ * coefficient min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0).  Nothing is scaled here: fc_adamw_step applies
+ * the coefficient while it reads the gradient.  Deterministic two-level reduction. */
+int64_t fc_grad_norm_ws_bytes(int64_t n);
+int fc_grad_norm(const float* g, int64_t n, float max_norm, float* out, void* ws, int64_t ws_bytes, hipStream_t stream);
+/* torch.optim.AdamW.step for optimizer = dict(type='AdamW', lr=0.001, weight_decay=0.0001) (configs/fcaf3d/fcaf3d.py:30)
+ * over flat parameter / gradient / moment buffers (n % 4 == 0): decoupled weight decay, bias corrections
+ * 1 - beta^step computed by the caller, gradient scaled by norm_and_clip[1] (device, nullable: the output of
+ * fc_grad_norm).  One pass: 16 B read + 12 B written per parameter. */
+int fc_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, float bias_correction1, float bias_correction2, const float* norm_and_clip,
+                  hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

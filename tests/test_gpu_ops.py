@@ -254,7 +254,9 @@ def test_dense_table_weight_gradient_kernels(Cin, Cout):
         return gw.cpu()
     ref = run(1)
     for fl in (0, 1 << 29, (1 << 29) | (1 << 16), 1 << 30, 3 << 8, (5 << 8) | (1 << 29)):
-        _close(run(fl), ref, what=f'dense-table wgrad {Cin}->{Cout} flags={fl:#x}')
+        got = run(fl)
+        _close(got, ref, what=f'dense-table wgrad {Cin}->{Cout} flags={fl:#x}')
+        assert torch.equal(got, run(fl)), f'weight gradient not repeatable bit for bit, flags={fl:#x}'
 
 
 @pytest.mark.parametrize('n_points,B', [(5000, 2), (150000, 1)])
@@ -404,6 +406,7 @@ def test_no_cpu_fallback():
 
 
 @pytest.mark.parametrize('n,C,act,res', [(5003, 64, 'relu', True), (853, 512, 'elu', False), (70, 128, None, False),
+                                         (1500, 256, 'relu', True), (14884, 128, 'relu', True),
                                          (40000, 256, 'elu', False)])      # last one: > 4M elements -> six-launch path
 # (ELU there: with ReLU one of the 10M pre-activations lands within 1 ulp of 0 and the 0/1 derivative flips)
 def test_bn_train_fused_paths(n, C, act, res):
