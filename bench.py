@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--priority-stream', action='store_true', help='run the main chain on a high-priority HIP stream')
     ap.add_argument('--infer-steps', type=int, default=4, help='untimed-region extra: simple_test batches for the inference scenes/s line (0 = skip)')
     ap.add_argument('--cpu-reps', type=int, default=5, help='repetitions of the C/OpenMP cpu_baseline (median)')
+    ap.add_argument('--no-force-dp', action='store_true', help='skip the untimed N=1-through-the-averager extra')
     ap.add_argument('--breakdown', action='store_true', help='diagnostic: HIP-event time per C-ABI entry point and per conv shape (stderr)')
     return ap.parse_args()
 
@@ -400,6 +401,11 @@ def timed_region(fn, n, world, dev):
 
 def main():
     args = parse()
+    # stdout carries ONE line, the JSON result: everything else that writes to file descriptor 1 during the run (RCCL's
+    # version banner, library warnings) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get('FC_FAULT_DUMP'):           # debugging aid: dump every thread's stack after n seconds and exit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['FC_FAULT_DUMP']), exit=True)
@@ -506,6 +512,30 @@ def main():
             dt4, _ = timed_region(lambda i: step(i, which=small), 6, world, dev)
             cfg4 = dict(global_batch=16, scenes_per_gpu_per_step=per, steps=6, ms_per_step=round(dt4 / 6 * 1e3, 3),
                         value=round(16 * 6 / dt4, 3), unit='scenes/s')
+    # (b2) N = 1 through the data-parallel machinery (1-rank RCCL group: autograd hooks, bucket launches on the weight-gradient
+    #      stream, in-place all-reduce of the flat gradient buffer) — what the DP path itself costs, without a second GPU
+    forced = None
+    if world == 1 and not args.no_force_dp and trainer.flat is not None:
+        try:
+            import socket
+            sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+            torch.distributed.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+            D.FORCE_AVERAGER = True
+            plain = trainer.averager
+            trainer.averager = D.GradientAverager(trainer.params, bucket_mb=64, flat=trainer.flat)
+            for i in range(3):
+                step(i)
+            dtf, _ = timed_region(lambda i: step(i), 10, 1, dev)
+            forced = dict(steps=10, ms_per_step=round(dtf / 10 * 1e3, 3), value=round(args.batch * 10 / dtf, 3), unit='scenes/s',
+                          buckets=len(trainer.averager.buckets), what='the same step with the gradient averager active in a 1-rank RCCL group')
+            trainer.averager.close()
+            trainer.averager = plain
+        except Exception as e:                                   # an extra: never fails the bench line
+            forced = dict(error=repr(e)[:200])
+        finally:
+            D.FORCE_AVERAGER = False
+            if torch.distributed.is_initialized():
+                torch.distributed.destroy_process_group()
     # (c) inference: simple_test (eval-mode BatchNorm, decode, multi-class BEV NMS on the device) — the only quantity the
     #     reference publishes a speed for (README.md:91-93, scenes/s on one GPU)
     infer = None
@@ -534,7 +564,7 @@ def main():
                        'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
                        'fwd_bwd_only': {'protocol': 'SURVEY 8(d): forward_train + backward (+ all-reduce), synchronised per iteration, median of 5',
                                         'ms': round(fb_med * 1e3, 3), 'scenes_per_s': round(args.batch * world / fb_med, 3)},
-                       'config4_global_batch_16': cfg4, 'inference': infer},
+                       'config4_global_batch_16': cfg4, 'forced_dp_n1': forced, 'inference': infer},
         }
         rl = probe.summary() if probe else None
         if rl:
@@ -550,7 +580,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args, model, cfg)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -16,6 +16,15 @@ def world_size():
     return dist.get_world_size() if is_dist() else 1
 
 
+# bench.py --gpus 1: run the gradient averager (hooks, buckets, RCCL launches) in a 1-rank process group, so that the
+# overhead of the data-parallel path itself is measured without a second GPU
+FORCE_AVERAGER = False
+
+
+def _averaging():
+    return world_size() > 1 or (FORCE_AVERAGER and is_dist())
+
+
 def init_dist(backend=None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun contract)."""
     if int(os.environ.get('WORLD_SIZE', '1')) <= 1 or is_dist():
@@ -38,46 +47,59 @@ def reduce_mean(tensor):
 
 
 class GradientAverager:
-    """Bucketed gradient all-reduce (sum / world) for pure data parallelism.
+    """Bucketed gradient all-reduce (sum / world) for pure data parallelism, IN PLACE on the flat gradient buffer.
 
-    Parameters are packed, in reverse registration order (≈ the order backward produces them), into
-    flat fp32 buckets of `bucket_mb`; each bucket is all-reduced with an async RCCL call as soon as all
-    of its gradients have been accumulated (autograd post-accumulate hooks), on RCCL's own stream, so
-    the collectives overlap the rest of backward.  xGMI is point-to-point (ring all-reduce is per-link
-    bound), hence few, large buckets."""
+    The gradients of all parameters live in one flat fp32 buffer (`flat.FlatParams`; parameters in registration order).  A
+    bucket is a run of consecutive parameters, i.e. one contiguous range of that buffer of about `bucket_mb`; buckets are
+    formed from the LAST parameter backwards (≈ the order backward produces gradients) and each is all-reduced with one
+    async RCCL call as soon as all of its gradients have been accumulated (autograd post-accumulate hooks), so the
+    collectives overlap the rest of backward.  No copy-in / copy-out: the weight-gradient kernels write into the buffer,
+    the collective reduces it where it lies, the optimizer reads it there (r2 copied 2 x 282 MB per step).  xGMI is
+    point-to-point (ring all-reduce is per-link bound), hence few, large buckets.
 
-    def __init__(self, params, bucket_mb=64):
+    Streams: with the weight gradients on their own HIP stream (functional.WGRAD_ASYNC) the collective is issued with THAT
+    stream current, after it has been made to wait for the main stream's position — RCCL's stream then waits for exactly
+    the kernels that produce the bucket, and the main stream (backward-data chain) never waits for a weight gradient
+    (r2 joined the two streams at every bucket)."""
+
+    def __init__(self, params, bucket_mb=64, flat=None):
+        from .flat import FlatParams, flat_of
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []
         self._handles = []
-        if world_size() == 1:
+        self.flat = flat
+        self._hooks = []
+        if not _averaging():
             return
+        if self.flat is None:
+            self.flat = flat_of(self.params[0]) or FlatParams(self.params)
+        assert all(flat_of(p) is self.flat for p in self.params), 'all parameters must live in one FlatParams'
+        order = sorted(self.params, key=lambda p: p._fc_flat[1])
         cur, cur_bytes = [], 0
-        for p in reversed(self.params):
+        for p in reversed(order):
             cur.append(p)
             cur_bytes += p.numel() * 4
             if cur_bytes >= bucket_mb * (1 << 20):
-                self.buckets.append(cur)
+                self.buckets.append(cur[::-1])
                 cur, cur_bytes = [], 0
         if cur:
-            self.buckets.append(cur)
-        self._flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
-                      for b in self.buckets]
-        self._views = []                       # per bucket: the flat buffer sliced into the parameters' shapes
-        for flat, b in zip(self._flat, self.buckets):
-            off, views = 0, []
-            for p in b:
-                views.append(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
-            self._views.append(views)
-        self._avg = dist.get_backend() == 'nccl'   # RCCL averages in the collective; gloo: sum then divide
-        self._pending = [0] * len(self.buckets)
+            self.buckets.append(cur[::-1])
+        self._ranges = [self.flat.range_of(b) for b in self.buckets]           # contiguous [begin, end) per bucket
+        for (lo, hi), b in zip(self._ranges, self.buckets):
+            assert hi - lo == sum(-(-p.numel() // 64) * 64 for p in b), 'a bucket must be a contiguous run of parameters'
+        self._avg = dist.get_backend() == 'nccl'   # RCCL averages in the collective; gloo: divide, then sum
         self._bucket_of = {}
         for bi, b in enumerate(self.buckets):
             for p in b:
                 self._bucket_of[p] = bi
-                p.register_post_accumulate_grad_hook(self._hook)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._hook))
         self._reset()
+
+    def close(self):
+        """detach the autograd hooks (a second averager may then take over the same parameters)"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self.buckets = [], []
 
     def _reset(self):
         self._pending = [len(b) for b in self.buckets]
@@ -109,21 +131,28 @@ class GradientAverager:
             if self._t0 is None:
                 self._t0 = now
             self.log.append(('launch', bi, now - self._t0))
-        if Fn.WGRAD_ASYNC:
-            Fn.join_wgrad_stream()            # weight gradients may still be in flight on their side stream
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.buckets[bi]]
-        torch._foreach_copy_(self._views[bi], grads)          # one multi-tensor launch per bucket
-        flat = self._flat[bi]
-        if self._avg:
-            h = dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True)
-        else:
-            flat.div_(world_size())
-            h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        # gradients autograd produced outside the flat buffer (small tensors: norms, head) are copied into their slices,
+        # parameters without a gradient contribute zeros — one multi-tensor launch each, on the current (main) stream
+        self.flat.gather(self.buckets[bi])
+        lo, hi = self._ranges[bi]
+        buf = self.flat.grad[lo:hi]
+        side = None
+        if buf.is_cuda and Fn.WGRAD_ASYNC:
+            main = torch.cuda.current_stream(buf.device)
+            side = Fn.wgrad_stream(buf.device)
+            side.wait_stream(main)             # the copies above, and every gradient the main stream itself produced
+        with (torch.cuda.stream(side) if side is not None else _nullctx()):
+            if self._avg:
+                h = dist.all_reduce(buf, op=dist.ReduceOp.AVG, async_op=True)
+            else:
+                buf.div_(world_size())
+                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
         self._handles.append((bi, h))
 
     def finish(self):
-        """Call after backward: flush buckets whose hooks did not all fire, wait, scatter back."""
-        if world_size() == 1:
+        """Call after backward: flush the buckets whose hooks did not all fire, wait, and make every `p.grad` the
+        (averaged) slice of the flat buffer."""
+        if not self.buckets:
             return
         while self._next < len(self.buckets):          # buckets some hook never completed (unused parameters), in order
             self._launch(self._next)
@@ -134,12 +163,19 @@ class GradientAverager:
             self.log.append(('finish_enter', -1, t_f - self._t0))
         for bi, h in self._handles:
             h.wait()
-            params = self.buckets[bi]
-            for p in params:
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-            torch._foreach_copy_([p.grad for p in params], self._views[bi])
+        for p in self.params:
+            v = self.flat.grad_view(p)
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
         self._reset()
+
+
+class _nullctx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 def summarize_bucket_log(averager, log):
@@ -155,7 +191,7 @@ def summarize_bucket_log(averager, log):
     if not steps:
         return None
     last = steps[-1]
-    return dict(buckets=len(averager.buckets), bucket_MB=[round(f.numel() * 4 / 2 ** 20, 1) for f in averager._flat],
+    return dict(buckets=len(averager.buckets), bucket_MB=[round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi in averager._ranges],
                 last_step_launch_ms_after_first_grad=[round(t * 1e3, 2) for k, b, t in last if k == 'launch'],
                 last_step_backward_end_ms=round([t for k, b, t in last if k == 'finish_enter'][0] * 1e3, 2),
                 backend=dist.get_backend())

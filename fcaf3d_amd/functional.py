@@ -114,6 +114,8 @@ class _SparseConv(torch.autograd.Function):
         feats = feats.contiguous()
         # only a LEAF kernel's gradient goes straight to AccumulateGrad (no kernel reads it before the join)
         ctx.w_leaf = weight.is_leaf and weight.is_contiguous()
+        # a leaf kernel that lives in flat buffers (flat.FlatParams): its gradient is written straight into its slice
+        ctx.flat = getattr(weight, '_fc_flat', None) if ctx.w_leaf else None
         weight = weight.contiguous()
         K, Cin, Cout = weight.shape
         n_in = feats.shape[0]
@@ -163,9 +165,12 @@ class _SparseConv(torch.autograd.Function):
             nbr, ridx = (kmap.nbr if kmap is not None else None), None      # wgrad walks rows in natural order (see conv.hip)
 
             col = ctx.col
+            flat = ctx.flat if (ctx.flat is not None and weight.grad is None) else None
 
             def launch():
-                g = torch.empty_like(weight)
+                # flat storage: a FRESH view of the parameter's slice of the flat gradient buffer — autograd adopts it as
+                # .grad without a copy because nothing else references the tensor object (an accumulating .grad takes a copy)
+                g = flat[0].grad_view(weight) if flat is not None else torch.empty_like(weight)
                 if col is not None:
                     ws = L.workspace(L.query('fc_stem_conv_wgrad_ws_bytes', n_out, K), dev)
                     L.call('fc_stem_conv_wgrad', L.ptr(col), L.ptr(gout), L.ptr(g), n_out, K, L.ptr(ws), ws.numel(), L.stream())

@@ -8,19 +8,93 @@
 `TrainStep` is what mmcv's `EpochBasedRunner.run_iter` + `OptimizerHook.after_train_iter` do for one batch:
 zero_grad -> model(return_loss=True, **batch) -> sum of the `loss*` entries (mmdet `_parse_losses`) -> backward ->
 (data parallel: gradient averaging, overlapped with backward) -> clip_grad_norm_ -> optimizer.step; `epoch_end()` is the
-LR hook's per-epoch update.  AdamW runs as ONE fused multi-tensor kernel (`fused=True`), the clip as torch's foreach path.
+LR hook's per-epoch update.  On the GPU the parameters, gradients and AdamW moments live in flat buffers (flat.FlatParams)
+and clip + AdamW are three launches of csrc/optim.hip (`FlatAdamW`); CPU parameters (the host-logic tests) take
+torch.optim.AdamW + clip_grad_norm_, the calls the reference makes.
 """
+import math
+
 import torch
 
+from . import _lib as L
 from . import dist as D
+from .flat import FlatParams
 
 
-def build_optimizer(model, cfg):
-    """cfg: the `optimizer` dict of a config (type AdamW / Adam / SGD, mmcv's constructor keys)."""
+class FlatAdamW:
+    """torch.optim.AdamW (betas 0.9 / 0.999, eps 1e-8, decoupled weight decay, no amsgrad) + clip_grad_norm_ over the flat
+    buffers of a `FlatParams`: `step(max_norm)` = fc_grad_norm (global 2-norm and clip coefficient, on the device) +
+    fc_adamw_step (one pass; the coefficient is applied while the gradient is read).  Keeps the slice of torch's optimizer
+    interface the runner and the LR hook use: `param_groups`, `defaults`, `zero_grad`, `state_dict` / `load_state_dict` in
+    torch's own layout (per-parameter `step`, `exp_avg`, `exp_avg_sq`), so mmcv-style checkpoints round-trip."""
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.flat = flat
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False)
+        self.param_groups = [dict(self.defaults, params=flat.params)]
+        self.exp_avg = torch.zeros_like(flat.data)
+        self.exp_avg_sq = torch.zeros_like(flat.data)
+        self.norm_clip = torch.zeros(2, dtype=torch.float32, device=flat.data.device)      # [global grad norm, clip coefficient]
+        self.steps = 0
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.flat.params:
+            p.grad = None                        # the flat gradient buffer is overwritten, not accumulated into
+
+    def step(self, max_norm=None, gathered=False):
+        """-> the global gradient norm (0-d device tensor) when max_norm is given"""
+        f = self.flat
+        if not f.data.is_cuda:
+            raise RuntimeError('FlatAdamW runs on the GPU only (HIP); CPU parameters take torch.optim.AdamW')
+        if not gathered:
+            f.gather()
+        g = self.param_groups[0]
+        self.steps += 1
+        b1, b2 = g['betas']
+        clip = None
+        if max_norm is not None:
+            ws = L.workspace(L.query('fc_grad_norm_ws_bytes', f.n), f.data.device)
+            L.call('fc_grad_norm', L.ptr(f.grad), f.n, float(max_norm), L.ptr(self.norm_clip), L.ptr(ws), ws.numel(), L.stream())
+            clip = self.norm_clip
+        L.call('fc_adamw_step', L.ptr(f.data), L.ptr(f.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), f.n, float(g['lr']),
+               float(b1), float(b2), float(g['eps']), float(g['weight_decay']), 1.0 - b1 ** self.steps, 1.0 - b2 ** self.steps,
+               L.ptr(clip), L.stream())
+        return self.norm_clip[0] if clip is not None else None
+
+    def _views(self, buf):
+        return [buf[o:o + p.numel()].view(p.shape) for p, o in zip(self.flat.params, self.flat.offsets)]
+
+    def state_dict(self):
+        m, v = self._views(self.exp_avg), self._views(self.exp_avg_sq)
+        state = {i: dict(step=torch.tensor(float(self.steps)), exp_avg=m[i].clone(), exp_avg_sq=v[i].clone())
+                 for i in range(len(m))} if self.steps else {}
+        group = {k: val for k, val in self.param_groups[0].items() if k != 'params'}
+        group['params'] = list(range(len(self.flat.params)))
+        return dict(state=state, param_groups=[group])
+
+    def load_state_dict(self, sd):
+        m, v = self._views(self.exp_avg), self._views(self.exp_avg_sq)
+        steps = 0
+        with torch.no_grad():
+            for i, st in sd['state'].items():
+                m[int(i)].copy_(st['exp_avg'])
+                v[int(i)].copy_(st['exp_avg_sq'])
+                steps = int(st['step'])
+        self.steps = steps
+        for k, val in sd['param_groups'][0].items():
+            if k != 'params':
+                self.param_groups[0][k] = tuple(val) if k == 'betas' else val
+
+
+def build_optimizer(model, cfg, flat=None):
+    """cfg: the `optimizer` dict of a config (type AdamW / Adam / SGD, mmcv's constructor keys).  `flat`: the model's
+    FlatParams (GPU): AdamW then runs on the flat buffers (FlatAdamW)."""
     cfg = dict(cfg)
     kind = cfg.pop('type')
     params = [p for p in model.parameters() if p.requires_grad]
     fused = all(p.is_cuda for p in params)
+    if kind == 'AdamW' and flat is not None:
+        return FlatAdamW(flat, **cfg)
     if kind == 'AdamW':
         return torch.optim.AdamW(params, fused=fused, **cfg)
     if kind == 'Adam':
@@ -77,15 +151,20 @@ class TrainStep:
     """One optimisation step of the reference's recipe on this process's GPU (one process per GPU; gradients are averaged
     over the process group, if any, by fcaf3d_amd.dist.GradientAverager while backward is still running)."""
 
-    def __init__(self, model, optimizer_cfg, optimizer_config=None, lr_config=None, bucket_mb=64):
+    def __init__(self, model, optimizer_cfg, optimizer_config=None, lr_config=None, bucket_mb=64, flat=None):
         self.model = model
-        self.optimizer = build_optimizer(model, optimizer_cfg)
+        self.params = [p for p in model.parameters() if p.requires_grad]
         clip = (optimizer_config or {}).get('grad_clip')
         self.max_norm = clip['max_norm'] if clip else None
         self.norm_type = clip.get('norm_type', 2) if clip else 2
+        # GPU: parameters and gradients move into flat buffers (flat.FlatParams re-points every p.data; call after
+        # model.to(device) and do not move the model afterwards); `flat=False` keeps the per-tensor torch path
+        on_gpu = all(p.is_cuda for p in self.params)
+        use_flat = (on_gpu and optimizer_cfg.get('type') == 'AdamW' and self.norm_type == 2) if flat is None else flat
+        self.flat = FlatParams(self.params) if use_flat else None
+        self.optimizer = build_optimizer(model, optimizer_cfg, flat=self.flat)
         self.lr = build_lr_updater(self.optimizer, lr_config) if lr_config else None
-        self.averager = D.GradientAverager(model.parameters(), bucket_mb=bucket_mb)
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.averager = D.GradientAverager(self.params, bucket_mb=bucket_mb, flat=self.flat)
         self.last_grad_norm = None
 
     @classmethod
@@ -98,6 +177,10 @@ class TrainStep:
         loss = parse_losses(losses)
         loss.backward()
         self.averager.finish()
+        if isinstance(self.optimizer, FlatAdamW):
+            # after finish() under data parallelism every gradient already sits (averaged) in the flat buffer
+            self.last_grad_norm = self.optimizer.step(self.max_norm, gathered=bool(self.averager.buckets))
+            return loss, losses
         if self.max_norm is not None:
             self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, norm_type=self.norm_type)
         self.optimizer.step()

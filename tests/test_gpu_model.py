@@ -523,6 +523,93 @@ def test_three_step_training_trajectory_vs_oracle():
         assert abs(a - b) <= 2e-2 * abs(b), (traj_g, traj_o)
 
 
+def test_flat_adamw_equals_torch_adamw_with_clip():
+    """csrc/optim.hip over flat buffers (fc_grad_norm + fc_adamw_step) == torch.nn.utils.clip_grad_norm_ +
+    torch.optim.AdamW (the calls mmcv's OptimizerHook makes for configs/fcaf3d/fcaf3d.py:30-31) on identical
+    gradients, over 5 steps with the clip biting on some and not on others; optimizer state round-trips in torch's
+    state_dict layout."""
+    from fcaf3d_amd.flat import FlatParams
+    from fcaf3d_amd.runner import FlatAdamW
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(27, 64, 64), (128,), (1, 18), (), (8, 256, 128), (3,), (27, 3, 64)]
+    ref = [torch.nn.Parameter(torch.randn(s, generator=g) * 0.1) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref]
+    flat = FlatParams(mine)
+    assert all(p.data_ptr() == flat.data.data_ptr() + 4 * o for p, o in zip(mine, flat.offsets))
+    opt_r = torch.optim.AdamW(ref, lr=1e-3, weight_decay=1e-4)
+    opt_m = FlatAdamW(flat, lr=1e-3, weight_decay=1e-4)
+    for step in range(5):
+        scale = (40.0, 0.01, 3.0, 25.0, 0.5)[step]           # global norm above and below max_norm = 10
+        grads = [torch.randn(s, generator=g) * scale for s in shapes]
+        for p, q, gr in zip(ref, mine, grads):
+            p.grad = gr.clone()
+            q.grad = gr.to(dev)                              # produced outside the flat buffer: gather() copies it in
+        if step == 2:
+            mine[3].grad = None                              # a parameter without a gradient this step: zeros
+            ref[3].grad = torch.zeros(())
+        norm_r = torch.nn.utils.clip_grad_norm_(ref, 10.0)
+        opt_r.step()
+        norm_m = opt_m.step(max_norm=10.0)
+        assert abs(float(norm_m) - float(norm_r)) <= 1e-5 * float(norm_r), (float(norm_m), float(norm_r))
+        for p, q in zip(ref, mine):
+            assert _rel(q, p) < 2e-6, (step, p.shape, _rel(q, p))
+    sd = opt_m.state_dict()
+    assert set(sd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'} and sd['param_groups'][0]['lr'] == 1e-3
+    for i, st in opt_r.state_dict()['state'].items():
+        assert _rel(sd['state'][i]['exp_avg'], st['exp_avg']) < 2e-6 and _rel(sd['state'][i]['exp_avg_sq'], st['exp_avg_sq']) < 2e-6
+    opt2 = FlatAdamW(FlatParams([torch.nn.Parameter(p.detach().clone()) for p in mine]), lr=1e-3, weight_decay=1e-4)
+    opt2.load_state_dict(sd)
+    assert opt2.steps == 5 and torch.equal(opt2.exp_avg, opt_m.exp_avg) and torch.equal(opt2.exp_avg_sq, opt_m.exp_avg_sq)
+
+
+def test_train_step_flat_buffers_equal_per_tensor_path():
+    """TrainStep with parameters / gradients in flat buffers + csrc/optim.hip (the default on the GPU) against the same
+    step with per-tensor gradients + torch's clip_grad_norm_ / fused AdamW (flat=False): identical losses step for step,
+    the same parameters after the first step (1e-6 of their scale) and, after 3 steps, parameters within 10 % of ONE
+    AdamW step (lr) — the only room left is Adam's own conditioning: the gradient of a BatchNorm bias is a sum that
+    cancels to ~1e-3 of its terms, a 1e-7 difference in the clip coefficient of step 1 moves it by percents at step 2,
+    and Adam normalises every element's update to ~lr whatever the gradient's size (measured: 4.5e-5 on
+    backbone.layer2.0.norm1.bn.bias, every conv kernel < 1e-6).  With the weight gradients on their own stream the conv
+    kernels' gradients ARE their slices of the flat buffer (no copy)."""
+    import fcaf3d_amd.functional as Fn
+    from fcaf3d_amd.runner import TrainStep
+    dev = _dev()
+    cfg = fa.get_config('fcaf3d_scannet-3d-18class', voxel_size=0.02)
+    runs = []
+    for flat in (True, False):
+        model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 2, seed=4)
+        model = model.to(dev).train()
+        tr = TrainStep.from_config(model, cfg, flat=flat)
+        assert (tr.flat is not None) == flat
+        Fn.WGRAD_ASYNC = flat
+        try:
+            losses = []
+            for step in range(3):
+                pts, gts, labs = _scenes([70 + step, 80 + step], n_points=10000)
+                loss, _ = tr(_to_gpu_batch(pts, gts, labs, dev))
+                losses.append(float(loss))
+                if step == 0:
+                    first = [p.detach().clone() for p in model.parameters()]
+                if flat:
+                    k = model.backbone.layer1[0].conv1.kernel
+                    assert k.grad.data_ptr() == tr.flat.grad_view(k).data_ptr(), 'conv weight gradient was copied'
+        finally:
+            Fn.WGRAD_ASYNC = False
+        runs.append((losses, [p.detach().clone() for p in model.parameters()], float(tr.last_grad_norm), first))
+        names = [k for k, _ in model.named_parameters()]
+    (l1, p1, n1, f1), (l2, p2, n2, f2) = runs
+    assert l1[0] == l2[0]
+    assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(l1, l2)), (l1, l2)
+    assert abs(n1 - n2) <= 1e-5 * n2
+    rels = sorted(((_rel(a, b), k) for a, b, k in zip(f1, f2, names)), reverse=True)
+    assert rels[0][0] < 1e-6, rels[:8]
+    lr = cfg.optimizer.lr
+    absd = sorted(((float((a - b).abs().max()), k) for a, b, k in zip(p1, p2, names)), reverse=True)
+    assert absd[0][0] < 0.1 * lr, absd[:8]
+    assert all(d < 1e-6 for d, k in absd if k.endswith('.kernel') and 'conv' in k.split('.')[-2]), absd[:8]
+
+
 def test_multiclass_nms_route_equals_per_class_loop():
     """`_nms` (all classes in one sort + one pair of launches) returns exactly what the reference's per-class loop
     (`_nms_per_class`, fcaf3d_neck_with_head.py:332-374) returns: boxes, scores, labels, order."""
