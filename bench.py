@@ -428,6 +428,7 @@ def main():
     model, cfg = build_model(args)
     model = model.to(dev).train()
     model.async_maps = True           # scenes are resident in HBM: coordinate work may run on its side stream
+    model.inputs_resident = True      # ... without waiting for the main stream (nothing enqueued there produces them)
     model.spatial_sort = args.spatial_sort
     import fcaf3d_amd.functional as Fn
     Fn.WGRAD_ASYNC = not args.no_wgrad_overlap

@@ -142,7 +142,7 @@ class _PinnedRing:
         stage.copy_(src)
         out = stage.to(device, non_blocking=True)
         e = torch.cuda.Event()
-        e.record()
+        e.record(torch.cuda.current_stream(out.device))          # the stream of the TARGET device carried the copy
         self.evts[i] = e
         return out
 

@@ -321,6 +321,7 @@ class Fcaf3DNeckWithHead(nn.Module):
         return results
 
     batched_decode = True      # False: the reference's per-scene loop (_get_bboxes_single), kept as the cross-check
+    NMS_WS_BUDGET = int(os.environ.get('FC_NMS_WS_MB', '512')) << 20      # bytes of suppression masks per NMS launch
 
     def _get_bboxes_batched(self, centernesses, bbox_preds, cls_scores, points, img_metas):
         """get_bboxes for ALL scenes at once (r2: the per-scene, per-level loop of the reference issued ~1 500 tiny launches
@@ -356,8 +357,23 @@ class Fcaf3DNeckWithHead(nn.Module):
         masked = torch.where(P > cfg.score_thr, P, P.new_full((1,), -1.0)).permute(0, 2, 1).reshape(B * C, n_max)
         sorted_scores, ordr = masked.sort(dim=1, descending=True, stable=True)
         cnts = (sorted_scores > cfg.score_thr).sum(dim=1).to(torch.int32)
-        seg_boxes = PB[:, None].expand(B, C, n_max, 7).gather(2, ordr.view(B, C, n_max, 1).expand(B, C, n_max, 7))
-        kept, kcount = _nms_run(seg_boxes.reshape(B * C, n_max, 7).contiguous(), cnts, cfg.iou_thr, yaw_flag)
+        # The suppression-mask workspace of one (scene, class) segment is n_max * ceil(n_max / 64) * 8 B (2 MB at 4 000
+        # candidates) and the workspace is grow-only: all B * C segments at once would pin 290 MB at B = 8, C = 18 and 3.2 GB
+        # with a 200-class head.  Scenes go through the NMS in chunks whose masks fit NMS_WS_BUDGET; at the
+        # benchmark's shapes that is still ONE chunk (one pair of launches).
+        seg_bytes = n_max * ((n_max + 63) // 64) * 8 + n_max * 7 * 4
+        per = max(1, min(B, self.NMS_WS_BUDGET // max(1, C * seg_bytes)))
+        kept_l, kcount_l = [], []
+        for b0 in range(0, B, per):
+            b1 = min(B, b0 + per)
+            o = ordr[b0 * C:b1 * C].view(b1 - b0, C, n_max, 1).expand(b1 - b0, C, n_max, 7)
+            seg_boxes = PB[b0:b1, None].expand(b1 - b0, C, n_max, 7).gather(2, o)
+            k_, c_ = _nms_run(seg_boxes.reshape((b1 - b0) * C, n_max, 7).contiguous(), cnts[b0 * C:b1 * C].contiguous(),
+                              cfg.iou_thr, yaw_flag)
+            kept_l.append(k_)
+            kcount_l.append(c_)
+        kept = kept_l[0] if len(kept_l) == 1 else torch.cat(kept_l)
+        kcount = kcount_l[0] if len(kcount_l) == 1 else torch.cat(kcount_l)
         valid = torch.arange(n_max, device=dev)[None, :] < kcount[:, None]
         sc_seg, p = torch.nonzero(valid, as_tuple=True)     # (scene, class)-major, ascending position = descending score
         idx = ordr[sc_seg, kept[sc_seg, p].long()]
@@ -470,14 +486,17 @@ class Fcaf3DNeckWithHead(nn.Module):
 def segmented_topk(seg, score, n_seg, k):
     """Indices of the rows the reference's per-(scene, level) loop keeps (fcaf3d_neck_with_head.py:238-243: `if len(scores) >
     nms_pre: topk(nms_pre)`), for every segment at once: segments in ascending id; inside a segment with more than k rows the k
-    best by descending score (ties: row order), inside a smaller one ALL rows in row order.  One stable sort of a float64 key
-    (segment id, then 1 - score | row / (N + 1)); seg (N,) int64 in [0, n_seg), score (N,) in [0, 1]."""
+    best by descending score (ties: row order), inside a smaller one ALL rows in row order.  Two STABLE sorts (by descending
+    score where the segment is cut, then by segment) — exact for any float32 scores (r2 packed segment and score into one
+    float64 key, which merged scores below ~1e-7 into ties: ADVICE r2).  seg (N,) int64 in [0, n_seg), score (N,)."""
     N = seg.numel()
     counts = torch.bincount(seg, minlength=n_seg)
     big = counts > k
     row = torch.arange(N, device=seg.device)
-    frac = torch.where(big[seg], 1.0 - score.double(), row.double() / (N + 1))
-    order = torch.sort(seg.double() * 2.0 + frac, stable=True).indices
+    # rows of uncut segments keep their row order: give them a constant key, the stable sort does the rest
+    key = torch.where(big[seg], -score.float(), score.new_zeros(()).float())
+    o1 = torch.sort(key, stable=True).indices
+    order = o1[torch.sort(seg[o1], stable=True).indices]
     starts = torch.cumsum(counts, 0) - counts
     keep = (row - starts[seg[order]]) < k
     return order[keep]

@@ -108,8 +108,9 @@ def _conv_fwd(x, w, nbr, out, n_in, n_out, K, Cin, Cout, out_index=None, flags=N
 
 class _SparseConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, weight, kmap, n_out):
-        """feats (n_in,Cin), weight (K,Cin,Cout), kmap KernelMap or None (identity, K==1)."""
+    def forward(ctx, feats, weight, kmap, n_out, training=True):
+        """feats (n_in,Cin), weight (K,Cin,Cout), kmap KernelMap or None (identity, K==1).  training: the caller is in
+        training mode with gradients enabled (only then does the stem keep its gathered inputs for the weight gradient)."""
         _chk(feats, weight)
         feats = feats.contiguous()
         # only a LEAF kernel's gradient goes straight to AccumulateGrad (no kernel reads it before the join)
@@ -120,11 +121,12 @@ class _SparseConv(torch.autograd.Function):
         K, Cin, Cout = weight.shape
         n_in = feats.shape[0]
         out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
-        ctx.col = None
-        if STEM_COL and kmap is not None and Cin == 3 and Cout == 64 and K <= 27 and not (FLAGS & 1) and ctx.needs_input_grad[1]:
+        col = None
+        if (STEM_COL and training and kmap is not None and Cin == 3 and Cout == 64 and K <= 27 and not (FLAGS & 1)
+                and ctx.needs_input_grad[1]):
             # stem in training: keep the gathered inputs (n_out, 84) for the weight gradient (conv.hip: k_stem_fwd / k_stem_wgrad_col)
-            ctx.col = torch.empty((n_out, 84), dtype=torch.float32, device=feats.device)
-            L.call('fc_stem_conv_fwd', L.ptr(feats), L.ptr(weight), L.ptr(kmap.nbr), L.ptr(out), L.ptr(ctx.col), n_in, n_out, K,
+            col = torch.empty((n_out, 84), dtype=torch.float32, device=feats.device)
+            L.call('fc_stem_conv_fwd', L.ptr(feats), L.ptr(weight), L.ptr(kmap.nbr), L.ptr(out), L.ptr(col), n_in, n_out, K,
                    L.stream())
         elif _pair_conv(kmap, n_out, Cin, Cout):
             _conv_pairs(feats, weight, kmap.pairs(), out, n_in, n_out, K, Cin, Cout, kmap.pair_tiles())
@@ -132,13 +134,14 @@ class _SparseConv(torch.autograd.Function):
             nbr, oidx = ((kmap.sorted_fwd() if _mfma_shape(Cin, Cout) else (kmap.nbr, None))
                          if kmap is not None else (None, None))
             _conv_fwd(feats, weight, nbr, out, n_in, n_out, K, Cin, Cout, oidx)
-        ctx.save_for_backward(feats, weight)
+        ctx.has_col = col is not None
+        ctx.save_for_backward(*((feats, weight, col) if col is not None else (feats, weight)))
         ctx.kmap = kmap
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        feats, weight = ctx.saved_tensors
+        feats, weight = ctx.saved_tensors[:2]
         kmap = ctx.kmap
         gout = gout.contiguous()
         K, Cin, Cout = weight.shape
@@ -164,7 +167,7 @@ class _SparseConv(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             nbr, ridx = (kmap.nbr if kmap is not None else None), None      # wgrad walks rows in natural order (see conv.hip)
 
-            col = ctx.col
+            col = ctx.saved_tensors[2] if ctx.has_col else None
             flat = ctx.flat if (ctx.flat is not None and weight.grad is None) else None
 
             def launch():
@@ -203,11 +206,11 @@ class _SparseConv(torch.autograd.Function):
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
             else:
                 gw = launch()
-        return gin, gw, None, None
+        return gin, gw, None, None, None
 
 
-def sparse_conv(feats, weight, kmap, n_out):
-    return _SparseConv.apply(feats, weight, kmap, n_out)
+def sparse_conv(feats, weight, kmap, n_out, training=True):
+    return _SparseConv.apply(feats, weight, kmap, n_out, training)
 
 
 # ---- normalisation + activation ---------------------------------------------------------------------

@@ -48,7 +48,7 @@ class MinkowskiConvolution(nn.Module):
         else:
             out_map = x.cmap.strided(self.stride)
             km = x.cmap.kernel_map(out_map, self.kernel_size)
-            f = Fn.sparse_conv(x.F, self.kernel, km, out_map.n)
+            f = Fn.sparse_conv(x.F, self.kernel, km, out_map.n, self.training and torch.is_grad_enabled())
         if self.bias is not None:
             f = f + self.bias
         return SparseTensor(f, coordinate_map_key=out_map)

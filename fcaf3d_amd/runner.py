@@ -138,11 +138,12 @@ def build_lr_updater(optimizer, cfg):
 
 
 def parse_losses(losses):
-    """mmdet BaseDetector._parse_losses: the training loss is the sum of every entry whose key contains 'loss'."""
+    """mmdet BaseDetector._parse_losses: every entry is reduced to a scalar (a tensor by its mean, a list of tensors by
+    the sum of their means) and the training loss is the sum of the entries whose key contains 'loss'."""
     total = None
     for k, v in losses.items():
         if 'loss' in k:
-            v = v if torch.is_tensor(v) else sum(v)
+            v = v.mean() if torch.is_tensor(v) else sum(x.mean() for x in v)
             total = v if total is None else total + v
     return total
 

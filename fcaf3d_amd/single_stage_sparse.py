@@ -24,6 +24,9 @@ class SingleStageSparse3DDetector(nn.Module):
         # True: voxelisation + every coordinate/kernel map of the step are built on a side HIP stream,
         # overlapping whatever the main stream still runs (inputs must already be resident on the device)
         self.async_maps = False
+        # with async_maps: True = the points were written before this step was enqueued (resident in HBM), the coordinate
+        # stream need not wait for the main stream; False (default) = it waits unless sparse.mark_inputs_ready() was called
+        self.inputs_resident = False
         # True: collated points are sorted along a Z-order curve before de-duplication, so that every level's row
         # order is spatially coherent (gather locality).  Only the ROW ORDER changes; per-scene results are sets.
         self.spatial_sort = False
@@ -94,7 +97,7 @@ class SingleStageSparse3DDetector(nn.Module):
 
     def extract_feat(self, points, img_metas):
         if self.async_maps:
-            with on_map_stream(points[0].device):
+            with on_map_stream(points[0].device, self.inputs_resident):
                 x = self._sparse_input(points)
         else:
             x = self._sparse_input(points)

@@ -39,7 +39,8 @@ def mark_inputs_ready(device=None):
     written: the coordinate side stream waits for this event before it reads them.  Without a mark the inputs are
     taken to be resident already (bench / tests), and the side stream does not wait for the main stream at all —
     that is what lets the coordinate work of step i+1 overlap the backward pass of step i."""
-    dev = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
+    idx = None if device is None else torch.device(device).index
+    dev = torch.cuda.current_device() if idx is None else idx
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
     _inputs_ready[dev] = ev
@@ -48,16 +49,22 @@ def mark_inputs_ready(device=None):
 class on_map_stream:
     """with on_map_stream(dev): ...   -> coordinate kernels go to the side stream; main waits on exit."""
 
-    def __init__(self, device):
+    def __init__(self, device, inputs_resident=False):
         self.side = map_stream(device)
         self.dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        self.inputs_resident = inputs_resident
 
     def __enter__(self):
         global _record_to
         ev = _inputs_ready.pop(self.dev, None)
+        self.main = torch.cuda.current_stream()
         if ev is not None:
             self.side.wait_event(ev)           # the producer of the points has finished writing them
-        self.main = torch.cuda.current_stream()
+        elif not self.inputs_resident:
+            # nobody marked the inputs and the caller did not declare them resident: whatever produced them was enqueued
+            # on the main stream (a non_blocking upload, a custom pipeline) — wait for it.  Skipping this wait is an
+            # explicit opt-in (SingleStageSparse3DDetector.inputs_resident; bench.py: scenes sit in HBM before the step)
+            self.side.wait_stream(self.main)
         self.prev = _record_to
         _record_to = self.main
         self.ctx = torch.cuda.stream(self.side)

@@ -113,18 +113,19 @@ def test_segmented_topk_equals_the_per_segment_loop():
     sizes = [0, 1, 49, 50, 51, 400, 1300]
     seg = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(sizes)])
     seg = seg[torch.randperm(seg.numel(), generator=g)]                     # rows of a segment are not contiguous
-    score = torch.rand(seg.numel(), generator=g)
-    score[::7] = score[3]                                                    # ties
-    sel = segmented_topk(seg, score, n_seg, k)
-    want = []
-    for s_ in range(n_seg):
-        rows = torch.nonzero(seg == s_).flatten()
-        if len(rows) > k:
-            sc = score[rows]
-            idx = torch.sort(-sc.double(), stable=True).indices[:k]          # descending score, ties in row order
-            rows = rows[idx]
-        want.append(rows)
-    assert torch.equal(sel, torch.cat(want))
+    for trial, scale in enumerate((1.0, 1e-9, 1e-3, 1e-30)):                 # tiny scores too: no precision floor
+        score = torch.rand(seg.numel(), generator=g) * scale
+        score[::7] = score[3]                                                # ties
+        sel = segmented_topk(seg, score, n_seg, k)
+        want = []
+        for s_ in range(n_seg):
+            rows = torch.nonzero(seg == s_).flatten()
+            if len(rows) > k:
+                sc = score[rows]
+                idx = torch.sort(-sc.double(), stable=True).indices[:k]      # descending score, ties in row order
+                rows = rows[idx]
+            want.append(rows)
+        assert torch.equal(sel, torch.cat(want)), (trial, scale)
 
 
 def test_bbox3d2result_batch_equals_per_scene_conversion():

@@ -16,6 +16,7 @@ def main():
     model, cfg = bench.build_model(args)
     model = model.to(dev).train()
     model.async_maps = True
+    model.inputs_resident = True
     b = bench.make_batches(args, 0, dev, n_batches=1)[0]
 
     def fwd():

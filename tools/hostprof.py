@@ -18,6 +18,7 @@ def main():
     model, cfg = bench.build_model(args)
     model = model.to(dev).train()
     model.async_maps = True
+    model.inputs_resident = True
     batches = bench.make_batches(args, 0, dev)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
 

@@ -16,6 +16,7 @@ def main():
     model, cfg = bench.build_model(args)
     model = model.to(dev).eval()
     model.async_maps = True
+    model.inputs_resident = True
     batches = bench.make_batches(args, 0, dev)
     tb = [dict(points=b['points'], img_metas=b['img_metas']) for b in batches]
 
