@@ -12,6 +12,15 @@
 #pragma clang fp contract(off)
 #include <float.h>
 
+// Angular sort key of sort_v ("sign of y, then |x| x / (x^2 + y^2)", eps 1e-8): monotone in
+// atan2(y, x) over (-pi, pi], built from +, *, / only — with contraction off it is bit-identical to the numpy restatement
+// (oracle/loss_oracle.py::sort_key), so the index order is EXACT across machines (r1/r2 used atan2f: two libms ordered
+// ~0.5 % of near-tied vertices differently).
+__device__ static inline float sort_key(float y, float x) {
+  const float r = x * fabsf(x) / (x * x + y * y + 1e-8f);
+  return y < 0.f ? r - 3.f : 1.f - r;
+}
+
 // ---------------------------------------------------------------------------------------------------
 __device__ static inline float focal_elem(float x, bool is_pos, float gamma, float alpha) {
   float p = 1.f / (1.f + expf(-x));
@@ -239,7 +248,7 @@ __global__ void k_riou3d(const float* __restrict__ pred, const float* __restrict
     float ang[24];
     for (int k = 0; k < 24; ++k) {
       if (!valid[k]) continue;
-      float g = atan2f(vert[k].y.v - my, vert[k].x.v - mx);
+      float g = sort_key(vert[k].y.v - my, vert[k].x.v - mx);
       int m = cnt - 1;
       while (m >= 0 && ang[m] > g) { ang[m + 1] = ang[m]; order[m + 1] = order[m]; --m; }   // stable insertion
       ang[m + 1] = g; order[m + 1] = k;
@@ -306,7 +315,7 @@ __global__ void k_sort_v(const float* __restrict__ vertices, const unsigned char
   if (num_valid[i] >= 3) {
     for (int k = 0; k < 24; ++k) {
       if (!m[k]) continue;
-      float g = atan2f(v[2 * k + 1], v[2 * k]);
+      float g = sort_key(v[2 * k + 1], v[2 * k]);
       int q = cnt - 1;
       while (q >= 0 && ang[q] > g) { ang[q + 1] = ang[q]; order[q + 1] = order[q]; --q; }     // stable insertion
       ang[q + 1] = g; order[q + 1] = k;

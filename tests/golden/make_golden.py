@@ -137,9 +137,13 @@ class _GT:
 def gen_assigner(head, out):
     from fcaf3d_amd.synthetic import make_scene
     cases = {}
-    for ci, (seed, n_scales, rotated) in enumerate([(0, 4, False), (1, 2, False), (2, 1, False),
-                                                    (3, 4, True), (4, 2, True)]):
-        pts, gt, labels = make_scene(seed, n_points=6000, n_boxes=7, rotated=rotated)
+    # >= 5 seeds x {1, 2, 4} levels, rotated GT included (cases 0-4 are r1's; 5-14 added in r3: every level
+    # count with axis-aligned AND rotated boxes on new seeds, crowded scenes (15 boxes) and a single box)
+    spec = [(0, 4, False, 7), (1, 2, False, 7), (2, 1, False, 7), (3, 4, True, 7), (4, 2, True, 7),
+            (5, 1, True, 7), (6, 4, False, 15), (7, 2, True, 15), (8, 1, False, 1), (9, 4, True, 1),
+            (10, 2, False, 3), (11, 4, True, 15), (12, 1, True, 15), (13, 2, False, 15), (14, 4, False, 3)]
+    for ci, (seed, n_scales, rotated, n_boxes) in enumerate(spec):
+        pts, gt, labels = make_scene(seed, n_points=6000, n_boxes=n_boxes, rotated=rotated)
         rng = np.random.default_rng(100 + seed)
         levels = []
         for l in range(n_scales):
@@ -155,7 +159,7 @@ def gen_assigner(head, out):
         cases[f'c{ci}_centerness'] = ct.numpy(); cases[f'c{ci}_bbox_targets'] = bt.numpy()
         cases[f'c{ci}_assigned'] = lb.numpy()
         print('assigner case', ci, 'positives', int((lb >= 0).sum()))
-    cases['n_cases'] = np.int64(5)
+    cases['n_cases'] = np.int64(len(spec))
     np.savez_compressed(out, **cases)
 
 

