@@ -47,7 +47,7 @@ def parse():
                     'stream, so that they overlap the backward-data chain: +3 % measured r2)')
     ap.add_argument('--priority-stream', action='store_true', help='run the main chain on a high-priority HIP stream')
     ap.add_argument('--infer-steps', type=int, default=4, help='untimed-region extra: simple_test batches for the inference scenes/s line (0 = skip)')
-    ap.add_argument('--cpu-reps', type=int, default=5, help='repetitions of the C/OpenMP cpu_baseline (median)')
+    ap.add_argument('--cpu-reps', type=int, default=3, help='repetitions of the conv-only part of the cpu_baseline (median)')
     ap.add_argument('--no-force-dp', action='store_true', help='skip the untimed N=1-through-the-averager extra')
     ap.add_argument('--breakdown', action='store_true', help='diagnostic: HIP-event time per C-ABI entry point and per conv shape (stderr)')
     return ap.parse_args()
@@ -315,63 +315,22 @@ def physical_cores():
     return cores or (os.cpu_count() or 1), os.cpu_count() or 1, info.get('Model name', 'unknown')
 
 
-def cpu_baseline(args, model, cfg):
-    """MinkowskiEngine's CPU algorithm restated (the reference's CPU backend itself is not installable here) on ONE scene
-    of the same workload, on this host's cores:
-      (1) C / OpenMP (oracle/conv_oracle.c): every sparse convolution of the network — forward, backward-data, backward-weights
-          — per offset gather -> GEMM -> scatter-add over the scene's real kernel maps; median of `--cpu-reps` runs.
-          These convolutions are >= 97 % of the step's FLOPs; normalisation / loss / map construction are not in this number.
-      (2) the Python/torch oracle (oracle/model_oracle.py), whole forward_train + backward once — the number r1 reported."""
-    from fcaf3d_amd.synthetic import WORKLOADS, make_scene
-    from oracle import conv_c, me_oracle as mo, model_oracle as MO
-    kw = dict(WORKLOADS[args.workload]['scene'])
-    if args.cpu_points:
-        kw['n_points'] = args.cpu_points
+def cpu_baseline(args):
+    """MinkowskiEngine's CPU algorithm restated (the reference's CPU backend itself is not installable here) on ONE scene of
+    the same workload, on this host's physical cores — oracle/cpu_bench.py, run as a SUBPROCESS so that OMP_NUM_THREADS is in
+    the environment before any OpenMP runtime starts (r2 set it too late and ran on half of the cores): the whole
+    forward_train + backward (kernel maps, normalisation, assignment, losses included) with the sparse convolutions in
+    C / OpenMP SIMD kernels, and the convolutions alone with their GFLOP/s and fraction of the host's fp32 peak."""
+    import subprocess
     phys, logical, cpu_name = physical_cores()
-    torch.set_num_threads(min(phys, 64))
-    P = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
-    p, g, l = make_scene(999, **kw)
-    # record every sparse convolution (map + shapes) while the Python oracle runs its timed forward + backward
-    layers = []
-    conv0 = mo.conv
-
-    def rec(feats, weight, nbr):
-        layers.append((nbr, feats.shape[0], weight.shape[1], weight.shape[2]))
-        return conv0(feats, weight, nbr)
-    mo.conv = rec
-    try:
-        t0 = time.time()
-        losses = MO.forward_train(P, cfg.model, [p], [g], [l])
-        sum(losses.values()).backward()
-        dt_py = time.time() - t0
-    finally:
-        mo.conv = conv0
-    rng = np.random.default_rng(0)
-    os.environ.setdefault('OMP_NUM_THREADS', str(phys))
-    data, flops = [], 0.0
-    for nbr, n_in, Cin, Cout in layers:
-        if Cin < 8:
-            continue                                        # the 3-channel stem: bandwidth, not GEMM
-        K, n_out = nbr.shape
-        data.append((nbr, n_in, Cin, Cout, rng.standard_normal((n_in, Cin), dtype=np.float32),
-                     rng.standard_normal((K, Cin, Cout), dtype=np.float32) * 0.05, rng.standard_normal((n_out, Cout), dtype=np.float32)))
-        flops += 3 * 2.0 * float((nbr >= 0).sum()) * Cin * Cout
-    times = []
-    for _ in range(max(args.cpu_reps, 1)):
-        t0 = time.time()
-        for nbr, n_in, Cin, Cout, x, w, go in data:
-            conv_c.conv_fwd(x, w, nbr)
-            conv_c.conv_dgrad(go, w, nbr, n_in)
-            conv_c.conv_wgrad(x, go, nbr, Cin, Cout)
-        times.append(time.time() - t0)
-    dt_c = float(np.median(times))
-    return dict(value=round(1.0 / dt_c, 5), unit='scenes/s', cores=conv_c.num_threads(), physical_cores=phys, logical_cpus=logical,
-                cpu=cpu_name, kind='port', gflops=round(flops / dt_c / 1e9, 1),
-                sample=f'1 scene of {kw["n_points"]} pts: the {len(data)} sparse convolutions of the network (fwd + dgrad + wgrad, '
-                       f'{flops / 1e9:.0f} GFLOP) in C/OpenMP (oracle/conv_oracle.c: MinkowskiEngine CPU algorithm restated, per offset '
-                       f'gather-GEMM-scatter), median of {len(times)} runs = {dt_c:.2f} s; norms / loss / map construction excluded',
-                python_oracle=dict(value=round(1.0 / dt_py, 5), unit='scenes/s', threads=torch.get_num_threads(),
-                                   sample=f'whole forward_train + backward once ({dt_py:.1f} s), oracle/model_oracle.py (torch CPU fp32)'))
+    env = dict(os.environ, OMP_NUM_THREADS=str(phys), OMP_PROC_BIND='spread', OMP_PLACES='cores', HIP_VISIBLE_DEVICES='')
+    cmd = [sys.executable, '-m', 'oracle.cpu_bench', '--workload', args.workload, '--config', CONFIG_OF[args.workload],
+           '--voxel-size', str(args.voxel_size), '--levels', str(args.levels), '--points', str(args.cpu_points),
+           '--reps', str(max(args.cpu_reps, 1))]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        return dict(error=(r.stderr or r.stdout)[-400:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def count_steps(args, n_batches):
@@ -578,7 +537,7 @@ def main():
         if world > 1 and dp_log:
             out['config']['data_parallel'] = D.summarize_bucket_log(trainer.averager, dp_log)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args, model, cfg)
+            out['cpu_baseline'] = cpu_baseline(args)
         else:
             out['cpu_baseline'] = None
         sys.stdout.flush()

@@ -93,21 +93,26 @@ def test_forward_train_parity(name, levels, B, n_points, kw):
         assert _rel(losses_g[k], losses_o[k]) < 1e-4, (k, float(losses_g[k]), float(losses_o[k]))
     sum(losses_g.values()).backward()
     sum(losses_o.values()).backward()
-    # Gradients after ~40 normalised layers carry fp32 round-off of EITHER implementation: the fp32 oracle itself sits up
-    # to 2.4e-2 (max-norm, relative to the tensor's largest entry) from the same oracle in fp64 on the 4-level configs.
-    # Yardstick = the fp64 oracle, with ABSOLUTE bounds: every parameter tensor within 6e-2, the median tensor within 5e-3
-    # (r2 measurements on the MI355X: worst 7e-4 / 5e-4 on the 1- and 2-level cases, 3.7e-2 at 4 levels x 30k points,
-    # 7.3e-3 and 1.2e-2 at full size — against 7e-4 / 3e-6 / 1.8e-2 / 2.4e-2 / 6e-4 for the fp32 oracle).
+    # Gradient yardsticks (r3, tests/diag_grad.py on the MI355X, 4 levels x 2 scenes x 30k points): tensor by tensor the HIP
+    # path sits at the SAME distance from the fp64 oracle as the fp32 oracle does (backbone.layer4.2.conv1.kernel 9.19e-2 vs
+    # 9.19e-2, layer3.0.conv1.kernel 5.32e-2 vs 5.31e-2, layer4.2.norm1.bn.bias 4.64e-2 vs 4.64e-2, ...) and within 1.05e-3
+    # of the fp32 oracle itself: what separates fp32 from fp64 is not round-off of the kernels but the discrete decisions
+    # both fp32 paths take alike (a ReLU / max-pool argmax / top-k on a pre-activation that is +1e-8 in fp32 and -1e-9 in
+    # fp64; in the deepest stage, 109-862 rows, one flipped row is several percent of a weight gradient).  So:
+    #   (1) against the fp32 oracle, every tensor within 3e-3 of its scale (r2 bound: 6e-2 against fp64);
+    #   (2) against the fp64 oracle, every tensor within 2x the fp32 oracle's own distance + 2e-3.
     P64 = {k: (v.detach().double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in P.items()}
     sum(MO.forward_train(P64, m, pts, gts, labs).values()).backward()
-    errs, errs_o = {}, {}
+    errs, errs_o, errs_32 = {}, {}, {}
     for k, p in model.named_parameters():
-        errs[k], errs_o[k] = _rel(p.grad, P64[k].grad), _rel(P[k].grad, P64[k].grad)
-    worst = max(errs, key=errs.get)
-    print(f'{name} L={levels} B={B} n={n_points}: gradient error vs the fp64 oracle: HIP worst {errs[worst]:.2e} ({worst}), '
-          f'median {np.median(list(errs.values())):.2e}; fp32 oracle worst {max(errs_o.values()):.2e}, '
-          f'median {np.median(list(errs_o.values())):.2e}')
-    assert errs[worst] < 6e-2, (worst, errs[worst])
+        errs[k], errs_o[k], errs_32[k] = _rel(p.grad, P64[k].grad), _rel(P[k].grad, P64[k].grad), _rel(p.grad, P[k].grad)
+    worst, worst32 = max(errs, key=errs.get), max(errs_32, key=errs_32.get)
+    print(f'{name} L={levels} B={B} n={n_points}: gradient error vs the fp32 oracle: worst {errs_32[worst32]:.2e} ({worst32}), '
+          f'median {np.median(list(errs_32.values())):.2e}; vs the fp64 oracle: HIP worst {errs[worst]:.2e} ({worst}), fp32 oracle '
+          f'on the same tensor {errs_o[worst]:.2e}; medians {np.median(list(errs.values())):.2e} / {np.median(list(errs_o.values())):.2e}')
+    assert errs_32[worst32] < 3e-3, (worst32, errs_32[worst32])
+    over = {k: (errs[k], errs_o[k]) for k in errs if errs[k] > 2.0 * errs_o[k] + 2e-3}
+    assert not over, over
     assert np.median(list(errs.values())) < 5e-3
 
 
@@ -401,10 +406,10 @@ def test_full_size_config5_backward_vs_oracle_digest():
     """BASELINE config 5 at FULL size, forward_train + BACKWARD (r2 checked extract_feat only): one 500 000-point S3DIS-shaped
     scene, pruning live at the real pts_threshold, so the gradients flow through MinkowskiPruning's gather / scatter
     (fcaf3d_neck_with_head.py:110-126), the interpolation-selected rows and the 100 000-row level-0 maps.  The yardstick is
-    the CPU oracle in fp64, run once in the build container (tests/golden/make_config5_golden.py, ~90 s) and stored as a
-    digest per parameter tensor: 2-norm, largest magnitude, 256 entries at seeded positions.  Bounds: losses 1e-4; every
-    tensor's norm within 2e-2 and its sampled entries within 6e-2 of the tensor's largest magnitude (the fp32 round-off
-    envelope of ~40 normalised layers measured in test_forward_train_parity), the median tensor within 5e-3."""
+    the CPU oracle in fp32 (the reference's precision; see the generator's header for why not fp64), run once in the build
+    container (tests/golden/make_config5_golden.py, ~90 s) and stored as a digest per parameter tensor: 2-norm, largest
+    magnitude, 256 entries at seeded positions.  Bounds: losses 1e-4; every tensor's sampled entries within 1e-2 of the
+    tensor's largest magnitude and its norm within 3e-2, the median tensor within 1e-3."""
     import importlib.util
     from fcaf3d_amd.synthetic import WORKLOADS
     spec = importlib.util.spec_from_file_location('make_config5_golden', os.path.join(G, 'make_config5_golden.py'))
@@ -432,9 +437,9 @@ def test_full_size_config5_backward_vs_oracle_digest():
         scale = max(gmax, 1e-12)
         errs[k] = max(float(np.abs(got - samples).max()) / scale, abs(float(g.norm()) - gnorm) / max(gnorm, 1e-12) / 3.0)
     worst = max(errs, key=errs.get)
-    print(f'config 5 backward vs fp64 oracle digest: worst {errs[worst]:.2e} ({worst}), median {np.median(list(errs.values())):.2e}')
-    assert errs[worst] < 6e-2, (worst, errs[worst])
-    assert np.median(list(errs.values())) < 5e-3
+    print(f'config 5 backward vs fp32 oracle digest: worst {errs[worst]:.2e} ({worst}), median {np.median(list(errs.values())):.2e}')
+    assert errs[worst] < 1e-2, (worst, errs[worst])
+    assert np.median(list(errs.values())) < 1e-3
 
 
 def test_out_of_range_coordinates_raise():
