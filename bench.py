@@ -238,9 +238,9 @@ class ConvProbe:
                 kmap._pairs_dev = (kmap.nbr >= 0).sum()
             return kmap._pairs_dev
 
-        def fwd(ctx, feats, weight, kmap, n_out):
+        def fwd(ctx, feats, weight, kmap, n_out, *rest):
             probe._pairs = pairs_of(kmap)
-            return fwd0(ctx, feats, weight, kmap, n_out)
+            return fwd0(ctx, feats, weight, kmap, n_out, *rest)
 
         def bwd(ctx, gout):
             probe._pairs = pairs_of(ctx.kmap)

@@ -38,6 +38,71 @@ int fc_voxelize(const float* points, int64_t n, int pt_stride, int batch_idx, fl
 }
 
 // ----------------------------------------------------------------------------------------------
+// Input pipeline fused with the voxelisation: one pass over the RAW points of a scene applies, in
+// registers and in the reference's order, what its train pipeline does on the CPU before the detector sees the cloud —
+//   GlobalAlignment (transforms_3d.py:409-490: p @ R^T + t), IndoorPointSample (:821-895: row gather),
+//   RandomFlip3D (:59-170: x or y negated), GlobalRotScaleTrans (:493-645: p @ rot_T, * scale, + trans)
+// — and then extract_feat's collate (single_stage_sparse.py:34-36: xyz / voxel_size floored, features / 255).
+// The augmented cloud is never written unless the caller asks for it (points_out, tests / visualisation).
+// xf (host, 24 floats): [0..8] alignment R (row-major; p' = R p + t), [9..11] t, [12] has_align, [13] flip x, [14] flip y,
+// [15] cos(angle), [16] sin(angle), [17] scale, [18..20] translation.  Every step rounds to fp32 as the reference's
+// tensor ops do (separate multiply / add: no contraction), so voxel indices agree except within an ulp of a cell face.
+struct AugXf { float v[24]; };
+__global__ void k_augment_voxelize(const float* __restrict__ pts, int64_t n_src, int pt_stride, const int* __restrict__ sample,
+                                   int64_t n_out, AugXf xf, int b, float vs, float feat_div, int nfeat,
+                                   int* __restrict__ coords, float* __restrict__ feats, float* __restrict__ points_out) {
+#pragma clang fp contract(off)
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const int64_t src = sample ? sample[i] : i;
+  const float* p = pts + src * pt_stride;
+  float x = p[0], y = p[1], z = p[2];
+  const float* a = xf.v;
+  if (a[12] != 0.f) {                                   // GlobalAlignment: points.rotate(R^T) then translate
+    const float nx = (x * a[0] + y * a[1]) + z * a[2];
+    const float ny = (x * a[3] + y * a[4]) + z * a[5];
+    const float nz = (x * a[6] + y * a[7]) + z * a[8];
+    x = nx + a[9]; y = ny + a[10]; z = nz + a[11];
+  }
+  if (a[13] != 0.f) x = -x;                             // RandomFlip3D 'horizontal'
+  if (a[14] != 0.f) y = -y;                             // ... 'vertical'
+  {                                                     // GlobalRotScaleTrans: p @ rot_T, rot_T = [[c, s, 0], [-s, c, 0], [0, 0, 1]]
+    const float c = a[15], sn = a[16];
+    const float nx = x * c - y * sn;
+    const float ny = x * sn + y * c;
+    x = nx * a[17] + a[18];
+    y = ny * a[17] + a[19];
+    z = z * a[17] + a[20];
+  }
+  int4 cd;
+  cd.x = b;
+  cd.y = (int)floorf(x / vs);
+  cd.z = (int)floorf(y / vs);
+  cd.w = (int)floorf(z / vs);
+  reinterpret_cast<int4*>(coords)[i] = cd;
+  for (int j = 0; j < nfeat; ++j) feats[i * nfeat + j] = p[3 + j] / feat_div;
+  if (points_out) {
+    float* o = points_out + i * (3 + nfeat);
+    o[0] = x; o[1] = y; o[2] = z;
+    for (int j = 0; j < nfeat; ++j) o[3 + j] = p[3 + j];
+  }
+}
+
+int fc_augment_voxelize(const float* points, int64_t n_src, int pt_stride, const int* sample_idx, int64_t n_out,
+                        const float* xform_host, int batch_idx, float voxel_size, float feat_div, int nfeat, int* coords,
+                        float* feats, float* points_out, hipStream_t stream) {
+  if (n_src < 0 || n_out < 0 || pt_stride < 3 + nfeat || voxel_size <= 0.f || !xform_host) return FC_EINVAL;
+  if (!sample_idx && n_out != n_src) return FC_EINVAL;
+  if (n_out == 0) return FC_OK;
+  AugXf xf;
+  for (int j = 0; j < 24; ++j) xf.v[j] = xform_host[j];
+  k_augment_voxelize<<<(unsigned)fc_cdiv(n_out, 256), 256, 0, stream>>>(points, n_src, pt_stride, sample_idx, n_out, xf, batch_idx,
+                                                                       voxel_size, feat_div, nfeat, coords, feats, points_out);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
 // Morton (Z-order) keys: batch index in the top bits, then x/y/z bit-interleaved.  Sorting the points by
 // this key before the hash insert makes "order of first occurrence" a space-filling-curve order on EVERY
 // pyramid level (a Z-order prefix is the Z-order of the parent cell), so the rows a convolution tile gathers

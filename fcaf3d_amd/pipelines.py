@@ -171,7 +171,8 @@ class IndoorInfoDataset:
 
     def get_ann_info(self, index):
         from .boxes import DepthInstance3DBoxes
-        ann = self.data_infos[index]['annos']
+        info = self.data_infos[index]
+        ann = info.get('annos', dict(gt_num=0))              # S3DIS infos written without detection annotations
         if ann['gt_num'] != 0:
             boxes = np.asarray(ann['gt_boxes_upright_depth'], np.float32)
             labels = np.asarray(ann['class']).astype(np.int64)
@@ -180,8 +181,14 @@ class IndoorInfoDataset:
             labels = np.zeros((0,), np.int64)
         gt = DepthInstance3DBoxes(torch.from_numpy(boxes), box_dim=boxes.shape[-1], with_yaw=self.with_yaw,
                                   origin=(0.5, 0.5, 0.5))
-        align = np.asarray(ann.get('axis_align_matrix', np.eye(4)), np.float32)
-        return dict(gt_bboxes_3d=gt, gt_labels_3d=torch.from_numpy(labels), axis_align_matrix=align)
+        out = dict(gt_bboxes_3d=gt, gt_labels_3d=torch.from_numpy(labels))
+        import os
+        if 'axis_align_matrix' in ann:                       # ScanNet (scannet_dataset.py:100-117); S3DIS / SUN RGB-D have none
+            out['axis_align_matrix'] = np.asarray(ann['axis_align_matrix'], np.float32)
+        for k in ('pts_instance_mask_path', 'pts_semantic_mask_path'):      # S3DIS / ScanNet (s3dis_dataset.py:91-99)
+            if k in info:
+                out[k] = os.path.join(self.data_root, info[k])
+        return out
 
     def load(self, index, device=None, points_file=None):
         import os
@@ -189,8 +196,275 @@ class IndoorInfoDataset:
         path = points_file or os.path.join(self.data_root, info['pts_path'])
         ann = self.get_ann_info(index)
         pts = load_points_from_file(path, self.load_dim, self.use_dim, device)
-        pts = global_alignment(pts, ann['axis_align_matrix'])
+        if 'axis_align_matrix' in ann:
+            pts = global_alignment(pts, ann['axis_align_matrix'])
         boxes = ann['gt_bboxes_3d'].tensor
         if device is not None:
             boxes = boxes.to(device); ann['gt_labels_3d'] = ann['gt_labels_3d'].to(device)
         return pts, boxes, ann['gt_labels_3d'], dict(sample_idx=info['point_cloud']['lidar_idx'], file_name=path)
+
+
+# ---- augmentation fused with the voxelisation (csrc/coords.hip k_augment_voxelize) ------------------------------------
+class LazyAugmentedPoints:
+    """A scene whose train-time augmentation has been DRAWN but not applied: the raw points on the device, the sample
+    indices and the transform parameters.  `SingleStageSparse3DDetector.voxelize` hands it to `fc_augment_voxelize`, which
+    aligns / samples / flips / rotates / scales / translates in registers and writes voxel coordinates + features
+    directly — the augmented cloud (2.4 MB per scene, read once by the voxelisation and never again) is not materialised.
+    `.materialize()` returns it anyway (tests, visualisation)."""
+
+    def __init__(self, raw, sample_idx, params, align=None):
+        assert raw.is_cuda, 'the fused input pipeline runs on the GPU (HIP); use TrainAugment.__call__ on the CPU'
+        self.raw = raw.contiguous()
+        self.sample_idx = sample_idx.to(torch.int32).contiguous() if sample_idx is not None else None
+        self.params, self.align = params, align
+        n = self.sample_idx.numel() if self.sample_idx is not None else raw.shape[0]
+        self.shape = (n, raw.shape[1])
+        self.device = raw.device
+
+    def xform(self):
+        x = np.zeros(24, np.float32)
+        if self.align is not None:
+            m = np.asarray(self.align, np.float32)
+            x[0:9] = m[:3, :3].reshape(-1)
+            x[9:12] = m[:3, 3]
+            x[12] = 1.0
+        p = self.params
+        x[13], x[14] = float(p.get('flip_h', False)), float(p.get('flip_v', False))
+        ang = p.get('angle', 0.0)
+        x[15], x[16] = math.cos(ang), math.sin(ang)
+        x[17] = p.get('scale', 1.0)
+        x[18:21] = np.asarray(p.get('trans', (0.0, 0.0, 0.0)), np.float32)
+        return x
+
+    def voxelize_into(self, batch_idx, voxel_size, feat_div, coords, feats, points_out=None):
+        from . import _lib as L
+        nfeat = self.raw.shape[1] - 3
+        x = self.xform()
+        L.call('fc_augment_voxelize', L.ptr(self.raw), self.raw.shape[0], self.raw.shape[1], L.ptr(self.sample_idx), self.shape[0],
+               x.ctypes.data, batch_idx, float(voxel_size), float(feat_div), nfeat, L.ptr(coords), L.ptr(feats),
+               L.ptr(points_out), L.stream())
+
+    def materialize(self):
+        out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        coords = torch.empty((self.shape[0], 4), dtype=torch.int32, device=self.device)
+        feats = torch.empty((self.shape[0], self.shape[1] - 3), dtype=torch.float32, device=self.device)
+        self.voxelize_into(0, 1.0, 1.0, coords, feats, out)
+        return out
+
+
+def _train_augment_lazy(self, points, boxes, generator=None, align=None):
+    """TrainAugment on the GPU without materialising the augmented cloud: draws the sample and the transform, moves the
+    (few) GT boxes now, and returns (LazyAugmentedPoints, boxes, params) — pass the first as the scene's `points`."""
+    _, idx = indoor_point_sample(points[:, :1], self.num_points, generator)
+    p = self.draw(generator, points.device)
+    empty = points[:0]
+    if p['flip_h']:
+        _, boxes = flip_bev(empty, boxes, 'horizontal', self.with_yaw)
+    if p['flip_v']:
+        _, boxes = flip_bev(empty, boxes, 'vertical', self.with_yaw)
+    _, boxes = rot_scale_trans(empty, boxes, p['angle'], p['scale'], p['trans'], self.with_yaw)
+    lazy = LazyAugmentedPoints(points, idx, p, align)
+    from .sparse import mark_inputs_ready
+    mark_inputs_ready(points.device)
+    return lazy, boxes, p
+
+
+TrainAugment.lazy = _train_augment_lazy
+
+
+# ---- the reference's pipeline classes by name (configs/fcaf3d/*.py train_pipeline / test_pipeline) ----------------------
+# `results` dicts carry the reference's keys (pts_filename, ann_info, points, gt_bboxes_3d, gt_labels_3d, bbox3d_fields,
+# pcd_horizontal_flip, pcd_vertical_flip, pcd_rotation, pcd_scale_factor, pcd_trans); points are (n, 3+C) tensors, boxes
+# `DepthInstance3DBoxes`.  Random draws come from numpy's global generator in the reference's call order, so a scene
+# processed under np.random.seed(s) takes the draws the reference's classes would take.
+from .registry import Registry  # noqa: E402
+
+PIPELINES = Registry('pipeline')
+
+
+@PIPELINES.register_module()
+class LoadPointsFromFile:
+    """mmdet3d/datasets/pipelines/loading.py:333-442 (coord_type='DEPTH')"""
+
+    def __init__(self, coord_type='DEPTH', load_dim=6, use_dim=(0, 1, 2), shift_height=False, use_color=False,
+                 file_client_args=None, device=None):
+        assert coord_type == 'DEPTH' and not shift_height, 'FCAF3D loads DEPTH-mode points without a height channel'
+        self.load_dim, self.use_dim, self.device = load_dim, tuple(range(use_dim)) if isinstance(use_dim, int) else tuple(use_dim), device
+        assert max(self.use_dim) < load_dim
+
+    def __call__(self, results):
+        results['points'] = load_points_from_file(results['pts_filename'], self.load_dim, self.use_dim, self.device)
+        return results
+
+
+@PIPELINES.register_module()
+class LoadAnnotations3D:
+    """mmdet3d/datasets/pipelines/loading.py:456-640: the 3D boxes and labels of `ann_info` become pipeline fields
+    (with_bbox_3d / with_label_3d, the only switches the FCAF3D configs use; point-wise masks are not loaded)."""
+
+    def __init__(self, with_bbox_3d=True, with_label_3d=True, with_mask_3d=False, with_seg_3d=False, **unused):
+        assert not with_mask_3d and not with_seg_3d, 'detection pipeline: no point-wise masks'
+        self.with_bbox_3d, self.with_label_3d = with_bbox_3d, with_label_3d
+
+    def __call__(self, results):
+        if self.with_bbox_3d:
+            results['gt_bboxes_3d'] = results['ann_info']['gt_bboxes_3d']
+            results['bbox3d_fields'].append('gt_bboxes_3d')
+        if self.with_label_3d:
+            results['gt_labels_3d'] = results['ann_info']['gt_labels_3d']
+        return results
+
+
+@PIPELINES.register_module()
+class GlobalAlignment:
+    """transforms_3d.py:409-490"""
+
+    def __init__(self, rotation_axis):
+        self.rotation_axis = rotation_axis
+
+    def __call__(self, results):
+        assert 'axis_align_matrix' in results['ann_info'], 'axis_align_matrix is not provided in GlobalAlignment'
+        results['points'] = global_alignment(results['points'], results['ann_info']['axis_align_matrix'], self.rotation_axis)
+        return results
+
+
+@PIPELINES.register_module()
+class IndoorPointSample:
+    """transforms_3d.py:821-895: np.random.choice(n, num_points, replace = n < num_points)"""
+
+    def __init__(self, num_points):
+        self.num_points = num_points
+
+    def __call__(self, results):
+        pts = results['points']
+        n = pts.shape[0]
+        choices = np.random.choice(n, self.num_points, replace=n < self.num_points)
+        results['points'] = pts[torch.from_numpy(choices).to(pts.device)]
+        return results
+
+
+def _boxes_of(results):
+    keys = results['bbox3d_fields']
+    assert len(keys) <= 1
+    return keys[0] if keys else None
+
+
+@PIPELINES.register_module()
+class RandomFlip3D:
+    """transforms_3d.py:59-170 with sync_2d=False: one uniform draw for the (absent) 2D flip of mmdet's RandomFlip, then
+    one per BEV direction."""
+
+    def __init__(self, sync_2d=True, flip_ratio_bev_horizontal=0.0, flip_ratio_bev_vertical=0.0, **unused):
+        assert not sync_2d, 'FCAF3D flips point clouds only (sync_2d=False)'
+        self.h, self.v = flip_ratio_bev_horizontal, flip_ratio_bev_vertical
+
+    def __call__(self, results):
+        np.random.rand()                                        # mmdet RandomFlip.__call__: the image flip draw
+        if 'pcd_horizontal_flip' not in results:
+            results['pcd_horizontal_flip'] = bool(np.random.rand() < self.h)
+        if 'pcd_vertical_flip' not in results:
+            results['pcd_vertical_flip'] = bool(np.random.rand() < self.v)
+        key = _boxes_of(results)
+        for flag, direction in (('pcd_horizontal_flip', 'horizontal'), ('pcd_vertical_flip', 'vertical')):
+            if results[flag]:
+                b = results[key] if key else None
+                t = b.tensor if b is not None else results['points'].new_zeros((0, 7))
+                results['points'], t = flip_bev(results['points'], t, direction, b.with_yaw if b is not None else True)
+                if b is not None:
+                    b.tensor = t
+        return results
+
+
+@PIPELINES.register_module()
+class GlobalRotScaleTrans:
+    """transforms_3d.py:493-645: rotation draw (applied only when the scene has boxes, as the reference's
+    `_rot_bbox_points` does when `bbox3d_fields` is set), scale draw, translation draw — in that order."""
+
+    def __init__(self, rot_range=(-0.78539816, 0.78539816), scale_ratio_range=(0.95, 1.05), translation_std=(0, 0, 0),
+                 shift_height=False):
+        assert not shift_height
+        self.rot_range = (-rot_range, rot_range) if isinstance(rot_range, (int, float)) else tuple(rot_range)
+        self.scale_ratio_range = tuple(scale_ratio_range)
+        self.translation_std = (translation_std,) * 3 if isinstance(translation_std, (int, float)) else tuple(translation_std)
+
+    def __call__(self, results):
+        key = _boxes_of(results)
+        b = results[key] if key else None
+        angle = float(np.random.uniform(self.rot_range[0], self.rot_range[1]))
+        pts = results['points']
+        t = b.tensor if b is not None else pts.new_zeros((0, 7))
+        with_yaw = b.with_yaw if b is not None else True
+        if b is None or len(b.tensor) != 0:
+            pts, t = rotate(pts, t, angle, with_yaw)
+            results['pcd_rotation'] = _rot_z_T(angle, pts)
+        if 'pcd_scale_factor' not in results:
+            results['pcd_scale_factor'] = float(np.random.uniform(self.scale_ratio_range[0], self.scale_ratio_range[1]))
+        trans = np.random.normal(scale=np.array(self.translation_std, dtype=np.float32), size=3).T
+        pts, t = rot_scale_trans(pts, t, 0.0, results['pcd_scale_factor'], trans, with_yaw)
+        results['pcd_trans'] = trans
+        results['points'] = pts
+        if b is not None:
+            b.tensor = t
+        return results
+
+
+@PIPELINES.register_module()
+class DefaultFormatBundle3D:
+    """formating.py:177-250 for point clouds: tensors stay tensors (mmcv's DataContainer wrapping is the dataloader's
+    business, not the path's); labels become int64 tensors."""
+
+    def __init__(self, class_names=None, with_gt=True, with_label=True):
+        self.class_names, self.with_label = class_names, with_label
+
+    def __call__(self, results):
+        if 'gt_labels_3d' in results and not torch.is_tensor(results['gt_labels_3d']):
+            results['gt_labels_3d'] = torch.as_tensor(np.asarray(results['gt_labels_3d'])).long()
+        return results
+
+
+@PIPELINES.register_module()
+class Collect3D:
+    """formating.py:253-330: the listed keys plus `img_metas` (box_type_3d, sample_idx, file name, the transform record)."""
+
+    META = ('box_type_3d', 'sample_idx', 'pts_filename', 'pcd_horizontal_flip', 'pcd_vertical_flip', 'pcd_rotation',
+            'pcd_scale_factor', 'pcd_trans')
+
+    def __init__(self, keys, meta_keys=None):
+        self.keys, self.meta_keys = tuple(keys), tuple(meta_keys) if meta_keys is not None else self.META
+
+    def __call__(self, results):
+        out = {k: results[k] for k in self.keys}
+        out['img_metas'] = {k: results[k] for k in self.meta_keys if k in results}
+        return out
+
+
+class Compose:
+    """mmdet's Compose over the classes above: `Compose(cfg.train_pipeline)(dataset.pre_pipeline(index))`"""
+
+    def __init__(self, cfgs, device=None):
+        self.transforms = []
+        for c in cfgs:
+            c = dict(c)
+            if c['type'] == 'LoadPointsFromFile':
+                c.setdefault('device', device)
+            self.transforms.append(PIPELINES.build(c))
+
+    def __call__(self, results):
+        for t in self.transforms:
+            results = t(results)
+            if results is None:
+                return None
+        return results
+
+
+def _pre_pipeline(self, index, points_file=None):
+    """Custom3DDataset.get_data_info + pre_pipeline (custom_3d.py:96-147): the `results` dict a pipeline starts from"""
+    import os
+    from .boxes import DepthInstance3DBoxes
+    info = self.data_infos[index]
+    return dict(pts_filename=points_file or os.path.join(self.data_root, info['pts_path']),
+                sample_idx=info['point_cloud']['lidar_idx'], ann_info=self.get_ann_info(index), bbox3d_fields=[],
+                box_type_3d=DepthInstance3DBoxes)
+
+
+IndoorInfoDataset.pre_pipeline = _pre_pipeline

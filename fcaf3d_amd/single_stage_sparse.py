@@ -46,8 +46,14 @@ class SingleStageSparse3DDetector(nn.Module):
         feats = torch.empty((total, nfeat), dtype=torch.float32, device=dev)
         off = 0
         for b, p in enumerate(points):
-            p = p.contiguous()
             n = p.shape[0]
+            if hasattr(p, 'voxelize_into'):
+                # a scene whose augmentation is drawn but not applied (pipelines.LazyAugmentedPoints): align / sample /
+                # flip / rotate / scale / translate + voxelise in ONE pass over the raw points (fc_augment_voxelize)
+                p.voxelize_into(b, self.voxel_size, 255.0, coords[off:], feats[off:])
+                off += n
+                continue
+            p = p.contiguous()
             L.call('fc_voxelize', L.ptr(p), n, p.shape[1], b, float(self.voxel_size), 255.0, nfeat,
                    L.ptr(coords[off:]), L.ptr(feats[off:]), L.stream())
             off += n

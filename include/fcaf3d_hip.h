@@ -35,6 +35,17 @@ extern "C" {
 int fc_voxelize(const float* points, int64_t n, int pt_stride, int batch_idx, float voxel_size, float feat_div,
                 int nfeat, int* coords, float* feats, hipStream_t stream);
 
+/* The reference's indoor TRAIN pipeline fused with the collate above, one pass over the raw points of a scene:
+ * GlobalAlignment (mmdet3d/datasets/pipelines/transforms_3d.py:409-490), IndoorPointSample (:821-895, sample_idx: n_out
+ * row indices, nullable = every row), RandomFlip3D (:59-170), GlobalRotScaleTrans (:493-645), then
+ * ME.utils.batch_sparse_collate's floor(xyz / voxel_size) and features / feat_div (single_stage_sparse.py:34-36).
+ * xform_host: 24 floats on the HOST — [0..8] alignment R row-major, [9..11] t, [12] has_align, [13] flip x, [14] flip y,
+ * [15] cos(angle), [16] sin(angle), [17] scale, [18..20] translation, [21..23] unused.  points_out (nullable):
+ * the augmented cloud (n_out, 3 + nfeat), for inspection — the detector itself needs coords / feats only. */
+int fc_augment_voxelize(const float* points, int64_t n_src, int pt_stride, const int* sample_idx, int64_t n_out,
+                        const float* xform_host, int batch_idx, float voxel_size, float feat_div, int nfeat, int* coords,
+                        float* feats, float* points_out, hipStream_t stream);
+
 /* Z-order key per voxel coordinate [b | x,y,z bit-interleaved]; sorting the collated points by it before
  * fc_hash_unique turns "order of first occurrence" into a space-filling-curve order on every pyramid level.
  * No reference counterpart (optional locality aid of this implementation, off by default). */

@@ -230,6 +230,69 @@ def test_pipeline_on_the_reference_scannet_fixture():
     assert torch.allclose(p[:, :3], expected_points, rtol=1e-2, atol=2e-4), (p[:, :3] - expected_points).abs().max()
 
 
+def test_compose_of_the_config_pipeline_reproduces_the_reference_test_numbers():
+    """the train_pipeline of configs/fcaf3d/fcaf3d_scannet-3d-18class.py:16-40, built BY NAME (LoadPointsFromFile,
+    LoadAnnotations3D, GlobalAlignment, IndoorPointSample, RandomFlip3D, GlobalRotScaleTrans, DefaultFormatBundle3D,
+    Collect3D) through fcaf3d_amd.pipelines.Compose, on the reference's ScanNet fixture under np.random.seed(0): the
+    classes take numpy's draws in the reference's order, so the points and boxes are the numbers the reference's own test
+    pins (tests/test_data/test_datasets/test_scannet_dataset.py:65-86) — without replaying a single draw by hand."""
+    import os
+    import numpy as np
+    import torch
+    from fcaf3d_amd import pipelines as pl
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    ds = pl.IndoorInfoDataset(G, os.path.join(G, 'scannet_infos.pkl'), with_yaw=False)
+    cfg = [dict(type='LoadPointsFromFile', coord_type='DEPTH', shift_height=False, load_dim=6, use_dim=[0, 1, 2, 3, 4, 5]),
+           dict(type='LoadAnnotations3D'), dict(type='GlobalAlignment', rotation_axis=2),
+           dict(type='IndoorPointSample', num_points=5),
+           dict(type='RandomFlip3D', sync_2d=False, flip_ratio_bev_horizontal=1.0, flip_ratio_bev_vertical=1.0),
+           dict(type='GlobalRotScaleTrans', rot_range=[-0.087266, 0.087266], scale_ratio_range=[1.0, 1.0], shift_height=False),
+           dict(type='DefaultFormatBundle3D', class_names=('cabinet',)),
+           dict(type='Collect3D', keys=['points', 'gt_bboxes_3d', 'gt_labels_3d'])]
+    np.random.seed(0)
+    out = pl.Compose(cfg)(ds.pre_pipeline(0, points_file=os.path.join(G, 'scannet_scene0000_00.bin')))
+    expected_points = torch.tensor([[1.8339e+00, 2.1093e+00, 2.2900e+00], [3.6079e+00, 1.4592e-01, 2.0687e+00],
+                                    [4.1886e+00, 5.0614e+00, -1.0841e-01], [6.8790e+00, 1.5086e+00, -9.3154e-02],
+                                    [4.8253e+00, 2.6668e-01, 1.4917e+00]])
+    expected_boxes = torch.tensor([[-1.1835, -3.6317, 1.5704, 1.7577, 0.3761, 0.5724, 0.0000],
+                                   [-3.1832, 3.2269, 1.1911, 0.6727, 0.2251, 0.6715, 0.0000],
+                                   [-0.9598, -2.2864, 0.0093, 0.7506, 2.5709, 1.2145, 0.0000],
+                                   [-2.6988, -2.7354, 0.8288, 0.7680, 1.8877, 0.2870, 0.0000],
+                                   [3.2989, 0.2885, -0.0090, 0.7600, 3.8814, 2.1603, 0.0000]])
+    assert torch.allclose(out['points'][:, :3], expected_points, rtol=1e-2, atol=2e-4)
+    assert torch.allclose(out['gt_bboxes_3d'].tensor[:5], expected_boxes, rtol=1e-2, atol=2e-4)
+    meta = out['img_metas']
+    assert meta['pcd_horizontal_flip'] and meta['pcd_vertical_flip'] and meta['sample_idx'] == 'scene0000_00'
+    expected_rot = torch.tensor([[0.99654, 0.08311407, 0.0], [-0.08311407, 0.99654, 0.0], [0.0, 0.0, 1.0]])
+    assert torch.allclose(meta['pcd_rotation'], expected_rot, atol=1e-5) and meta['pcd_scale_factor'] == 1.0
+    assert out['gt_labels_3d'].dtype == torch.int64 and len(out['gt_labels_3d']) == 27
+
+
+def test_s3dis_fixture_loads_through_the_s3dis_pipeline_head():
+    """the reference's S3DIS fixture (tests/data/s3dis: s3dis_infos.pkl + points/Area_1_office_2.bin, copied as data) through
+    the head of configs/fcaf3d/fcaf3d_s3dis-3d-5class.py:16-24 — LoadPointsFromFile + LoadAnnotations3D, no GlobalAlignment
+    (S3DIS rooms carry no axis_align_matrix): 100 x 6 points as stored, a scene without an `annos` entry yields empty
+    Depth-mode boxes (S3DISDataset.get_ann_info, s3dis_dataset.py:66-100)."""
+    import os
+    import numpy as np
+    from fcaf3d_amd import pipelines as pl
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    ds = pl.IndoorInfoDataset(G, os.path.join(G, 's3dis_infos.pkl'), with_yaw=False)
+    assert len(ds) == 1
+    res = ds.pre_pipeline(0, points_file=os.path.join(G, 's3dis_Area_1_office_2.bin'))
+    assert res['sample_idx'] == 'Area_1_office_2' and len(res['ann_info']['gt_bboxes_3d']) == 0
+    out = pl.Compose([dict(type='LoadPointsFromFile', coord_type='DEPTH', shift_height=False, load_dim=6, use_dim=[0, 1, 2, 3, 4, 5]),
+                      dict(type='LoadAnnotations3D'), dict(type='IndoorPointSample', num_points=64),
+                      dict(type='RandomFlip3D', sync_2d=False, flip_ratio_bev_horizontal=0.5, flip_ratio_bev_vertical=0.5),
+                      dict(type='GlobalRotScaleTrans', rot_range=[-0.087266, 0.087266], scale_ratio_range=[.9, 1.1],
+                           translation_std=[.1, .1, .1], shift_height=False),
+                      dict(type='DefaultFormatBundle3D', class_names=('table', 'chair', 'sofa', 'bookcase', 'board')),
+                      dict(type='Collect3D', keys=['points', 'gt_bboxes_3d', 'gt_labels_3d'])])(res)
+    raw = np.fromfile(os.path.join(G, 's3dis_Area_1_office_2.bin'), np.float32).reshape(-1, 6)
+    assert raw.shape == (100, 6) and out['points'].shape == (64, 6) and out['gt_bboxes_3d'].tensor.shape[0] == 0
+    assert set(np.round(out['points'][:, 3:].numpy().ravel(), 3)) <= set(np.round(raw[:, 3:].ravel(), 3))    # colours untouched
+
+
 def test_pipeline_on_the_reference_sunrgbd_fixture():
     """rotated boxes (with_yaw): the reference's SUN RGB-D fixture through flip(no) -> rotate -> scale -> sample against
     the numbers of tests/test_data/test_datasets/test_sunrgbd_dataset.py:96-126 (np.random.seed(0): the draw sequence —
