@@ -323,14 +323,30 @@ def cpu_baseline(args):
     C / OpenMP SIMD kernels, and the convolutions alone with their GFLOP/s and fraction of the host's fp32 peak."""
     import subprocess
     phys, logical, cpu_name = physical_cores()
-    env = dict(os.environ, OMP_NUM_THREADS=str(phys), OMP_PROC_BIND='spread', OMP_PLACES='cores', HIP_VISIBLE_DEVICES='')
+    # lscpu reports the HOST's cores; the container may be allowed fewer (cgroup / affinity mask): 128 OpenMP threads pinned onto
+    # a smaller mask ran the r3 kernels at 24 GFLOP/s.  Use the CPUs this process may actually run on, at most one per core.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = logical
+    try:                                                   # ... and a cgroup CPU quota caps it further
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            avail = min(avail, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    threads = max(1, min(phys, avail))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='')
+    env.pop('OMP_PROC_BIND', None); env.pop('OMP_PLACES', None)
     cmd = [sys.executable, '-m', 'oracle.cpu_bench', '--workload', args.workload, '--config', CONFIG_OF[args.workload],
            '--voxel-size', str(args.voxel_size), '--levels', str(args.levels), '--points', str(args.cpu_points),
            '--reps', str(max(args.cpu_reps, 1))]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     if r.returncode != 0:
         return dict(error=(r.stderr or r.stdout)[-400:])
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out['affinity_cpus'] = avail
+    return out
 
 
 def count_steps(args, n_batches):

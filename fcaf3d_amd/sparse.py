@@ -96,6 +96,10 @@ def _next_pow2(n):
 SORT_ROWS = True      # process conv rows in occupancy-mask order on sparse 27-offset maps
 SORT_MIN_ROWS = int(os.environ.get('FC_SORT_MIN_ROWS', '8192'))
 SORT_DENSE = os.environ.get('FC_SORT_DENSE', '0') != '0'     # mask-sorted rows also on the generated / union (neck) maps
+# ... r3 A/B: only on the dense maps with at most this many rows (the 55k-row neck level issues 1.14x its useful MFMA work
+# in natural order and 1.02x in mask order, and its argsort is cheap — unlike the 441k-row level's)
+SORT_DENSE_MAX_ROWS = int(os.environ.get('FC_SORT_DENSE_MAX_ROWS', '0'))
+PAIRS_DENSE = os.environ.get('FC_PAIRS_DENSE', '0') != '0'   # pair lists (exact work) also on small dense maps (77 % occupied at 6.9k rows)
 WGRAD_PAIRS = os.environ.get('FC_WGRAD_PAIRS', '1') != '0'    # weight gradients reduce over exact pair lists there
 # ... and with at most this many result rows the convolution itself runs per offset over the pair lists
 PAIR_CONV_ROWS = int(os.environ.get('FC_PAIR_CONV_ROWS', '16384'))
@@ -318,9 +322,10 @@ class CoordMap:
             # useful MFMA work instead of 1.30x / 1.14x / 1.07x and the isolated kernels gain 3...10 %, but in the full step
             # the extra argsort + permuted tables + scattered output rows cancel it exactly: 233.5 vs 233.5 scenes/s on the
             # same box.  FC_SORT_DENSE=1 turns it on.)
+            dense = self.dense_hint and out_map.dense_hint
             km.sort_rows = (SORT_ROWS and K == 27 and out_map.n >= SORT_MIN_ROWS
-                            and (SORT_DENSE or not (self.dense_hint and out_map.dense_hint)))
-            km.use_pairs = WGRAD_PAIRS and K == 27 and not (self.dense_hint and out_map.dense_hint)
+                            and (SORT_DENSE or not dense or out_map.n <= SORT_DENSE_MAX_ROWS))
+            km.use_pairs = WGRAD_PAIRS and K == 27 and (not dense or (PAIRS_DENSE and out_map.n <= PAIR_CONV_ROWS))
             self._kmaps[key] = km
         return km
 
