@@ -61,12 +61,20 @@ __global__ void k_stats_partial(const float* __restrict__ x, const int* __restri
       float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
       if (mode == 1) mu = *reinterpret_cast<const float4*>(mean + (int64_t)s * C + cl * 4);
       for (int64_t rb = r0 + rl; rb < r1; rb += 4 * nrl) {
+        float4 vv[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                     // the four rows are requested together (see k_norm_bwd_partial)
+          const int64_t r = rb + (int64_t)u * nrl;
+          ok[u] = r < r1;
+          const int64_t rc = ok[u] ? r : r0;
+          if (chk) ok[u] = ok[u] && seg[rc * seg_stride] == s;
+          vv[u] = *reinterpret_cast<const float4*>(x + rc * C + cl * 4);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          int64_t r = rb + (int64_t)u * nrl;
-          if (r >= r1) continue;
-          if (chk && seg[r * seg_stride] != s) continue;
-          float4 v = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
+          if (!ok[u]) continue;
+          float4 v = vv[u];
           if (mode == 1) {
             v.x -= mu.x; v.y -= mu.y; v.z -= mu.z; v.w -= mu.w;
             v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w;
@@ -112,9 +120,19 @@ __global__ __launch_bounds__(1024) void k_stats_final(const float* __restrict__ 
   const int cgroups = (C + 63) / 64;
   const int s = blockIdx.x / cgroups, cg = blockIdx.x % cgroups;
   const int c = cg * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;
-  float acc = 0.f;
-  if (c < C)
-    for (int64_t b = j; b < nblocks; b += 16) acc += part[(b * nseg + s) * C + c];
+  // four partials in flight per thread (r3: one dependent load per iteration made these tiny launches 13 us each); the
+  // summation order is fixed by the code, hence still deterministic
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < C) {
+    int64_t b = j;
+    for (; b + 48 < nblocks; b += 64) {
+      const float v0 = part[(b * nseg + s) * C + c], v1 = part[((b + 16) * nseg + s) * C + c];
+      const float v2 = part[((b + 32) * nseg + s) * C + c], v3 = part[((b + 48) * nseg + s) * C + c];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; b < nblocks; b += 16) a0 += part[(b * nseg + s) * C + c];
+  }
+  float acc = (a0 + a1) + (a2 + a3);
   red[j][threadIdx.x & 63] = acc;
   if (mode == 0 && (threadIdx.x & 63) == 0) {
     float cc = 0.f;
@@ -199,35 +217,47 @@ __global__ void k_norm_bwd_partial(const float* __restrict__ x, const float* __r
   // r2: the test is a dependent 4-byte load in front of every row load (InstanceNorm of the 580k-row stem: 1.4 TB/s)
   const bool chk = seg && s_lo != s_hi;
   for (int s = 0; s < nseg; ++s) {
-    float4 a1[2], a2[2];
+    float4 a1[4], a2[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { a1[u] = make_float4(0.f, 0.f, 0.f, 0.f); a2[u] = a1[u]; }
+    for (int u = 0; u < 4; ++u) { a1[u] = make_float4(0.f, 0.f, 0.f, 0.f); a2[u] = a1[u]; }
     if (s >= s_lo && s <= s_hi) {
       float4 mu = *reinterpret_cast<const float4*>(mean + (int64_t)s * C + cl * 4);
       float4 va = *reinterpret_cast<const float4*>(var + (int64_t)s * C + cl * 4);
       float4 is = make_float4(1.f / sqrtf(va.x + eps), 1.f / sqrtf(va.y + eps), 1.f / sqrtf(va.z + eps),
                               1.f / sqrtf(va.w + eps));
-      for (int64_t rb = r0 + rl; rb < r1; rb += 2 * nrl) {
+      for (int64_t rb = r0 + rl; rb < r1; rb += 4 * nrl) {
+        // branch-free batch: the 4 x (x, gy, y) rows are requested together (rows past the range re-read row r0 and are
+        // dropped by `ok`), r3 — a `continue` in front of each load serialised them
+        float4 xv[4], gv[4], yv[4];
+        bool ok[4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          int64_t r = rb + (int64_t)u * nrl;
-          if (r >= r1) continue;
-          if (chk && seg[r * seg_stride] != s) continue;
-          float4 xv = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
-          float4 g = *reinterpret_cast<const float4*>(gy + r * C + cl * 4);
+        for (int u = 0; u < 4; ++u) {
+          const int64_t r = rb + (int64_t)u * nrl;
+          ok[u] = r < r1;
+          const int64_t rc = ok[u] ? r : r0;
+          if (chk) ok[u] = ok[u] && seg[rc * seg_stride] == s;
+          xv[u] = *reinterpret_cast<const float4*>(x + rc * C + cl * 4);
+          gv[u] = *reinterpret_cast<const float4*>(gy + rc * C + cl * 4);
+          if (act) yv[u] = *reinterpret_cast<const float4*>(y + rc * C + cl * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!ok[u]) continue;
+          float4 g = gv[u];
           if (act) {
-            float4 yv = *reinterpret_cast<const float4*>(y + r * C + cl * 4);
-            g.x *= act_bwd_from_y(yv.x, act); g.y *= act_bwd_from_y(yv.y, act);
-            g.z *= act_bwd_from_y(yv.z, act); g.w *= act_bwd_from_y(yv.w, act);
+            g.x *= act_bwd_from_y(yv[u].x, act); g.y *= act_bwd_from_y(yv[u].y, act);
+            g.z *= act_bwd_from_y(yv[u].z, act); g.w *= act_bwd_from_y(yv[u].w, act);
           }
           a1[u].x += g.x; a1[u].y += g.y; a1[u].z += g.z; a1[u].w += g.w;
-          a2[u].x += g.x * (xv.x - mu.x) * is.x; a2[u].y += g.y * (xv.y - mu.y) * is.y;
-          a2[u].z += g.z * (xv.z - mu.z) * is.z; a2[u].w += g.w * (xv.w - mu.w) * is.w;
+          a2[u].x += g.x * (xv[u].x - mu.x) * is.x; a2[u].y += g.y * (xv[u].y - mu.y) * is.y;
+          a2[u].z += g.z * (xv[u].z - mu.z) * is.z; a2[u].w += g.w * (xv[u].w - mu.w) * is.w;
         }
       }
     }
-    float4 b1 = make_float4(a1[0].x + a1[1].x, a1[0].y + a1[1].y, a1[0].z + a1[1].z, a1[0].w + a1[1].w);
-    float4 b2 = make_float4(a2[0].x + a2[1].x, a2[0].y + a2[1].y, a2[0].z + a2[1].z, a2[0].w + a2[1].w);
+    float4 b1 = make_float4((a1[0].x + a1[1].x) + (a1[2].x + a1[3].x), (a1[0].y + a1[1].y) + (a1[2].y + a1[3].y),
+                            (a1[0].z + a1[1].z) + (a1[2].z + a1[3].z), (a1[0].w + a1[1].w) + (a1[2].w + a1[3].w));
+    float4 b2 = make_float4((a2[0].x + a2[1].x) + (a2[2].x + a2[3].x), (a2[0].y + a2[1].y) + (a2[2].y + a2[3].y),
+                            (a2[0].z + a2[1].z) + (a2[2].z + a2[3].z), (a2[0].w + a2[1].w) + (a2[2].w + a2[3].w));
     __syncthreads();
     *reinterpret_cast<float4*>(&sm[(rl * 2 + 0) * C + cl * 4]) = b1;
     *reinterpret_cast<float4*>(&sm[(rl * 2 + 1) * C + cl * 4]) = b2;
@@ -383,11 +413,19 @@ __global__ void k_bn1_partial(const float* __restrict__ x, int64_t n, int C, int
   if (r1 > n) r1 = n;
   const float4 sh = *reinterpret_cast<const float4*>(x + cl * 4);
   float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
-  for (int64_t r = r0 + rl; r < r1; r += nrl) {
-    float4 v = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
-    v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; v.w -= sh.w;
-    a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
-    a2.x += v.x * v.x; a2.y += v.y * v.y; a2.z += v.z * v.z; a2.w += v.w * v.w;
+  for (int64_t rb = r0 + rl; rb < r1; rb += 4 * (int64_t)nrl) {      // four rows in flight per thread (padding rows read the shift: 0)
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = rb + (int64_t)u * nrl;
+      v[u] = r < r1 ? *reinterpret_cast<const float4*>(x + r * C + cl * 4) : sh;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u].x -= sh.x; v[u].y -= sh.y; v[u].z -= sh.z; v[u].w -= sh.w;
+      a1.x += v[u].x; a1.y += v[u].y; a1.z += v[u].z; a1.w += v[u].w;
+      a2.x += v[u].x * v[u].x; a2.y += v[u].y * v[u].y; a2.z += v[u].z * v[u].z; a2.w += v[u].w * v[u].w;
+    }
   }
   *reinterpret_cast<float4*>(&sm[(rl * 2 + 0) * C + cl * 4]) = a1;
   *reinterpret_cast<float4*>(&sm[(rl * 2 + 1) * C + cl * 4]) = a2;
@@ -471,20 +509,28 @@ __global__ void k_bn1_apply(const float* __restrict__ x, int64_t n, int C, int64
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   int64_t r1 = r0 + rpb;
   if (r1 > n) r1 = n;
-  for (int64_t r = r0 + rl; r < r1; r += nrl) {
-    float v[4], o[4];
-    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
+  for (int64_t rb = r0 + rl; rb < r1; rb += 4 * (int64_t)nrl) {      // four rows in flight per thread
+    float v[4][4], rs[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (v[j] - mu[j]) * is[j] * g[j] + bt[j];
-    if (residual) {
-      float rs[4];
-      *reinterpret_cast<float4*>(rs) = *reinterpret_cast<const float4*>(residual + r * C + cl * 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] += rs[j];
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = rb + (int64_t)u * nrl;
+      const int64_t rc = r < r1 ? r : r0;
+      *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(x + rc * C + cl * 4);
+      if (residual) *reinterpret_cast<float4*>(rs[u]) = *reinterpret_cast<const float4*>(residual + rc * C + cl * 4);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = act_fwd(o[j], act);
-    *reinterpret_cast<float4*>(y + r * C + cl * 4) = *reinterpret_cast<float4*>(o);
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = rb + (int64_t)u * nrl;
+      if (r >= r1) continue;
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (v[u][j] - mu[j]) * is[j] * g[j] + bt[j];
+        if (residual) o[j] += rs[u][j];
+        o[j] = act_fwd(o[j], act);
+      }
+      *reinterpret_cast<float4*>(y + r * C + cl * 4) = *reinterpret_cast<float4*>(o);
+    }
   }
 }
 
@@ -499,11 +545,26 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
   __shared__ float r1[16][65], r2[16][65];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;
   float a1 = 0.f, a2 = 0.f;
-  if (c < C)
-    for (int b = j; b < nb; b += 16) {
-      a1 += part[((int64_t)b * 2) * C + c];
-      a2 += part[((int64_t)b * 2 + 1) * C + c];
+  if (c < C) {
+    float p1[4] = {0.f, 0.f, 0.f, 0.f}, p2[4] = {0.f, 0.f, 0.f, 0.f};      // four blocks' partials in flight (see k_stats_final)
+    int b = j;
+    for (; b + 48 < nb; b += 64) {
+      float u[4], w[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u[q] = part[((int64_t)(b + 16 * q) * 2) * C + c];
+        w[q] = part[((int64_t)(b + 16 * q) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { p1[q] += u[q]; p2[q] += w[q]; }
     }
+    for (; b < nb; b += 16) {
+      p1[0] += part[((int64_t)b * 2) * C + c];
+      p2[0] += part[((int64_t)b * 2 + 1) * C + c];
+    }
+    a1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+    a2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
+  }
   r1[j][threadIdx.x & 63] = a1;
   r2[j][threadIdx.x & 63] = a2;
   __syncthreads();
@@ -554,21 +615,32 @@ __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __rest
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   int64_t r1 = r0 + rpb;
   if (r1 > n) r1 = n;
-  for (int64_t r = r0 + rl; r < r1; r += nrl) {
-    float xv[4], gv[4], yv[4], o[4], gr[4];
-    *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + r * C + cl * 4);
-    *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(gy + r * C + cl * 4);
-    if (act) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y + r * C + cl * 4);
+  for (int64_t rb = r0 + rl; rb < r1; rb += 4 * (int64_t)nrl) {      // four rows (x, gy, y of each) in flight per thread
+    float xv[4][4], gv[4][4], yv[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float gg = gv[j];
-      if (act) gg *= act_bwd_from_y(yv[j], act);
-      float xh = (xv[j] - mu[j]) * is[j];
-      gr[j] = gg;
-      o[j] = g[j] * is[j] * (gg - s1[j] - xh * s2[j]);
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = rb + (int64_t)u * nrl;
+      const int64_t rc = r < r1 ? r : r0;
+      *reinterpret_cast<float4*>(xv[u]) = *reinterpret_cast<const float4*>(x + rc * C + cl * 4);
+      *reinterpret_cast<float4*>(gv[u]) = *reinterpret_cast<const float4*>(gy + rc * C + cl * 4);
+      if (act) *reinterpret_cast<float4*>(yv[u]) = *reinterpret_cast<const float4*>(y + rc * C + cl * 4);
     }
-    *reinterpret_cast<float4*>(gx + r * C + cl * 4) = *reinterpret_cast<float4*>(o);
-    if (gres) *reinterpret_cast<float4*>(gres + r * C + cl * 4) = *reinterpret_cast<float4*>(gr);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = rb + (int64_t)u * nrl;
+      if (r >= r1) continue;
+      float o[4], gr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gg = gv[u][j];
+        if (act) gg *= act_bwd_from_y(yv[u][j], act);
+        float xh = (xv[u][j] - mu[j]) * is[j];
+        gr[j] = gg;
+        o[j] = g[j] * is[j] * (gg - s1[j] - xh * s2[j]);
+      }
+      *reinterpret_cast<float4*>(gx + r * C + cl * 4) = *reinterpret_cast<float4*>(o);
+      if (gres) *reinterpret_cast<float4*>(gres + r * C + cl * 4) = *reinterpret_cast<float4*>(gr);
+    }
   }
 }
 
