@@ -15,10 +15,17 @@
 struct Face6 { float d[6]; };
 
 // distances of point p to the 6 faces of box b = [cx,cy,cz,w,l,h,yaw] in the box frame
-__device__ static inline Face6 face_distances(const float* __restrict__ b, float px, float py, float pz) {
+// (ca, sa) = cos / sin of -yaw: computed ONCE per box by box_trig() at every call site (r3: they were re-evaluated for
+// every (location, box) pair — 15 M cosf + sinf per step), the same function everywhere so that `centerness > kth`
+// still compares bit-identical values
+__device__ static inline void box_trig(const float* __restrict__ b, float* ca, float* sa) {
+  const float a = -b[6];
+  *ca = cosf(a);
+  *sa = sinf(a);
+}
+
+__device__ static inline Face6 face_distances(const float* __restrict__ b, float ca, float sa, float px, float py, float pz) {
   float sx = px - b[0], sy = py - b[1], sz = pz - b[2];
-  float a = -b[6];
-  float ca = cosf(a), sa = sinf(a);
   float rx = sx * ca + sy * sa;
   float ry = -sx * sa + sy * ca;
   float cx = b[0] + rx, cy = b[1] + ry, cz = b[2] + sz;
@@ -46,16 +53,24 @@ __device__ static inline float centerness_of(const Face6& f) {
 
 __global__ void k_count(const float* __restrict__ pts, const int* __restrict__ scene, const int* __restrict__ level, int64_t N,
                         const float* __restrict__ boxes, const int* __restrict__ box_count, int M, int L,
-                        int* __restrict__ counts) {
+                        const float* __restrict__ trig, int* __restrict__ counts) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   int s = scene[i], l = level[i];
   float px = pts[i * 3], py = pts[i * 3 + 1], pz = pts[i * 3 + 2];
   int m = box_count[s];
   for (int j = 0; j < m; ++j) {
-    Face6 f = face_distances(boxes + ((int64_t)s * M + j) * 7, px, py, pz);
+    const float* b = boxes + ((int64_t)s * M + j) * 7;
+    Face6 f = face_distances(b, trig[2 * (s * M + j)], trig[2 * (s * M + j) + 1], px, py, pz);
     if (is_inside(f)) atomicAdd(&counts[((int64_t)s * M + j) * L + l], 1);
   }
+}
+
+// (cos, sin) of -yaw of every padded box slot, once per step
+__global__ void k_box_trig(const float* __restrict__ boxes, int BM, float* __restrict__ trig) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= BM) return;
+  box_trig(boxes + (int64_t)t * 7, &trig[2 * t], &trig[2 * t + 1]);
 }
 
 __global__ void k_best(const int* __restrict__ counts, int BM, int L, int limit, int* __restrict__ best) {
@@ -78,10 +93,11 @@ __global__ void k_best(const int* __restrict__ counts, int BM, int L, int limit,
 __global__ __launch_bounds__(256) void k_kth(const float* __restrict__ pts, const float* __restrict__ boxes,
                                              const int* __restrict__ box_count, const int* __restrict__ best,
                                              const int* __restrict__ order, const int* __restrict__ seg_start, int B, int M,
-                                             int L, int topk, float* __restrict__ kth) {
+                                             int L, int topk, const float* __restrict__ trig, float* __restrict__ kth) {
   const int s = blockIdx.x / M, j = blockIdx.x % M;
   if (j >= box_count[s]) return;
   const float* b = boxes + ((int64_t)s * M + j) * 7;
+  const float ca = trig[2 * (s * M + j)], sa = trig[2 * (s * M + j) + 1];
   const int l = best[s * M + j];
   const int r0 = seg_start[l * B + s], r1 = seg_start[l * B + s + 1];
   // n_scene = all locations of the scene over all levels (torch.topk is taken over all of them, padded with -1)
@@ -94,12 +110,25 @@ __global__ __launch_bounds__(256) void k_kth(const float* __restrict__ pts, cons
   __shared__ int red_c[4];
   if (threadIdx.x == 0) ncand_s = 0;
   __syncthreads();
-  for (int t = r0 + threadIdx.x; t < r1; t += 256) {
-    int i = order[t];
-    Face6 f = face_distances(b, pts[(int64_t)i * 3], pts[(int64_t)i * 3 + 1], pts[(int64_t)i * 3 + 2]);
-    if (!is_inside(f)) continue;
-    int p = atomicAdd(&ncand_s, 1);
-    if (p < KTH_CAP) cand[p] = centerness_of(f);
+  // four rows in flight per thread: their `order` entries, then their coordinates, are requested together (r3: one
+  // dependent order -> point chain per iteration over up to 55k rows made this launch 142 us)
+  for (int tb = r0 + threadIdx.x; tb < r1; tb += 4 * 256) {
+    int idx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) idx[u] = order[tb + 256 * u < r1 ? tb + 256 * u : tb];
+    float px[4], py[4], pz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      px[u] = pts[(int64_t)idx[u] * 3]; py[u] = pts[(int64_t)idx[u] * 3 + 1]; pz[u] = pts[(int64_t)idx[u] * 3 + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (tb + 256 * u >= r1) continue;
+      Face6 f = face_distances(b, ca, sa, px[u], py[u], pz[u]);
+      if (!is_inside(f)) continue;
+      int p = atomicAdd(&ncand_s, 1);
+      if (p < KTH_CAP) cand[p] = centerness_of(f);
+    }
   }
   __syncthreads();
   const int ncand = ncand_s;
@@ -121,7 +150,7 @@ __global__ __launch_bounds__(256) void k_kth(const float* __restrict__ pts, cons
     } else {
       for (int t = r0 + threadIdx.x; t < r1; t += 256) {
         int i = order[t];
-        Face6 f = face_distances(b, pts[(int64_t)i * 3], pts[(int64_t)i * 3 + 1], pts[(int64_t)i * 3 + 2]);
+        Face6 f = face_distances(b, ca, sa, pts[(int64_t)i * 3], pts[(int64_t)i * 3 + 1], pts[(int64_t)i * 3 + 2]);
         if (!is_inside(f)) continue;
         float c = centerness_of(f);
         if (!(c < prev)) continue;
@@ -156,7 +185,7 @@ __global__ __launch_bounds__(256) void k_kth(const float* __restrict__ pts, cons
 __global__ void k_final(const float* __restrict__ pts, const int* __restrict__ scene, const int* __restrict__ level, int64_t N,
                         const float* __restrict__ boxes, const long long* __restrict__ labels,
                         const int* __restrict__ box_count, const int* __restrict__ best, const float* __restrict__ kth, int M,
-                        float* __restrict__ ct_out, float* __restrict__ bt_out, long long* __restrict__ lab_out) {
+                        const float* __restrict__ trig, float* __restrict__ ct_out, float* __restrict__ bt_out, long long* __restrict__ lab_out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   int s = scene[i], l = level[i];
@@ -168,7 +197,7 @@ __global__ void k_final(const float* __restrict__ pts, const int* __restrict__ s
   for (int j = 0; j < m; ++j) {
     const float* b = boxes + ((int64_t)s * M + j) * 7;
     if (best[s * M + j] != l) continue;
-    Face6 f = face_distances(b, px, py, pz);
+    Face6 f = face_distances(b, trig[2 * (s * M + j)], trig[2 * (s * M + j) + 1], px, py, pz);
     if (!is_inside(f)) continue;
     float c = centerness_of(f);
     if (!(c > kth[s * M + j])) continue;
@@ -185,7 +214,7 @@ __global__ void k_final(const float* __restrict__ pts, const int* __restrict__ s
 extern "C" {
 
 int64_t fc_assign_ws_bytes(int B, int M, int L) {
-  return (int64_t)B * M * (L + 2) * 4 + 256;
+  return (int64_t)B * M * (L + 4) * 4 + 256;
 }
 
 // points (N,3); scene/level (N) int32; boxes (B,M,7) [cx,cy,cz,w,l,h,yaw] gravity centre, padded; labels (B,M) int64;
@@ -201,15 +230,18 @@ int fc_assign_targets(const float* points, const int* scene, const int* level, i
   int* counts = (int*)ws;
   int* best = counts + (int64_t)B * M * L;
   float* kth = (float*)(best + (int64_t)B * M);
+  float* trig = kth + (int64_t)B * M;
   FC_HIP(hipMemsetAsync(counts, 0, sizeof(int) * (size_t)B * M * L, stream));
   unsigned g = (unsigned)fc_cdiv(N, 256);
-  k_count<<<g, 256, 0, stream>>>(points, scene, level, N, boxes, box_count, M, L, counts);
+  k_box_trig<<<(unsigned)fc_cdiv(B * M, 64), 64, 0, stream>>>(boxes, B * M, trig);
+  FC_CHECK_LAUNCH();
+  k_count<<<g, 256, 0, stream>>>(points, scene, level, N, boxes, box_count, M, L, trig, counts);
   FC_CHECK_LAUNCH();
   k_best<<<(unsigned)fc_cdiv(B * M, 64), 64, 0, stream>>>(counts, B * M, L, limit, best);
   FC_CHECK_LAUNCH();
-  k_kth<<<(unsigned)(B * M), 256, 0, stream>>>(points, boxes, box_count, best, order, seg_start, B, M, L, topk, kth);
+  k_kth<<<(unsigned)(B * M), 256, 0, stream>>>(points, boxes, box_count, best, order, seg_start, B, M, L, topk, trig, kth);
   FC_CHECK_LAUNCH();
-  k_final<<<g, 256, 0, stream>>>(points, scene, level, N, boxes, labels, box_count, best, kth, M, centerness_t, bbox_t,
+  k_final<<<g, 256, 0, stream>>>(points, scene, level, N, boxes, labels, box_count, best, kth, M, trig, centerness_t, bbox_t,
                                  labels_out);
   FC_CHECK_LAUNCH();
   return FC_OK;

@@ -22,10 +22,14 @@ __device__ static inline float sort_key(float y, float x) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// t^gamma; gamma == 2 (every FCAF3D config, fcaf3d_neck_with_head.py:29-34) is the plain product — what torch's pow
+// does for an exponent of 2 as well — instead of the ~60-instruction general powf
+__device__ static inline float pow_gamma(float t, float gamma) { return gamma == 2.f ? t * t : powf(t, gamma); }
+
 __device__ static inline float focal_elem(float x, bool is_pos, float gamma, float alpha) {
   float p = 1.f / (1.f + expf(-x));
-  if (is_pos) return -alpha * powf(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
-  return -(1.f - alpha) * powf(p, gamma) * logf(fmaxf(1.f - p, FLT_MIN));
+  if (is_pos) return -alpha * pow_gamma(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
+  return -(1.f - alpha) * pow_gamma(p, gamma) * logf(fmaxf(1.f - p, FLT_MIN));
 }
 
 // one thread per row: loss_rows[r] = w[r] * sum_c focal(x[r,c])   (class order fixed -> deterministic)
@@ -49,8 +53,8 @@ __global__ void k_focal_bwd(const float* __restrict__ x, const long long* __rest
   long long y = label[r];
   float p = 1.f / (1.f + expf(-x[t]));
   float g;
-  if (y == c) g = -alpha * powf(1.f - p, gamma) * (1.f - p - gamma * p * logf(fmaxf(p, FLT_MIN)));
-  else g = -(1.f - alpha) * powf(p, gamma) * (gamma * (1.f - p) * logf(fmaxf(1.f - p, FLT_MIN)) - p);
+  if (y == c) g = -alpha * pow_gamma(1.f - p, gamma) * (1.f - p - gamma * p * logf(fmaxf(p, FLT_MIN)));
+  else g = -(1.f - alpha) * pow_gamma(p, gamma) * (gamma * (1.f - p) * logf(fmaxf(1.f - p, FLT_MIN)) - p);
   gx[t] = g * gscale[0] * (w ? w[r] : 1.f);
 }
 
