@@ -537,6 +537,74 @@ int fc_gen_coords(const int* coords, int64_t n, int half_stride, int* out_coords
 }
 
 // ----------------------------------------------------------------------------------------------
+// Structure of a GENERATED set (r3): the children set of MinkowskiGenerativeConvolutionTranspose(k2,s2) holds all 8
+// children of every parent, child k of parent row i at row 8i + k (k = bx + 2by + 4bz).  Its 3x3x3 kernel map and the
+// row of any voxel inside it therefore follow from the PARENT level by index arithmetic — no hash of the 8x larger set
+// is ever built or probed (the 441k-row finest neck level was 90 % of all hash probes of a step).
+//   neighbour of child (i, k) at offset d in {-1,0,1}^3 (child-stride units): t = bit_k + d in {-1..2} per axis,
+//   parent offset D = floor(t / 2) in {-1,0,1}, child bit t - 2D  ->  8 * parent_nbr[D][i] + bits   (or -1)
+__global__ void k_kernel_map_children(const int* __restrict__ pnbr, int64_t n_parent, int* __restrict__ nbr) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // child row
+  const int d = blockIdx.y;                                                 // child offset index, x fastest
+  const int64_t n_child = n_parent * 8;
+  if (c >= n_child) return;
+  const int64_t i = c >> 3;
+  const int k = (int)(c & 7);
+  int Didx = 0, bits = 0, mul = 1, dd = d;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const int t = ((k >> ax) & 1) + (dd % 3 - 1);
+    dd /= 3;
+    const int D = t < 0 ? -1 : (t > 1 ? 1 : 0);
+    Didx += (D + 1) * mul;
+    mul *= 3;
+    bits |= (t - 2 * D) << ax;
+  }
+  const int j = pnbr[(int64_t)Didx * n_parent + i];
+  nbr[(int64_t)d * n_child + c] = j < 0 ? -1 : 8 * j + bits;
+}
+
+int fc_kernel_map_children(const int* parent_nbr, int64_t n_parent, int* nbr, hipStream_t stream) {
+  if (n_parent < 0 || (!parent_nbr && n_parent > 0) || 8 * n_parent > 0x7fffffffLL) return FC_EINVAL;
+  if (n_parent == 0) return FC_OK;
+  dim3 grid((unsigned)fc_cdiv(n_parent * 8, 256), 27);
+  k_kernel_map_children<<<grid, 256, 0, stream>>>(parent_nbr, n_parent, nbr);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+// rows[i] = row of query voxel i (coordinates multiples of the child stride T) in the children set of the parent table's
+// set (stride 2T), or -1 when its parent cell is absent; *n_found counts the hits (zeroed here)
+__global__ void k_child_rows(const int4* __restrict__ q, int64_t n, const unsigned long long* __restrict__ keys,
+                             const int* __restrict__ vals, unsigned long long mask, int T, int* __restrict__ rows,
+                             int* __restrict__ n_found) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int hit = 0;
+  if (i < n) {
+    const int4 c = q[i];
+    const int P = 2 * T;
+    const int px = fc_floor_div(c.y, P) * P, py = fc_floor_div(c.z, P) * P, pz = fc_floor_div(c.w, P) * P;
+    const int r = fc_lookup(keys, vals, mask, fc_pack(c.x, px, py, pz));
+    const int bits = ((c.y - px) / T) | (((c.z - py) / T) << 1) | (((c.w - pz) / T) << 2);
+    rows[i] = r < 0 ? -1 : 8 * r + bits;
+    hit = r >= 0;
+  }
+  const unsigned long long bal = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_found, __popcll(bal));
+}
+
+int fc_child_rows(const int* query_coords, int64_t n, const unsigned long long* parent_keys, const int* parent_vals,
+                  int64_t cap, int child_stride, int* rows, int* n_found_dev, hipStream_t stream) {
+  if (n < 0 || child_stride < 1 || (cap & (cap - 1)) || !n_found_dev) return FC_EINVAL;
+  FC_HIP(hipMemsetAsync(n_found_dev, 0, sizeof(int), stream));
+  if (n == 0) return FC_OK;
+  k_child_rows<<<(unsigned)fc_cdiv(n, 256), 256, 0, stream>>>((const int4*)query_coords, n, parent_keys, parent_vals,
+                                                              (unsigned long long)(cap - 1), child_stride, rows, n_found_dev);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
 // union map (a + b on different coordinate sets, Appendix A.8): for each row of b either the row of the
 // equal coordinate in a, or n_a + (rank among b's new rows).  new_coords receives b's new rows in order.
 __global__ void k_union_probe(const int4* __restrict__ coords_b, int64_t n_b, const unsigned long long* __restrict__ keys,

@@ -99,6 +99,7 @@ SORT_DENSE = os.environ.get('FC_SORT_DENSE', '0') != '0'     # mask-sorted rows 
 # ... r3 A/B: only on the dense maps with at most this many rows (the 55k-row neck level issues 1.14x its useful MFMA work
 # in natural order and 1.02x in mask order, and its argsort is cheap — unlike the 441k-row level's)
 SORT_DENSE_MAX_ROWS = int(os.environ.get('FC_SORT_DENSE_MAX_ROWS', '0'))
+STRUCTURED_MAPS = os.environ.get('FC_STRUCTURED_MAPS', '1') != '0'   # generated sets: maps by index arithmetic (r3), A/B switch
 PAIRS_DENSE = os.environ.get('FC_PAIRS_DENSE', '0') != '0'   # pair lists (exact work) also on small dense maps (77 % occupied at 6.9k rows)
 WGRAD_PAIRS = os.environ.get('FC_WGRAD_PAIRS', '1') != '0'    # weight gradients reduce over exact pair lists there
 # ... and with at most this many result rows the convolution itself runs per offset over the pair lists
@@ -242,9 +243,9 @@ class CoordMap:
     """One coordinate set: coords (N,4) int32 [b,x,y,z], tensor stride, voxel hash, cached maps."""
 
     def __init__(self, coords, stride, keys, vals, batch_size):
-        self.coords, self.keys, self.vals = _rec(coords, keys, vals)
+        self.coords = _rec(coords)
+        self._keys, self._vals = (_rec(keys, vals) if keys is not None else (None, None))
         self.stride = stride
-        self.cap = keys.numel()
         self.batch_size = batch_size
         self.n = coords.shape[0]
         self._kmaps = {}
@@ -254,6 +255,36 @@ class CoordMap:
         self._perm = None
         self._counts = None
         self.dense_hint = False         # True for generated children sets and their unions
+        self._gen_parent = None         # generated children set: the set it was generated from (rows 8i + k)
+
+    # ---- voxel hash: built on demand for generated sets (their maps come from the parent level, see generate()) ----
+    def _ensure_table(self):
+        if self._keys is None:
+            n = self.n
+            cap = _next_pow2(max(2 * n, 2))
+            dev = self.coords.device
+            keys = torch.empty(cap, dtype=torch.int64, device=dev)
+            vals = torch.empty(cap, dtype=torch.int32, device=dev)
+            scratch = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            ws = L.workspace(L.query('fc_hash_unique_ws_bytes', n), dev)
+            L.call('fc_hash_unique', L.ptr(self.coords), n, 1, L.ptr(keys), L.ptr(vals), cap, L.ptr(scratch), None, None,
+                   L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())          # rows are unique already: table only
+            self._keys, self._vals = _rec(keys, vals)
+
+    @property
+    def keys(self):
+        self._ensure_table()
+        return self._keys
+
+    @property
+    def vals(self):
+        self._ensure_table()
+        return self._vals
+
+    @property
+    def cap(self):
+        return self.keys.numel()
 
     # ---- construction -------------------------------------------------------------------------
     @staticmethod
@@ -293,15 +324,19 @@ class CoordMap:
         return self._strided[s]
 
     def generate(self):
-        """Children set of MinkowskiGenerativeConvolutionTranspose(k2,s2): row 8i+k."""
+        """Children set of MinkowskiGenerativeConvolutionTranspose(k2,s2): row 8i+k.  No hash is built for it (r3): its
+        k3 kernel map and the rows of the backbone level inside it follow from THIS level by index arithmetic
+        (fc_kernel_map_children / fc_child_rows); the table appears on demand (interpolation, a union that adds rows)."""
         if self._generated is None:
             assert self.stride % 2 == 0
             half = self.stride // 2
             out = torch.empty((self.n * 8, 4), dtype=torch.int32, device=self.coords.device)
             L.call('fc_gen_coords', L.ptr(self.coords), self.n, half, L.ptr(out), L.stream())
             # children of a unique stride-T set are unique: 8n rows, no read-back needed
-            self._generated, _, _ = CoordMap.from_coords(out, half, self.batch_size, expect_n=8 * self.n)
-            self._generated.dense_hint = True
+            g = CoordMap(out, half, None, None, self.batch_size)
+            g.dense_hint = True
+            g._gen_parent = self
+            self._generated = g
         return self._generated
 
     def kernel_map(self, out_map, kernel_size):
@@ -312,8 +347,12 @@ class CoordMap:
             offs = kernel_offsets(kernel_size, self.stride, self.coords.device)
             K = offs.shape[0]
             nbr = torch.empty((K, out_map.n), dtype=torch.int32, device=self.coords.device)
-            L.call('fc_kernel_map', L.ptr(out_map.coords), out_map.n, L.ptr(self.keys), L.ptr(self.vals), self.cap,
-                   L.ptr(offs), K, L.ptr(nbr), L.stream())
+            if out_map is self and kernel_size == 3 and self._gen_parent is not None and STRUCTURED_MAPS:
+                par = self._gen_parent                       # generated set: from the parent level's own k3 table
+                L.call('fc_kernel_map_children', L.ptr(par.kernel_map(par, 3).nbr), par.n, L.ptr(nbr), L.stream())
+            else:
+                L.call('fc_kernel_map', L.ptr(out_map.coords), out_map.n, L.ptr(self.keys), L.ptr(self.vals), self.cap,
+                       L.ptr(offs), K, L.ptr(nbr), L.stream())
             km = KernelMap(nbr, self.n, out_map.n)
             km._out_map = out_map            # keep alive so id() stays unique
             # generated / union sets are ~94 % dense (2x2x2 blocks): nothing to skip there
@@ -339,6 +378,19 @@ class CoordMap:
         if id(other) in self._unions:
             return self._unions[id(other)][:3]
         dev = self.coords.device
+        if other._gen_parent is not None and STRUCTURED_MAPS:
+            # `other` is a generated children set: where each of MY voxels sits in it follows from its parent level's hash
+            # (8 * parent row + child bits); if all of them are inside — the usual case, the backbone level inside the
+            # generated set — the union IS `other`, with one probe pass and one count read-back and no hash of `other`
+            par = other._gen_parent
+            rows = torch.empty(self.n, dtype=torch.int32, device=dev)
+            found = torch.zeros(1, dtype=torch.int32, device=dev)
+            L.call('fc_child_rows', L.ptr(self.coords), self.n, L.ptr(par.keys), L.ptr(par.vals), par.cap, self.stride,
+                   L.ptr(rows), L.ptr(found), L.stream())
+            if int(found.item()) == self.n:
+                _rec(rows)
+                self._unions[id(other)] = (other, rows, True, other)
+                return other, rows, True
 
         def probe(q, table):
             rows = torch.empty(q.n, dtype=torch.int32, device=dev)

@@ -92,6 +92,18 @@ int fc_kernel_map_transpose(const int* nbr, int64_t n_out, int64_t n_in, int K, 
  * out[8i+k] = coords[i] + {0,half_stride}^3 (x fastest). */
 int fc_gen_coords(const int* coords, int64_t n, int half_stride, int* out_coords, hipStream_t stream);
 
+/* Kernel map and membership of a GENERATED children set (the output set of ME.MinkowskiGenerativeConvolutionTranspose,
+ * fcaf3d_neck_with_head.py:60-66, on which the neck's k3 convolutions run, :52, :69) from the PARENT level by index
+ * arithmetic instead of hash probes: child k of parent row i sits at row 8i + k.
+ *   fc_kernel_map_children: nbr (27, 8 n_parent) of the children set onto itself (k3 s1) from the parent set's own
+ *     k3 s1 table parent_nbr (27, n_parent) — identical to fc_kernel_map on the children's hash;
+ *   fc_child_rows: row of each query voxel (stride T) in the children set of the set behind the parent table (stride 2T),
+ *     -1 if its parent cell is absent; *n_found_dev = number of hits — what the sparse `a + b` union (:101) needs when
+ *     the backbone level lies inside the generated set. */
+int fc_kernel_map_children(const int* parent_nbr, int64_t n_parent, int* nbr, hipStream_t stream);
+int fc_child_rows(const int* query_coords, int64_t n, const unsigned long long* parent_keys, const int* parent_vals,
+                  int64_t cap, int child_stride, int* rows, int* n_found_dev, hipStream_t stream);
+
 /* SparseTensor `a + b` on different coordinate maps — fcaf3d_neck_with_head.py:101: row of every b
  * voxel in the union (a's rows first, then b's new voxels in order); new_coords gets b's new rows. */
 int64_t fc_union_map_ws_bytes(int64_t n_b);

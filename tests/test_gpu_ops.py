@@ -408,6 +408,57 @@ def test_generate_union_interp_prune():
     assert sum(len(p) for p in perms) == pm.n
 
 
+def test_generated_set_maps_by_index_arithmetic_equal_the_hash_path():
+    """r3: the k3 kernel map of a generated children set (fc_kernel_map_children, from the parent level's table) and the
+    rows of a backbone level inside it (fc_child_rows, from the parent level's hash) against (a) the generic hash-probe
+    path on the same sets (FC_STRUCTURED_MAPS off) and (b) the oracle's kernel map — exact; two generations deep, as the
+    neck chains them; and a union that really adds rows still falls back to the generic path."""
+    import fcaf3d_amd.sparse as SP
+    from fcaf3d_amd.sparse import CoordMap
+    dev = _dev()
+    _, c_ref, _ = _scene_coords(13, n_points=8000)
+    c16 = c_ref.copy(); c16[:, 1:] = np.floor_divide(c16[:, 1:], 16) * 16
+    top, _, _ = mo.unique_first(c16)                                   # stride 16
+    c8 = c_ref.copy(); c8[:, 1:] = np.floor_divide(c8[:, 1:], 8) * 8
+    mid, _, _ = mo.unique_first(c8)                                    # stride 8: every voxel lies in a child of `top`
+
+    def build(structured):
+        SP.STRUCTURED_MAPS = structured
+        try:
+            cm_top, _, _ = CoordMap.from_coords(torch.from_numpy(top).to(dev), 16, 2)
+            g1 = cm_top.generate()
+            cm_mid, _, _ = CoordMap.from_coords(torch.from_numpy(mid).to(dev), 8, 2)
+            u, rows, swapped = cm_mid.union(g1)
+            g2 = u.generate()
+            return (g1.kernel_map(g1, 3).nbr.cpu().numpy(), rows.cpu().numpy(), swapped, u is g1,
+                    g2.kernel_map(g2, 3).nbr.cpu().numpy(), g1.coords.cpu().numpy(), g2.coords.cpu().numpy(), g1._keys is None)
+    try:
+        a = build(True)
+        b = build(False)
+    finally:
+        SP.STRUCTURED_MAPS = True
+    assert a[2] and a[3] and b[2] and b[3], 'the strided level lies inside the generated set'
+    assert a[7] and not b[7], 'structured path must not build the generated set\'s hash; the generic path does'
+    for x, y in zip(a[:7], b[:7]):
+        assert np.array_equal(x, y)
+    g1_ref = mo.gen_conv_transpose_coords(top, 16)
+    assert np.array_equal(a[5], g1_ref)
+    assert np.array_equal(a[0], mo.kernel_map(g1_ref, g1_ref, mo.kernel_offsets(3, 8)))
+    g2_ref = mo.gen_conv_transpose_coords(g1_ref, 8)
+    assert np.array_equal(a[4], mo.kernel_map(g2_ref, g2_ref, mo.kernel_offsets(3, 4)))
+    # rows: where each stride-8 voxel sits in g1
+    lut = {tuple(c): i for i, c in enumerate(g1_ref.tolist())}
+    assert np.array_equal(a[1], np.array([lut[tuple(c)] for c in mid.tolist()], np.int32))
+    # a level with a voxel OUTSIDE the generated set: generic union (rows appended), the lazy hash appears
+    extra = np.concatenate([mid, np.array([[0, 4000, 4000, 4000]], np.int32)])
+    cm_top, _, _ = CoordMap.from_coords(torch.from_numpy(top).to(dev), 16, 2)
+    g1 = cm_top.generate()
+    cm_x, _, _ = CoordMap.from_coords(torch.from_numpy(extra).to(dev), 8, 2)
+    u, rows, swapped = cm_x.union(g1)
+    uc_ref, _ = mo.union_add(extra, torch.zeros(len(extra), 1), g1_ref, torch.zeros(len(g1_ref), 1))
+    assert not swapped and np.array_equal(u.coords.cpu().numpy(), uc_ref) and g1._keys is not None
+
+
 def test_no_cpu_fallback():
     import fcaf3d_amd.functional as Fn
     with pytest.raises(RuntimeError):
