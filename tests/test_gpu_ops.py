@@ -424,14 +424,13 @@ def test_generated_set_maps_by_index_arithmetic_equal_the_hash_path():
 
     def build(structured):
         SP.STRUCTURED_MAPS = structured
-        try:
-            cm_top, _, _ = CoordMap.from_coords(torch.from_numpy(top).to(dev), 16, 2)
-            g1 = cm_top.generate()
-            cm_mid, _, _ = CoordMap.from_coords(torch.from_numpy(mid).to(dev), 8, 2)
-            u, rows, swapped = cm_mid.union(g1)
-            g2 = u.generate()
-            return (g1.kernel_map(g1, 3).nbr.cpu().numpy(), rows.cpu().numpy(), swapped, u is g1,
-                    g2.kernel_map(g2, 3).nbr.cpu().numpy(), g1.coords.cpu().numpy(), g2.coords.cpu().numpy(), g1._keys is None)
+        cm_top, _, _ = CoordMap.from_coords(torch.from_numpy(top).to(dev), 16, 2)
+        g1 = cm_top.generate()
+        cm_mid, _, _ = CoordMap.from_coords(torch.from_numpy(mid).to(dev), 8, 2)
+        u, rows, swapped = cm_mid.union(g1)
+        g2 = u.generate()
+        return (g1.kernel_map(g1, 3).nbr.cpu().numpy(), rows.cpu().numpy(), swapped, u is g1,
+                g2.kernel_map(g2, 3).nbr.cpu().numpy(), g1.coords.cpu().numpy(), g2.coords.cpu().numpy(), g1._keys is None)
     try:
         a = build(True)
         b = build(False)
