@@ -69,13 +69,9 @@ __device__ static inline void tie_min(float a, float b, float* v, float* wa) {
   *wa = a < b ? 1.f : (a == b ? 0.5f : 0.f);
 }
 
-// pred (n,6) [cx,cy,cz,w,l,h]; target rows of `tstride` floats whose first 6 are [cx,cy,cz,w,l,h]
-__global__ void k_aiou3d(const float* __restrict__ pred, const float* __restrict__ target, int tstride, int64_t n,
-                         float eps, float* __restrict__ iou, float* __restrict__ dpred) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* p = pred + i * 6;
-  const float* t = target + i * tstride;
+// p, t: [cx,cy,cz,w,l,h]; returns the IoU, writes d IoU / d p into dp[6] when dp != NULL (the gradient torch autograd
+// gives through max / min / clamp of iou3d_calculator.py:201-330, ties split evenly)
+__device__ static inline float aiou3d_eval(const float* __restrict__ p, const float* __restrict__ t, float eps, float* dp) {
   float wh[3], dwh_dc[3], dwh_ds[3], sp[3];
   float a1 = 1.f, a2 = 1.f, ov = 1.f;
   for (int a = 0; a < 3; ++a) {
@@ -98,19 +94,155 @@ __global__ void k_aiou3d(const float* __restrict__ pred, const float* __restrict
   float un = a1 + a2 - ov;
   float upass = un > eps ? 1.f : 0.f;     // torch.max(union, eps)
   float U = un > eps ? un : eps;
-  iou[i] = ov / U;
-  if (!dpred) return;
-  for (int a = 0; a < 3; ++a) {
-    int b = (a + 1) % 3, c = (a + 2) % 3;
-    float dov_dwh = wh[b] * wh[c];
-    float dov_dc = dov_dwh * dwh_dc[a];
-    float dov_ds = dov_dwh * dwh_ds[a];
-    float da1_ds = sp[b] * sp[c];          // area1 = prod (p2-p1): d/ds_a = prod of the others
-    float dU_dc = upass * (-dov_dc);
-    float dU_ds = upass * (da1_ds - dov_ds);
-    dpred[i * 6 + a] = (dov_dc * U - ov * dU_dc) / (U * U);
-    dpred[i * 6 + 3 + a] = (dov_ds * U - ov * dU_ds) / (U * U);
+  if (dp) {
+    for (int a = 0; a < 3; ++a) {
+      int b = (a + 1) % 3, c = (a + 2) % 3;
+      float dov_dwh = wh[b] * wh[c];
+      float dov_dc = dov_dwh * dwh_dc[a];
+      float dov_ds = dov_dwh * dwh_ds[a];
+      float da1_ds = sp[b] * sp[c];          // area1 = prod (p2-p1): d/ds_a = prod of the others
+      float dU_dc = upass * (-dov_dc);
+      float dU_ds = upass * (da1_ds - dov_ds);
+      dp[a] = (dov_dc * U - ov * dU_dc) / (U * U);
+      dp[3 + a] = (dov_ds * U - ov * dU_ds) / (U * U);
+    }
   }
+  return ov / U;
+}
+
+// pred (n,6) [cx,cy,cz,w,l,h]; target rows of `tstride` floats whose first 6 are [cx,cy,cz,w,l,h]
+__global__ void k_aiou3d(const float* __restrict__ pred, const float* __restrict__ target, int tstride, int64_t n,
+                         float eps, float* __restrict__ iou, float* __restrict__ dpred) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float dp[6];
+  iou[i] = aiou3d_eval(pred + i * 6, target + i * tstride, eps, dpred ? dp : nullptr);
+  if (dpred)
+    for (int a = 0; a < 6; ++a) dpred[i * 6 + a] = dp[a];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The three losses of Fcaf3DNeckWithHead._loss_single (fcaf3d_neck_with_head.py:160-203) for ALL locations of the batch in
+// one pass (r3; yaw-less heads: ScanNet / S3DIS).  Row r of scene s carries the weights w_pos = inv_pos[s] =
+// 1 / (B max(n_pos_s, 1)) and w_den = inv_den[s] = 1 / (B max(sum of centerness targets_s, 1e-6)), so the sums below are
+// the means over scenes of the per-scene losses:
+//   loss_cls        = sum_r w_pos sum_c focal(cls[r,c], labels[r] == c)                          (:180, mmcv sigmoid_focal_loss)
+//   loss_centerness = sum_{r positive} w_pos BCEWithLogits(centerness[r], ct[r])                   (:191-193)
+//   loss_bbox       = sum_{r: ct w_den > 0} ct[r] w_den (1 - IoU(decode(points[r], bbox_pred[r]), bt[r]))   (:194-199, :281-300,
+//                      iou3d_loss.py:21-35)       decode: centre = p + (d1-d0, d3-d2, d5-d4)/2, size = (d0+d1, d2+d3, d4+d5)
+// Forward: per-block partial sums [nb][4] in a fixed order -> k_fcaf3d_loss_final (deterministic).  Backward: the same
+// per-row arithmetic with the incoming scalar gradients; rows without weight write exact zeros.
+__device__ static inline void decode6(const float* __restrict__ pt, const float* __restrict__ d, float* box) {
+  box[0] = pt[0] + (d[1] - d[0]) / 2;
+  box[1] = pt[1] + (d[3] - d[2]) / 2;
+  box[2] = pt[2] + (d[5] - d[4]) / 2;
+  box[3] = d[0] + d[1];
+  box[4] = d[2] + d[3];
+  box[5] = d[4] + d[5];
+}
+
+__device__ static inline float bce_logits(float x, float t) {          // torch BCEWithLogits: max(x,0) - x t + log1p(exp(-|x|))
+  return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+
+__global__ __launch_bounds__(256) void k_fcaf3d_loss_fwd(const float* __restrict__ points, const float* __restrict__ bbox_pred,
+                                                         const float* __restrict__ centerness, const float* __restrict__ cls,
+                                                         const float* __restrict__ ct, const float* __restrict__ bt,
+                                                         const long long* __restrict__ labels, const int* __restrict__ scene,
+                                                         const float* __restrict__ inv_pos, const float* __restrict__ inv_den,
+                                                         int64_t N, int C, float gamma, float alpha, float* __restrict__ part) {
+  __shared__ float red[4][3];
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float v[3] = {0.f, 0.f, 0.f};
+  if (r < N) {
+    const int s = scene[r];
+    const float wp = inv_pos[s], wd = inv_den[s];
+    const long long y = labels[r];
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc += focal_elem(cls[r * C + c], y == c, gamma, alpha);
+    v[0] = acc * wp;
+    if (y >= 0) v[1] = bce_logits(centerness[r], ct[r]) * wp;
+    const float w = ct[r] * wd;
+    if (w > 0.f) {
+      float box[6];
+      decode6(points + r * 3, bbox_pred + r * 6, box);
+      v[2] = (1.f - aiou3d_eval(box, bt + r * 7, 1e-6f, nullptr)) * w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    for (int off = 32; off > 0; off >>= 1) v[j] += __shfl_xor(v[j], off, 64);
+  if ((threadIdx.x & 63) == 0)
+    for (int j = 0; j < 3; ++j) red[threadIdx.x >> 6][j] = v[j];
+  __syncthreads();
+  if (threadIdx.x < 3) part[(int64_t)blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// out[j] = lw[j] * sum_b part[b][j]  (one block, fixed order; double accumulation)
+__global__ __launch_bounds__(256) void k_fcaf3d_loss_final(const float* __restrict__ part, int64_t nb, float lw0, float lw1,
+                                                           float lw2, float* __restrict__ o0, float* __restrict__ o1,
+                                                           float* __restrict__ o2) {
+  __shared__ double red[4][3];
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int64_t b = threadIdx.x; b < nb; b += 256)
+    for (int j = 0; j < 3; ++j) v[j] += (double)part[b * 4 + j];
+  for (int j = 0; j < 3; ++j)
+    for (int off = 32; off > 0; off >>= 1) v[j] += __shfl_xor(v[j], off, 64);
+  if ((threadIdx.x & 63) == 0)
+    for (int j = 0; j < 3; ++j) red[threadIdx.x >> 6][j] = v[j];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *o0 = lw0 * (float)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]));
+    *o1 = lw1 * (float)((red[0][1] + red[1][1]) + (red[2][1] + red[3][1]));
+    *o2 = lw2 * (float)((red[0][2] + red[1][2]) + (red[2][2] + red[3][2]));
+  }
+}
+
+// gradients of (lw0 g0 loss_cls + lw1 g1 loss_centerness + lw2 g2 loss_bbox) w.r.t. cls (N,C), centerness (N), bbox_pred (N,6);
+// g0..g2: device scalars (NULL = that loss is not part of the objective)
+__global__ __launch_bounds__(256) void k_fcaf3d_loss_bwd(const float* __restrict__ points, const float* __restrict__ bbox_pred,
+                                                         const float* __restrict__ centerness, const float* __restrict__ cls,
+                                                         const float* __restrict__ ct, const float* __restrict__ bt,
+                                                         const long long* __restrict__ labels, const int* __restrict__ scene,
+                                                         const float* __restrict__ inv_pos, const float* __restrict__ inv_den,
+                                                         int64_t N, int C, float gamma, float alpha, float lw0, float lw1,
+                                                         float lw2, const float* __restrict__ g0, const float* __restrict__ g1,
+                                                         const float* __restrict__ g2, float* __restrict__ gcls,
+                                                         float* __restrict__ gcent, float* __restrict__ gbbox) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= N) return;
+  const int s = scene[r];
+  const float wp = inv_pos[s], wd = inv_den[s];
+  const long long y = labels[r];
+  const float s0 = g0 ? g0[0] * lw0 * wp : 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float x = cls[r * C + c];
+    const float p = 1.f / (1.f + expf(-x));
+    float g;
+    if (y == c) g = -alpha * pow_gamma(1.f - p, gamma) * (1.f - p - gamma * p * logf(fmaxf(p, FLT_MIN)));
+    else g = -(1.f - alpha) * pow_gamma(p, gamma) * (gamma * (1.f - p) * logf(fmaxf(1.f - p, FLT_MIN)) - p);
+    gcls[r * C + c] = g * s0;
+  }
+  float gc = 0.f;
+  if (y >= 0 && g1) {
+    const float x = centerness[r];
+    gc = (1.f / (1.f + expf(-x)) - ct[r]) * (g1[0] * lw1 * wp);
+  }
+  gcent[r] = gc;
+  float gb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float w = ct[r] * wd;
+  if (w > 0.f && g2) {
+    float box[6], dp[6];
+    const float* d = bbox_pred + r * 6;
+    decode6(points + r * 3, d, box);
+    aiou3d_eval(box, bt + r * 7, 1e-6f, dp);
+    const float sc = -(g2[0] * lw2 * w);                    // loss = w (1 - IoU)
+    for (int a = 0; a < 3; ++a) {                           // centre_a = p + (d[2a+1] - d[2a]) / 2, size_a = d[2a] + d[2a+1]
+      gb[2 * a] = sc * (dp[3 + a] - dp[a] / 2);
+      gb[2 * a + 1] = sc * (dp[3 + a] + dp[a] / 2);
+    }
+  }
+  for (int j = 0; j < 6; ++j) gbbox[r * 6 + j] = gb[j];
 }
 
 extern "C" {
@@ -139,6 +271,43 @@ int fc_aiou3d_fwd_bwd(const float* pred, const float* target, int target_stride,
   if (n < 0 || target_stride < 6) return FC_EINVAL;
   if (n == 0) return FC_OK;
   k_aiou3d<<<(unsigned)fc_cdiv(n, 128), 128, 0, stream>>>(pred, target, target_stride, n, eps, iou, dpred);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+int64_t fc_fcaf3d_loss_ws_bytes(int64_t n) { return fc_cdiv(n > 0 ? n : 1, 256) * 4 * (int64_t)sizeof(float); }
+
+int fc_fcaf3d_loss_fwd(const float* points, const float* bbox_pred, const float* centerness, const float* cls_score,
+                       const float* centerness_t, const float* bbox_t, const long long* labels, const int* scene,
+                       const float* inv_pos, const float* inv_den, int64_t n, int n_classes, float gamma, float alpha,
+                       float lw_cls, float lw_centerness, float lw_bbox, float* loss_cls, float* loss_centerness,
+                       float* loss_bbox, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (n < 0 || n_classes < 1 || !loss_cls || !loss_centerness || !loss_bbox) return FC_EINVAL;
+  if (ws_bytes < fc_fcaf3d_loss_ws_bytes(n)) return FC_EWS;
+  const int64_t nb = n > 0 ? fc_cdiv(n, 256) : 0;
+  if (nb) {
+    k_fcaf3d_loss_fwd<<<(unsigned)nb, 256, 0, stream>>>(points, bbox_pred, centerness, cls_score, centerness_t, bbox_t, labels,
+                                                       scene, inv_pos, inv_den, n, n_classes, gamma, alpha, (float*)ws);
+    FC_CHECK_LAUNCH();
+  }
+  k_fcaf3d_loss_final<<<1, 256, 0, stream>>>((const float*)ws, nb, lw_cls, lw_centerness, lw_bbox, loss_cls, loss_centerness,
+                                             loss_bbox);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+int fc_fcaf3d_loss_bwd(const float* points, const float* bbox_pred, const float* centerness, const float* cls_score,
+                       const float* centerness_t, const float* bbox_t, const long long* labels, const int* scene,
+                       const float* inv_pos, const float* inv_den, int64_t n, int n_classes, float gamma, float alpha,
+                       float lw_cls, float lw_centerness, float lw_bbox, const float* g_cls, const float* g_centerness,
+                       const float* g_bbox, float* grad_cls_score, float* grad_centerness, float* grad_bbox_pred,
+                       hipStream_t stream) {
+  if (n < 0 || n_classes < 1) return FC_EINVAL;
+  if (n == 0) return FC_OK;
+  k_fcaf3d_loss_bwd<<<(unsigned)fc_cdiv(n, 256), 256, 0, stream>>>(points, bbox_pred, centerness, cls_score, centerness_t, bbox_t,
+                                                                  labels, scene, inv_pos, inv_den, n, n_classes, gamma, alpha,
+                                                                  lw_cls, lw_centerness, lw_bbox, g_cls, g_centerness, g_bbox,
+                                                                  grad_cls_score, grad_centerness, grad_bbox_pred);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }

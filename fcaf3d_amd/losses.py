@@ -188,3 +188,47 @@ class IoU3DLoss(nn.Module):
             # reference's early-out `if not torch.any(weight > 0): return pred.sum() * weight.sum()`
             loss = torch.where(weight > 0, loss, torch.zeros_like(loss))
         return self.loss_weight * _reduce(loss, weight, reduction, avg_factor)
+
+
+class _FusedHeadLossFn(torch.autograd.Function):
+    """The three losses of the FCAF3D head over all locations of the batch in two launches forward, one backward
+    (csrc/loss.hip k_fcaf3d_loss_*; yaw-less heads).  Same values as FocalLoss + CrossEntropyLoss(use_sigmoid) + IoU3DLoss on
+    `_bbox_pred_to_bbox` with per-row weights — kept as the cross-check (`Fcaf3DNeckWithHead.fused_loss = False`)."""
+
+    @staticmethod
+    def forward(ctx, bbox_pred, centerness, cls_score, points, ct, bt, labels, scene, inv_pos, inv_den, cfg):
+        gamma, alpha, lw_cls, lw_cent, lw_bbox = cfg
+        if not bbox_pred.is_cuda:
+            raise RuntimeError('the fused head loss runs on the GPU only (HIP)')
+        n, C = cls_score.shape
+        dev = bbox_pred.device
+        t = [x.contiguous() for x in (points, bbox_pred, centerness, cls_score, ct, bt, labels, scene, inv_pos, inv_den)]
+        out = [torch.empty((), dtype=torch.float32, device=dev) for _ in range(3)]
+        ws = L.workspace(L.query('fc_fcaf3d_loss_ws_bytes', n), dev)
+        L.call('fc_fcaf3d_loss_fwd', *[L.ptr(x) for x in t], n, C, float(gamma), float(alpha), float(lw_cls), float(lw_cent),
+               float(lw_bbox), L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(ws), ws.numel(), L.stream())
+        ctx.save_for_backward(*t)
+        ctx.cfg = cfg
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2]               # loss_cls, loss_centerness, loss_bbox
+
+    @staticmethod
+    def backward(ctx, g_cls, g_cent, g_bbox):
+        t = ctx.saved_tensors
+        gamma, alpha, lw_cls, lw_cent, lw_bbox = ctx.cfg
+        n, C = t[3].shape
+        dev = t[1].device
+        gs = [g.reshape(1).to(torch.float32).contiguous() if g is not None else None for g in (g_cls, g_cent, g_bbox)]
+        d_cls = torch.empty((n, C), dtype=torch.float32, device=dev)
+        d_cent = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        d_bbox = torch.empty((n, 6), dtype=torch.float32, device=dev)
+        L.call('fc_fcaf3d_loss_bwd', *[L.ptr(x) for x in t], n, C, float(gamma), float(alpha), float(lw_cls), float(lw_cent),
+               float(lw_bbox), L.ptr(gs[0]), L.ptr(gs[1]), L.ptr(gs[2]), L.ptr(d_cls), L.ptr(d_cent), L.ptr(d_bbox), L.stream())
+        return d_bbox, d_cent, d_cls, None, None, None, None, None, None, None, None
+
+
+def fused_head_loss(bbox_pred, centerness, cls_score, points, ct, bt, labels, scene, inv_pos, inv_den, gamma, alpha,
+                    lw_cls, lw_centerness, lw_bbox):
+    """-> (loss_cls, loss_centerness, loss_bbox); bbox_pred (N,6), centerness (N,1), cls_score (N,C)."""
+    return _FusedHeadLossFn.apply(bbox_pred, centerness, cls_score, points, ct, bt, labels.to(torch.int64),
+                                  scene.to(torch.int32), inv_pos, inv_den, (gamma, alpha, lw_cls, lw_centerness, lw_bbox))

@@ -245,6 +245,25 @@ int fc_focal_loss_bwd(const float* logits, const long long* labels, const float*
 int fc_aiou3d_fwd_bwd(const float* pred, const float* target, int target_stride, int64_t n, float eps, float* iou,
                       float* dpred, hipStream_t stream);
 
+/* Fcaf3DNeckWithHead._loss_single (fcaf3d_neck_with_head.py:160-203) for every location of the batch in one pass, yaw-less
+ * heads: sigmoid focal loss (:180), BCE-with-logits centerness loss on the positives (:191-193) and the axis-aligned
+ * IoU loss on _bbox_pred_to_bbox (:281-300; iou3d_loss.py:21-35), each row weighted by its scene's 1 / (B * normaliser)
+ * (inv_pos, inv_den: (B,) device arrays; scene: (n) int32), summed deterministically and scaled by the loss weights.
+ * labels int64 in {-1, 0..C-1}; bbox_t (n,7) gravity-centre targets.  Backward: gradients w.r.t. cls_score (n,C),
+ * centerness (n), bbox_pred (n,6) for incoming scalar gradients g_* (device, NULL = loss unused). */
+int64_t fc_fcaf3d_loss_ws_bytes(int64_t n);
+int fc_fcaf3d_loss_fwd(const float* points, const float* bbox_pred, const float* centerness, const float* cls_score,
+                       const float* centerness_t, const float* bbox_t, const long long* labels, const int* scene,
+                       const float* inv_pos, const float* inv_den, int64_t n, int n_classes, float gamma, float alpha,
+                       float lw_cls, float lw_centerness, float lw_bbox, float* loss_cls, float* loss_centerness,
+                       float* loss_bbox, void* ws, int64_t ws_bytes, hipStream_t stream);
+int fc_fcaf3d_loss_bwd(const float* points, const float* bbox_pred, const float* centerness, const float* cls_score,
+                       const float* centerness_t, const float* bbox_t, const long long* labels, const int* scene,
+                       const float* inv_pos, const float* inv_den, int64_t n, int n_classes, float gamma, float alpha,
+                       float lw_cls, float lw_centerness, float lw_bbox, const float* g_cls, const float* g_centerness,
+                       const float* g_bbox, float* grad_cls_score, float* grad_centerness, float* grad_bbox_pred,
+                       hipStream_t stream);
+
 /* rotated 3D IoU of (n,7) [cx,cy,cz,w,l,h,yaw] boxes and its gradient w.r.t. pred — cal_iou_3d,
  * rotated_iou/oriented_iou_loss.py:86-109 + box_intersection_2d.py:13-184 + cuda_op sort_v.
  * weight (nullable): rows with weight <= 0 are skipped (iou = 0, dpred = 0). */

@@ -572,6 +572,34 @@ def test_three_step_training_trajectory_vs_oracle():
         assert abs(a - b) <= 2e-2 * abs(b), (traj_g, traj_o)
 
 
+def test_fused_head_loss_equals_the_three_loss_modules():
+    """csrc/loss.hip k_fcaf3d_loss_* (focal + centerness BCE + decode + axis-aligned IoU with per-row scene weights, two
+    launches forward, one backward) == FocalLoss + CrossEntropyLoss(use_sigmoid) + IoU3DLoss on `_bbox_pred_to_bbox`, the
+    modules the reference's config names (fcaf3d_neck_with_head.py:24-34) — which are themselves checked against the oracle
+    by test_forward_train_parity: losses to 1e-6, every parameter gradient to 1e-5 of its scale; unequal loss weights so that
+    each incoming gradient is exercised; a scene without boxes included."""
+    dev = _dev()
+    runs = []
+    for fused in (True, False):
+        model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 2, seed=6,
+                          loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=0.7),
+                          loss_bbox=dict(type='IoU3DLoss', with_yaw=False, loss_weight=1.3),
+                          loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=0.9))
+        model = model.to(dev).train()
+        model.neck_with_head.fused_loss = fused
+        pts, gts, labs = _scenes([61, 62, 63], n_points=12000)
+        gts[1] = gts[1][:0]; labs[1] = labs[1][:0]                       # a scene without ground truth
+        losses = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
+        (losses['loss_cls'] * 1.0 + losses['loss_bbox'] * 2.0 + losses['loss_centerness'] * 0.5).backward()
+        runs.append(({k: float(v) for k, v in losses.items()}, [p.grad.detach().clone() for p in model.parameters()],
+                     [k for k, _ in model.named_parameters()]))
+    (l1, g1, names), (l2, g2, _) = runs
+    for k in l1:
+        assert abs(l1[k] - l2[k]) <= 1e-6 * max(1.0, abs(l2[k])), (k, l1[k], l2[k])
+    rels = sorted(((_rel(a, b), k) for a, b, k in zip(g1, g2, names)), reverse=True)
+    assert rels[0][0] < 1e-5, rels[:6]
+
+
 def test_flat_adamw_equals_torch_adamw_with_clip():
     """csrc/optim.hip over flat buffers (fc_grad_norm + fc_adamw_step) == torch.nn.utils.clip_grad_norm_ +
     torch.optim.AdamW (the calls mmcv's OptimizerHook makes for configs/fcaf3d/fcaf3d.py:30-31) on identical
