@@ -269,24 +269,51 @@ class Fcaf3DNeckWithHead(nn.Module):
             loss_bbox=torch.mean(torch.stack(loss_bbox)),
             loss_cls=torch.mean(torch.stack(loss_cls)))
 
-    def _loss_batched(self, centernesses, bbox_preds, cls_scores, points, gt_bboxes, gt_labels):
-        """The same three losses as the per-scene loop (reference :140-157, :160-203), evaluated over all
-        locations of all scenes at once: every row carries the weight 1/(B * normaliser of its scene), so
-        the weighted sums equal the mean over scenes of the per-scene losses."""
+    early_targets = os.environ.get('FC_EARLY_TARGETS', '1') != '0'
+
+    def _targets(self, cmaps, gt_bboxes, gt_labels):
+        """Locations, assigned targets and per-scene normalisers of one batch — everything the loss needs that does not
+        depend on the network's outputs: locations = voxel corners of the head's coordinate sets (:276-277), targets from
+        the assigner, normalisers n_pos / sum of centerness targets per scene, averaged over the ranks in ONE all-reduce
+        (the reference: two `reduce_mean` per scene, :179, :187)."""
+        from .sparse import _rec
         B = len(gt_bboxes)
-        dev = points[0].full.device
+        dev = cmaps[0].coords.device
         with torch.no_grad():
-            pts = torch.cat([p.full for p in points])
-            scene = torch.cat([p.cmap.coords[:, 0] for p in points])
-            level = torch.cat([torch.full((p.full.shape[0],), l, dtype=torch.int32, device=dev)
-                               for l, p in enumerate(points)])
-            ct, bt, labels = self.assigner.assign_batched(pts, scene, level, [p.cmap for p in points],
-                                                          gt_bboxes, gt_labels)
+            pts = torch.cat([cm.coords[:, 1:].float() * self.voxel_size for cm in cmaps])
+            scene = torch.cat([cm.coords[:, 0] for cm in cmaps])
+            level = torch.cat([torch.full((cm.n,), l, dtype=torch.int32, device=dev) for l, cm in enumerate(cmaps)])
+            ct, bt, labels = self.assigner.assign_batched(pts, scene, level, cmaps, gt_bboxes, gt_labels)
             posf = (labels >= 0).float()
             cols = torch.stack((posf, ct, torch.zeros_like(ct), torch.zeros_like(ct)), dim=1)
             norms = reduce_mean(Fn.seg_col_sums(cols, scene, B)[:, :2])             # (B,2): n_pos, Σ centerness
             inv_pos = 1.0 / (B * norms[:, 0].clamp(min=1.))
             inv_den = 1.0 / (B * norms[:, 1].clamp(min=1e-6))
+        out = dict(pts=pts, scene=scene, ct=ct, bt=bt, labels=labels, posf=posf, inv_pos=inv_pos, inv_den=inv_den)
+        _rec(*out.values())                                          # built on the coordinate stream, consumed on the main one
+        return out
+
+    def prepare_targets(self, cmaps, gt_bboxes, gt_labels):
+        """Called by the detector as soon as the head's coordinate sets exist (SingleStageSparse3DDetector._sparse_input, on
+        the coordinate stream): `loss()` then finds the assignment done.  Identity of the coordinate-map objects is the key."""
+        self._prepared = None
+        if self.early_targets and hasattr(self.assigner, 'assign_batched') and len(cmaps) == self.assigner.n_scales \
+                and cmaps[0].coords.is_cuda:
+            self._prepared = (tuple(id(cm) for cm in cmaps), cmaps, self._targets(cmaps, gt_bboxes, gt_labels))
+
+    def _loss_batched(self, centernesses, bbox_preds, cls_scores, points, gt_bboxes, gt_labels):
+        """The same three losses as the per-scene loop (reference :140-157, :160-203), evaluated over all
+        locations of all scenes at once: every row carries the weight 1/(B * normaliser of its scene), so
+        the weighted sums equal the mean over scenes of the per-scene losses."""
+        B = len(gt_bboxes)
+        cmaps = [p.cmap for p in points]
+        prep, self._prepared = getattr(self, '_prepared', None), None
+        if prep is not None and prep[0] == tuple(id(cm) for cm in cmaps):
+            tg = prep[2]
+        else:
+            tg = self._targets(cmaps, gt_bboxes, gt_labels)
+        pts, scene, ct, bt, labels, posf, inv_pos, inv_den = (tg[k] for k in ('pts', 'scene', 'ct', 'bt', 'labels', 'posf',
+                                                                               'inv_pos', 'inv_den'))
         centerness = torch.cat([c.full for c in centernesses])
         bbox_pred = torch.cat([b.full for b in bbox_preds])
         cls_score = torch.cat([c.full for c in cls_scores])

@@ -64,11 +64,15 @@ class SingleStageSparse3DDetector(nn.Module):
             coords, feats = coords[order], feats[order]
         return coords, feats
 
-    def _sparse_input(self, points):
+    def _sparse_input(self, points, gt=None):
         coordinates, features = self.voxelize(points)
         x = SparseTensor(features, coordinates=coordinates, batch_size=len(points))
         _rec(x.F)
-        self.plan_maps(x.cmap)
+        head_maps = self.plan_maps(x.cmap)
+        if gt is not None and head_maps is not None and hasattr(self.neck_with_head, 'prepare_targets'):
+            # training: the target assignment depends on the head's LOCATIONS (coordinate sets, known now) and the ground
+            # truth only — it runs here, on the coordinate stream, instead of between forward and backward (r3)
+            self.neck_with_head.prepare_targets(head_maps, *gt)
         return x
 
     def plan_maps(self, cm0):
@@ -90,29 +94,33 @@ class SingleStageSparse3DDetector(nn.Module):
             levels.append(mi)
             prev = mi
         if bottleneck or not levels:
-            return
+            return None
         x = levels[-1]
         x.scene_counts
+        head_maps = [x]                                            # coordinate sets of the head's levels, coarse -> fine
         for i in range(len(levels) - 2, -1, -1):
             g = x.generate(); g.kernel_map(g, 3).prefetch(bwd)
             u, _, _ = levels[i].union(g)
             if nh.pts_threshold >= 0 and any(c > nh.pts_threshold for c in u.scene_counts):
-                return
+                return None
             u.kernel_map(u, 3).prefetch(bwd)
             x = u
+            head_maps.append(x)
+        return head_maps[::-1]                                     # finest first, the order of the head's outputs
 
-    def extract_feat(self, points, img_metas):
+    def extract_feat(self, points, img_metas, gt=None):
+        """gt (training only, optional): (gt_bboxes_3d, gt_labels_3d) — lets the target assignment start with the maps"""
         if self.async_maps:
             with on_map_stream(points[0].device, self.inputs_resident):
-                x = self._sparse_input(points)
+                x = self._sparse_input(points, gt)
         else:
-            x = self._sparse_input(points)
+            x = self._sparse_input(points, gt)
         x = self.backbone(x)
         x = self.neck_with_head(x)
         return x
 
     def forward_train(self, points, gt_bboxes_3d, gt_labels_3d, img_metas):
-        x = self.extract_feat(points, img_metas)
+        x = self.extract_feat(points, img_metas, (gt_bboxes_3d, gt_labels_3d))
         return self.neck_with_head.loss(*x, gt_bboxes_3d, gt_labels_3d, img_metas)
 
     def simple_test(self, points, img_metas, imgs=None, rescale=False):
