@@ -146,14 +146,15 @@ HBM_BYTES = {
     'fc_maxpool_bwd': lambda a, pr: 4.0 * a[3] * 3 * a[2],
     # (x, seg, seg_stride, n, C, mean, var, eps, gamma, beta, residual, act, y)
     'fc_norm_act_fwd': lambda a, pr: 4.0 * a[3] * a[4] * (2 + (1 if a[10] else 0)),
-    # (x, y, gy, seg, seg_stride, n, C, nseg, mean, var, cnt, eps, gamma, act, gx, gres, ..): x, y, gy read; gx (gres) written
-    'fc_norm_act_bwd': lambda a, pr: 4.0 * a[5] * a[6] * (4 + (1 if a[15] else 0)),
+    # (x, y, gy, seg, seg_stride, n, C, nseg, mean, var, cnt, eps, gamma, beta, act, gx, gres, ..): x, gy (and y when the forward
+    # had a residual) read; gx (gres) written
+    'fc_norm_act_bwd': lambda a, pr: 4.0 * a[5] * a[6] * (3 + (1 if a[1] else 0) + (1 if a[16] else 0)),
     'fc_col_stats': lambda a, pr: 4.0 * a[3] * a[4],
     'fc_bn_stats_train': lambda a, pr: 4.0 * a[1] * a[2],
     # (x, n, C, eps, gamma, beta, residual, act, ..): x read, y written (+ residual)
     'fc_bn_act_train_fwd': lambda a, pr: 4.0 * a[1] * a[2] * (2 + (1 if a[6] else 0)),
-    # (x, y, gy, n, C, mean, var, eps, gamma, act, gx, gres, ..)
-    'fc_bn_act_train_bwd': lambda a, pr: 4.0 * a[3] * a[4] * (4 + (1 if a[11] else 0)),
+    # (x, y, gy, n, C, mean, var, eps, gamma, beta, act, gx, gres, ..)
+    'fc_bn_act_train_bwd': lambda a, pr: 4.0 * a[3] * a[4] * (3 + (1 if a[1] else 0) + (1 if a[12] else 0)),
     # (coords, n, q, keys, vals, cap, out_coords, ..): 16 B coordinate read + 16 B key/value insert per row
     'fc_hash_unique': lambda a, pr: 32.0 * a[1],
     # (out_coords, n_out, keys, vals, cap, offsets, K, nbr): 16 B coordinate + K x (12 B probe + 4 B write) per row

@@ -168,6 +168,17 @@ __device__ static inline float act_bwd_from_y(float y, int act) {
   return 1.f;
 }
 
+// The pre-activation of a normalised element, ONE instruction sequence for the forward kernels and for the backward
+// kernels that recompute it (r3: without a residual the backward pass derives act'(.) from x instead of reading y —
+// 2 of 7 passes over the matrix gone; the explicit fmaf keeps the recomputed sign bit-identical to the forward's)
+__device__ static inline float bn_pre(float v, float mu, float is, float g, float b) { return fmaf((v - mu) * is, g, b); }
+// derivative of the activation from its PRE-activation p (ReLU: p > 0; ELU(alpha=1): p > 0 ? 1 : exp(p) = y + 1)
+__device__ static inline float act_bwd_from_pre(float p, int act) {
+  if (act == 1) return p > 0.f ? 1.f : 0.f;
+  if (act == 2) return p > 0.f ? 1.f : expf(p);
+  return 1.f;
+}
+
 // y = act( (x-mean[seg])*invstd[seg]*gamma + beta (+ residual) ) ; invstd = 1/sqrt(var+eps)
 __global__ void k_norm_act_fwd(const float* __restrict__ x, const int* __restrict__ seg, int seg_stride, int64_t n, int C,
                                const float* __restrict__ mean, const float* __restrict__ var, float eps,
@@ -185,10 +196,10 @@ __global__ void k_norm_act_fwd(const float* __restrict__ x, const int* __restric
   float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
   float4 b = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 o;
-  o.x = (v.x - mu.x) * (1.f / sqrtf(va.x + eps)) * g.x + b.x;
-  o.y = (v.y - mu.y) * (1.f / sqrtf(va.y + eps)) * g.y + b.y;
-  o.z = (v.z - mu.z) * (1.f / sqrtf(va.z + eps)) * g.z + b.z;
-  o.w = (v.w - mu.w) * (1.f / sqrtf(va.w + eps)) * g.w + b.w;
+  o.x = bn_pre(v.x, mu.x, 1.f / sqrtf(va.x + eps), g.x, b.x);
+  o.y = bn_pre(v.y, mu.y, 1.f / sqrtf(va.y + eps), g.y, b.y);
+  o.z = bn_pre(v.z, mu.z, 1.f / sqrtf(va.z + eps), g.z, b.z);
+  o.w = bn_pre(v.w, mu.w, 1.f / sqrtf(va.w + eps), g.w, b.w);
   if (residual) {
     float4 rs = *reinterpret_cast<const float4*>(residual + r * C + c);
     o.x += rs.x; o.y += rs.y; o.z += rs.z; o.w += rs.w;
@@ -199,9 +210,11 @@ __global__ void k_norm_act_fwd(const float* __restrict__ x, const int* __restric
 
 // backward pass 1: per (block, seg, channel) partial sums of g' and g'*xhat, g' = gy * act'(y)
 // part layout: [block][seg][2][C]
+// y == NULL (no residual in the forward): act'(.) is recomputed from x with gamma / beta (bn_pre) instead of read from y
 __global__ void k_norm_bwd_partial(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
                                    const int* __restrict__ seg, int seg_stride, int64_t n, int C, int nseg,
                                    const float* __restrict__ mean, const float* __restrict__ var, float eps, int act,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                    int64_t rpb, float* __restrict__ part) {
   extern __shared__ float sm[];               // [rl][2][C]
   __shared__ int srange[2];
@@ -225,6 +238,9 @@ __global__ void k_norm_bwd_partial(const float* __restrict__ x, const float* __r
       float4 va = *reinterpret_cast<const float4*>(var + (int64_t)s * C + cl * 4);
       float4 is = make_float4(1.f / sqrtf(va.x + eps), 1.f / sqrtf(va.y + eps), 1.f / sqrtf(va.z + eps),
                               1.f / sqrtf(va.w + eps));
+      const float4 gm = gamma ? *reinterpret_cast<const float4*>(gamma + cl * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 bt = beta ? *reinterpret_cast<const float4*>(beta + cl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool from_y = act && y;
       for (int64_t rb = r0 + rl; rb < r1; rb += 4 * nrl) {
         // branch-free batch: the 4 x (x, gy, y) rows are requested together (rows past the range re-read row r0 and are
         // dropped by `ok`), r3 — a `continue` in front of each load serialised them
@@ -238,15 +254,20 @@ __global__ void k_norm_bwd_partial(const float* __restrict__ x, const float* __r
           if (chk) ok[u] = ok[u] && seg[rc * seg_stride] == s;
           xv[u] = *reinterpret_cast<const float4*>(x + rc * C + cl * 4);
           gv[u] = *reinterpret_cast<const float4*>(gy + rc * C + cl * 4);
-          if (act) yv[u] = *reinterpret_cast<const float4*>(y + rc * C + cl * 4);
+          if (from_y) yv[u] = *reinterpret_cast<const float4*>(y + rc * C + cl * 4);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (!ok[u]) continue;
           float4 g = gv[u];
-          if (act) {
+          if (from_y) {
             g.x *= act_bwd_from_y(yv[u].x, act); g.y *= act_bwd_from_y(yv[u].y, act);
             g.z *= act_bwd_from_y(yv[u].z, act); g.w *= act_bwd_from_y(yv[u].w, act);
+          } else if (act) {
+            g.x *= act_bwd_from_pre(bn_pre(xv[u].x, mu.x, is.x, gm.x, bt.x), act);
+            g.y *= act_bwd_from_pre(bn_pre(xv[u].y, mu.y, is.y, gm.y, bt.y), act);
+            g.z *= act_bwd_from_pre(bn_pre(xv[u].z, mu.z, is.z, gm.z, bt.z), act);
+            g.w *= act_bwd_from_pre(bn_pre(xv[u].w, mu.w, is.w, gm.w, bt.w), act);
           }
           a1[u].x += g.x; a1[u].y += g.y; a1[u].z += g.z; a1[u].w += g.w;
           a2[u].x += g.x * (xv[u].x - mu.x) * is.x; a2[u].y += g.y * (xv[u].y - mu.y) * is.y;
@@ -281,7 +302,8 @@ __global__ void k_norm_bwd_partial(const float* __restrict__ x, const float* __r
 __global__ void k_norm_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
                                  const int* __restrict__ seg, int seg_stride, int64_t n, int C,
                                  const float* __restrict__ mean, const float* __restrict__ var, float eps,
-                                 const float* __restrict__ gamma, const float* __restrict__ sums /*[seg][2][C]*/,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ sums /*[seg][2][C]*/,
                                  const float* __restrict__ cnt, int act, float* __restrict__ gx, float* __restrict__ gres) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4n = C / 4;
@@ -290,7 +312,7 @@ __global__ void k_norm_bwd_apply(const float* __restrict__ x, const float* __res
   int c = (int)(t % c4n) * 4;
   int s = seg_of(seg, seg_stride, r);
   float inv_n = 1.f / cnt[s];
-  float xv[4], gv[4], muv[4], vav[4], gam[4], s1[4], s2[4], yv[4], o[4], gr[4];
+  float xv[4], gv[4], muv[4], vav[4], gam[4], bet[4] = {0.f, 0.f, 0.f, 0.f}, s1[4], s2[4], yv[4], o[4], gr[4];
   *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + r * C + c);
   *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(gy + r * C + c);
   *reinterpret_cast<float4*>(muv) = *reinterpret_cast<const float4*>(mean + (int64_t)s * C + c);
@@ -299,12 +321,15 @@ __global__ void k_norm_bwd_apply(const float* __restrict__ x, const float* __res
   *reinterpret_cast<float4*>(s2) = *reinterpret_cast<const float4*>(sums + ((int64_t)s * 2 + 1) * C + c);
   if (gamma) *reinterpret_cast<float4*>(gam) = *reinterpret_cast<const float4*>(gamma + c);
   else gam[0] = gam[1] = gam[2] = gam[3] = 1.f;
-  if (act) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y + r * C + c);
+  const bool from_y = act && y;
+  if (from_y) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y + r * C + c);
+  if (beta) *reinterpret_cast<float4*>(bet) = *reinterpret_cast<const float4*>(beta + c);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float g = gv[j];
-    if (act) g *= act_bwd_from_y(yv[j], act);
     float is = 1.f / sqrtf(vav[j] + eps);
+    if (from_y) g *= act_bwd_from_y(yv[j], act);
+    else if (act) g *= act_bwd_from_pre(bn_pre(xv[j], muv[j], is, gam[j], bet[j]), act);
     float xh = (xv[j] - muv[j]) * is;
     gr[j] = g;
     o[j] = gam[j] * is * (g - s1[j] * inv_n - xh * s2[j] * inv_n);
@@ -525,7 +550,7 @@ __global__ void k_bn1_apply(const float* __restrict__ x, int64_t n, int C, int64
       float o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        o[j] = (v[u][j] - mu[j]) * is[j] * g[j] + bt[j];
+        o[j] = bn_pre(v[u][j], mu[j], is[j], g[j], bt[j]);
         if (residual) o[j] += rs[u][j];
         o[j] = act_fwd(o[j], act);
       }
@@ -590,8 +615,8 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
 __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
                                 int64_t n, int C, int64_t rpb, const float* __restrict__ part, int nb,
                                 const float* __restrict__ mean, const float* __restrict__ var, float eps,
-                                const float* __restrict__ gamma, int act, float* __restrict__ gx, float* __restrict__ gres,
-                                float* __restrict__ sums /*[2][C]*/) {
+                                const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                float* __restrict__ gx, float* __restrict__ gres, float* __restrict__ sums /*[2][C]*/) {
   extern __shared__ float sm[];
   const int c4n = C / 4;
   const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
@@ -605,13 +630,15 @@ __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __rest
   const float inv_n = 1.f / (float)n;
   float s1[4] = {t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n};
   float s2[4] = {t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n};
-  float mu[4], is[4], g[4];
+  float mu[4], is[4], g[4], bt[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     mu[j] = mean[cl * 4 + j];
     is[j] = 1.f / sqrtf(var[cl * 4 + j] + eps);
     g[j] = gamma ? gamma[cl * 4 + j] : 1.f;
+    bt[j] = beta ? beta[cl * 4 + j] : 0.f;
   }
+  const bool from_y = act && y;
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   int64_t r1 = r0 + rpb;
   if (r1 > n) r1 = n;
@@ -623,7 +650,7 @@ __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __rest
       const int64_t rc = r < r1 ? r : r0;
       *reinterpret_cast<float4*>(xv[u]) = *reinterpret_cast<const float4*>(x + rc * C + cl * 4);
       *reinterpret_cast<float4*>(gv[u]) = *reinterpret_cast<const float4*>(gy + rc * C + cl * 4);
-      if (act) *reinterpret_cast<float4*>(yv[u]) = *reinterpret_cast<const float4*>(y + rc * C + cl * 4);
+      if (from_y) *reinterpret_cast<float4*>(yv[u]) = *reinterpret_cast<const float4*>(y + rc * C + cl * 4);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -633,7 +660,8 @@ __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float gg = gv[u][j];
-        if (act) gg *= act_bwd_from_y(yv[u][j], act);
+        if (from_y) gg *= act_bwd_from_y(yv[u][j], act);
+        else if (act) gg *= act_bwd_from_pre(bn_pre(xv[u][j], mu[j], is[j], g[j], bt[j]), act);
         float xh = (xv[u][j] - mu[j]) * is[j];
         gr[j] = gg;
         o[j] = g[j] * is[j] * (gg - s1[j] - xh * s2[j]);
@@ -804,8 +832,8 @@ int fc_bn_act_train_fwd(const float* x, int64_t n, int C, float eps, const float
 
 // its backward: sums (2,C) = [d beta, d gamma]
 int fc_bn_act_train_bwd(const float* x, const float* y, const float* gy, int64_t n, int C, const float* mean,
-                        const float* var, float eps, const float* gamma, int act, float* gx, float* gres, float* sums,
-                        void* ws, int64_t ws_bytes, hipStream_t stream) {
+                        const float* var, float eps, const float* gamma, const float* beta, int act, float* gx, float* gres,
+                        float* sums, void* ws, int64_t ws_bytes, hipStream_t stream) {
   if (n < 1 || act < 0 || act > 2) return FC_EINVAL;
   int threads; size_t sf, sb;
   if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
@@ -813,10 +841,10 @@ int fc_bn_act_train_bwd(const float* x, const float* y, const float* gy, int64_t
   int64_t nb, rpb;
   bn1_plan(n, &nb, &rpb);
   float* part = (float*)ws;
-  k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, 0, n, C, 1, mean, var, eps, act, rpb, part);
+  k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, 0, n, C, 1, mean, var, eps, act, gamma, beta, rpb, part);
   FC_CHECK_LAUNCH();
-  k_bn1_bwd_apply<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, n, C, rpb, part, (int)nb, mean, var, eps, gamma, act, gx, gres,
-                                                        sums);
+  k_bn1_bwd_apply<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, n, C, rpb, part, (int)nb, mean, var, eps, gamma, beta, act, gx,
+                                                        gres, sums);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
@@ -841,7 +869,8 @@ int64_t fc_norm_act_bwd_ws_bytes(int64_t n, int C, int nseg) {
 // sums (nseg,2,C): [.,0,.] = sum g' (= d beta per segment), [.,1,.] = sum g'*xhat (= d gamma per segment)
 int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* seg, int seg_stride, int64_t n, int C,
                     int nseg, const float* mean, const float* var, const float* cnt, float eps, const float* gamma,
-                    int act, float* gx, float* gres, float* sums, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                    const float* beta, int act, float* gx, float* gres, float* sums, void* ws, int64_t ws_bytes,
+                    hipStream_t stream) {
   if (n < 0 || nseg < 1 || nseg > MAXSEG || act < 0 || act > 2) return FC_EINVAL;
   int threads; size_t sf, sb;
   if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
@@ -853,13 +882,13 @@ int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* 
   int64_t nb, rpb;
   red_plan(n, &nb, &rpb);
   float* part = (float*)ws;
-  k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, seg, seg_stride, n, C, nseg, mean, var, eps, act, rpb,
-                                                          part);
+  k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, seg, seg_stride, n, C, nseg, mean, var, eps, act, gamma,
+                                                          beta, rpb, part);
   FC_CHECK_LAUNCH();
   k_stats_final<<<(unsigned)(nseg * ((2 * C + 63) / 64)), 1024, 0, stream>>>(part, nullptr, nb, nseg, 2 * C, 2, sums, nullptr);
   FC_CHECK_LAUNCH();
   k_norm_bwd_apply<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, y, gy, seg, seg_stride, n, C, mean, var, eps,
-                                                                           gamma, sums, cnt, act, gx, gres);
+                                                                           gamma, beta, sums, cnt, act, gx, gres);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }

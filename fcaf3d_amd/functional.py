@@ -255,14 +255,15 @@ class _NormAct(torch.autograd.Function):
         b = beta.reshape(-1).contiguous() if beta is not None else None
         L.call('fc_norm_act_fwd', L.ptr(x), L.ptr(seg), 4 if seg is not None else 0, n, C, L.ptr(mean), L.ptr(var),
                float(eps), L.ptr(g), L.ptr(b), L.ptr(res), act, L.ptr(y), L.stream())
-        ctx.save_for_backward(x, y, g, mean, var, cnt, seg)
+        # without a residual the backward pass recomputes act'(.) from x, gamma, beta (norm.hip bn_pre): y is not read there
+        ctx.save_for_backward(x, y if res is not None else None, g, mean, var, cnt, seg, b)
         ctx.cfg = (nseg, float(eps), act, residual is not None, stats_const,
                    gamma.shape if gamma is not None else None, beta.shape if beta is not None else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, g, mean, var, cnt, seg = ctx.saved_tensors
+        x, y, g, mean, var, cnt, seg, b = ctx.saved_tensors
         nseg, eps, act, has_res, stats_const, gshape, bshape = ctx.cfg
         gy = gy.contiguous()
         n, C = x.shape
@@ -272,7 +273,7 @@ class _NormAct(torch.autograd.Function):
         sums = torch.empty((nseg, 2, C), dtype=torch.float32, device=dev)
         ws = L.workspace(L.query('fc_norm_act_bwd_ws_bytes', n, C, nseg), dev)
         L.call('fc_norm_act_bwd', L.ptr(x), L.ptr(y), L.ptr(gy), L.ptr(seg), 4 if seg is not None else 0, n, C, nseg,
-               L.ptr(mean), L.ptr(var), L.ptr(cnt), eps, L.ptr(g), act, L.ptr(gx), L.ptr(gres), L.ptr(sums),
+               L.ptr(mean), L.ptr(var), L.ptr(cnt), eps, L.ptr(g), L.ptr(b), act, L.ptr(gx), L.ptr(gres), L.ptr(sums),
                L.ptr(ws), ws.numel(), L.stream())
         if stats_const:
             raise RuntimeError('backward through eval-mode normalisation is not supported')
@@ -311,7 +312,7 @@ class _BNTrainSmall(torch.autograd.Function):
         L.call('fc_bn_act_train_fwd', L.ptr(x), n, C, float(eps), L.ptr(g), L.ptr(b), L.ptr(res), act, float(momentum),
                L.ptr(y), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(cnt), L.ptr(rmean), L.ptr(rvar), L.ptr(nbt), L.ptr(ws),
                ws.numel(), L.stream())
-        ctx.save_for_backward(x, y, g, stats)
+        ctx.save_for_backward(x, y if res is not None else None, g, stats, b)
         ctx.cfg = (float(eps), act, residual is not None, gamma.shape, beta.shape)
         ctx.mark_non_differentiable(stats, cnt)
         ctx.set_materialize_grads(False)           # no zero-filled grads for the two statistics outputs
@@ -319,7 +320,7 @@ class _BNTrainSmall(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gs, _gc):
-        x, y, g, stats = ctx.saved_tensors
+        x, y, g, stats, b = ctx.saved_tensors
         eps, act, has_res, gshape, bshape = ctx.cfg
         gy = gy.contiguous()
         n, C = x.shape
@@ -329,7 +330,7 @@ class _BNTrainSmall(torch.autograd.Function):
         sums = torch.empty((2, C), dtype=torch.float32, device=dev)
         ws = L.workspace(L.query('fc_bn_small_ws_bytes', C), dev)
         L.call('fc_bn_act_train_bwd', L.ptr(x), L.ptr(y), L.ptr(gy), n, C, L.ptr(stats[0]), L.ptr(stats[1]), eps, L.ptr(g),
-               act, L.ptr(gx), L.ptr(gres), L.ptr(sums), L.ptr(ws), ws.numel(), L.stream())
+               L.ptr(b), act, L.ptr(gx), L.ptr(gres), L.ptr(sums), L.ptr(ws), ws.numel(), L.stream())
         return gx, sums[1].reshape(gshape), sums[0].reshape(bshape), gres, None, None, None, None, None, None
 
 

@@ -203,7 +203,8 @@ int fc_norm_act_fwd(const float* x, const int* seg, int seg_stride, int64_t n, i
 int64_t fc_norm_act_bwd_ws_bytes(int64_t n, int C, int nseg);
 int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* seg, int seg_stride, int64_t n, int C,
                     int nseg, const float* mean, const float* var, const float* cnt, float eps, const float* gamma,
-                    int act, float* gx, float* gres, float* sums, void* ws, int64_t ws_bytes, hipStream_t stream);
+                    const float* beta, int act, float* gx, float* gres, float* sums, void* ws, int64_t ws_bytes,
+                    hipStream_t stream);
 
 /* Training-mode ME.MinkowskiBatchNorm (+ fused ReLU/ELU / residual; the BasicBlock norms of me_resnet.py:3, :56-63 and the
  * neck norms of fcaf3d_neck_with_head.py:53, :62, :68) for small feature matrices in TWO launches per direction: batch statistics, running-buffer update (nn.BatchNorm1d momentum / unbiased variance) and apply. */
@@ -217,8 +218,8 @@ int fc_bn_act_train_fwd(const float* x, int64_t n, int C, float eps, const float
                         float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
                         int64_t ws_bytes, hipStream_t stream);
 int fc_bn_act_train_bwd(const float* x, const float* y, const float* gy, int64_t n, int C, const float* mean,
-                        const float* var, float eps, const float* gamma, int act, float* gx, float* gres, float* sums,
-                        void* ws, int64_t ws_bytes, hipStream_t stream);
+                        const float* var, float eps, const float* gamma, const float* beta, int act, float* gx, float* gres,
+                        float* sums, void* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* ME.MinkowskiMaxPooling(k=2,s=2) — me_resnet.py:24. */
 int fc_maxpool_fwd(const float* in, const int* nbr, int64_t n_out, int K, int C, float* out, int* argrow,
