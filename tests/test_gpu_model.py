@@ -99,9 +99,10 @@ def test_forward_train_parity(name, levels, B, n_points, kw):
     # of the fp32 oracle itself: what separates fp32 from fp64 is not round-off of the kernels but the discrete decisions
     # both fp32 paths take alike (a ReLU / max-pool argmax / top-k on a pre-activation that is +1e-8 in fp32 and -1e-9 in
     # fp64; in the deepest stage, 109-862 rows, one flipped row is several percent of a weight gradient).  So:
-    #   (1) against the fp32 oracle, every tensor within 1e-2 of its scale (r2 bound: 6e-2 against fp64; measured worst
-    #       4.9e-3 on backbone.layer3.5.conv1.kernel at 4 levels x 30k points, median 1.8e-4 — two fp32 implementations
-    #       also take a handful of those decisions differently);
+    #   (1) against the fp32 oracle: the MEDIAN tensor within 1e-3 of its scale, every tensor within the flip envelope
+    #       6e-2 (which of two fp32 implementations sides with fp64 on such a decision is chance: with another rounding of
+    #       the BatchNorm pre-activation the HIP path sat at 3.0e-6 median from fp64 and 3.7e-2 from the fp32 oracle on
+    #       backbone.layer3.0.conv1.kernel — exactly the fp32 oracle's own distance from fp64 there);
     #   (2) against the fp64 oracle, every tensor within 2x the fp32 oracle's own distance + 2e-3.
     P64 = {k: (v.detach().double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in P.items()}
     sum(MO.forward_train(P64, m, pts, gts, labs).values()).backward()
@@ -112,7 +113,7 @@ def test_forward_train_parity(name, levels, B, n_points, kw):
     print(f'{name} L={levels} B={B} n={n_points}: gradient error vs the fp32 oracle: worst {errs_32[worst32]:.2e} ({worst32}), '
           f'median {np.median(list(errs_32.values())):.2e}; vs the fp64 oracle: HIP worst {errs[worst]:.2e} ({worst}), fp32 oracle '
           f'on the same tensor {errs_o[worst]:.2e}; medians {np.median(list(errs.values())):.2e} / {np.median(list(errs_o.values())):.2e}')
-    assert errs_32[worst32] < 1e-2, (worst32, errs_32[worst32])
+    assert errs_32[worst32] < 6e-2, (worst32, errs_32[worst32])
     assert np.median(list(errs_32.values())) < 1e-3
     over = {k: (errs[k], errs_o[k]) for k in errs if errs[k] > 2.0 * errs_o[k] + 2e-3}
     assert not over, over
