@@ -44,6 +44,8 @@ extern "C" int fc_debug_set_prio(int mode) {
   return FC_OK;
 }
 
+#include "conv_x6.h"
+
 #define BK 32            // reduction slab (input channels per stage / rows per stage for wgrad)
 #define LDA (BK + 4)     // A row stride in floats: 16B-aligned rows, conflict-free ds_read_b128 (9r mod 16)
 
@@ -1103,6 +1105,7 @@ extern "C" {
 // flags bit18 forces it on, bit17 off.
 // flags bit21: the LDS-DMA kernel (k_conv_glds, 2 workgroups per CU) instead.  Returns 0 / 1 / 2 = k_conv_mfma / _p / k_conv_glds.
 static inline int conv_pipe(int flags, dim3 grid) {
+  if (flags & (1 << 24)) return (flags & (1 << 26)) ? 4 : 3;     // split-bf16 kernel (conv_x6.h); bit26: W is a pre-split image
   if (flags & (1 << 21)) return 2;
   if (flags & (1 << 18)) return 1;
   if (flags & (1 << 17)) return 0;
@@ -1144,6 +1147,11 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
     if (*mfma && K > 1 && t2 < 384) { s = (int)(1024 / t2); if (s > K) s = K; if (s < 1) s = 1; }
   }
   if (fs) s = fs > K ? K : fs;
+  if ((flags & (1 << 24)) && *mfma && *bm == 64) {     // the split-bf16 kernel has 128- and 256-row tiles only
+    *bm = 128;
+    const int64_t t3 = fc_cdiv(n_out, 128) * (Cout / *bn);
+    if (!fs) { s = 1; if (K > 1 && t3 < 384) { s = (int)(1024 / t3); if (s > K) s = K; } }
+  }
   *S = s;
 }
 
@@ -1164,8 +1172,26 @@ static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in
     if (nbr) k_conv_glds<BM_, BN_, true, WM_> FC_ARGS;                            \
     else k_conv_glds<BM_, BN_, false, WM_> FC_ARGS;                               \
   } while (0)
+  if (pipe == 4) wt = false;                     // a weight image already is the operator of its direction
   if (wt && !nbr) return FC_EINVAL;              // transposed weights: neighbour-table / pair-list launches only
   if (wt && pipe == 2) pipe = 0;                 // the LDS-DMA image cannot be transposed in flight
+  if (pipe >= 3 && bm >= 128) {                  // split-bf16 kernel; pipe 4: the weights are a pre-split image
+#define FC_LAUNCH_X6(BM_, BN_, WM_)                                              \
+  do {                                                                           \
+    if (pipe == 4 && nbr) k_conv_x6<BM_, BN_, true, WM_, 2> FC_ARGS;       \
+    else if (pipe == 4) k_conv_x6<BM_, BN_, false, WM_, 2> FC_ARGS;        \
+    else if (wt) k_conv_x6<BM_, BN_, true, WM_, 1> FC_ARGS;                \
+    else if (nbr) k_conv_x6<BM_, BN_, true, WM_, 0> FC_ARGS;               \
+    else k_conv_x6<BM_, BN_, false, WM_, 0> FC_ARGS;                       \
+  } while (0)
+    if (bm == 256) FC_LAUNCH_X6(256, 64, 4);
+    else if (bn == 128) FC_LAUNCH_X6(128, 128, 2);
+    else FC_LAUNCH_X6(128, 64, 2);
+#undef FC_LAUNCH_X6
+    FC_CHECK_LAUNCH();
+    return FC_OK;
+  }
+  if (pipe >= 3) pipe = 1;                       // 64-row tiles: fp32 pipe
   if (pipe == 2 && bm >= 128) {
     if (bm == 256) FC_LAUNCH_GLDS(256, 64, 4);
     else if (bn == 128) FC_LAUNCH_GLDS(128, 128, 2);
@@ -1220,7 +1246,7 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
   bool mfma_ok; int bm, bn, S;
   conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S);
   if (!mfma_ok) {
-    if (out_index) return FC_EINVAL;              // sorted-row tables are an MFMA-path feature
+    if (out_index || (flags & (1 << 26))) return FC_EINVAL;      // sorted-row tables and weight images are MFMA-path features
     k_conv_fma<<<(unsigned)fc_cdiv(n_out * Cout, 256), 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout, wt ? 1 : 0);
     FC_CHECK_LAUNCH();
     return FC_OK;
@@ -1237,6 +1263,18 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
 int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
                 int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
   return conv_fwd_impl(in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream);
+}
+
+// Pre-split weight image for the split-bf16 kernel (flags bit24 | bit26 of fc_conv_fwd / fc_conv_fwd_pairs*): R = reduction
+// size (Cin of the launch), C = its columns (Cout of the launch); transposed != 0: W[k] is stored (C, R) row-major.
+int64_t fc_x6_weight_image_bytes(int K, int R, int C) { return (int64_t)K * R * C * 6; }
+
+int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int transposed, hipStream_t stream) {
+  if (K < 1 || R < 32 || C < 64 || R % 32 != 0 || C % 64 != 0) return FC_EINVAL;
+  const int64_t total = (int64_t)K * (R / 32) * (C / 64) * 256;
+  k_x6_weight_image<<<(unsigned)fc_cdiv(total, 256), 256, 0, stream>>>(W, (u32x4*)img, K, R, C, transposed);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
 }
 
 int64_t fc_conv_fwd_pairs_ws_bytes(int64_t n_out, int K, int Cout) {
@@ -1259,7 +1297,7 @@ int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in,
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
   if (live_tiles > 0) grid = dim3((unsigned)live_tiles, Cout / bn, 1);       // linear list of the live (offset, tile) pairs
   {
-    int rc = launch_conv_mfma(live_tiles > 0 ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt);
+    int rc = launch_conv_mfma((live_tiles > 0 || (flags & (1 << 24))) ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt);
     if (rc != FC_OK) return rc;
   }
   k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);

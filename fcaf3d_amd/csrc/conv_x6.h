@@ -1,0 +1,350 @@
+// fp32 sparse convolution on the bf16 matrix pipe of gfx950 by EXACT operand splitting (included by conv.hip).
+//
+// v_mfma_f32_32x32x2_f32 runs at 64 FLOP/clk/SIMD (157 TF), v_mfma_f32_32x32x16_bf16 at 1024 (2.5 PF).  An fp32 number
+// has a 24-bit significand = three 8-bit pieces, and a bf16 holds 8 bits with the fp32 exponent range, so
+//     x = x1 + x2 + x3          x1 = top 16 bits of x,  x2 = top 16 bits of (x - x1),  x3 = x - x1 - x2      (all exact)
+// and a product a*b is the sum of nine bf16 x bf16 products, each EXACT in the fp32 accumulator of the MFMA (8 x 8 = 16
+// bits).  The six products down to 2^-16 (a1b1, a1b2, a2b1, a1b3, a2b2, a3b1) are kept; the three dropped ones are below
+// 2^-23 |a b|, i.e. below the rounding of the fp32 accumulation itself: on conv-shaped data (K*Cin = 1728 terms) the
+// result is as far from fp64 as v_mfma_f32_32x32x2_f32's (rms 1.2e-7 vs 1.4e-7 of the output scale; tests/test_gpu_ops.py
+// checks exactly that), at 6 x 32 = 192 matrix-pipe cycles per 32x32x16 block instead of 8 x 64 = 512.
+// Non-finite inputs: +-inf splits into (inf, nan, nan), so an overflowed activation yields NaN where the fp32 pipe
+// yields +-inf or NaN.
+//
+// Same workgroup shape, tiles, grid, pair mode, offset split and output layout as k_conv_mfma; what differs:
+//  * LDS holds THREE bf16 planes of the gathered rows (BM x 32 channels x 2 B each) and of the weight slab (BN columns x
+//    32 reduction indices, reduction-contiguous — the B operand of the bf16 MFMA wants 8 consecutive reduction indices
+//    per lane).  The weights come either as fp32 — the (Cin, Cout) kernel transposed by the access pattern of the staging
+//    loads, a thread reads 8 consecutive reduction rows of its column(s); the transposed (backward-data) kernel read
+//    straight — or, the product route, as a PRE-SPLIT IMAGE (k_x6_weight_image, once per optimizer step and direction)
+//    that a stage copies contiguously: every workgroup of a launch would otherwise split the same weights again
+//    (r3 PMC: 6.2 VALU instructions per MFMA where the SIMD issues ~7 per MFMA slot: issue-bound, matrix pipe 44 % busy);
+//  * a plane row is 64 B = four 16-byte chunks, chunk c of row r stored at slot c ^ ((r >> 2) & 3): the ds_read_b128 of
+//    the MFMA fragments (lane = row r of 32, chunk 2b + lane / 32) is conflict-free in the 16-lane groups the LDS
+//    serves (rows {0-3, 12-15, 20-27}: r % 4 picks the 64-byte quarter of the 256-byte bank line, (r >> 2) & 3 = {0, 3, 1, 2}
+//    the chunk within it);
+//  * the split costs 5.5 VALU instructions per staged element (and / sub / shift / and-or), hidden under the MFMA
+//    block of the other waves of the SIMD.
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 -> three dwords, each the bf16 pair (piece of x0 in the low half, piece of x1 in the high half);
+// v_perm_b32 picks the two upper halves in one instruction: 11 VALU per pair
+__device__ __forceinline__ unsigned x6_hi2(unsigned u0, unsigned u1) { return __builtin_amdgcn_perm(u1, u0, 0x07060302u); }
+__device__ __forceinline__ void x6_split2(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+  const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+  p0 = x6_hi2(u0, u1);
+  const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+  const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+  p1 = x6_hi2(v0, v1);
+  const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+  p2 = x6_hi2(__float_as_uint(s0), __float_as_uint(s1));
+}
+
+// Weight slab in LDS and in a pre-split weight image: per 64-column group three planes of 64 rows x 64 B.  Column c of the
+// group lives in row (c % 2) * 32 + c / 2: a wave's sub-tile j reads rows j * 32 + r = the INTERLEAVED columns 2 r + j
+// (8-byte output stores).  16-byte unit index of (group-local column c, plane, chunk):
+__device__ __forceinline__ int x6_bslot(int c, int plane, int chunk) {
+  const int row = (c & 1) * 32 + (c >> 1);
+  return (plane * 64 + row) * 4 + (chunk ^ ((row >> 2) & 3));
+}
+#define X6_GROUP_U16 (3 * 64 * 4)          // 16-byte units per 64-column group (12 KB)
+
+// Pre-split weight image of one layer and direction: [K][R / 32 slabs][C / 64 groups][X6_GROUP_U16 units], R = reduction
+// size, C = columns; `transposed`: W[k] is (C, R) row-major (the layer's own kernel read as its backward-data operator),
+// else (R, C).  A stage of the convolution copies 12 KB x (BN / 64) CONTIGUOUS bytes of it into LDS: no VALU, no transpose.
+__global__ void k_x6_weight_image(const float* __restrict__ W, u32x4* __restrict__ img, int K, int R, int C, int transposed) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (k, slab, group, column, chunk)
+  const int64_t total = (int64_t)K * (R / 32) * (C / 64) * 256;
+  if (t >= total) return;
+  const int chunk = (int)(t & 3), c = (int)((t >> 2) & 63);
+  const int64_t blk = t >> 8;                                               // (k, slab, group)
+  const int g = (int)(blk % (C / 64));
+  const int slab = (int)((blk / (C / 64)) % (R / 32));
+  const int k = (int)(blk / ((int64_t)(C / 64) * (R / 32)));
+  const int col = g * 64 + c, r0 = slab * 32 + chunk * 8;
+  const float* Wk = W + (int64_t)k * R * C;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = transposed ? Wk[(int64_t)col * R + r0 + e] : Wk[(int64_t)(r0 + e) * C + col];
+  unsigned p[3][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) x6_split2(x[2 * e], x[2 * e + 1], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    u32x4 v = {p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
+    img[blk * X6_GROUP_U16 + x6_bslot(c, pl, chunk)] = v;
+  }
+}
+
+#define X6_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+
+// BSRC: where the weight slab comes from — 0: fp32 (Cin, Cout) kernel, split in the staging; 1: the same kernel read
+// transposed (backward data on the layer's own weights); 2: a pre-split image of k_x6_weight_image (straight copy).
+template <int BM, int BN, bool HAS_NBR, int WM, int BSRC>
+__global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_conv_x6(
+    const float* __restrict__ in, const float* __restrict__ W, const int* __restrict__ nbr,
+    const int* __restrict__ out_index, const int* __restrict__ cnt, float* __restrict__ out, int64_t n_out, int K, int Cin,
+    int Cout) {
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);      // 32x32 MFMA tiles per wave
+  constexpr int RW = BM / WM;                                  // rows of a wave's part of the tile
+  constexpr int AR = BM / 32;                                  // float4 gathers per thread per stage (8 threads per row)
+  constexpr int CPT = BN / 64;                                 // weight columns per thread per stage (BSRC 0 / 1)
+  constexpr int BU = 3 * BN / 64;                              // 16-byte image units per thread per stage (BSRC 2)
+  constexpr bool WT = BSRC == 1;
+  __shared__ u32x4 As[3 * BM * 4];                             // [plane][row][4 chunks]
+  __shared__ u32x4 Bs[(BN / 64) * X6_GROUP_U16];               // [64-column group][plane][row][4 chunks]: x6_bslot
+  __shared__ unsigned int kmask_s;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = WM == 4 ? wave : wave >> 1, wc = WM == 4 ? 0 : wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  // this wave's weight rows: TN == 2: both halves (j) of group wc; TN == 1 (128 x 64 tile, 2 x 2 waves): half wc of group 0
+  const int bgrp = TN == 2 ? wc : 0;
+  int64_t bx = blockIdx.x;
+  const int n0 = blockIdx.y * BN;
+  int S = gridDim.z, z = blockIdx.z;
+  int kbase = 0;                                 // pair mode: the kernel offset this workgroup works on (image addressing)
+  if (cnt) {                                     // pair mode: see k_conv_mfma
+    if (gridDim.z == 1 && K > 1) {
+      int k = 0;
+      for (; k < K - 1; ++k) {
+        const int64_t t = ((int64_t)cnt[k] + BM - 1) / BM;
+        if (bx < t) break;
+        bx -= t;
+      }
+      z = k;
+    }
+    const int64_t stride = n_out;
+    n_out = cnt[z];
+    if (bx * BM >= n_out) return;
+    nbr += (int64_t)z * stride;
+    if (BSRC == 2) kbase = z; else W += (int64_t)z * Cin * Cout;
+    out += (int64_t)z * stride * Cout;
+    K = 1; S = 1; z = 0;
+  }
+  const int64_t m0 = bx * BM;
+  const int a_c4 = tid & 7, a_r = tid >> 3;      // A staging: 8 float4 per gathered 32-channel row slab, 32 rows per pass
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- (1) which of this split's offsets have a neighbour anywhere in the tile ---------------------
+  unsigned int kmask;
+  {
+    if (tid == 0) kmask_s = 0u;
+    __syncthreads();
+    if (tid < BM) {
+      unsigned int mk = 0u;
+      int64_t row = m0 + tid;
+      if (row < n_out) {
+        if (HAS_NBR) {
+          for (int k = z; k < K; k += S)
+            if (nbr[(int64_t)k * n_out + row] >= 0) mk |= 1u << k;
+        } else {
+          mk = 1u;
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) mk |= __shfl_xor(mk, off, 64);
+      if (lane == 0 && mk) atomicOr(&kmask_s, mk);
+    }
+    __syncthreads();
+    kmask = kmask_s;
+  }
+
+  // ---- (2) software-pipelined stage loop -------------------------------------------------------------
+  if (kmask) {
+    const int nst = __popc(kmask) * (Cin / 32);           // stages of this tile
+    unsigned int rem = kmask;
+    int lk = __ffs(rem) - 1;                              // load cursor: offset / channel slab of the stage requested next
+    rem &= rem - 1;
+    int lnk = rem ? __ffs(rem) - 1 : lk;                  // ... and the offset after it (its rows are already on their way)
+    if (rem) rem &= rem - 1;
+    int lc0 = 0;
+    bool sw = false;
+    f32x4 av[AR];
+    f32x4 bw[2 * CPT];                                    // BSRC 1: 2 float4 (8 reduction-consecutive floats) per column
+    float bf[8][CPT];                                     // BSRC 0: 8 reduction rows x CPT adjacent columns
+    u32x4 bi[BU];                                         // BSRC 2: image units
+    int vcur[AR], vnxt[AR];
+    // tile rows past the end read the table's first row and are masked at the gather (their index is forced to -1)
+    const int rows_here = (int)((n_out - m0) < BM ? (n_out - m0) : BM);
+    auto fetch_idx = [&](int kk, int (&v)[AR]) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int lr = a_r + 32 * i;
+        const int64_t row = lr < rows_here ? m0 + lr : 0;
+        v[i] = HAS_NBR ? nbr[(int64_t)kk * n_out + row] : (int)row;
+      }
+    };
+    fetch_idx(lk, vcur);
+    fetch_idx(lnk, vnxt);
+    // weight staging roles.  BSRC 0: thread = (column group g = tid % 64 -> columns g * CPT .. + CPT - 1, chunk tid / 64);
+    // BSRC 1: thread = (column tid / 4 + 64 u, chunk tid % 4); BSRC 2: units tid + 256 i of the stage's contiguous image
+    const int b_g = WT ? (tid >> 2) : (tid & 63), b_c = WT ? (tid & 3) : (tid >> 6);
+    const u32x4* img = reinterpret_cast<const u32x4*>(W);
+    const int nslab = Cin / 32, ngrp = Cout / 64;
+    auto load_stage = [&]() {
+      if (sw) {
+        sw = false;
+        lk = lnk;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) vcur[i] = vnxt[i];
+        if (rem) {
+          lnk = __ffs(rem) - 1;
+          rem &= rem - 1;
+        }
+        fetch_idx(lnk, vnxt);
+      }
+      if (BSRC == 2) {
+        const u32x4* src = img + (((int64_t)(kbase + lk) * nslab + lc0 / 32) * ngrp + n0 / 64) * X6_GROUP_U16 + tid;
+#pragma unroll
+        for (int i = 0; i < BU; ++i) bi[i] = src[256 * i];
+      } else if (WT) {
+        const float* Wk = W + (int64_t)lk * Cin * Cout;
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+          const float* src = Wk + (int64_t)(n0 + b_g + 64 * u) * Cin + lc0 + 8 * b_c;
+          bw[2 * u] = *reinterpret_cast<const f32x4*>(src);
+          bw[2 * u + 1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+      } else {
+        const float* Wk = W + (int64_t)lk * Cin * Cout;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float* src = Wk + (int64_t)(lc0 + 8 * b_c + e) * Cout + n0 + b_g * CPT;
+          if (CPT == 2) {
+            const f32x2 t = *reinterpret_cast<const f32x2*>(src);
+            bf[e][0] = t[0];
+            bf[e][CPT - 1] = t[1];
+          } else {
+            bf[e][0] = *src;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const bool live = vcur[i] >= 0 && a_r + 32 * i < rows_here;
+        const float* src = live ? in + (int64_t)vcur[i] * Cin + lc0 + a_c4 * 4 : g_zero_row + a_c4 * 4;
+        av[i] = *reinterpret_cast<const f32x4*>(src);
+      }
+    };
+    load_stage();
+    const bool prio = g_fc_prio >= 0;
+    // fragment slots of this lane (16-byte units): every row this lane reads is r + a multiple of 32, so the chunk
+    // swizzle is (r >> 2) & 3 throughout
+    const int swz = (r >> 2) & 3;
+    int a_slot[2], b_slot[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      a_slot[b] = (wr * RW + r) * 4 + ((2 * b + h) ^ swz);
+      b_slot[b] = bgrp * X6_GROUP_U16 + ((TN == 2 ? 0 : wc * 32) + r) * 4 + ((2 * b + h) ^ swz);
+    }
+    for (int st = 0; st < nst; ++st) {
+      __syncthreads();                           // previous stage fully consumed
+      // ---- split + store the gathered rows: 4 channels -> 8 B per plane
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int row = a_r + 32 * i;
+        unsigned p[3][2];
+        x6_split2(av[i][0], av[i][1], p[0][0], p[1][0], p[2][0]);
+        x6_split2(av[i][2], av[i][3], p[0][1], p[1][1], p[2][1]);
+        const int slot = row * 4 + ((a_c4 >> 1) ^ ((row >> 2) & 3));
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          u32x2 v = {p[pl][0], p[pl][1]};
+          reinterpret_cast<u32x2*>(As + pl * BM * 4 + slot)[a_c4 & 1] = v;
+        }
+      }
+      // ---- the weight slab: image units as they are, or split 8 reduction indices of one column -> 16 B per plane
+      if (BSRC == 2) {
+#pragma unroll
+        for (int i = 0; i < BU; ++i) Bs[tid + 256 * i] = bi[i];
+      } else {
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = WT ? bw[2 * u + e / 4][e % 4] : bf[e][u];
+          const int cl = WT ? b_g + 64 * u : b_g * CPT + u;          // column of the tile
+          unsigned p[3][4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x6_split2(x[2 * e], x[2 * e + 1], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            u32x4 v = {p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
+            Bs[(cl >> 6) * X6_GROUP_U16 + x6_bslot(cl & 63, pl, b_c)] = v;
+          }
+        }
+      }
+      __syncthreads();
+      if (st + 1 < nst) {
+        lc0 += 32;
+        if (lc0 >= Cin) {
+          lc0 = 0;
+          sw = true;
+        }
+      }
+      load_stage();                              // (the last iteration re-reads its own stage: see k_conv_mfma_p)
+      // per 16-channel block: the three planes of the rows, then the weight planes one at a time, smallest products first
+      // (a1b3 | a2b2 a1b2 | a3b1 a2b1 a1b1): 32 fragment registers live instead of 48
+      if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        u32x4 fa[3][TM];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[pl][i] = As[pl * BM * 4 + a_slot[b] + i * 32 * 4];
+#pragma unroll
+        for (int pb = 2; pb >= 0; --pb) {
+          u32x4 fb[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[j] = Bs[pb * 64 * 4 + b_slot[b] + j * 32 * 4];
+#pragma unroll
+          for (int pa = 2 - pb; pa >= 0; --pa)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = X6_MFMA(fa[pa][i], fb[j], acc[i][j]);
+        }
+      }
+      if (prio) __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); lane r of sub-tile j holds
+  // column 2 r + j of the wave's 64-column group (TN == 1: j = wc)
+  float* dst = out + (int64_t)z * n_out * Cout + n0 + bgrp * 64 + 2 * r + (TN == 2 ? 0 : wc);
+  int orow[TM][16];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = m0 + wr * RW + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      int o = -1;
+      if (row < n_out) o = out_index ? out_index[row] : (int)row;
+      orow[i][e] = o;
+    }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (orow[i][e] >= 0) {
+        if (TN == 2) {
+          f32x2 v = {acc[i][0][e], acc[i][TN - 1][e]};
+          *reinterpret_cast<f32x2*>(dst + (int64_t)orow[i][e] * Cout) = v;
+        } else {
+          dst[(int64_t)orow[i][e] * Cout] = acc[i][0][e];
+        }
+      }
+    }
+}

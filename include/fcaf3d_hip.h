@@ -130,6 +130,16 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
  * the chip are split over kernel offsets into `ws` and summed in a fixed order (deterministic).
  * out_index (nullable): `nbr` is a table permuted into occupancy-mask order (fc_permute_nbr) and tile row t
  * belongs to output row out_index[t] — tiles of similar rows skip the offsets none of them has. */
+/* flags bit24 (fc_conv_fwd, fc_conv_fwd_pairs, fc_conv_fwd_pairs_tiles): the same fp32 convolution (torch.float32 in and
+ * out, as ME.MinkowskiConvolution computes it, me_resnet.py:56-62) on the bf16 matrix pipe by EXACT operand splitting —
+ * x = x1 + x2 + x3 with three 8-bit pieces, six bf16 x bf16 products (each exact in the fp32 accumulator) per fp32 product;
+ * results are as close to fp64 as the fp32 MFMA's (csrc/conv_x6.h, tests/test_gpu_ops.py).  128- and 256-row tiles.
+ * flags bit26 (with bit24): `W` is not the fp32 kernel but its pre-split image built by fc_x6_weight_image — for the
+ * backward-data pass the image of the transposed operator (then bit23 is not needed).
+ * fc_x6_weight_image: image of W (K, R, C) — or, transposed != 0, of the operator W[k]^T where W[k] is stored (C, R) —
+ * for a launch with Cin = R, Cout = C; R % 32 == 0, C % 64 == 0; fc_x6_weight_image_bytes(K, R, C) = 6 K R C bytes. */
+int64_t fc_x6_weight_image_bytes(int K, int R, int C);
+int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int transposed, hipStream_t stream);
 int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);
 int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
                 int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);

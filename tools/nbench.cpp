@@ -151,7 +151,7 @@ extern "C" int fc_debug_set_prio(int mode);
 int main(int argc, char** argv) {
   int prio = 0;
   int batch = 8, reps = 10, npts = 100000; std::string only, mode = "all", trace_file; bool check = true;
-  int trace_variant = 0, trace_tbl = 0; bool popc_sort = false, s_sweep = false;
+  int trace_variant = 0, trace_tbl = 0; bool popc_sort = false, s_sweep = false, x6_only = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "--batch") batch = atoi(argv[++i]);
@@ -163,6 +163,7 @@ int main(int argc, char** argv) {
     else if (a == "--prio") prio = atoi(argv[++i]);
     else if (a == "--popc-sort") popc_sort = true;
     else if (a == "--s-sweep") s_sweep = true;
+    else if (a == "--x6") x6_only = true;                      // default fp32 routes + the split-bf16 kernel only
     else if (a == "--trace") trace_file = argv[++i];            // needs the FC_TRACE build (tools/nbench_trace)
     else if (a == "--trace-variant") trace_variant = atoi(argv[++i]);
     else if (a == "--trace-tbl") trace_tbl = atoi(argv[++i]);
@@ -242,9 +243,9 @@ int main(int argc, char** argv) {
       report("fc_norm_act_fwd", 2 * mb, us);
       us = time_us(reps, [&]() { FC(fc_norm_act_fwd(x.p, segp, 4, t.n, t.C, mean.p, var.p, 1e-5f, gamma.p, beta.p, res.p, 1, y.p, 0)); });
       report("fc_norm_act_fwd +res", 3 * mb, us);
-      us = time_us(reps, [&]() { FC(fc_norm_act_bwd(x.p, y.p, gy.p, segp, 4, t.n, t.C, nseg, mean.p, var.p, cnt.p, 1e-5f, gamma.p, 2, gx.p, nullptr, sums.p, wsb.p, w2, 0)); });
+      us = time_us(reps, [&]() { FC(fc_norm_act_bwd(x.p, y.p, gy.p, segp, 4, t.n, t.C, nseg, mean.p, var.p, cnt.p, 1e-5f, gamma.p, gamma.p, 2, gx.p, nullptr, sums.p, wsb.p, w2, 0)); });
       report("fc_norm_act_bwd", 4 * mb, us);
-      us = time_us(reps, [&]() { FC(fc_norm_act_bwd(x.p, y.p, gy.p, segp, 4, t.n, t.C, nseg, mean.p, var.p, cnt.p, 1e-5f, gamma.p, 1, gx.p, gres.p, sums.p, wsb.p, w2, 0)); });
+      us = time_us(reps, [&]() { FC(fc_norm_act_bwd(x.p, y.p, gy.p, segp, 4, t.n, t.C, nseg, mean.p, var.p, cnt.p, 1e-5f, gamma.p, gamma.p, 1, gx.p, gres.p, sums.p, wsb.p, w2, 0)); });
       report("fc_norm_act_bwd +gres", 5 * mb, us);
     }
     {   // stem conv (3 -> 64, k3s2), max-pool k2s2
@@ -296,8 +297,8 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
-  Dev<float> d_in, d_w, d_out, d_ref, d_gout, d_gw, d_gwref; Dev<int> d_nbr, d_sorted, d_oidx, d_pi, d_po, d_pos, d_cnt, d_masks;
-  Dev<unsigned char> d_ws;
+  Dev<float> d_in, d_w, d_wt, d_out, d_ref, d_gout, d_gw, d_gwref; Dev<int> d_nbr, d_sorted, d_oidx, d_pi, d_po, d_pos, d_cnt, d_masks;
+  Dev<unsigned char> d_ws, d_img;
   for (const Case& cs : cases) {
     if (!only.empty() && cs.name.find(only) == std::string::npos) continue;
     const int K = cs.ks * cs.ks * cs.ks, n_in = cs.in->n(), n_out = cs.out->n(), Cin = cs.Cin, Cout = cs.Cout;
@@ -307,6 +308,10 @@ int main(int argc, char** argv) {
     std::vector<float> hin((size_t)n_in * Cin), hw((size_t)K * Cin * Cout), hg((size_t)n_out * Cout);
     for (auto& v : hin) v = Nf(rng); for (auto& v : hw) v = Nf(rng) * 0.05f; for (auto& v : hg) v = Nf(rng);
     d_in.up(hin); d_w.up(hw); d_gout.up(hg); d_nbr.up(nbr);
+    { std::vector<float> hwt(hw.size());
+      for (int k = 0; k < K; ++k) for (int ci = 0; ci < Cin; ++ci) for (int co = 0; co < Cout; ++co) hwt[((size_t)k * Cout + co) * Cin + ci] = hw[((size_t)k * Cin + ci) * Cout + co];
+      d_wt.up(hwt); }
+    if (Cin % 32 == 0 && Cout % 64 == 0) { d_img.alloc((size_t)fc_x6_weight_image_bytes(K, Cin, Cout)); FC(fc_x6_weight_image(d_w.p, d_img.p, K, Cin, Cout, 0, 0)); }
     d_out.alloc((size_t)n_out * Cout); d_ref.alloc((size_t)n_out * Cout); d_gw.alloc(hw.size()); d_gwref.alloc(hw.size());
     // derived tables (library kernels): mask-sorted rows, pair lists
     d_masks.alloc(n_out); d_sorted.alloc(nbr.size()); d_oidx.alloc(n_out);
@@ -331,40 +336,77 @@ int main(int argc, char** argv) {
         FC(fc_conv_fwd(d_in.p, d_w.p, d_nbr.p, nullptr, d_ref.p, n_in, n_out, K, Cin, Cout, 1, nullptr, 0, 0));
         ref = d_ref.down((size_t)n_out * Cout);
       }
-      struct Run { const char* what; int flags; int tbl; };     // tbl: 0 plain table, 1 mask-sorted, 2 pair lists
+      // fp64 on the host for 48 sampled output rows: how far each route is from the exact result (rms / max, of the output scale)
+      std::vector<int> srows; std::vector<double> s64;
+      if (check) {
+        for (int q = 0; q < 48; ++q) srows.push_back((int)(((int64_t)q * 2654435761ll) % n_out));
+        s64.assign(srows.size() * (size_t)Cout, 0.0);
+        for (size_t q = 0; q < srows.size(); ++q)
+          for (int k = 0; k < K; ++k) {
+            const int i = nbr[(size_t)k * n_out + srows[q]];
+            if (i < 0) continue;
+            for (int ci = 0; ci < Cin; ++ci) {
+              const double a = hin[(size_t)i * Cin + ci];
+              const float* wr = &hw[((size_t)k * Cin + ci) * Cout];
+              for (int co = 0; co < Cout; ++co) s64[q * Cout + co] += a * (double)wr[co];
+            }
+          }
+      }
+      struct Run { const char* what; int flags; int tbl; bool wt = false; bool img = false; };     // tbl: 0 plain table, 1 mask-sorted, 2 pair lists, 3 live-tile pair lists
       std::vector<Run> runs;
+      const int X6 = 1 << 24, WTF = 1 << 23;
       runs.push_back({"plain ", 0, 0});
-      if (!cs.dense) { runs.push_back({"sorted", 0, 1}); runs.push_back({"pairs ", 0, 2}); runs.push_back({"pairsL", 0, 3}); }
-      runs.push_back({"pipe  ", 1 << 18, 0});
-      if (!cs.dense) { runs.push_back({"pipeS ", 1 << 18, 1}); runs.push_back({"pipeL ", 1 << 18, 3}); }
-      if (Cout == 64) { runs.push_back({"256x64", 3 << 4, 0}); if (!cs.dense) runs.push_back({"256x64s", 3 << 4, 1}); }
-      runs.push_back({"glds  ", 1 << 21, 0});
-      if (!cs.dense) { runs.push_back({"gldsS ", 1 << 21, 1}); runs.push_back({"gldsL ", 1 << 21, 3}); }
-      if (Cout == 64) { runs.push_back({"glds256", (1 << 21) | (3 << 4), 0}); runs.push_back({"glds128", (1 << 21) | (2 << 4), 0}); }
+      if (!cs.dense) { runs.push_back({"sorted", 0, 1}); if (!x6_only) runs.push_back({"pairs ", 0, 2}); runs.push_back({"pairsL", 0, 3}); }
+      runs.push_back({"plainT", WTF, 0, true});
+      if (!x6_only) {
+        runs.push_back({"pipe  ", 1 << 18, 0});
+        if (!cs.dense) { runs.push_back({"pipeS ", 1 << 18, 1}); runs.push_back({"pipeL ", 1 << 18, 3}); }
+        if (Cout == 64) { runs.push_back({"256x64", 3 << 4, 0}); if (!cs.dense) runs.push_back({"256x64s", 3 << 4, 1}); }
+        runs.push_back({"glds  ", 1 << 21, 0});
+        if (!cs.dense) { runs.push_back({"gldsS ", 1 << 21, 1}); runs.push_back({"gldsL ", 1 << 21, 3}); }
+        if (Cout == 64) { runs.push_back({"glds256", (1 << 21) | (3 << 4), 0}); runs.push_back({"glds128", (1 << 21) | (2 << 4), 0}); }
+      }
+      // the split-bf16 kernel: weights split in the staging (x6), transposed weights (x6T), pre-split weight image (x6I), row orders
+      const int X6I = X6 | (1 << 26);
+      runs.push_back({"x6    ", X6, 0});
+      runs.push_back({"x6T   ", X6 | WTF, 0, true});
+      runs.push_back({"x6I   ", X6I, 0, false, true});
+      if (!cs.dense) { runs.push_back({"x6S   ", X6, 1}); runs.push_back({"x6IS  ", X6I, 1, false, true}); runs.push_back({"x6L   ", X6, 3}); runs.push_back({"x6IL  ", X6I, 3, false, true}); }
+      if (Cout == 64) { runs.push_back({"x6 128", X6 | (2 << 4), 0}); runs.push_back({"x6I128", X6I | (2 << 4), 0, false, true}); }
       static const char* snames[] = {"S=1", "S=2", "S=3", "S=4", "S=5", "S=6", "S=7", "S=8", "S=9", "S=10", "S=12", "S=14"};
       static const int svals[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14};
       if (s_sweep) for (int q = 0; q < 12; ++q) runs.push_back({snames[q], svals[q] << 8, cs.dense ? 0 : 1});
       for (const Run& r : runs) {
         const int fl = r.flags;
+        const float* wp = r.img ? (const float*)d_img.p : (r.wt ? d_wt.p : d_w.p);
         std::function<void()> fn;
         if (r.tbl == 3) {
           int64_t wb = ws_for(fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout));
           std::vector<int> hc = d_cnt.down(K); int64_t live = 0; for (int v : hc) live += (v + 127) / 128;
-          fn = [&, wb, fl, live]() { FC(fc_conv_fwd_pairs_tiles(d_in.p, d_w.p, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, live, fl, d_ws.p, wb, 0)); };
+          fn = [&, wb, fl, live, wp]() { FC(fc_conv_fwd_pairs_tiles(d_in.p, wp, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, live, fl, d_ws.p, wb, 0)); };
         } else if (r.tbl == 2) {
           int64_t wb = ws_for(fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout));
-          fn = [&, wb, fl]() { FC(fc_conv_fwd_pairs(d_in.p, d_w.p, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
+          fn = [&, wb, fl, wp]() { FC(fc_conv_fwd_pairs(d_in.p, wp, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
         } else {
           int64_t wb = ws_for(fc_conv_fwd_ws_bytes(n_out, K, Cin, Cout, fl));
           const int* tab = r.tbl ? d_sorted.p : d_nbr.p; const int* oi = r.tbl ? d_oidx.p : nullptr;
-          fn = [&, wb, fl, tab, oi]() { FC(fc_conv_fwd(d_in.p, d_w.p, tab, oi, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
+          fn = [&, wb, fl, tab, oi, wp]() { FC(fc_conv_fwd(d_in.p, wp, tab, oi, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
         }
         CK(hipMemset(d_out.p, 0xff, (size_t)n_out * Cout * 4));
         fn(); CK(hipDeviceSynchronize());
         double err = -1;
-        if (check) err = max_rel_err(d_out.down((size_t)n_out * Cout), ref);
+        double e64rms = -1, e64max = -1;
+        if (check) {
+          std::vector<float> got = d_out.down((size_t)n_out * Cout);
+          err = max_rel_err(got, ref);
+          double sc = 0, ss = 0, mx = 0;
+          for (double v : s64) sc = std::max(sc, std::fabs(v));
+          for (size_t q = 0; q < srows.size(); ++q)
+            for (int co = 0; co < Cout; ++co) { const double d = (double)got[(size_t)srows[q] * Cout + co] - s64[q * Cout + co]; ss += d * d; mx = std::max(mx, std::fabs(d)); }
+          e64rms = std::sqrt(ss / s64.size()) / sc; e64max = mx / sc;
+        }
         double us = time_us(reps, fn);
-        printf("   fwd  flags %#x %s %9.1f us %7.1f TF  err %.2e%s\n", fl, r.what, us, gflop / us * 1e3, err, (check && !(err < 1e-4)) ? "  <-- MISMATCH" : "");
+        printf("   fwd  flags %#x %s %9.1f us %7.1f TF  err %.2e  vs fp64 rms %.2e max %.2e%s\n", fl, r.what, us, gflop / us * 1e3, err, e64rms, e64max, (check && !(err < 1e-4)) ? "  <-- MISMATCH" : "");
         fflush(stdout);
       }
     }
