@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_X6_TFLOPS = round(2500.0 / 6, 1)   # fp32 products as 6 bf16 MFMA products each (csrc/conv_x6.h): bf16 dense peak / 6
 
 
 def parse():
@@ -289,13 +290,23 @@ class ConvProbe:
                     n += 1
         achieved = flops / (ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
+        tj = os.path.join(ROOT, 'profiles', 'r3_traffic.json')
         if os.path.exists(tj):          # PMC passes cannot run inside the timed region: committed rocprofv3 result
             t = json.load(open(tj))
-            traffic, traffic_src = t['hbm_bytes_per_launch'], 'profiles/r2_traffic.json (' + t['method'] + ')'
-        return dict(bound='mfma', kernel='k_conv_mfma (sparse conv fwd + dgrad, dense GEMMs of convT/heads)',
-                    achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_unit='B/launch',
+            traffic, traffic_src = t['hbm_bytes_per_launch'], 'profiles/r3_traffic.json (' + t['method'] + ')'
+        import fcaf3d_amd.functional as Fn
+        x6 = bool(Fn.X6)
+        peak = PEAK_X6_TFLOPS if x6 else PEAK_F32_MFMA_TFLOPS
+        return dict(bound='mfma',
+                    kernel=('k_conv_x6 (sparse conv fwd + dgrad, dense GEMMs of convT/heads: fp32 in / fp32 accumulate, every fp32 '
+                            'product as 6 exact bf16 x bf16 products on v_mfma_f32_32x32x16_bf16)') if x6 else
+                    'k_conv_mfma (sparse conv fwd + dgrad, dense GEMMs of convT/heads)',
+                    achieved=round(achieved, 3), peak=peak, unit='TFLOP/s',
+                    peak_source=('bf16 dense MFMA peak 2500 TFLOP/s / 6 matrix products per fp32 product (MI355X_MICROARCH.md); '
+                                 'achieved counts the ALGORITHMIC fp32 FLOPs 2 P Cin Cout') if x6 else
+                    'v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)',
+                    frac=round(achieved / peak, 4), vs_f32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    traffic=traffic, traffic_unit='B/launch',
                     traffic_source=traffic_src, algorithmic_bytes_per_launch=round(alg_bytes / n), launches=n,
                     avg_launch_us=round(ms * 1e3 / n, 2), flops_per_launch=round(flops / n / 1e9, 4),
                     time_share_ms_per_step=None)

@@ -90,6 +90,31 @@ CONV_WT = 1 << 23          # flags bit of fc_conv_fwd / fc_conv_fwd_pairs_tiles:
 DGRAD_WT = os.environ.get('FC_DGRAD_TRANSPOSE', '0') != '1'      # backward-data reads the layer's own kernel (no transpose launch)
 
 
+# fp32 convolutions on the bf16 matrix pipe by exact three-way operand splitting (csrc/conv_x6.h): forward and backward-data
+# of every MFMA-shaped layer.  The kernel reads the weights as a pre-split image, rebuilt when the weights change.
+X6 = os.environ.get('FC_X6', '1') != '0'
+CONV_X6 = (1 << 24) | (1 << 26)
+
+
+def _x6_image(weight, transposed):
+    """pre-split image of a (K, Cin, Cout) kernel for the forward launch (transposed=False: reduction Cin, columns Cout) or
+    for the backward-data launch on the same kernel (transposed=True: reduction Cout, columns Cin).  Built at every call:
+    a cache across calls would have to know when the weights changed, and torch's fused optimizers update parameters
+    without touching their version counters (measured: torch.optim.AdamW(fused=True) leaves `_version` at 0).  A training
+    loop that owns the optimizer step can hand over images it built itself for exactly one step (`PREBUILT`)."""
+    pre = PREBUILT.get(id(weight))
+    if pre is not None and pre[transposed] is not None:
+        return pre[transposed]
+    K, Cin, Cout = weight.shape
+    R, C = (Cout, Cin) if transposed else (Cin, Cout)
+    img = torch.empty(L.query('fc_x6_weight_image_bytes', K, R, C), dtype=torch.uint8, device=weight.device)
+    L.call('fc_x6_weight_image', L.ptr(weight), L.ptr(img), K, R, C, 1 if transposed else 0, L.stream())
+    return img
+
+
+PREBUILT = {}          # id(weight tensor) -> (forward image, backward-data image), valid for the current step only
+
+
 def _conv_pairs(x, w, lists, out, n_in, n_out, K, Cin, Cout, live_tiles=0, flags=None):
     pi, _, pos, cnt = lists
     flags = FLAGS if flags is None else flags
@@ -128,12 +153,15 @@ class _SparseConv(torch.autograd.Function):
             col = torch.empty((n_out, 84), dtype=torch.float32, device=feats.device)
             L.call('fc_stem_conv_fwd', L.ptr(feats), L.ptr(weight), L.ptr(kmap.nbr), L.ptr(out), L.ptr(col), n_in, n_out, K,
                    L.stream())
-        elif _pair_conv(kmap, n_out, Cin, Cout):
-            _conv_pairs(feats, weight, kmap.pairs(), out, n_in, n_out, K, Cin, Cout, kmap.pair_tiles())
         else:
-            nbr, oidx = ((kmap.sorted_fwd() if _mfma_shape(Cin, Cout) else (kmap.nbr, None))
-                         if kmap is not None else (None, None))
-            _conv_fwd(feats, weight, nbr, out, n_in, n_out, K, Cin, Cout, oidx)
+            x6 = X6 and _mfma_shape(Cin, Cout)
+            w, fl = (_x6_image(weight, False), FLAGS | CONV_X6) if x6 else (weight, FLAGS)
+            if _pair_conv(kmap, n_out, Cin, Cout):
+                _conv_pairs(feats, w, kmap.pairs(), out, n_in, n_out, K, Cin, Cout, kmap.pair_tiles(), flags=fl)
+            else:
+                nbr, oidx = ((kmap.sorted_fwd() if _mfma_shape(Cin, Cout) else (kmap.nbr, None))
+                             if kmap is not None else (None, None))
+                _conv_fwd(feats, w, nbr, out, n_in, n_out, K, Cin, Cout, oidx, flags=fl)
         ctx.has_col = col is not None
         ctx.save_for_backward(*((feats, weight, col) if col is not None else (feats, weight)))
         ctx.kmap = kmap
@@ -152,7 +180,9 @@ class _SparseConv(torch.autograd.Function):
             # the (Cout -> Cin) operator of the backward-data pass: the kernels read the layer's own (K, Cin, Cout) kernel as
             # its transpose (flags CONV_WT; r2: 50 transpose launches and 0.34 ms per step gone); identity maps (dense GEMMs)
             # still take a transposed copy
-            if DGRAD_WT and kmap is not None:
+            if X6 and _mfma_shape(Cout, Cin):
+                wt, fl = _x6_image(weight, True), FLAGS | CONV_X6
+            elif DGRAD_WT and kmap is not None:
                 wt, fl = weight, FLAGS | CONV_WT
             else:
                 wt, fl = torch.empty((K, Cout, Cin), dtype=torch.float32, device=dev), FLAGS

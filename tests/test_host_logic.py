@@ -25,7 +25,7 @@ def test_assigner_matches_reference_goldens():
         ref_lb = d[f'c{ci}_assigned']
         assert np.array_equal(lb.numpy(), ref_lb), f'case {ci}'
         pos = ref_lb >= 0
-        assert pos.sum() > 50
+        assert pos.sum() >= 12 * len(d[f'c{ci}_gt'])               # the case is not vacuous (topk = 18 locations per box, minus overlaps)
         assert np.allclose(ct.numpy()[pos], d[f'c{ci}_centerness'][pos], atol=1e-6)
         assert np.allclose(bt.numpy()[pos], d[f'c{ci}_bbox_targets'][pos], atol=1e-6)
 

@@ -18,12 +18,12 @@ def per_kernel(path, counter, match):
 
 def main():
     fetch_csv, write_csv, out = sys.argv[1:4]
-    match = ('k_conv_mfma', 'k_conv_glds')        # k_conv_mfma, k_conv_mfma_p, k_conv_glds: the forward / backward-data family
+    match = ('k_conv_mfma', 'k_conv_glds', 'k_conv_x6')        # the forward / backward-data family
     f, nf = per_kernel(fetch_csv, 'FETCH_SIZE', match)
     w, nw = per_kernel(write_csv, 'WRITE_SIZE', match)
     fetch_b = 2.0 * f * 1024 / max(nf, 1)        # KB -> B, x2 gfx950 correction
     write_b = w * 1024 / max(nw, 1)
-    json.dump(dict(kernel='k_conv_mfma* + k_conv_glds', launches_fetch_pass=nf, launches_write_pass=nw,
+    json.dump(dict(kernel='k_conv_x6 + k_conv_mfma* + k_conv_glds', launches_fetch_pass=nf, launches_write_pass=nw,
                    fetch_bytes_per_launch=round(fetch_b), write_bytes_per_launch=round(write_b),
                    hbm_bytes_per_launch=round(fetch_b + write_b),
                    method='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py; FETCH_SIZE x2 '
