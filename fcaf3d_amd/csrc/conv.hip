@@ -45,6 +45,7 @@ extern "C" int fc_debug_set_prio(int mode) {
 }
 
 #include "conv_x6.h"
+#include "wgrad_x6.h"
 
 #define BK 32            // reduction slab (input channels per stage / rows per stage for wgrad)
 #define LDA (BK + 4)     // A row stride in floats: 16B-aligned rows, conflict-free ds_read_b128 (9r mod 16)
@@ -1800,6 +1801,7 @@ static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool 
   bool mfma_ok = !(flags & 1) && (Cin % 64 == 0) && (Cout % 64 == 0);
   int tbm, tbn;
   wgrad_tiles(Cin, Cout, flags, &tbm, &tbn);
+  if ((flags & (1 << 24)) && !dense_table && Cin % 128 == 0) tbm = 128;      // split-bf16 pair-list kernel: 128-channel tiles
   int64_t tiles = mfma_ok ? (int64_t)K * (Cin / tbm) * (Cout / tbn) : (int64_t)K;
   // aim for ~1728 workgroups (r2 sweep: 2048 rounded UP left a nearly empty last round on most layers — 128->128 on 55k
   // rows 559 us at 38 splits, 448 at 32), at least 512 rows per split, at most 256 splits
@@ -1911,8 +1913,26 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
   } else if (mfma_ok && wgrad_multi_ok(n_out, K, Cin, Cout, flags, dense_table)) {
     const int bn = (Cout % 128 == 0) ? 128 : 64;
     dim3 grid((unsigned)S, (unsigned)((K / WGRAD_KO) * (Cin / 64) * (Cout / bn)));
+    if (flags & (1 << 24)) {                     // split-bf16 (wgrad_x6.h)
+      if (bn == 128) k_wgrad_x6<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+      else k_wgrad_x6<64, 64, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+    } else
     if (bn == 128) k_wgrad_multi<128, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
     else k_wgrad_multi<64, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
+  } else if (mfma_ok && cnt && (flags & (1 << 24)) && (Cin % 128 == 0 || Cout % 128 == 0)) {
+    // split-bf16 over the pair lists (r3 nbench: 128 x 128 tiles 119 -> 95 us on 15k rows 128->128, 111 -> 89 / 109 -> 87 on
+    // the 256- and 512-channel levels; 64 x 64 tiles — one accumulator per wave, a dependent MFMA chain — lose to the fp32
+    // kernel and stay there).  128-channel Cin tiles only while they still fill the chip (862 rows, 512->128: 216 workgroups
+    // of 128 x 128 tiles 49 us, fp32 36 us)
+    const int bn = (Cout % 128 == 0) ? 128 : 64;
+    int bm = (Cin % 128 == 0) ? 128 : 64;
+    if (bm == 128 && bn == 128 && (int64_t)S * K * (Cin / 128) * (Cout / 128) < 512) bm = 64;
+    dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
+#define FC_WX6(BM_, BN_) k_wgrad_x6<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps)
+    if (bm == 128 && bn == 128) FC_WX6(128, 128);
+    else if (bm == 128) FC_WX6(128, 64);
+    else FC_WX6(64, 128);
+#undef FC_WX6
   } else if (mfma_ok) {
     int bm, bn;
     wgrad_tiles(Cin, Cout, flags, &bm, &bn);

@@ -1,0 +1,180 @@
+// fp32 weight gradient of the sparse convolution on the bf16 matrix pipe by exact operand splitting (see conv_x6.h for
+// the arithmetic; included by conv.hip).
+//
+//     gW[k][ci][co] = sum_o  in[nbr[k][o]][ci] * gout[o][co]
+//
+// GEMM with M = Cin, N = Cout and the REDUCTION over rows, so both bf16 MFMA operands want 8 consecutive ROWS of one
+// channel per lane, while memory holds rows of channels.  The transposition happens in the staging registers: wave w of the
+// workgroup owns rows 8 w .. 8 w + 7 of a 32-row stage, lane l channel l of a 64-channel pass; it loads its channel of those
+// 8 rows (8 dword loads, each a fully coalesced 256-byte row segment across the wave — the row indices are wave-uniform and
+// travel in scalar registers), splits the 8 values into three bf16 pieces each and stores ONE 16-byte chunk per plane:
+// LDS image [plane][channel][4 chunks], chunk c = rows 8 c .. 8 c + 7, slot c ^ ((channel >> 2) & 3) — the image and the
+// fragment reads of conv_x6.h with "channel" in the place of "row".
+// KO kernel offsets per workgroup share the staged gout rows (dense tables; k_wgrad_multi's idea), PAIRS: the reduction
+// runs over the exact pair list of ONE offset (both operands gathered).  Partial sums per row range go to `part` and are
+// combined by k_wgrad_reduce in a fixed order, exactly as for the fp32 kernels.
+#pragma once
+
+template <int BMc, int BNc, int KO, bool PAIRS>
+__global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) void k_wgrad_x6(
+    const float* __restrict__ in, const float* __restrict__ gout, const int* __restrict__ nbr,
+    const int* __restrict__ row_index, const int* __restrict__ cnt, float* __restrict__ part, int64_t n_out, int K, int Cin,
+    int Cout, int64_t rows_per_split) {
+  constexpr int TM = BMc / 64, TN = BNc / 64;    // 32x32 tiles per wave (waves 2 x 2 over the BMc x BNc tile)
+  constexpr int PA = BMc / 64, PG = BNc / 64;    // 64-channel staging passes per offset / for gout
+  __shared__ u32x4 As[KO * 3 * BMc * 4];         // [offset][plane][channel][4 chunks]
+  __shared__ u32x4 Gs[3 * BNc * 4];              // [plane][channel][4 chunks]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles_n = Cout / BNc, tiles_m = Cin / BMc;
+  int y = blockIdx.y;
+  const int tn = y % tiles_n; y /= tiles_n;
+  const int tm = y % tiles_m; y /= tiles_m;
+  const int k0 = y * KO;
+  const int ci0 = tm * BMc, co0 = tn * BNc;
+  int64_t total = n_out;
+  if (PAIRS) {
+    total = cnt[k0];
+    rows_per_split = ((total + gridDim.x - 1) / gridDim.x + 31) / 32 * 32;
+  }
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_split;
+  int64_t r_end = r_begin + rows_per_split;
+  if (r_end > total) r_end = total;
+
+  f32x16 acc[KO][TM][TN];
+#pragma unroll
+  for (int o = 0; o < KO; ++o)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[o][i][j][e] = 0.f;
+
+  if (r_begin < r_end) {
+    // row indices of this wave's 8 rows of a stage: scalar (wave-uniform); requested at the top of a stage for the NEXT
+    // one, they arrive under the split + LDS-store phase and the row loads after the barrier find them ready (one set live:
+    // a second, deeper-prefetched set spills the scalar registers)
+    int ia[KO][8], ig[8];
+    auto fetch_idx = [&](int64_t rb, int (&va)[KO][8], int (&vg)[8]) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int64_t row = rb + 8 * wave + e;
+        const int64_t rc = row < r_end ? row : r_end - 1;
+#pragma unroll
+        for (int o = 0; o < KO; ++o) {
+          const int kk = k0 + o < K ? k0 + o : K - 1;
+          const int t = nbr[(int64_t)kk * n_out + rc];
+          va[o][e] = (row < r_end && k0 + o < K) ? t : -1;
+        }
+        vg[e] = row < r_end ? (PAIRS ? row_index[(int64_t)k0 * n_out + rc] : (int)rc) : -1;
+      }
+    };
+    float av[KO][PA][8], gv[PG][8];
+    auto load_rows = [&]() {                     // rows of the stage whose indices sit in ia / ig
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int p = 0; p < PG; ++p) {
+          const float* gp = ig[e] >= 0 ? gout + (int64_t)ig[e] * Cout + co0 + p * 64 : g_zero_row;
+          gv[p][e] = gp[lane];
+        }
+#pragma unroll
+        for (int o = 0; o < KO; ++o)
+#pragma unroll
+          for (int p = 0; p < PA; ++p) {
+            const float* ap = ia[o][e] >= 0 ? in + (int64_t)ia[o][e] * Cin + ci0 + p * 64 : g_zero_row;
+            av[o][p][e] = ap[lane];
+          }
+      }
+    };
+    fetch_idx(r_begin, ia, ig);
+    load_rows();
+    const bool prio = g_fc_prio == 0;
+    const int swz = (r >> 2) & 3;
+    int a_slot[2], b_slot[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      a_slot[b] = (wr * (BMc / 2) + r) * 4 + ((2 * b + h) ^ swz);
+      b_slot[b] = (wc * (BNc / 2) + r) * 4 + ((2 * b + h) ^ swz);
+    }
+    // staging slot of this lane's channel (within a 64-channel pass) and this wave's row group
+    const int st_slot = lane * 4 + (wave ^ ((lane >> 2) & 3));
+    for (int64_t rb = r_begin; rb < r_end; rb += 32) {
+      fetch_idx(rb + 32 < r_end ? rb + 32 : rb, ia, ig);        // (past the end the last stage is re-read and never used)
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < PG; ++p) {
+        unsigned q[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x6_split2(gv[p][2 * e], gv[p][2 * e + 1], q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          u32x4 v = {q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+          Gs[(pl * BNc + p * 64) * 4 + st_slot] = v;
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < KO; ++o)
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+          unsigned q[3][4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x6_split2(av[o][p][2 * e], av[o][p][2 * e + 1], q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            u32x4 v = {q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+            As[((o * 3 + pl) * BMc + p * 64) * 4 + st_slot] = v;
+          }
+        }
+      __syncthreads();
+      load_rows();
+      if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        u32x4 fb[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[pl][j] = Gs[pl * BNc * 4 + b_slot[b] + j * 32 * 4];
+        u32x4 fa[KO][3][TM];
+#pragma unroll
+        for (int o = 0; o < KO; ++o)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[o][pl][i] = As[(o * 3 + pl) * BMc * 4 + a_slot[b] + i * 32 * 4];
+        // smallest products first (a1b3 | a2b2 a1b2 | a3b1 a2b1 a1b1); the offsets innermost: KO x TM x TN independent
+        // accumulators between two MFMAs on the same one
+#pragma unroll
+        for (int pb = 2; pb >= 0; --pb)
+#pragma unroll
+          for (int pa = 2 - pb; pa >= 0; --pa)
+#pragma unroll
+            for (int o = 0; o < KO; ++o)
+#pragma unroll
+              for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[o][i][j] = X6_MFMA(fa[o][pa][i], fb[pb][j], acc[o][i][j]);
+      }
+      if (prio) __builtin_amdgcn_s_setprio(0);
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < KO; ++o) {
+    if (k0 + o >= K) break;
+    float* dst = part + ((int64_t)blockIdx.x * K + k0 + o) * Cin * Cout;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = ci0 + wr * (BMc / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int col = co0 + wc * (BNc / 2) + j * 32 + r;
+          dst[(int64_t)row * Cout + col] = acc[o][i][j][e];
+        }
+  }
+}

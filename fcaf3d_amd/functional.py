@@ -93,7 +93,8 @@ DGRAD_WT = os.environ.get('FC_DGRAD_TRANSPOSE', '0') != '1'      # backward-data
 # fp32 convolutions on the bf16 matrix pipe by exact three-way operand splitting (csrc/conv_x6.h): forward and backward-data
 # of every MFMA-shaped layer.  The kernel reads the weights as a pre-split image, rebuilt when the weights change.
 X6 = os.environ.get('FC_X6', '1') != '0'
-CONV_X6 = (1 << 24) | (1 << 26)
+CONV_X6 = (1 << 24) | (1 << 26)          # forward / backward-data: split-bf16 kernel, weights as a pre-split image
+WGRAD_X6 = 1 << 24                       # weight gradient: split-bf16 kernels
 
 
 def _x6_image(weight, transposed):
@@ -208,15 +209,16 @@ class _SparseConv(torch.autograd.Function):
                     ws = L.workspace(L.query('fc_stem_conv_wgrad_ws_bytes', n_out, K), dev)
                     L.call('fc_stem_conv_wgrad', L.ptr(col), L.ptr(gout), L.ptr(g), n_out, K, L.ptr(ws), ws.numel(), L.stream())
                     return g
-                wsb = L.query('fc_conv_wgrad_ws_bytes', n_out, K, Cin, Cout, FLAGS)
+                fl = FLAGS | WGRAD_X6 if X6 else FLAGS      # split-bf16 where the library has a kernel for the shape (wgrad_x6.h)
+                wsb = L.query('fc_conv_wgrad_ws_bytes', n_out, K, Cin, Cout, fl)
                 ws = L.workspace(wsb, dev)
                 if kmap is not None and kmap.use_pairs and not (FLAGS & 1) and Cin % 64 == 0 and Cout % 64 == 0:
                     pi, po, _, cnt = kmap.pairs()
                     L.call('fc_conv_wgrad_pairs', L.ptr(feats), L.ptr(gout), L.ptr(pi), L.ptr(po), L.ptr(cnt), L.ptr(g), n_in,
-                           n_out, K, Cin, Cout, FLAGS, L.ptr(ws), ws.numel(), L.stream())
+                           n_out, K, Cin, Cout, fl, L.ptr(ws), ws.numel(), L.stream())
                 else:
                     L.call('fc_conv_wgrad', L.ptr(feats), L.ptr(gout), L.ptr(nbr), L.ptr(ridx), L.ptr(g), n_in, n_out, K, Cin,
-                           Cout, FLAGS, L.ptr(ws), ws.numel(), L.stream())
+                           Cout, fl, L.ptr(ws), ws.numel(), L.stream())
                 return g
             if WGRAD_ASYNC and ctx.w_leaf:
                 global _join_queued

@@ -163,7 +163,9 @@ int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in,
 
 /* backward-weights of ME.MinkowskiConvolution (autograd of me_resnet.py:19-21, :56-62 and fcaf3d_neck_with_head.py:52,
  * :60-69; `gW[k] += in[i]^T (x) gout[o]`): gW[k] = sum_o in[nbr[k][o]]^T (x) gout[o];
- * deterministic two-level reduction. */
+ * deterministic two-level reduction.  flags bit24 (both entry points): the split-bf16 kernels (csrc/wgrad_x6.h: fp32 in, fp32
+ * accumulate, six exact bf16 x bf16 products per fp32 product) where one exists for the shape — dense tables that qualify for
+ * the multi-offset kernel, pair lists with a 128-wide Cin or Cout; the fp32 MFMA kernels otherwise. */
 int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);
 int fc_conv_wgrad(const float* in, const float* gout, const int* nbr, const int* row_index, float* gW, int64_t n_in,
                   int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);

@@ -454,10 +454,11 @@ int main(int argc, char** argv) {
       std::vector<int> wg_s = {0};
       if (s_sweep) wg_s = {0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32};
       for (int fsw : wg_s)
-      for (int reg = 0; reg < (s_sweep ? 1 : 4); reg += (reg == 0 ? 2 : 1))          // 0: default, 2: r1 LDS kernel, 3: multi-offset kernel only under its first rule (Cin = 64, >= 32768 rows)
+      for (int reg = 0; reg < (s_sweep ? 1 : 5); reg += (reg == 0 ? 2 : 1))          // 0: default, 2: r1 LDS kernel, 3: multi-offset kernel only under its first rule (Cin = 64, >= 32768 rows), 4: split-bf16
         for (int pairs = (s_sweep && !cs.dense ? 1 : 0); pairs < (cs.dense ? 1 : 2); ++pairs) {
           if (reg == 3 && pairs) continue;
-          const int fl = ((reg == 2) << 16) | ((reg == 3) << 30) | (fsw << 8);
+          if (x6_only && (reg == 2 || reg == 3)) continue;
+          const int fl = ((reg == 2) << 16) | ((reg == 3) << 30) | ((reg == 4) << 24) | (fsw << 8);
           int64_t wb = ws_for(fc_conv_wgrad_ws_bytes(n_out, K, Cin, Cout, fl));
           std::function<void()> fn;
           if (pairs) fn = [&, wb, fl]() { FC(fc_conv_wgrad_pairs(d_in.p, d_gout.p, d_pi.p, d_po.p, d_cnt.p, d_gw.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
@@ -467,7 +468,7 @@ int main(int argc, char** argv) {
           double err = -1;
           if (check) err = max_rel_err(d_gw.down(hw.size()), ref);
           double us = time_us(reps, fn);
-          printf("   wgrad %s %s S=%-2d %9.1f us %7.1f TF  err %.2e%s\n", reg == 2 ? "ldsr1" : reg == 3 ? "m-r1 " : "lds ", pairs ? "pairs" : "table", fsw, us, gflop / us * 1e3, err, (check && !(err < 2e-4)) ? "  <-- MISMATCH" : "");
+          printf("   wgrad %s %s S=%-2d %9.1f us %7.1f TF  err %.2e%s\n", reg == 2 ? "ldsr1" : reg == 3 ? "m-r1 " : reg == 4 ? "x6   " : "lds ", pairs ? "pairs" : "table", fsw, us, gflop / us * 1e3, err, (check && !(err < 2e-4)) ? "  <-- MISMATCH" : "");
           fflush(stdout);
         }
     }
