@@ -1125,7 +1125,7 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   // is topped up to ~1024 workgroups by splitting over kernel offsets
   *bm = (n_out > 64 && wg128 >= 4) ? 128 : 64;
   // 64-wide outputs on big maps: 256 x 64 tiles, 4 waves along the rows (r2: +6 % on the 441k-row level, 88 / 95 TF)
-  if (*bn == 64 && Cout == 64 && fc_cdiv(n_out, 256) >= 1024) *bm = 256;
+  if (*bn == 64 && Cout == 64 && fc_cdiv(n_out, 256) >= 1024 && !(flags & (1 << 24))) *bm = 256;      // (split-bf16: 128 x 64 at 4 waves / SIMD is ahead, 613 vs 628 us)
   const int64_t tiles = fc_cdiv(n_out, *bm) * (Cout / *bn);
   int s = 1;
   // split over kernel offsets: the LARGEST split that still fits one resident round (1024 workgroup slots) — one workgroup

@@ -239,7 +239,10 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
       }
     };
     load_stage();
-    const bool prio = g_fc_prio >= 0;
+    // wave priorities (tools/nbench --prio): unlike the fp32 kernels this one LOSES 15-20 % with s_setprio 1 around the MFMA
+    // block (r3: 441k rows 64->128 1259 -> 1083 us without) — the waves that are splitting / storing the next stage need
+    // the VALU slots between a multiplying wave's MFMAs.  Default: none; 1: MFMA block (the fp32 kernels' scheme); 2: staging.
+    const int pmode = g_fc_prio;
     // fragment slots of this lane (16-byte units): every row this lane reads is r + a multiple of 32, so the chunk
     // swizzle is (r >> 2) & 3 throughout
     const int swz = (r >> 2) & 3;
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
     }
     for (int st = 0; st < nst; ++st) {
       __syncthreads();                           // previous stage fully consumed
+      if (pmode == 2) __builtin_amdgcn_s_setprio(1);
       // ---- split + store the gathered rows: 4 channels -> 8 B per plane
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
           }
         }
       }
+      if (pmode == 2) __builtin_amdgcn_s_setprio(0);
       __syncthreads();
       if (st + 1 < nst) {
         lc0 += 32;
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
       load_stage();                              // (the last iteration re-reads its own stage: see k_conv_mfma_p)
       // per 16-channel block: the three planes of the rows, then the weight planes one at a time, smallest products first
       // (a1b3 | a2b2 a1b2 | a3b1 a2b1 a1b1): 32 fragment registers live instead of 48
-      if (prio) __builtin_amdgcn_s_setprio(1);
+      if (pmode == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         u32x4 fa[3][TM];
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
               for (int j = 0; j < TN; ++j) acc[i][j] = X6_MFMA(fa[pa][i], fb[j], acc[i][j]);
         }
       }
-      if (prio) __builtin_amdgcn_s_setprio(0);
+      if (pmode == 1) __builtin_amdgcn_s_setprio(0);
     }
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); lane r of sub-tile j holds

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
     };
     fetch_idx(r_begin, ia, ig);
     load_rows();
-    const bool prio = g_fc_prio == 0;
+    const int pmode = g_fc_prio;                 // wave priorities, see k_conv_x6: default none; 1: MFMA block; 2: staging
     const int swz = (r >> 2) & 3;
     int a_slot[2], b_slot[2];
 #pragma unroll
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
     for (int64_t rb = r_begin; rb < r_end; rb += 32) {
       fetch_idx(rb + 32 < r_end ? rb + 32 : rb, ia, ig);        // (past the end the last stage is re-read and never used)
       __syncthreads();
+      if (pmode == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int p = 0; p < PG; ++p) {
         unsigned q[3][4];
@@ -129,9 +130,10 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
             As[((o * 3 + pl) * BMc + p * 64) * 4 + st_slot] = v;
           }
         }
+      if (pmode == 2) __builtin_amdgcn_s_setprio(0);
       __syncthreads();
       load_rows();
-      if (prio) __builtin_amdgcn_s_setprio(1);
+      if (pmode == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         u32x4 fb[3][TN];
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[o][i][j] = X6_MFMA(fa[o][pa][i], fb[pb][j], acc[o][i][j]);
       }
-      if (prio) __builtin_amdgcn_s_setprio(0);
+      if (pmode == 1) __builtin_amdgcn_s_setprio(0);
     }
   }
 #pragma unroll
