@@ -12,6 +12,11 @@
 
 #define FLOAT_MAX_VOL 1e8f
 
+// The small per-box tables (counts, best, kth, trig) are handed from one launch to the next through the workspace.  Read them
+// past the CU's vector L1 (agent-scope loads, `global_load ... sc1`): see the note at fc_assign_targets.
+__device__ static inline int ld_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ static inline float ld_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct Face6 { float d[6]; };
 
 // distances of point p to the 6 faces of box b = [cx,cy,cz,w,l,h,yaw] in the box frame
@@ -61,16 +66,17 @@ __global__ void k_count(const float* __restrict__ pts, const int* __restrict__ s
   int m = box_count[s];
   for (int j = 0; j < m; ++j) {
     const float* b = boxes + ((int64_t)s * M + j) * 7;
-    Face6 f = face_distances(b, trig[2 * (s * M + j)], trig[2 * (s * M + j) + 1], px, py, pz);
+    Face6 f = face_distances(b, ld_f(&trig[2 * (s * M + j)]), ld_f(&trig[2 * (s * M + j) + 1]), px, py, pz);
     if (is_inside(f)) atomicAdd(&counts[((int64_t)s * M + j) * L + l], 1);
   }
 }
 
 // (cos, sin) of -yaw of every padded box slot, once per step
-__global__ void k_box_trig(const float* __restrict__ boxes, int BM, float* __restrict__ trig) {
+__global__ void k_box_trig(const float* __restrict__ boxes, int BM, float* __restrict__ trig, int* __restrict__ counts, int L) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= BM) return;
   box_trig(boxes + (int64_t)t * 7, &trig[2 * t], &trig[2 * t + 1]);
+  for (int l = 0; l < L; ++l) counts[(int64_t)t * L + l] = 0;      // (the per-level inside counters k_count adds to)
 }
 
 __global__ void k_best(const int* __restrict__ counts, int BM, int L, int limit, int* __restrict__ best) {
@@ -78,7 +84,7 @@ __global__ void k_best(const int* __restrict__ counts, int BM, int L, int limit,
   if (t >= BM) return;
   int first_starved = -1;
   for (int l = 0; l < L; ++l)
-    if (counts[(int64_t)t * L + l] < limit) { first_starved = l; break; }
+    if (ld_i(&counts[(int64_t)t * L + l]) < limit) { first_starved = l; break; }
   int b;
   if (first_starved < 0) b = L - 1;
   else b = first_starved - 1 < 0 ? 0 : first_starved - 1;
@@ -97,8 +103,8 @@ __global__ __launch_bounds__(256) void k_kth(const float* __restrict__ pts, cons
   const int s = blockIdx.x / M, j = blockIdx.x % M;
   if (j >= box_count[s]) return;
   const float* b = boxes + ((int64_t)s * M + j) * 7;
-  const float ca = trig[2 * (s * M + j)], sa = trig[2 * (s * M + j) + 1];
-  const int l = best[s * M + j];
+  const float ca = ld_f(&trig[2 * (s * M + j)]), sa = ld_f(&trig[2 * (s * M + j) + 1]);
+  const int l = ld_i(&best[s * M + j]);
   const int r0 = seg_start[l * B + s], r1 = seg_start[l * B + s + 1];
   // n_scene = all locations of the scene over all levels (torch.topk is taken over all of them, padded with -1)
   int n_scene = 0;
@@ -196,11 +202,11 @@ __global__ void k_final(const float* __restrict__ pts, const int* __restrict__ s
   float owner_c = 0.f;
   for (int j = 0; j < m; ++j) {
     const float* b = boxes + ((int64_t)s * M + j) * 7;
-    if (best[s * M + j] != l) continue;
-    Face6 f = face_distances(b, trig[2 * (s * M + j)], trig[2 * (s * M + j) + 1], px, py, pz);
+    if (ld_i(&best[s * M + j]) != l) continue;
+    Face6 f = face_distances(b, ld_f(&trig[2 * (s * M + j)]), ld_f(&trig[2 * (s * M + j) + 1]), px, py, pz);
     if (!is_inside(f)) continue;
     float c = centerness_of(f);
-    if (!(c > kth[s * M + j])) continue;
+    if (!(c > ld_f(&kth[s * M + j]))) continue;
     float vol = b[3] * b[4] * b[5];
     if (vol < best_vol) { best_vol = vol; owner = j; owner_c = c; }
   }
@@ -217,6 +223,12 @@ int64_t fc_assign_ws_bytes(int B, int M, int L) {
   return (int64_t)B * M * (L + 4) * 4 + 256;
 }
 
+// r3 finding (tools/trace_det.py): with this call on the coordinate stream, overlapping the main stream's split-bf16
+// convolutions of the previous step, ~30 % of the calls returned a few dozen wrong rows — k_final had read an OLD kth / best
+// entry although k_kth had long finished: the tables sit at the same workspace address in every call, a CU's vector L1 keeps
+// the line from the previous call, and under that overlap the invalidate at the kernel boundary did not cover every CU the
+// late-placed waves landed on (never seen beside the fp32 kernels or on an idle chip: 0 of 60 calls).  The consumers now
+// read the tables past the L1 (ld_i / ld_f: 0 of 36 calls wrong), and the counters are zeroed by k_box_trig, not a memset.
 // points (N,3); scene/level (N) int32; boxes (B,M,7) [cx,cy,cz,w,l,h,yaw] gravity centre, padded; labels (B,M) int64;
 // box_count (B); order (N) = location rows grouped by (level, scene); seg_start (L*B+1) offsets into `order`.
 // outputs: centerness targets (N) (0 for background), box targets (N,7), labels (N) int64 (-1 = background).
@@ -231,9 +243,8 @@ int fc_assign_targets(const float* points, const int* scene, const int* level, i
   int* best = counts + (int64_t)B * M * L;
   float* kth = (float*)(best + (int64_t)B * M);
   float* trig = kth + (int64_t)B * M;
-  FC_HIP(hipMemsetAsync(counts, 0, sizeof(int) * (size_t)B * M * L, stream));
   unsigned g = (unsigned)fc_cdiv(N, 256);
-  k_box_trig<<<(unsigned)fc_cdiv(B * M, 64), 64, 0, stream>>>(boxes, B * M, trig);
+  k_box_trig<<<(unsigned)fc_cdiv(B * M, 64), 64, 0, stream>>>(boxes, B * M, trig, counts, L);
   FC_CHECK_LAUNCH();
   k_count<<<g, 256, 0, stream>>>(points, scene, level, N, boxes, box_count, M, L, trig, counts);
   FC_CHECK_LAUNCH();

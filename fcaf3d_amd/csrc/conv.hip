@@ -1278,6 +1278,13 @@ int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int trans
   return FC_OK;
 }
 
+int fc_x6_weight_images(const int64_t* desc, int n, int64_t total_blocks, hipStream_t stream) {
+  if (!desc || n < 1 || total_blocks < 1 || total_blocks > 0x7fffffffll) return FC_EINVAL;
+  k_x6_weight_images<<<(unsigned)total_blocks, 256, 0, stream>>>(reinterpret_cast<const long long*>(desc), n);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
 int64_t fc_conv_fwd_pairs_ws_bytes(int64_t n_out, int K, int Cout) {
   return (int64_t)K * n_out * Cout * (int64_t)sizeof(float);
 }

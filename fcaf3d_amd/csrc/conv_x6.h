@@ -56,10 +56,8 @@ __device__ __forceinline__ int x6_bslot(int c, int plane, int chunk) {
 // Pre-split weight image of one layer and direction: [K][R / 32 slabs][C / 64 groups][X6_GROUP_U16 units], R = reduction
 // size, C = columns; `transposed`: W[k] is (C, R) row-major (the layer's own kernel read as its backward-data operator),
 // else (R, C).  A stage of the convolution copies 12 KB x (BN / 64) CONTIGUOUS bytes of it into LDS: no VALU, no transpose.
-__global__ void k_x6_weight_image(const float* __restrict__ W, u32x4* __restrict__ img, int K, int R, int C, int transposed) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (k, slab, group, column, chunk)
-  const int64_t total = (int64_t)K * (R / 32) * (C / 64) * 256;
-  if (t >= total) return;
+__device__ __forceinline__ void x6_weight_image_unit(const float* __restrict__ W, u32x4* __restrict__ img, int64_t t, int R, int C,
+                                                     int transposed) {
   const int chunk = (int)(t & 3), c = (int)((t >> 2) & 63);
   const int64_t blk = t >> 8;                                               // (k, slab, group)
   const int g = (int)(blk % (C / 64));
@@ -78,6 +76,28 @@ __global__ void k_x6_weight_image(const float* __restrict__ W, u32x4* __restrict
     u32x4 v = {p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
     img[blk * X6_GROUP_U16 + x6_bslot(c, pl, chunk)] = v;
   }
+}
+
+__global__ void k_x6_weight_image(const float* __restrict__ W, u32x4* __restrict__ img, int K, int R, int C, int transposed) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (k, slab, group, column, chunk)
+  if (t < (int64_t)K * (R / 32) * (C / 64) * 256) x6_weight_image_unit(W, img, t, R, C, transposed);
+}
+
+// Images of MANY kernels in one launch (every convolution of a model, both directions, after an optimizer step):
+// desc[e] = {W, img, K, R, C, transposed, first block, -}; an entry owns the blocks [first block, first block of e + 1) and
+// K (R / 32) (C / 64) of them are live (256 threads = one (k, slab, group) unit each).
+__global__ void k_x6_weight_images(const long long* __restrict__ desc, int n) {
+  int lo = 0, hi = n - 1;
+  const long long b = blockIdx.x;
+  while (lo < hi) {                                                         // last entry whose first block <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[8 * mid + 6] <= b) lo = mid; else hi = mid - 1;
+  }
+  const long long* d = desc + 8 * lo;
+  const int K = (int)d[2], R = (int)d[3], C = (int)d[4];
+  const int64_t t = (b - d[6]) * 256 + threadIdx.x;
+  if (t < (int64_t)K * (R / 32) * (C / 64) * 256)
+    x6_weight_image_unit(reinterpret_cast<const float*>(d[0]), reinterpret_cast<u32x4*>(d[1]), t, R, C, (int)d[5]);
 }
 
 #define X6_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)

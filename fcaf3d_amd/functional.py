@@ -93,6 +93,8 @@ DGRAD_WT = os.environ.get('FC_DGRAD_TRANSPOSE', '0') != '1'      # backward-data
 # fp32 convolutions on the bf16 matrix pipe by exact three-way operand splitting (csrc/conv_x6.h): forward and backward-data
 # of every MFMA-shaped layer.  The kernel reads the weights as a pre-split image, rebuilt when the weights change.
 X6 = os.environ.get('FC_X6', '1') != '0'
+X6_CONV = os.environ.get('FC_X6_CONV', '1') != '0'        # A/B switches: forward / backward-data only, weight gradient only
+X6_WGRAD = os.environ.get('FC_X6_WGRAD', '1') != '0'
 CONV_X6 = (1 << 24) | (1 << 26)          # forward / backward-data: split-bf16 kernel, weights as a pre-split image
 WGRAD_X6 = 1 << 24                       # weight gradient: split-bf16 kernels
 
@@ -103,17 +105,23 @@ def _x6_image(weight, transposed):
     a cache across calls would have to know when the weights changed, and torch's fused optimizers update parameters
     without touching their version counters (measured: torch.optim.AdamW(fused=True) leaves `_version` at 0).  A training
     loop that owns the optimizer step can hand over images it built itself for exactly one step (`PREBUILT`)."""
-    pre = PREBUILT.get(id(weight))
-    if pre is not None and pre[transposed] is not None:
-        return pre[transposed]
     K, Cin, Cout = weight.shape
+    if PREBUILT:
+        pre = PREBUILT.get((weight.data_ptr(), K, Cin, Cout))
+        if pre is not None and pre[transposed] is not None:
+            global PREBUILT_EVENT
+            if PREBUILT_EVENT is not None:         # first consumer of the step: the images were built on another stream
+                torch.cuda.current_stream().wait_event(PREBUILT_EVENT)
+                PREBUILT_EVENT = None
+            return pre[transposed]
     R, C = (Cout, Cin) if transposed else (Cin, Cout)
     img = torch.empty(L.query('fc_x6_weight_image_bytes', K, R, C), dtype=torch.uint8, device=weight.device)
     L.call('fc_x6_weight_image', L.ptr(weight), L.ptr(img), K, R, C, 1 if transposed else 0, L.stream())
     return img
 
 
-PREBUILT = {}          # id(weight tensor) -> (forward image, backward-data image), valid for the current step only
+PREBUILT = {}          # (data_ptr, K, Cin, Cout) of a kernel -> (forward image, backward-data image): WeightImages.table, set by the
+PREBUILT_EVENT = None   # training loop for the duration of one step; the event the first consumer waits for
 
 
 def _conv_pairs(x, w, lists, out, n_in, n_out, K, Cin, Cout, live_tiles=0, flags=None):
@@ -155,7 +163,7 @@ class _SparseConv(torch.autograd.Function):
             L.call('fc_stem_conv_fwd', L.ptr(feats), L.ptr(weight), L.ptr(kmap.nbr), L.ptr(out), L.ptr(col), n_in, n_out, K,
                    L.stream())
         else:
-            x6 = X6 and _mfma_shape(Cin, Cout)
+            x6 = X6 and X6_CONV and _mfma_shape(Cin, Cout)
             w, fl = (_x6_image(weight, False), FLAGS | CONV_X6) if x6 else (weight, FLAGS)
             if _pair_conv(kmap, n_out, Cin, Cout):
                 _conv_pairs(feats, w, kmap.pairs(), out, n_in, n_out, K, Cin, Cout, kmap.pair_tiles(), flags=fl)
@@ -181,7 +189,7 @@ class _SparseConv(torch.autograd.Function):
             # the (Cout -> Cin) operator of the backward-data pass: the kernels read the layer's own (K, Cin, Cout) kernel as
             # its transpose (flags CONV_WT; r2: 50 transpose launches and 0.34 ms per step gone); identity maps (dense GEMMs)
             # still take a transposed copy
-            if X6 and _mfma_shape(Cout, Cin):
+            if X6 and X6_CONV and _mfma_shape(Cout, Cin):
                 wt, fl = _x6_image(weight, True), FLAGS | CONV_X6
             elif DGRAD_WT and kmap is not None:
                 wt, fl = weight, FLAGS | CONV_WT
@@ -209,7 +217,7 @@ class _SparseConv(torch.autograd.Function):
                     ws = L.workspace(L.query('fc_stem_conv_wgrad_ws_bytes', n_out, K), dev)
                     L.call('fc_stem_conv_wgrad', L.ptr(col), L.ptr(gout), L.ptr(g), n_out, K, L.ptr(ws), ws.numel(), L.stream())
                     return g
-                fl = FLAGS | WGRAD_X6 if X6 else FLAGS      # split-bf16 where the library has a kernel for the shape (wgrad_x6.h)
+                fl = FLAGS | WGRAD_X6 if (X6 and X6_WGRAD) else FLAGS      # split-bf16 where the library has a kernel for the shape (wgrad_x6.h)
                 wsb = L.query('fc_conv_wgrad_ws_bytes', n_out, K, Cin, Cout, fl)
                 ws = L.workspace(wsb, dev)
                 if kmap is not None and kmap.use_pairs and not (FLAGS & 1) and Cin % 64 == 0 and Cout % 64 == 0:
@@ -497,3 +505,58 @@ class _HeadSplit(torch.autograd.Function):
 
 def head_split(y, bias, scale, n_reg, n_cls):
     return _HeadSplit.apply(y, bias, scale, n_reg, n_cls)
+
+
+class WeightImages:
+    """Pre-split images (csrc/conv_x6.h) of every convolution kernel of a model, forward and backward-data, built by ONE
+    launch — for a training loop that knows when the weights change (runner.TrainStep builds them right after the optimizer
+    step, on the weight-gradient stream, and hands them to the next step through `PREBUILT`).  Kernels that reach
+    `sparse_conv` as a fresh tensor (the transposed convolution's permuted copy) are not covered and build their own."""
+
+    def __init__(self, weights):
+        ents, off = [], 0
+        self.table = {}
+        dev = None
+        for w in weights:
+            if w.dim() == 2:                       # 1 x 1 convolution: (Cin, Cout), used as (1, Cin, Cout)
+                K, (Cin, Cout) = 1, w.shape
+            else:
+                K, Cin, Cout = w.shape
+            dev = w.device
+            pair = [None, None]
+            for tr, (R, C) in ((0, (Cin, Cout)), (1, (Cout, Cin))):
+                if R % 32 or C % 64 or not w.is_contiguous():
+                    continue
+                nbytes = L.query('fc_x6_weight_image_bytes', K, R, C)
+                pair[tr] = (off, nbytes, K, R, C)
+                off += (nbytes + 255) // 256 * 256
+            if pair[0] or pair[1]:
+                ents.append((w, pair))
+        self.n = 0
+        if not ents:
+            return
+        self.buf = torch.empty(off, dtype=torch.uint8, device=dev)
+        desc, blk = [], 0
+        for w, pair in ents:
+            views = []
+            for tr in (0, 1):
+                if pair[tr] is None:
+                    views.append(None)
+                    continue
+                o, nb, K, R, C = pair[tr]
+                v = self.buf[o:o + nb]
+                views.append(v)
+                desc += [w.data_ptr(), v.data_ptr(), K, R, C, tr, blk, 0]
+                blk += K * (R // 32) * (C // 64)
+            self.table[(w.data_ptr(), K, w.shape[-2], w.shape[-1])] = tuple(views)
+        self.n = len(desc) // 8
+        self.blocks = blk
+        self.desc = torch.tensor(desc, dtype=torch.int64).to(dev)
+        self.event = None
+
+    def build(self):
+        """enqueue the build on the CURRENT stream; records the event consumers on other streams wait for"""
+        if self.n:
+            L.call('fc_x6_weight_images', L.ptr(self.desc), self.n, self.blocks, L.stream())
+            self.event = torch.cuda.Event()
+            self.event.record()

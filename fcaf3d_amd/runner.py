@@ -13,6 +13,7 @@ and clip + AdamW are three launches of csrc/optim.hip (`FlatAdamW`); CPU paramet
 torch.optim.AdamW + clip_grad_norm_, the calls the reference makes.
 """
 import math
+import os
 
 import torch
 
@@ -167,20 +168,53 @@ class TrainStep:
         self.lr = build_lr_updater(self.optimizer, lr_config) if lr_config else None
         self.averager = D.GradientAverager(self.params, bucket_mb=bucket_mb, flat=self.flat)
         self.last_grad_norm = None
+        # split-bf16 convolutions read pre-split weight images: with the flat optimizer this loop is the only writer of the
+        # weights, so it builds all of them in one launch right after its step (on the weight-gradient stream, under the
+        # next step's voxelisation and stem) instead of ~100 per-layer launches on the critical path of the next step.
+        # Whoever else writes the parameters (load_state_dict, ...) does so through torch and moves their version counters
+        # (the flat optimizer writes through raw pointers and does not); then the images are rebuilt before use.
+        from . import functional as Fn
+        self.images = None
+        if self.flat is not None and Fn.X6 and os.environ.get('FC_X6_PREBUILD', '1') != '0':
+            from .nn import MinkowskiConvolution
+            ws = [m.kernel for m in model.modules() if isinstance(m, MinkowskiConvolution) and m.kernel.requires_grad]
+            self.images = Fn.WeightImages(ws)
+            self._image_ws, self.images_version = ws, None
 
     @classmethod
     def from_config(cls, model, cfg, **kw):
         return cls(model, cfg.optimizer, cfg.get('optimizer_config'), cfg.get('lr_config'), **kw)
 
+    def _build_images(self, side_stream):
+        from . import functional as Fn
+        if side_stream:
+            side, main = Fn.wgrad_stream(self.flat.data.device), torch.cuda.current_stream()
+            side.wait_stream(main)                   # the optimizer step (and every reader of the old images) is enqueued on main
+            with torch.cuda.stream(side):
+                self.images.build()
+        else:
+            self.images.build()
+        self.images_version = sum(w._version for w in self._image_ws)
+
     def __call__(self, batch):
+        from . import functional as Fn
         self.optimizer.zero_grad(set_to_none=True)
-        losses = self.model(return_loss=True, **batch)
-        loss = parse_losses(losses)
-        loss.backward()
+        if self.images is not None and self.images.n:
+            if self.images_version != sum(w._version for w in self._image_ws):      # first step, or somebody wrote the weights through torch
+                self._build_images(side_stream=False)
+            Fn.PREBUILT, Fn.PREBUILT_EVENT = self.images.table, self.images.event
+        try:
+            losses = self.model(return_loss=True, **batch)
+            loss = parse_losses(losses)
+            loss.backward()
+        finally:
+            Fn.PREBUILT, Fn.PREBUILT_EVENT = {}, None
         self.averager.finish()
         if isinstance(self.optimizer, FlatAdamW):
             # after finish() under data parallelism every gradient already sits (averaged) in the flat buffer
             self.last_grad_norm = self.optimizer.step(self.max_norm, gathered=bool(self.averager.buckets))
+            if self.images is not None and self.images.n:
+                self._build_images(side_stream=True)
             return loss, losses
         if self.max_norm is not None:
             self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, norm_type=self.norm_type)

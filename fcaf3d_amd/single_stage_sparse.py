@@ -1,5 +1,6 @@
 """Detector shell — host-side mirror of mmdet3d/models/detectors/single_stage_sparse.py:9-62 and the
 `forward(return_loss=...)` dispatch of detectors/base.py:45-60."""
+import os
 import torch
 from torch import nn
 
@@ -111,7 +112,7 @@ class SingleStageSparse3DDetector(nn.Module):
     def extract_feat(self, points, img_metas, gt=None):
         """gt (training only, optional): (gt_bboxes_3d, gt_labels_3d) — lets the target assignment start with the maps"""
         if self.async_maps:
-            with on_map_stream(points[0].device, self.inputs_resident):
+            with on_map_stream(points[0].device, self.inputs_resident and os.environ.get('FC_MAP_WAIT') != '1'):
                 x = self._sparse_input(points, gt)
         else:
             x = self._sparse_input(points, gt)

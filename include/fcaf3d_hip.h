@@ -140,6 +140,11 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
  * for a launch with Cin = R, Cout = C; R % 32 == 0, C % 64 == 0; fc_x6_weight_image_bytes(K, R, C) = 6 K R C bytes. */
 int64_t fc_x6_weight_image_bytes(int K, int R, int C);
 int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int transposed, hipStream_t stream);
+/* The images of many kernels in ONE launch (all convolutions of a model, both directions, right after the optimizer step —
+ * the reference's optimizer hook is where its weights change, mmcv OptimizerHook.after_train_iter): `desc` is a DEVICE array
+ * of n entries of 8 int64 {W pointer, image pointer, K, R, C, transposed, first block, 0}; entry e owns the blocks from its
+ * first block up to the next entry's, K (R / 32) (C / 64) of them; total_blocks = the last entry's first block + its blocks. */
+int fc_x6_weight_images(const int64_t* desc, int n, int64_t total_blocks, hipStream_t stream);
 int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);
 int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
                 int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);
