@@ -55,3 +55,16 @@ __device__ static inline int fc_floor_div(int a, int b) {
   int q = a / b, r = a % b;
   return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q;
 }
+
+// Loads for data one launch hands to the next through a small table at a FIXED address (per-stream workspace, persistent
+// buffers): read it past the CU's vector L1.  r3 (csrc/assign.hip, tools/trace_det.py): with another stream's kernels keeping
+// the CUs busy, a consumer wave that lands on a CU late can still hit that CU's line from the previous use of the address —
+// the L2 is coherent, the L1 is not.  `nt` / agent-scope loads are served by the L2.
+typedef float fc_f4v __attribute__((ext_vector_type(4)));
+__device__ static inline float fc_ld(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ static inline int fc_ld(const int* p) { return __builtin_nontemporal_load(p); }
+__device__ static inline double fc_ld(const double* p) { return __builtin_nontemporal_load(p); }
+__device__ static inline float4 fc_ld4(const float* p) {
+  const fc_f4v v = __builtin_nontemporal_load(reinterpret_cast<const fc_f4v*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_fcaf3d_loss_final(const float* __restri
   __shared__ double red[4][3];
   double v[3] = {0.0, 0.0, 0.0};
   for (int64_t b = threadIdx.x; b < nb; b += 256)
-    for (int j = 0; j < 3; ++j) v[j] += (double)part[b * 4 + j];
+    for (int j = 0; j < 3; ++j) v[j] += (double)fc_ld(&part[b * 4 + j]);
   for (int j = 0; j < 3; ++j)
     for (int off = 32; off > 0; off >>= 1) v[j] += __shfl_xor(v[j], off, 64);
   if ((threadIdx.x & 63) == 0)

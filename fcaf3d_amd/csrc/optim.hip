@@ -41,7 +41,7 @@ __global__ __launch_bounds__(1024) void k_sqsum_final(const double* __restrict__
                                                       float* __restrict__ out) {
   __shared__ double red[16];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < nb; i += 1024) acc += part[i];
+  for (int i = threadIdx.x; i < nb; i += 1024) acc += fc_ld(&part[i]);
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_adamw(of4* __restrict__ p, const of4* _
                                                float wd, float step_size, float bc2_sqrt, const float* __restrict__ clip) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
-  const float c = clip ? clip[1] : 1.f;
+  const float c = clip ? fc_ld(&clip[1]) : 1.f;      // written by k_sqsum_final one launch ago, same address every step
   of4 pv = p[i], gv = g[i], mv = m[i], vv = v[i];
   const float decay = 1.f - lr * wd;
 #pragma unroll

@@ -120,16 +120,6 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
 
 /* ---- sparse convolution ------------------------------------------------------------------- */
 
-/* ME.MinkowskiConvolution forward (me_resnet.py:19-21,56-62; BasicBlock; fcaf3d_neck_with_head.py:52,69),
- * its backward-data pass (call with the transposed table and fc_transpose_weight'ed kernel), and with
- * nbr == NULL (K = 1, identity) the dense GEMMs of MinkowskiGenerativeConvolutionTranspose (:60-66)
- * and of the 1x1 head convolutions (:83-85, :257-263).  out[o] = sum_k in[nbr[k][o]] @ W[k].
- * flags bit0: force the generic FMA kernel instead of the MFMA kernel.  flags bit23 (also fc_conv_fwd_pairs /
- * _pairs_tiles; needs nbr != NULL): W[k] is stored TRANSPOSED, (Cout, Cin) row-major — the backward-data pass run on the
- * layer's own (K, Cin, Cout) kernel without a transposed copy.  Layers with too few rows to fill
- * the chip are split over kernel offsets into `ws` and summed in a fixed order (deterministic).
- * out_index (nullable): `nbr` is a table permuted into occupancy-mask order (fc_permute_nbr) and tile row t
- * belongs to output row out_index[t] — tiles of similar rows skip the offsets none of them has. */
 /* flags bit24 (fc_conv_fwd, fc_conv_fwd_pairs, fc_conv_fwd_pairs_tiles): the same fp32 convolution (torch.float32 in and
  * out, as ME.MinkowskiConvolution computes it, me_resnet.py:56-62) on the bf16 matrix pipe by EXACT operand splitting —
  * x = x1 + x2 + x3 with three 8-bit pieces, six bf16 x bf16 products (each exact in the fp32 accumulator) per fp32 product;
@@ -140,11 +130,23 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
  * for a launch with Cin = R, Cout = C; R % 32 == 0, C % 64 == 0; fc_x6_weight_image_bytes(K, R, C) = 6 K R C bytes. */
 int64_t fc_x6_weight_image_bytes(int K, int R, int C);
 int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int transposed, hipStream_t stream);
-/* The images of many kernels in ONE launch (all convolutions of a model, both directions, right after the optimizer step —
- * the reference's optimizer hook is where its weights change, mmcv OptimizerHook.after_train_iter): `desc` is a DEVICE array
+/* The images of many kernels in ONE launch (all convolutions of a model — me_resnet.py:56-62, fcaf3d_neck_with_head.py:52,60-69 —
+ * both directions, right after the optimizer step: the reference's optimizer hook, mmcv OptimizerHook.after_train_iter, is where
+ * its weights change): `desc` is a DEVICE array
  * of n entries of 8 int64 {W pointer, image pointer, K, R, C, transposed, first block, 0}; entry e owns the blocks from its
  * first block up to the next entry's, K (R / 32) (C / 64) of them; total_blocks = the last entry's first block + its blocks. */
 int fc_x6_weight_images(const int64_t* desc, int n, int64_t total_blocks, hipStream_t stream);
+
+/* ME.MinkowskiConvolution forward (me_resnet.py:19-21,56-62; BasicBlock; fcaf3d_neck_with_head.py:52,69),
+ * its backward-data pass (call with the transposed table and fc_transpose_weight'ed kernel), and with
+ * nbr == NULL (K = 1, identity) the dense GEMMs of MinkowskiGenerativeConvolutionTranspose (:60-66)
+ * and of the 1x1 head convolutions (:83-85, :257-263).  out[o] = sum_k in[nbr[k][o]] @ W[k].
+ * flags bit0: force the generic FMA kernel instead of the MFMA kernel.  flags bit23 (also fc_conv_fwd_pairs /
+ * _pairs_tiles; needs nbr != NULL): W[k] is stored TRANSPOSED, (Cout, Cin) row-major — the backward-data pass run on the
+ * layer's own (K, Cin, Cout) kernel without a transposed copy.  Layers with too few rows to fill
+ * the chip are split over kernel offsets into `ws` and summed in a fixed order (deterministic).
+ * out_index (nullable): `nbr` is a table permuted into occupancy-mask order (fc_permute_nbr) and tile row t
+ * belongs to output row out_index[t] — tiles of similar rows skip the offsets none of them has. */
 int64_t fc_conv_fwd_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flags);
 int fc_conv_fwd(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
                 int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, hipStream_t stream);

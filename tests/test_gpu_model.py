@@ -148,6 +148,45 @@ def test_async_map_stream_is_bitwise_equivalent():
         assert torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
 
 
+def test_target_assignment_is_stable_beside_concurrent_convolutions():
+    """The batched target assignment on a side stream while the main stream runs forward + backward (the bench's overlap of
+    step i + 1's coordinate stream with step i's backward) must return bitwise the same targets every time.  r3: with the
+    split-bf16 convolutions on the main stream ~30 % of such calls came back with a few dozen rows assigned against a STALE
+    kth / best entry — the hand-off tables sit at the same workspace address in every call and a CU's vector L1 still held
+    the previous call's line (tools/trace_det.py); csrc/assign.hip now reads them past the L1."""
+    dev = _dev()
+    model, m = _build('fcaf3d_scannet-3d-18class', 0.02, 4)
+    model = model.to(dev).train()
+    pts, gts, labs = _scenes([61, 62, 63, 64], n_points=60000)
+    batch = _to_gpu_batch(pts, gts, labs, dev)
+    head = model.neck_with_head
+    seen = {}
+    t0 = head._targets
+
+    def grab(cmaps, gtb, gtl):
+        seen['args'] = (cmaps, gtb, gtl)
+        return t0(cmaps, gtb, gtl)
+    head._targets = grab
+    sum(model(return_loss=True, **batch).values()).backward()
+    head._targets = t0
+    cmaps, gtb, gtl = seen['args']
+    ref = t0(cmaps, gtb, gtl)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    outs = []
+    for rep in range(3):
+        model.zero_grad(set_to_none=True)
+        losses = model(return_loss=True, **batch)                 # main stream: enqueue a step's worth of convolutions ...
+        with torch.cuda.stream(side):                             # ... and assign beside it, again and again
+            for _ in range(8):
+                outs.append(t0(cmaps, gtb, gtl))
+        sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    for o in outs:
+        for k in ('ct', 'bt', 'labels', 'inv_pos', 'inv_den'):
+            assert torch.equal(o[k], ref[k]), k
+
+
 def _fake_cmap(scene_ids, dev):
     from fcaf3d_amd.sparse import CoordMap
     c = torch.zeros((len(scene_ids), 4), dtype=torch.int32, device=dev)
