@@ -92,7 +92,8 @@ def test_kernel_maps_exact(ks, s):
     assert np.array_equal(nt, ref_t)
 
 
-def _conv_case(dev, n_points, Cin, Cout, ks, s, flags, seed=5, B=2, level_q=1):
+def _conv_case(dev, n_points, Cin, Cout, ks, s, flags, seed=5, B=2, level_q=1, x6=None):
+    """x6: None = the default route (split-bf16 kernels where they exist), False = the fp32 MFMA / FMA kernels"""
     import fcaf3d_amd.functional as Fn
     from fcaf3d_amd.sparse import CoordMap
     _, c_ref, _ = _scene_coords(seed, n_points=n_points, B=B)
@@ -113,13 +114,16 @@ def _conv_case(dev, n_points, Cin, Cout, ks, s, flags, seed=5, B=2, level_q=1):
     gx_r, gw_r = torch.autograd.grad(out_r, [xr, wr], go)
     xg = x.to(dev).requires_grad_(True); wg = w.to(dev).requires_grad_(True)
     Fn.FLAGS = flags
+    x6_0 = Fn.X6
+    if x6 is not None:
+        Fn.X6 = x6
     try:
         km = cm.kernel_map(om, ks)
         out_g = Fn.sparse_conv(xg, wg, km, om.n)
         gx_g, gw_g = torch.autograd.grad(out_g, [xg, wg], go.to(dev))
     finally:
-        Fn.FLAGS = 0
-    tag = f'conv n={len(uc)} {Cin}->{Cout} k{ks}s{s} flags={flags}'
+        Fn.FLAGS, Fn.X6 = 0, x6_0
+    tag = f'conv n={len(uc)} {Cin}->{Cout} k{ks}s{s} flags={flags} x6={x6}'
     _close(out_g, out_r, what=tag + ' fwd')
     _close(gx_g, gx_r, what=tag + ' dgrad')
     _close(gw_g, gw_r, what=tag + ' wgrad')
@@ -179,6 +183,51 @@ def test_conv_mfma_k3s2_and_k1s2():
     _conv_case(_dev(), 8000, 64, 64, 1, 2, 0, level_q=2)
 
 
+@pytest.mark.parametrize('Cin,Cout,n,q', [(64, 64, 6000, 4), (128, 128, 6000, 4), (256, 256, 6000, 4), (64, 128, 100000, 1)])
+def test_conv_fp32_mfma_route(Cin, Cout, n, q):
+    """the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32; FC_X6=0) stay a tested route"""
+    _conv_case(_dev(), n, Cin, Cout, 3, 1, 0, level_q=q, B=1 if n > 50000 else 2, x6=False)
+
+
+def test_split_bf16_convolution_is_as_close_to_fp64_as_the_fp32_mfma():
+    """csrc/conv_x6.h / wgrad_x6.h: fp32 products as six exact bf16 x bf16 products with fp32 accumulation.  Forward,
+    backward-data and backward-weights of a 27-offset convolution against the SAME computation in fp64: the split route's
+    rms error must not exceed the fp32 MFMA route's (measured r3: it is ~10 % smaller — fewer, wider accumulation steps),
+    on ReLU-like activations (half the inputs exactly zero) and on dense ones."""
+    import fcaf3d_amd.functional as Fn
+    from fcaf3d_amd.sparse import CoordMap
+    dev = _dev()
+    _, c_ref, _ = _scene_coords(11, n_points=60000, B=2)
+    uc, _, _ = mo.unique_first(c_ref)
+    cm, _, _ = CoordMap.from_coords(torch.from_numpy(uc).to(dev), 1, 2)
+    km = cm.kernel_map(cm, 3)
+    nbr = km.nbr.cpu().numpy()
+    g = torch.Generator().manual_seed(3)
+    for Cin, Cout, relu in ((64, 128, True), (128, 64, False)):
+        x = torch.randn(len(uc), Cin, generator=g)
+        if relu:
+            x = x.clamp(min=0)
+        w = torch.randn(27, Cin, Cout, generator=g) / np.sqrt(27 * Cin)
+        go = torch.randn(len(uc), Cout, generator=g)
+        x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        out64 = mo.conv(x64, w64, nbr)
+        gx64, gw64 = torch.autograd.grad(out64, [x64, w64], go.double())
+        errs = {}
+        for x6 in (True, False):
+            Fn.X6 = x6
+            try:
+                xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+                out = Fn.sparse_conv(xg, wg, km, cm.n)
+                gx, gw = torch.autograd.grad(out, [xg, wg], go.to(dev))
+            finally:
+                Fn.X6 = True
+            errs[x6] = [float((a.double().cpu() - b).pow(2).mean().sqrt() / b.abs().max())
+                        for a, b in ((out, out64.detach()), (gx, gx64), (gw, gw64))]
+        print(f'{Cin}->{Cout} relu={relu}: rms error / scale vs fp64 (fwd, dgrad, wgrad): split-bf16 {errs[True]}, fp32 MFMA {errs[False]}')
+        for e6, e32 in zip(errs[True], errs[False]):
+            assert e6 <= 1.05 * e32 + 1e-9 and e6 < 1e-6, (errs[True], errs[False])
+
+
 @pytest.mark.parametrize('Cin,Cout', [(64, 64), (64, 128)])
 def test_conv_mfma_large_tiles(Cin, Cout):
     # > 65k output rows -> the 128-row tile variants
@@ -197,8 +246,8 @@ def test_conv_mfma_large_tiles(Cin, Cout):
 def test_conv_kernel_variants_behind_flags(flags, what):
     """every flag-selected kernel variant (conv.hip; the defaults are chosen by measurement) against the oracle,
     forward + backward-data + backward-weights, on a strided and an unstrided map"""
-    _conv_case(_dev(), 9000, 64, 128, 3, 1, flags, level_q=4)
-    _conv_case(_dev(), 9000, 64, 64, 3, 2, flags, level_q=2)
+    _conv_case(_dev(), 9000, 64, 128, 3, 1, flags, level_q=4, x6=False)
+    _conv_case(_dev(), 9000, 64, 64, 3, 2, flags, level_q=2, x6=False)
 
 
 def test_pair_list_convolution_linear_live_tile_launch():
