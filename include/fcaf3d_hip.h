@@ -123,7 +123,7 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
 /* flags bit24 (fc_conv_fwd, fc_conv_fwd_pairs, fc_conv_fwd_pairs_tiles): the same fp32 convolution (torch.float32 in and
  * out, as ME.MinkowskiConvolution computes it, me_resnet.py:56-62) on the bf16 matrix pipe by EXACT operand splitting —
  * x = x1 + x2 + x3 with three 8-bit pieces, six bf16 x bf16 products (each exact in the fp32 accumulator) per fp32 product;
- * results are as close to fp64 as the fp32 MFMA's (csrc/conv_x6.h, tests/test_gpu_ops.py).  128- and 256-row tiles.
+ * results sit at fp32 rounding level against fp64, like the fp32 MFMA's (csrc/conv_x6.h, tests/test_gpu_ops.py).  128- and 256-row tiles.
  * flags bit26 (with bit24): `W` is not the fp32 kernel but its pre-split image built by fc_x6_weight_image — for the
  * backward-data pass the image of the transposed operator (then bit23 is not needed).
  * fc_x6_weight_image: image of W (K, R, C) — or, transposed != 0, of the operator W[k]^T where W[k] is stored (C, R) —

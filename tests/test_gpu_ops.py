@@ -189,11 +189,13 @@ def test_conv_fp32_mfma_route(Cin, Cout, n, q):
     _conv_case(_dev(), n, Cin, Cout, 3, 1, 0, level_q=q, B=1 if n > 50000 else 2, x6=False)
 
 
-def test_split_bf16_convolution_is_as_close_to_fp64_as_the_fp32_mfma():
+def test_split_bf16_convolution_sits_at_fp32_rounding_level_against_fp64():
     """csrc/conv_x6.h / wgrad_x6.h: fp32 products as six exact bf16 x bf16 products with fp32 accumulation.  Forward,
-    backward-data and backward-weights of a 27-offset convolution against the SAME computation in fp64: the split route's
-    rms error must not exceed the fp32 MFMA route's (measured r3: it is ~10 % smaller — fewer, wider accumulation steps),
-    on ReLU-like activations (half the inputs exactly zero) and on dense ones."""
+    backward-data and backward-weights of a 27-offset convolution against the SAME computation in fp64: both routes sit at
+    fp32 rounding level (rms error 2...5e-8 of the output scale, fp32 epsilon = 6e-8); which one is closer depends on the
+    pass (r3, 64->128 on ReLU-like inputs: forward 2.5e-8 vs 2.1e-8, backward-data 3.5e-8 vs 4.1e-8, backward-weights
+    4.5e-8 vs 2.8e-8; tools/nbench on the 441k-row benchmark layers: forward 1.6e-7 vs 1.8e-7).  Bound: within 2x of the
+    fp32 MFMA route and below 1e-7, on ReLU-like activations (half the inputs exactly zero) and on dense ones."""
     import fcaf3d_amd.functional as Fn
     from fcaf3d_amd.sparse import CoordMap
     dev = _dev()
@@ -225,7 +227,7 @@ def test_split_bf16_convolution_is_as_close_to_fp64_as_the_fp32_mfma():
                         for a, b in ((out, out64.detach()), (gx, gx64), (gw, gw64))]
         print(f'{Cin}->{Cout} relu={relu}: rms error / scale vs fp64 (fwd, dgrad, wgrad): split-bf16 {errs[True]}, fp32 MFMA {errs[False]}')
         for e6, e32 in zip(errs[True], errs[False]):
-            assert e6 <= 1.05 * e32 + 1e-9 and e6 < 1e-6, (errs[True], errs[False])
+            assert e6 <= 2.0 * e32 + 1e-9 and e6 < 1e-7, (errs[True], errs[False])
 
 
 @pytest.mark.parametrize('Cin,Cout', [(64, 64), (64, 128)])
