@@ -187,3 +187,36 @@ def test_checkpoint_roundtrip_mmcv_layout(tmp_path):
     import pytest
     with pytest.raises(RuntimeError):
         load_state_dict(c, {k[len('module.'):]: v for k, v in sd.items()}, strict=True)
+
+
+def test_weight_image_table_layout():
+    """functional.WeightImages: one buffer, one descriptor table for every convolution kernel and both directions — entries
+    only for shapes the split kernels take (reduction % 32, columns % 64), 256-byte aligned images of 6 K R C bytes, block
+    ranges that tile [0, total) in descriptor order, lookup by (data pointer, K, Cin, Cout) incl. the 2-D 1x1 kernels."""
+    import fcaf3d_amd.functional as Fn
+    ws = [torch.zeros(27, 64, 128), torch.zeros(27, 3, 64), torch.zeros(128, 64), torch.zeros(8, 32, 64), torch.zeros(27, 64, 32)]
+    wi = Fn.WeightImages(ws)
+    d = wi.desc.view(-1, 8).tolist()
+    # (27,64,128): both directions; (27,3,64): none; (128,64) as (1,128,64): both; (8,32,64): forward only (backward: reduction 64, columns 32);
+    # (27,64,32): backward only (forward columns 32)
+    assert wi.n == len(d) == 6
+    blocks = 0
+    for w_ptr, img_ptr, K, R, C, tr, first, _ in d:
+        assert R % 32 == 0 and C % 64 == 0 and tr in (0, 1)
+        assert first == blocks
+        blocks += K * (R // 32) * (C // 64)
+        assert (img_ptr - wi.buf.data_ptr()) % 256 == 0
+        assert img_ptr + 6 * K * R * C <= wi.buf.data_ptr() + wi.buf.numel()
+    assert blocks == wi.blocks
+    f, b = wi.table[(ws[0].data_ptr(), 27, 64, 128)]
+    assert f.numel() == 6 * 27 * 64 * 128 == b.numel() and f.data_ptr() != b.data_ptr()
+    assert (ws[1].data_ptr(), 27, 3, 64) not in wi.table
+    f, b = wi.table[(ws[2].data_ptr(), 1, 128, 64)]
+    assert f is not None and b is not None
+    f, b = wi.table[(ws[3].data_ptr(), 8, 32, 64)]
+    assert f is not None and b is None
+    f, b = wi.table[(ws[4].data_ptr(), 27, 64, 32)]
+    assert f is None and b is not None
+    # images never overlap
+    spans = sorted((r[1], r[1] + 6 * r[2] * r[3] * r[4]) for r in d)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
