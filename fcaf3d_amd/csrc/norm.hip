@@ -126,17 +126,17 @@ __global__ __launch_bounds__(1024) void k_stats_final(const float* __restrict__ 
   if (c < C) {
     int64_t b = j;
     for (; b + 48 < nblocks; b += 64) {
-      const float v0 = part[(b * nseg + s) * C + c], v1 = part[((b + 16) * nseg + s) * C + c];
-      const float v2 = part[((b + 32) * nseg + s) * C + c], v3 = part[((b + 48) * nseg + s) * C + c];
+      const float v0 = fc_ld(&part[(b * nseg + s) * C + c]), v1 = fc_ld(&part[((b + 16) * nseg + s) * C + c]);      // (one block reads the
+      const float v2 = fc_ld(&part[((b + 32) * nseg + s) * C + c]), v3 = fc_ld(&part[((b + 48) * nseg + s) * C + c]);   //  table once: past the L1)
       a0 += v0; a1 += v1; a2 += v2; a3 += v3;
     }
-    for (; b < nblocks; b += 16) a0 += part[(b * nseg + s) * C + c];
+    for (; b < nblocks; b += 16) a0 += fc_ld(&part[(b * nseg + s) * C + c]);
   }
   float acc = (a0 + a1) + (a2 + a3);
   red[j][threadIdx.x & 63] = acc;
   if (mode == 0 && (threadIdx.x & 63) == 0) {
     float cc = 0.f;
-    for (int64_t b = j; b < nblocks; b += 16) cc += part_cnt[b * nseg + s];
+    for (int64_t b = j; b < nblocks; b += 16) cc += fc_ld(&part_cnt[b * nseg + s]);
     redc[j] = cc;
   }
   __syncthreads();
@@ -473,10 +473,13 @@ __global__ void k_bn1_partial(const float* __restrict__ x, int64_t n, int C, int
 __device__ static inline void bn1_reduce_parts(const float* __restrict__ part, int nb, int C, int cl, int rl, int nrl,
                                                float* sm /*[nrl][2][C]*/, float4* s1, float4* s2) {
   float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+  // a SMALL table (the deep levels: a few KB at the same workspace address layer after layer) can survive in a CU's L1
+  // from the previous layer: read it past the L1 (fc_common.h: fc_ld4); a big one streams through the L1 anyway
+  const bool past_l1 = (int64_t)nb * C * 8 <= 32768;
   for (int b = rl; b < nb; b += nrl) {
     const float* src = part + ((int64_t)b * 2) * C;
-    float4 u = *reinterpret_cast<const float4*>(src + cl * 4);
-    float4 w = *reinterpret_cast<const float4*>(src + C + cl * 4);
+    float4 u = past_l1 ? fc_ld4(src + cl * 4) : *reinterpret_cast<const float4*>(src + cl * 4);
+    float4 w = past_l1 ? fc_ld4(src + C + cl * 4) : *reinterpret_cast<const float4*>(src + C + cl * 4);
     a1.x += u.x; a1.y += u.y; a1.z += u.z; a1.w += u.w;
     a2.x += w.x; a2.y += w.y; a2.z += w.z; a2.w += w.w;
   }
@@ -577,15 +580,15 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
       float u[4], w[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        u[q] = part[((int64_t)(b + 16 * q) * 2) * C + c];
-        w[q] = part[((int64_t)(b + 16 * q) * 2 + 1) * C + c];
+        u[q] = fc_ld(&part[((int64_t)(b + 16 * q) * 2) * C + c]);
+        w[q] = fc_ld(&part[((int64_t)(b + 16 * q) * 2 + 1) * C + c]);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) { p1[q] += u[q]; p2[q] += w[q]; }
     }
     for (; b < nb; b += 16) {
-      p1[0] += part[((int64_t)b * 2) * C + c];
-      p2[0] += part[((int64_t)b * 2 + 1) * C + c];
+      p1[0] += fc_ld(&part[((int64_t)b * 2) * C + c]);
+      p2[0] += fc_ld(&part[((int64_t)b * 2 + 1) * C + c]);
     }
     a1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
     a2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);

@@ -548,6 +548,7 @@ class WeightImages:
                 views.append(v)
                 desc += [w.data_ptr(), v.data_ptr(), K, R, C, tr, blk, 0]
                 blk += K * (R // 32) * (C // 64)
+            K = 1 if w.dim() == 2 else w.shape[0]
             self.table[(w.data_ptr(), K, w.shape[-2], w.shape[-1])] = tuple(views)
         self.n = len(desc) // 8
         self.blocks = blk
