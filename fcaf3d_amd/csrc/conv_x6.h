@@ -24,8 +24,10 @@
 //    the MFMA fragments (lane = row r of 32, chunk 2b + lane / 32) is conflict-free in the 16-lane groups the LDS
 //    serves (rows {0-3, 12-15, 20-27}: r % 4 picks the 64-byte quarter of the 256-byte bank line, (r >> 2) & 3 = {0, 3, 1, 2}
 //    the chunk within it);
-//  * the split costs 5.5 VALU instructions per staged element (and / sub / shift / and-or), hidden under the MFMA
-//    block of the other waves of the SIMD.
+//  * the split of the gathered rows costs 5.5 VALU instructions per staged element (and / sub / v_perm_b32).  It is NOT
+//    hidden: r3 knock-out builds of the 441k-row 64->128 launch run 905 us compute-only = 540 (MFMA) + 367 (everything else),
+//    a wave's staging VALU and another wave's MFMAs do not overlap on a SIMD; what would remove it is activation planes
+//    written by the producing kernel (open item 1).
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
