@@ -13,7 +13,8 @@ from . import bev
 from . import loss_oracle as lo
 from . import me_oracle as mo
 
-LAYERS = {14: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
+LAYERS = {14: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3), 50: (4, 3, 6, 3), 101: (3, 4, 23, 3)}
+BOTTLENECK = (50, 101)   # MinkowskiEngine.modules.resnet_block.Bottleneck (me_resnet.py:114-119): 1x1 -> 3x3 (stride) -> 1x1 (x4)
 TRAINING = True     # False: BatchNorm uses the running statistics of the state_dict (model.eval())
 
 
@@ -68,9 +69,21 @@ def backbone(x, P, depth=34, n_outs=4):
     oc, ocache = _strided(x, 2)
     x = SP(oc, mo.max_pool(x.F, _kmap(x, oc, 2, 'down')), x.stride * 2, ocache)
     outs = []
+    def k3d(w):                      # ME stores a kernel_size = 1, stride = 1 kernel as (Cin, Cout)
+        return w if w.dim() == 3 else w.unsqueeze(0)
     for li in range(n_outs):
         for j in range(LAYERS[depth][li]):
             pre = f'backbone.layer{li + 1}.{j}'
+            if depth in BOTTLENECK:
+                # ME BottleneckBase.forward: conv1 (1x1) - norm - relu - conv2 (3x3, the block's stride) - norm - relu -
+                # conv3 (1x1, 4 x planes) - norm, + downsample(x) (first block of a layer: 1x1 stride-2 conv + norm), relu
+                s = 2 if j == 0 else 1
+                res = bn(conv(x, k3d(P[pre + '.downsample.0.kernel']), 1, 2), P, pre + '.downsample.1') if j == 0 else x
+                out = bn(conv(x, k3d(P[pre + '.conv1.kernel']), 1, 1), P, pre + '.norm1', 'relu')
+                out = bn(conv(out, P[pre + '.conv2.kernel'], 3, s), P, pre + '.norm2', 'relu')
+                out = conv(out, k3d(P[pre + '.conv3.kernel']), 1, 1)
+                x = bn(out, P, pre + '.norm3', 'relu', residual=res.F)
+                continue
             if j == 0:
                 res = bn(conv(x, P[pre + '.downsample.0.kernel'], 1, 2), P, pre + '.downsample.1')
                 out = bn(conv(x, P[pre + '.conv1.kernel'], 3, 2), P, pre + '.norm1', 'relu')

@@ -126,6 +126,35 @@ def test_forward_train_parity(name, levels, B, n_points, kw):
     assert np.median(list(errs.values())) < 5e-3
 
 
+def test_bottleneck_backbone_parity_depth50():
+    """MEResNet3D depth 50 (ME Bottleneck blocks: 1x1 - 3x3 - 1x1 with a 4x expansion, me_resnet.py:114-119; no FCAF3D config
+    uses it, the class supports it): forward_train losses and gradients against the oracle, 2 levels (256 / 512 channels into the
+    neck), one 12k-point scene."""
+    dev = _dev()
+    torch.manual_seed(2)
+    cfg = fa.get_config('fcaf3d_scannet-3d-18class', voxel_size=0.02)
+    m = cfg.model
+    m.backbone['depth'] = 50
+    m.backbone['n_outs'] = 2
+    m.neck_with_head['in_channels'] = (256, 512)
+    m.neck_with_head.assigner['n_scales'] = 2
+    model = fa.build_detector(m, train_cfg=m.get('train_cfg'), test_cfg=m.get('test_cfg'))
+    assert type(model.backbone.layer1[0]).__name__ == 'Bottleneck' and len(model.backbone.layer1) == 4
+    P = _oracle_params(model)
+    model = model.to(dev).train()
+    pts, gts, labs = _scenes([91], n_points=12000)
+    losses_g = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
+    losses_o = MO.forward_train(P, m, pts, gts, labs)
+    for k in ('loss_centerness', 'loss_bbox', 'loss_cls'):
+        assert _rel(losses_g[k], losses_o[k]) < 1e-4, (k, float(losses_g[k]), float(losses_o[k]))
+    sum(losses_g.values()).backward()
+    sum(losses_o.values()).backward()
+    errs = {k: _rel(p.grad, P[k].grad) for k, p in model.named_parameters()}
+    worst = max(errs, key=errs.get)
+    print(f'depth 50: gradient error vs the fp32 oracle: worst {errs[worst]:.2e} ({worst}), median {np.median(list(errs.values())):.2e}')
+    assert errs[worst] < 6e-2 and np.median(list(errs.values())) < 1e-3, (worst, errs[worst])
+
+
 def test_async_map_stream_is_bitwise_equivalent():
     """Coordinate work on the side HIP stream (bench mode) must not change a single bit."""
     dev = _dev()
