@@ -4,8 +4,9 @@
 // has a 24-bit significand = three 8-bit pieces, and a bf16 holds 8 bits with the fp32 exponent range, so
 //     x = x1 + x2 + x3          x1 = top 16 bits of x,  x2 = top 16 bits of (x - x1),  x3 = x - x1 - x2      (all exact)
 // and a product a*b is the sum of nine bf16 x bf16 products, each EXACT in the fp32 accumulator of the MFMA (8 x 8 = 16
-// bits).  The six products down to 2^-16 (a1b1, a1b2, a2b1, a1b3, a2b2, a3b1) are kept; the three dropped ones are below
-// 2^-23 |a b|, i.e. below the rounding of the fp32 accumulation itself: against fp64 both routes sit at fp32 rounding level
+// bits).  The six products down to 2^-16 (a1b1, a1b2, a2b1, a1b3, a2b2, a3b1) are kept; the three dropped ones sum to at most
+// 2^-21 |a b| (the pieces are cut by truncation: |x2| < 2^-7 |x|, |x3| < 2^-15 |x|; oracle/x6_oracle.py and its test pin these
+// bounds), 2^-25 |a b| on average — in a convolution's sum below the rounding of the fp32 accumulation: against fp64 both routes sit at fp32 rounding level
 // (rms error 2...5e-8 of the output scale on 27 x 64...128-term sums, which one is closer depends on the pass: tests/test_gpu_ops.py;
 // tools/nbench --x6 prints it for every benchmark layer), at 6 x 32 = 192 matrix-pipe cycles per 32x32x16 block instead of
 // 8 x 64 = 512.

@@ -122,7 +122,8 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
 
 /* flags bit24 (fc_conv_fwd, fc_conv_fwd_pairs, fc_conv_fwd_pairs_tiles): the same fp32 convolution (torch.float32 in and
  * out, as ME.MinkowskiConvolution computes it, me_resnet.py:56-62) on the bf16 matrix pipe by EXACT operand splitting —
- * x = x1 + x2 + x3 with three 8-bit pieces, six bf16 x bf16 products (each exact in the fp32 accumulator) per fp32 product;
+ * x = x1 + x2 + x3 with three 8-bit pieces, six bf16 x bf16 products (each exact in the fp32 accumulator) per fp32 product
+ * (the three dropped ones: <= 2^-21 of the product, 2^-25 on average);
  * results sit at fp32 rounding level against fp64, like the fp32 MFMA's (csrc/conv_x6.h, tests/test_gpu_ops.py).  128- and 256-row tiles.
  * flags bit26 (with bit24): `W` is not the fp32 kernel but its pre-split image built by fc_x6_weight_image — for the
  * backward-data pass the image of the transposed operator (then bit23 is not needed).

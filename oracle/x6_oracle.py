@@ -1,0 +1,40 @@
+"""ORACLE — test infrastructure only.  The arithmetic of the split-bf16 convolution kernels (fcaf3d_amd/csrc/conv_x6.h,
+wgrad_x6.h) restated in numpy: an fp32 value as three bf16 pieces by truncation, an fp32 product as the six bf16 x bf16
+products the kernels keep, accumulated in fp32 in blocks of 16 products (one v_mfma_f32_32x32x16_bf16 per piece pair).
+Pins the properties the kernels rely on (tests/test_oracle_golden.py):
+  * x == x1 + x2 + x3 exactly for every finite fp32 (24 = 8 + 8 + 8 significand bits, bf16 has the fp32 exponent range);
+  * every piece product is exact in fp32 (8 x 8 = 16 bits);
+  * |x2| < 2^-7 |x|, |x3| < 2^-15 |x| (truncation), so the three dropped products (x2 y3, x3 y2, x3 y3) sum to at most
+    2^-21 |x y| (2^-25 on average); a round-to-nearest split would make that 2^-25 / unbiased at the same instruction count
+    (v_cvt_pk_bf16_f32) — not done: inside a convolution's sum both are below the fp32 accumulation's own rounding.
+There is no reference counterpart: the reference computes the same convolutions in fp32 on ME's kernels (me_resnet.py:56-62)."""
+import numpy as np
+
+
+def split3(x):
+    """fp32 array -> (x1, x2, x3) fp32 arrays, each representable in bf16 (low 16 bits zero), x1 + x2 + x3 == x"""
+    x = np.asarray(x, dtype=np.float32)
+    mask = np.uint32(0xffff0000)
+    x1 = (x.view(np.uint32) & mask).view(np.float32)
+    r = x - x1
+    x2 = (r.view(np.uint32) & mask).view(np.float32)
+    r2 = r - x2
+    x3 = (r2.view(np.uint32) & mask).view(np.float32)
+    return x1, x2, x3
+
+
+# (piece of a, piece of b) in the order the kernels accumulate them inside a 16-channel block: smallest products first
+TERMS = ((0, 2), (1, 1), (0, 1), (0, 0), (1, 0), (2, 0))
+
+
+def matmul_x6(a, b, block=16):
+    """(M,K) @ (K,N) the way the kernels do it: per block of `block` reduction indices and per kept piece pair ONE fp32-rounded
+    update of the accumulator with the exactly summed products (the MFMA's internal sum is modelled as exact)."""
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    pa, pb = split3(a), split3(b)
+    acc = np.zeros((a.shape[0], b.shape[1]), np.float32)
+    for k0 in range(0, a.shape[1], block):
+        for i, j in TERMS:
+            upd = pa[i][:, k0:k0 + block].astype(np.float64) @ pb[j][k0:k0 + block].astype(np.float64)
+            acc = (acc.astype(np.float64) + upd).astype(np.float32)
+    return acc
