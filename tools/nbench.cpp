@@ -2,7 +2,9 @@
 // (no Python, no torch: a fresh GPU box spends its minutes on kernels, not on `import torch`).
 //
 //   hipcc -O2 --offload-arch=gfx950 tools/nbench.cpp -Iinclude -Lfcaf3d_amd -lfcaf3d_hip -Wl,-rpath,'$ORIGIN/../fcaf3d_amd' -o tools/nbench
-//   tools/nbench [--batch 8] [--only L3] [--mode fwd|wgrad|all] [--reps 10] [--s-sweep] [--no-check]
+//   tools/nbench [--batch 8] [--only L3] [--mode fwd|wgrad|all] [--reps 10] [--s-sweep] [--no-check] [--x6] [--prio N]
+//   (--x6: the default fp32 routes beside the split-bf16 kernels only; every forward run also prints its rms / max error against an
+//    fp64 evaluation of 48 sampled output rows; --prio: wave-priority mode of the kernels, conv.hip g_fc_prio)
 //
 // Scenes follow fcaf3d_amd/synthetic.py (room 6 x 5 x 2.7 m, floor + walls + 15 cuboids, 100 000 points, 5 mm noise,
 // 2 cm voxels); coordinate sets and kernel maps are built on the HOST with ME's rules (first-occurrence row order,
