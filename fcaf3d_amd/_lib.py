@@ -11,7 +11,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfcaf3d_hip.so')
+LIB_PATH = os.environ.get('FC_LIB') or os.path.join(_HERE, 'libfcaf3d_hip.so')      # FC_LIB: an A/B build of the same library
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'fcaf3d_hip.h')
 
 _SCALARS = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float,
@@ -28,7 +28,7 @@ def parse_header(path=HEADER):
         argl = []
         for a in args.split(','):
             a = ' '.join(a.split())
-            if not a:
+            if not a or a == 'void':
                 continue
             if '*' in a:
                 argl.append((a.split('*')[-1].strip(), ctypes.c_void_p))

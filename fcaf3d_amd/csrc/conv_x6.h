@@ -5,8 +5,9 @@
 //     x = x1 + x2 + x3          x1 = top 16 bits of x,  x2 = top 16 bits of (x - x1),  x3 = x - x1 - x2      (all exact)
 // and a product a*b is the sum of nine bf16 x bf16 products, each EXACT in the fp32 accumulator of the MFMA (8 x 8 = 16
 // bits).  The six products down to 2^-16 (a1b1, a1b2, a2b1, a1b3, a2b2, a3b1) are kept; the three dropped ones sum to at most
-// 2^-21 |a b| (the pieces are cut by truncation: |x2| < 2^-7 |x|, |x3| < 2^-15 |x|; oracle/x6_oracle.py and its test pin these
-// bounds), 2^-25 |a b| on average — in a convolution's sum below the rounding of the fp32 accumulation: against fp64 both routes sit at fp32 rounding level
+// 2^-24 |a b| with no common sign (r4: the pieces are cut by round-to-nearest-even: |x2| <= 2^-8 |x|, |x3| <= 2^-17 |x|;
+// oracle/x6_oracle.py and its test pin these bounds; the truncating split of r3 gave 2^-21, biased towards zero)
+// — in a convolution's sum below the rounding of the fp32 accumulation: against fp64 both routes sit at fp32 rounding level
 // (rms error 2...5e-8 of the output scale on 27 x 64...128-term sums, which one is closer depends on the pass: tests/test_gpu_ops.py;
 // tools/nbench --x6 prints it for every benchmark layer), at 6 x 32 = 192 matrix-pipe cycles per 32x32x16 block instead of
 // 8 x 64 = 512.
@@ -25,7 +26,7 @@
 //    the MFMA fragments (lane = row r of 32, chunk 2b + lane / 32) is conflict-free in the 16-lane groups the LDS
 //    serves (rows {0-3, 12-15, 20-27}: r % 4 picks the 64-byte quarter of the 256-byte bank line, (r >> 2) & 3 = {0, 3, 1, 2}
 //    the chunk within it);
-//  * the split of the gathered rows costs 5.5 VALU instructions per staged element (and / sub / v_perm_b32).  It is NOT
+//  * the split of the gathered rows costs 4.5 VALU instructions per staged element (r3: 5.5 with and / sub / v_perm_b32).  It is NOT
 //    hidden: r3 knock-out builds of the 441k-row 64->128 launch run 905 us compute-only = 540 (MFMA) + 367 (everything else),
 //    a wave's staging VALU and another wave's MFMAs do not overlap on a SIMD; what would remove it is activation planes
 //    written by the producing kernel (open item 1).
@@ -35,9 +36,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// two fp32 -> three dwords, each the bf16 pair (piece of x0 in the low half, piece of x1 in the high half);
-// v_perm_b32 picks the two upper halves in one instruction: 11 VALU per pair
+// two fp32 -> three dwords, each the bf16 pair (piece of x0 in the low half, piece of x1 in the high half).
+// Round-to-nearest-even pieces (r4; v_cvt_pk_bf16_f32 converts and packs a pair in one instruction): x1 = RN8(x),
+// x2 = RN8(x - x1), x3 = x - x1 - x2 — still EXACT (the second residual has at most 7 significant bits: |x - x1| <= 2^-9 of
+// x's binade top, its low end is x's last bit), with |x2| <= 2^-8 |x|, |x3| <= 2^-17 |x| and residuals of either sign: the
+// three dropped products sum to <= 2^-24 |a b| and carry no common sign (the truncating split of r3, -DFC_X6_TRUNC: <= 2^-21,
+// all with the sign of a b).  9 VALU per pair (3 cvt_pk, 2 shift/and pairs, 2 packed subtractions), r3: 11.
+typedef __bf16 x6_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float x6_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned x6_hi2(unsigned u0, unsigned u1) { return __builtin_amdgcn_perm(u1, u0, 0x07060302u); }
+#ifdef FC_X6_TRUNC
 __device__ __forceinline__ void x6_split2(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
   const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
   p0 = x6_hi2(u0, u1);
@@ -47,6 +55,19 @@ __device__ __forceinline__ void x6_split2(float x0, float x1, unsigned& p0, unsi
   const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
   p2 = x6_hi2(__float_as_uint(s0), __float_as_uint(s1));
 }
+#else
+__device__ __forceinline__ unsigned x6_rn2(float x0, float x1) {
+  const x6_f32x2 v = {x0, x1};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, x6_bf16x2));
+}
+__device__ __forceinline__ void x6_split2(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = x6_rn2(x0, x1);
+  const float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+  p1 = x6_rn2(r0, r1);
+  const float s0 = r0 - __uint_as_float(p1 << 16), s1 = r1 - __uint_as_float(p1 & 0xffff0000u);
+  p2 = x6_rn2(s0, s1);
+}
+#endif
 
 // Weight slab in LDS and in a pre-split weight image: per 64-column group three planes of 64 rows x 64 B.  Column c of the
 // group lives in row (c % 2) * 32 + c / 2: a wave's sub-tile j reads rows j * 32 + r = the INTERLEAVED columns 2 r + j

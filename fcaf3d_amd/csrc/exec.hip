@@ -1,0 +1,367 @@
+// Native launch-list executor (r4): the forward / backward pass of the FCAF3D network body as ONE C-ABI call per direction.
+//
+// r4 host profile (tools/hostprof.py, profiles/r4_hostprof.txt): the training step was HOST-bound at every batch size —
+// 16.7 ms of Python per step at 2 scenes (drained 16.75 ms), 20.3 ms at 8 (drained 22.8): ~1 000 launches per step, each
+// reached through nn.Module.__call__ -> autograd.Function.apply -> torch.empty -> ctypes (~16 us per launch), where the HIP
+// launch itself costs ~3.5 us.  The network body is a STATIC sequence of operators (me_resnet.py:43-50, BasicBlock,
+// fcaf3d_neck_with_head.py:94-108; only row counts and addresses change from step to step), so the host side builds the
+// operator list once per model (fcaf3d_amd/executor.py) and this interpreter walks it: every operator is one of the
+// library's own entry points (the kernels, tiles, routes and results are those of the per-operator path — tests compare the
+// two bit for bit in the forward pass), every operand an index into a table of device addresses / row counts that the host
+// refreshes per step.  Streams: 0 = the caller's stream (the step's dependent chain), 1 = the head branch of the neck
+// (out_block_i + forward_single, i > 0), 2 = weight gradients; cross-stream order through hipEvents owned by the library
+// (created once per process, never destroyed: a handful).
+//
+// Reference: what this replaces is mmcv's per-module Python dispatch of the same graph (mmdet3d/models/detectors/
+// single_stage_sparse.py:43-50 `extract_feat`, torch.autograd's backward over it).
+#include "fc_common.h"
+#include "../../include/fcaf3d_hip.h"
+
+namespace {
+
+enum : int64_t {
+  OP_STEM_FWD = 1, OP_COL_STATS, OP_NORM_FWD, OP_MAXPOOL_FWD, OP_CONV, OP_BN_FWD, OP_UNION_FWD, OP_HEAD_FWD, OP_RECORD, OP_WAIT,
+  OP_HEAD_BWD, OP_WGRAD, OP_BN_BWD, OP_NORM_BWD, OP_MAXPOOL_BWD, OP_STEM_WGRAD, OP_GATHER, OP_ADD, OP_SMALL_GRADS,
+  OP_PERMUTE_GENT, OP_HEAD_WFIN, OP_COPY
+};
+constexpr int OPW = 20;            // int64 words per operator
+constexpr int MAPW = 20;           // int64 words per kernel-map descriptor
+constexpr int NSTREAM = 3;
+constexpr int MAX_EVENTS = 64;
+constexpr int CONV_X6 = (1 << 24) | (1 << 26), WGRAD_X6 = 1 << 24;
+
+hipEvent_t g_events[MAX_EVENTS];
+bool g_events_ready = false;
+
+int ensure_events() {
+  if (g_events_ready) return 0;
+  for (int i = 0; i < MAX_EVENTS; ++i) FC_HIP(hipEventCreateWithFlags(&g_events[i], hipEventDisableTiming));
+  g_events_ready = true;
+  return 0;
+}
+
+inline double as_double(int64_t v) { double d; __builtin_memcpy(&d, &v, 8); return d; }
+
+__global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, int64_t n4) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n4) return;
+  float4 a = reinterpret_cast<float4*>(dst)[t];
+  const float4 b = reinterpret_cast<const float4*>(src)[t];
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  reinterpret_cast<float4*>(dst)[t] = a;
+}
+
+// desc[e] = {src, dst, C, nseg, seg_stride (floats), -, -, -}: dst[c] = sum_s src[s * seg_stride + c]  (the d gamma / d beta sums of every
+// normalisation layer, written by the backward kernels into one persistent buffer, land in their gradient slices in ONE launch)
+__global__ void k_small_grads(const long long* __restrict__ desc, int n) {
+  const int e = blockIdx.x;
+  if (e >= n) return;
+  const long long* d = desc + 8 * e;
+  const float* src = reinterpret_cast<const float*>(d[0]);
+  float* dst = reinterpret_cast<float*>(d[1]);
+  const int C = (int)d[2], nseg = (int)d[3];
+  const long long stride = d[4];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nseg; ++k) s += fc_ld(src + k * stride + c);
+    dst[c] = s;
+  }
+}
+
+// gW' (Cin, 8 Cout) of the generative transposed convolution's dense GEMM -> the layer's kernel gradient (8, Cin, Cout)
+__global__ void k_permute_gent(const float* __restrict__ src, float* __restrict__ dst, int Cin, int Cout) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // index into dst
+  const int64_t total = (int64_t)8 * Cin * Cout;
+  if (t >= total) return;
+  const int d = (int)(t % Cout), c = (int)((t / Cout) % Cin), k = (int)(t / ((int64_t)Cout * Cin));
+  dst[t] = src[(int64_t)c * 8 * Cout + (int64_t)k * Cout + d];
+}
+
+// the packed head kernel's gradient: sum of the per-level partials (nl, R, ld) -> centerness (R, 1), reg (R, n_reg), cls (R, n_cls)
+__global__ void k_head_wfin(const float* __restrict__ part, int nl, int R, int ld, int n_reg, int n_cls, float* __restrict__ g_cent,
+                            float* __restrict__ g_reg, float* __restrict__ g_cls) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ncol = 1 + n_reg + n_cls;
+  if (t >= R * ncol) return;
+  const int r = t / ncol, c = t % ncol;
+  float s = 0.f;
+  for (int l = 0; l < nl; ++l) s += part[((int64_t)l * R + r) * ld + c];
+  if (c == 0) g_cent[r] = s;
+  else if (c <= n_reg) g_reg[r * n_reg + c - 1] = s;
+  else g_cls[r * n_cls + c - 1 - n_reg] = s;
+}
+
+struct Ctx {
+  const int64_t* addr;
+  const int64_t* dims;
+  const int64_t* maps;
+  hipStream_t streams[NSTREAM];
+  void* ws[NSTREAM];
+  int64_t ws_bytes[NSTREAM];
+  int64_t need[NSTREAM];
+  bool dry;
+  int64_t bn_small_elems;
+  int flags;
+};
+
+template <class T>
+inline T* P(const Ctx& c, int64_t idx) { return idx < 0 ? nullptr : reinterpret_cast<T*>(c.addr[idx]); }
+
+inline bool want_ws(Ctx& c, int s, int64_t bytes) {     // true: the launch may go ahead
+  if (bytes > c.need[s]) c.need[s] = bytes;
+  return !c.dry;
+}
+
+int run_op(Ctx& c, const int64_t* op) {
+  const int s = (int)op[1];
+  hipStream_t st = c.streams[s];
+  switch (op[0]) {
+    case OP_STEM_FWD: {   // in, W, map, out, col
+      const int64_t* m = c.maps + op[4] * MAPW;
+      if (c.dry) return 0;
+      return fc_stem_conv_fwd(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[3]), P<float>(c, op[5]),
+                              P<float>(c, op[6]), m[0], m[1], (int)m[2], st);
+    }
+    case OP_COL_STATS: {  // x, seg, n(dim), C, nseg(dim), mean, var, cnt
+      const int64_t n = c.dims[op[4]];
+      const int C = (int)op[5], nseg = (int)c.dims[op[6]];
+      if (!want_ws(c, s, fc_col_stats_ws_bytes(n, C, nseg))) return 0;
+      return fc_col_stats(P<const float>(c, op[2]), P<const int>(c, op[3]), op[3] >= 0 ? 4 : 0, n, C, nseg, P<float>(c, op[7]),
+                          P<float>(c, op[8]), P<float>(c, op[9]), c.ws[s], c.ws_bytes[s], st);
+    }
+    case OP_NORM_FWD: {   // x, seg, n(dim), C, mean, var, eps, gamma, beta, res, act, y
+      if (c.dry) return 0;
+      return fc_norm_act_fwd(P<const float>(c, op[2]), P<const int>(c, op[3]), op[3] >= 0 ? 4 : 0, c.dims[op[4]], (int)op[5],
+                             P<const float>(c, op[6]), P<const float>(c, op[7]), (float)as_double(op[8]), P<const float>(c, op[9]),
+                             P<const float>(c, op[10]), P<const float>(c, op[11]), (int)op[12], P<float>(c, op[13]), st);
+    }
+    case OP_MAXPOOL_FWD: {  // in, map, C, out, arg
+      const int64_t* m = c.maps + op[3] * MAPW;
+      if (c.dry) return 0;
+      return fc_maxpool_fwd(P<const float>(c, op[2]), reinterpret_cast<const int*>(m[3]), m[1], (int)m[2], (int)op[4], P<float>(c, op[5]),
+                            P<int>(c, op[6]), st);
+    }
+    case OP_CONV: {  // in, img, map (-1: dense GEMM over n rows), dir, out, n(dim, dense only), Cin, Cout
+      const int Cin = (int)op[8], Cout = (int)op[9];
+      const int fl = c.flags | CONV_X6;
+      if (op[4] < 0) {
+        const int64_t n = c.dims[op[7]];
+        if (!want_ws(c, s, fc_conv_fwd_ws_bytes(n, 1, Cin, Cout, fl))) return 0;
+        return fc_conv_fwd(P<const float>(c, op[2]), P<const float>(c, op[3]), nullptr, nullptr, P<float>(c, op[6]), n, n, 1, Cin, Cout, fl,
+                           c.ws[s], c.ws_bytes[s], st);
+      }
+      const int64_t* m = c.maps + op[4] * MAPW;
+      const bool bwd = op[5] != 0;
+      const int64_t n_in = bwd ? m[1] : m[0], n_out = bwd ? m[0] : m[1];
+      const int K = (int)m[2];
+      if (m[19] & (bwd ? 2 : 1)) {                       // per offset over the exact pair lists
+        const int b = bwd ? 14 : 9;
+        if (!want_ws(c, s, fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout))) return 0;
+        return fc_conv_fwd_pairs_tiles(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[b]),
+                                       reinterpret_cast<const int*>(m[b + 3]), reinterpret_cast<const int*>(m[b + 2]), P<float>(c, op[6]),
+                                       n_in, n_out, K, Cin, Cout, m[b + 4], fl, c.ws[s], c.ws_bytes[s], st);
+      }
+      if (!want_ws(c, s, fc_conv_fwd_ws_bytes(n_out, K, Cin, Cout, fl))) return 0;
+      return fc_conv_fwd(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[bwd ? 7 : 5]),
+                         reinterpret_cast<const int*>(m[bwd ? 8 : 6]), P<float>(c, op[6]), n_in, n_out, K, Cin, Cout, fl, c.ws[s],
+                         c.ws_bytes[s], st);
+    }
+    case OP_BN_FWD: {  // x, n(dim), C, eps, gamma, beta, res, act, momentum, y, mean, var, cnt, rmean, rvar, nbt, train
+      const int64_t n = c.dims[op[3]];
+      const int C = (int)op[4];
+      const float eps = (float)as_double(op[5]), mom = (float)as_double(op[10]);
+      if (!op[18]) {      // eval mode: the running statistics are the statistics
+        if (c.dry) return 0;
+        return fc_norm_act_fwd(P<const float>(c, op[2]), nullptr, 0, n, C, P<const float>(c, op[15]), P<const float>(c, op[16]), eps,
+                               P<const float>(c, op[6]), P<const float>(c, op[7]), P<const float>(c, op[8]), (int)op[9], P<float>(c, op[11]),
+                               st);
+      }
+      if (n * C <= c.bn_small_elems) {
+        if (!want_ws(c, s, fc_bn_small_ws_bytes(C))) return 0;
+        return fc_bn_act_train_fwd(P<const float>(c, op[2]), n, C, eps, P<const float>(c, op[6]), P<const float>(c, op[7]),
+                                   P<const float>(c, op[8]), (int)op[9], mom, P<float>(c, op[11]), P<float>(c, op[12]), P<float>(c, op[13]),
+                                   P<float>(c, op[14]), P<float>(c, op[15]), P<float>(c, op[16]), P<long long>(c, op[17]), c.ws[s],
+                                   c.ws_bytes[s], st);
+      }
+      if (!want_ws(c, s, fc_bn_stats_ws_bytes(n, C))) return 0;
+      int rc = fc_bn_stats_train(P<const float>(c, op[2]), n, C, mom, P<float>(c, op[12]), P<float>(c, op[13]), P<float>(c, op[14]),
+                                 P<float>(c, op[15]), P<float>(c, op[16]), P<long long>(c, op[17]), c.ws[s], c.ws_bytes[s], st);
+      if (rc) return rc;
+      return fc_norm_act_fwd(P<const float>(c, op[2]), nullptr, 0, n, C, P<const float>(c, op[12]), P<const float>(c, op[13]), eps,
+                             P<const float>(c, op[6]), P<const float>(c, op[7]), P<const float>(c, op[8]), (int)op[9], P<float>(c, op[11]), st);
+    }
+    case OP_UNION_FWD: {  // fa, fb, rows, n_a(dim), n_b(dim), n_union(dim), C, out:  out[:n_a] = fa, rest 0, out[rows[i]] += fb[i]
+      if (c.dry) return 0;
+      const int64_t n_a = c.dims[op[5]], n_b = c.dims[op[6]], n_u = c.dims[op[7]];
+      const int C = (int)op[8];
+      float* out = P<float>(c, op[9]);
+      FC_HIP(hipMemcpyAsync(out, P<const float>(c, op[2]), sizeof(float) * n_a * C, hipMemcpyDeviceToDevice, st));
+      if (n_u > n_a) FC_HIP(hipMemsetAsync(out + n_a * C, 0, sizeof(float) * (n_u - n_a) * C, st));
+      return fc_scatter_rows_add(P<const float>(c, op[3]), P<const int>(c, op[4]), n_b, C, out, st);
+    }
+    case OP_HEAD_FWD: {  // y, ld, bias, scale, n(dim), n_reg, n_cls, cent, bbox, cls, cmax
+      if (c.dry) return 0;
+      return fc_head_split_fwd(P<const float>(c, op[2]), (int)op[3], P<const float>(c, op[4]), P<const float>(c, op[5]), c.dims[op[6]],
+                               (int)op[7], (int)op[8], P<float>(c, op[9]), P<float>(c, op[10]), P<float>(c, op[11]), P<float>(c, op[12]), st);
+    }
+    case OP_RECORD:
+      if (c.dry) return 0;
+      FC_HIP(hipEventRecord(g_events[op[2]], st));
+      return 0;
+    case OP_WAIT:
+      if (c.dry) return 0;
+      FC_HIP(hipStreamWaitEvent(st, g_events[op[2]], 0));
+      return 0;
+    case OP_HEAD_BWD: {  // y, ld, scale, bbox, g_cent, g_bbox, g_cls, n(dim), n_reg, n_cls, gy, gs_row
+      if (c.dry) return 0;
+      return fc_head_split_bwd(P<const float>(c, op[2]), (int)op[3], P<const float>(c, op[4]), P<const float>(c, op[5]),
+                               P<const float>(c, op[6]), P<const float>(c, op[7]), P<const float>(c, op[8]), c.dims[op[9]], (int)op[10],
+                               (int)op[11], P<float>(c, op[12]), P<float>(c, op[13]), st);
+    }
+    case OP_WGRAD: {  // in, gout, map (-1: dense), gW, n(dim, dense only), Cin, Cout
+      const int Cin = (int)op[7], Cout = (int)op[8];
+      const int fl = c.flags | WGRAD_X6;
+      if (op[4] < 0) {
+        const int64_t n = c.dims[op[6]];
+        if (!want_ws(c, s, fc_conv_wgrad_ws_bytes(n, 1, Cin, Cout, fl))) return 0;
+        return fc_conv_wgrad(P<const float>(c, op[2]), P<const float>(c, op[3]), nullptr, nullptr, P<float>(c, op[5]), n, n, 1, Cin, Cout, fl,
+                             c.ws[s], c.ws_bytes[s], st);
+      }
+      const int64_t* m = c.maps + op[4] * MAPW;
+      const int K = (int)m[2];
+      if (!want_ws(c, s, fc_conv_wgrad_ws_bytes(m[1], K, Cin, Cout, fl))) return 0;
+      if ((m[19] & 4) && Cin % 64 == 0 && Cout % 64 == 0)
+        return fc_conv_wgrad_pairs(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[9]),
+                                   reinterpret_cast<const int*>(m[10]), reinterpret_cast<const int*>(m[12]), P<float>(c, op[5]), m[0], m[1],
+                                   K, Cin, Cout, fl, c.ws[s], c.ws_bytes[s], st);
+      return fc_conv_wgrad(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[3]), nullptr,
+                           P<float>(c, op[5]), m[0], m[1], K, Cin, Cout, fl, c.ws[s], c.ws_bytes[s], st);
+    }
+    case OP_BN_BWD: {  // x, y, gy, n(dim), C, mean, var, cnt, eps, gamma, beta, act, gx, gres, sums
+      const int64_t n = c.dims[op[5]];
+      const int C = (int)op[6];
+      const float eps = (float)as_double(op[10]);
+      if (n * C <= c.bn_small_elems) {
+        if (!want_ws(c, s, fc_bn_small_ws_bytes(C))) return 0;
+        return fc_bn_act_train_bwd(P<const float>(c, op[2]), P<const float>(c, op[3]), P<const float>(c, op[4]), n, C,
+                                   P<const float>(c, op[7]), P<const float>(c, op[8]), eps, P<const float>(c, op[11]),
+                                   P<const float>(c, op[12]), (int)op[13], P<float>(c, op[14]), P<float>(c, op[15]), P<float>(c, op[16]),
+                                   c.ws[s], c.ws_bytes[s], st);
+      }
+      if (!want_ws(c, s, fc_norm_act_bwd_ws_bytes(n, C, 1))) return 0;
+      return fc_norm_act_bwd(P<const float>(c, op[2]), P<const float>(c, op[3]), P<const float>(c, op[4]), nullptr, 0, n, C, 1,
+                             P<const float>(c, op[7]), P<const float>(c, op[8]), P<const float>(c, op[9]), eps, P<const float>(c, op[11]),
+                             P<const float>(c, op[12]), (int)op[13], P<float>(c, op[14]), P<float>(c, op[15]), P<float>(c, op[16]), c.ws[s],
+                             c.ws_bytes[s], st);
+    }
+    case OP_NORM_BWD: {  // x, y, gy, seg, n(dim), C, nseg(dim), mean, var, cnt, eps, gamma, beta, act, gx, gres, sums
+      const int64_t n = c.dims[op[6]];
+      const int C = (int)op[7], nseg = (int)c.dims[op[8]];
+      if (!want_ws(c, s, fc_norm_act_bwd_ws_bytes(n, C, nseg))) return 0;
+      return fc_norm_act_bwd(P<const float>(c, op[2]), P<const float>(c, op[3]), P<const float>(c, op[4]), P<const int>(c, op[5]),
+                             op[5] >= 0 ? 4 : 0, n, C, nseg, P<const float>(c, op[9]), P<const float>(c, op[10]), P<const float>(c, op[11]),
+                             (float)as_double(op[12]), P<const float>(c, op[13]), P<const float>(c, op[14]), (int)op[15], P<float>(c, op[16]),
+                             P<float>(c, op[17]), P<float>(c, op[18]), c.ws[s], c.ws_bytes[s], st);
+    }
+    case OP_MAXPOOL_BWD: {  // gout, arg, map, C, gin
+      const int64_t* m = c.maps + op[4] * MAPW;
+      if (c.dry) return 0;
+      const int C = (int)op[5];
+      FC_HIP(hipMemsetAsync(P<float>(c, op[6]), 0, sizeof(float) * m[0] * C, st));
+      return fc_maxpool_bwd(P<const float>(c, op[2]), P<const int>(c, op[3]), m[1], C, P<float>(c, op[6]), st);
+    }
+    case OP_STEM_WGRAD: {  // col, gout, map, gW
+      const int64_t* m = c.maps + op[4] * MAPW;
+      if (!want_ws(c, s, fc_stem_conv_wgrad_ws_bytes(m[1], (int)m[2]))) return 0;
+      return fc_stem_conv_wgrad(P<const float>(c, op[2]), P<const float>(c, op[3]), P<float>(c, op[5]), m[1], (int)m[2], c.ws[s],
+                                c.ws_bytes[s], st);
+    }
+    case OP_GATHER: {  // src, idx, n(dim), C, dst
+      if (c.dry) return 0;
+      return fc_gather_rows(P<const float>(c, op[2]), P<const int>(c, op[3]), c.dims[op[4]], (int)op[5], P<float>(c, op[6]), st);
+    }
+    case OP_ADD: {  // dst += src over n(dim) * C floats (C % 4 == 0)
+      if (c.dry) return 0;
+      const int64_t n4 = c.dims[op[4]] * op[5] / 4;
+      if (n4 > 0) k_add_inplace<<<(unsigned)fc_cdiv(n4, 256), 256, 0, st>>>(P<float>(c, op[2]), P<const float>(c, op[3]), n4);
+      FC_CHECK_LAUNCH();
+      return 0;
+    }
+    case OP_SMALL_GRADS: {  // desc (device), n
+      if (c.dry) return 0;
+      if (op[3] > 0) k_small_grads<<<(unsigned)op[3], 128, 0, st>>>(P<const long long>(c, op[2]), (int)op[3]);
+      FC_CHECK_LAUNCH();
+      return 0;
+    }
+    case OP_PERMUTE_GENT: {  // src (Cin, 8 Cout), dst (8, Cin, Cout), Cin, Cout
+      if (c.dry) return 0;
+      const int64_t total = 8 * op[4] * op[5];
+      k_permute_gent<<<(unsigned)fc_cdiv(total, 256), 256, 0, st>>>(P<const float>(c, op[2]), P<float>(c, op[3]), (int)op[4], (int)op[5]);
+      FC_CHECK_LAUNCH();
+      return 0;
+    }
+    case OP_HEAD_WFIN: {  // part, nl, R, ld, n_reg, n_cls, g_cent, g_reg, g_cls
+      if (c.dry) return 0;
+      const int total = (int)(op[4] * (1 + op[6] + op[7]));
+      k_head_wfin<<<(unsigned)fc_cdiv(total, 256), 256, 0, st>>>(P<const float>(c, op[2]), (int)op[3], (int)op[4], (int)op[5], (int)op[6],
+                                                                 (int)op[7], P<float>(c, op[8]), P<float>(c, op[9]), P<float>(c, op[10]));
+      FC_CHECK_LAUNCH();
+      return 0;
+    }
+    case OP_COPY: {  // dst, src, n(dim), C
+      if (c.dry) return 0;
+      FC_HIP(hipMemcpyAsync(P<float>(c, op[2]), P<const float>(c, op[3]), sizeof(float) * c.dims[op[4]] * op[5], hipMemcpyDeviceToDevice, st));
+      return 0;
+    }
+    default:
+      return FC_EINVAL;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fc_exec_op_words(void) { return OPW; }
+int fc_exec_map_words(void) { return MAPW; }
+
+// Runs operators [op_begin, op_end) of `ops` (HOST array, fc_exec_op_words() int64 per operator; layouts: fcaf3d_amd/executor.py).
+// addr / dims / maps: HOST arrays of device addresses, row counts and kernel-map descriptors the operators index.
+// streams / ws / ws_bytes: 3 entries each (0 main, 1 head branch, 2 weight gradients).  A first pass sizes the scratch space of
+// every operator; if a stream's workspace is too small NOTHING is launched, ws_need[3] holds the required sizes and the call
+// returns -2.  cfg[0] = bn_small_elems (functional.BN_SMALL_ELEMS), cfg[1] = kernel-variant flags (functional.FLAGS).
+int fc_exec(const int64_t* ops, int64_t op_begin, int64_t op_end, const int64_t* addr, const int64_t* dims, const int64_t* maps,
+            const int64_t* streams, const int64_t* ws, const int64_t* ws_bytes, int64_t* ws_need, const int64_t* cfg) {
+  if (!ops || op_begin < 0 || op_end < op_begin) return FC_EINVAL;
+  int rc = ensure_events();
+  if (rc) return rc;
+  Ctx c;
+  c.addr = addr; c.dims = dims; c.maps = maps;
+  for (int i = 0; i < NSTREAM; ++i) {
+    c.streams[i] = reinterpret_cast<hipStream_t>(streams[i]);
+    c.ws[i] = reinterpret_cast<void*>(ws[i]);
+    c.ws_bytes[i] = ws_bytes[i];
+    c.need[i] = 0;
+  }
+  c.bn_small_elems = cfg[0];
+  c.flags = (int)cfg[1];
+  c.dry = true;
+  for (int64_t i = op_begin; i < op_end; ++i) {
+    rc = run_op(c, ops + i * OPW);
+    if (rc) return rc;
+  }
+  bool ok = true;
+  for (int i = 0; i < NSTREAM; ++i) {
+    if (ws_need) ws_need[i] = c.need[i];
+    if (c.need[i] > c.ws_bytes[i]) ok = false;
+  }
+  if (!ok) return FC_EWS;
+  c.dry = false;
+  for (int64_t i = op_begin; i < op_end; ++i) {
+    rc = run_op(c, ops + i * OPW);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+}  // extern "C"

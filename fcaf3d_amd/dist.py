@@ -106,11 +106,20 @@ class GradientAverager:
         self._handles = []
         self._next = 0                         # buckets are reduced strictly in index order (see _hook)
         self._t0 = None
+        self._streams = {}                     # raw stream -> torch Stream: where this step's gradients were accumulated
 
     def _hook(self, p):
         if self.log is not None and self._t0 is None:
             import time
             self._t0 = time.perf_counter()     # first gradient of the step: backward is under way
+        if p.is_cuda:
+            # the stream this gradient was accumulated on (autograd runs a hook under the AccumulateGrad node's stream: the
+            # stream of the parameter's forward use — the main stream, or the neck's head-branch stream): _launch orders the
+            # bucket's gather copy and its collective behind every such stream
+            from . import _lib as L
+            raw = L.stream()
+            if raw not in self._streams:
+                self._streams[raw] = torch.cuda.current_stream(p.device)
         # Collectives must be issued in the SAME order on every rank.  A bucket becomes ready when its last gradient
         # arrives, which — if some parameter gets a gradient on one rank only — need not happen in the same order
         # everywhere; so a ready bucket is launched only once every bucket before it has been (torch DDP's rule), and
@@ -132,7 +141,15 @@ class GradientAverager:
                 self._t0 = now
             self.log.append(('launch', bi, now - self._t0))
         # gradients autograd produced outside the flat buffer (small tensors: norms, head) are copied into their slices,
-        # parameters without a gradient contribute zeros — one multi-tensor launch each, on the current (main) stream
+        # parameters without a gradient contribute zeros — one multi-tensor launch each, on the current stream.  The
+        # bucket's gradients may have been accumulated on SEVERAL streams (head branch of the neck on its own stream, the
+        # rest on the main stream): every hook of the bucket has fired, so all producing kernels are enqueued — the current
+        # stream waits for each of those streams before it reads them.
+        if self.flat.grad.is_cuda:
+            cur = torch.cuda.current_stream(self.flat.grad.device)
+            for s in self._streams.values():
+                if s != cur:
+                    cur.wait_stream(s)
         self.flat.gather(self.buckets[bi])
         lo, hi = self._ranges[bi]
         buf = self.flat.grad[lo:hi]

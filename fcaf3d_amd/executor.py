@@ -1,0 +1,685 @@
+"""The network body (MEResNet3D backbone + Fcaf3DNeckWithHead.forward) as a STATIC operator list walked by the native executor
+(csrc/exec.hip: one C-ABI call per direction) instead of ~1 000 Python-dispatched launches per step.
+
+r4 (profiles/r4_hostprof.txt): the training step was host-bound at every batch size (16.7 ms of Python per step at 2 scenes per
+GPU, 20.3 ms at 8).  The operator sequence of `SingleStageSparse3DDetector.extract_feat` (single_stage_sparse.py:43-50;
+me_resnet.py:43-50; fcaf3d_neck_with_head.py:94-108, :256-279) is fixed by the module graph; only row counts and addresses change
+from step to step.  `NetProgram` walks the module graph ONCE and emits
+
+  * forward operators  — the entry points `nn.py` / `functional.py` would call, in the same order, with the same arguments;
+  * backward operators — what torch.autograd would replay over them (backward-data, weight gradients on their own stream,
+    normalisation backward, gradient accumulation where a tensor has two consumers), gradients written straight into the flat
+    gradient buffer (flat.FlatParams) or a buffer of the same layout;
+
+as rows of int64 (operand layouts: csrc/exec.hip `run_op`).  Operands are indices into three host tables refreshed per step with
+a few vectorised numpy operations: `addr` (device addresses: arena tensors = base + aligned prefix sum of rows x bytes per row;
+parameters, buffers, weight images: static), `dims` (row counts) and `maps` (KernelMap.desc()).
+
+The module path stays the general route (and the cross-check of the tests: forward bit for bit, gradients to rounding): the
+program covers BasicBlock backbones (depth 14 / 18 / 34) with the FCAF3D neck when no pruning bites (`plan_maps` succeeded), the
+split-bf16 convolution route (FC_X6=1) and heads of at most 64 fused columns; anything else falls back.
+"""
+import os
+import struct
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import functional as Fn
+from . import nn as MEnn
+
+ENABLED = os.environ.get('FC_EXEC', '1') != '0'
+
+(OP_STEM_FWD, OP_COL_STATS, OP_NORM_FWD, OP_MAXPOOL_FWD, OP_CONV, OP_BN_FWD, OP_UNION_FWD, OP_HEAD_FWD, OP_RECORD, OP_WAIT,
+ OP_HEAD_BWD, OP_WGRAD, OP_BN_BWD, OP_NORM_BWD, OP_MAXPOOL_BWD, OP_STEM_WGRAD, OP_GATHER, OP_ADD, OP_SMALL_GRADS,
+ OP_PERMUTE_GENT, OP_HEAD_WFIN, OP_COPY) = range(1, 23)
+OPW, MAPW = 20, 20
+ALIGN = 256
+S_MAIN, S_HEAD, S_WGRAD = 0, 1, 2
+EV_FORK, EV_HEAD_DONE, EV_W0, EV_W1, EV_WEND, EV_BWD0, EV_HB = 0, 8, 9, 10, 11, 12, 16       # EV_FORK + level, EV_HB + level
+
+
+def _f(x):
+    """a float immediate: the bit pattern of a double in an int64 word"""
+    return struct.unpack('<q', struct.pack('<d', float(x)))[0]
+
+
+def supported(det):
+    bb, nh = det.backbone, det.neck_with_head
+    if not (ENABLED and Fn.X6 and Fn.X6_CONV and Fn.X6_WGRAD and not (Fn.FLAGS & 1) and Fn.STEM_COL and Fn.DGRAD_WT):
+        return False
+    if getattr(bb.BLOCK, 'expansion', 1) != 1 or det.spatial_sort:
+        return False
+    if 1 + nh.n_reg_outs + nh.n_classes > 64 or bb.conv1[0].in_channels != 3:
+        return False
+    return type(nh).forward_single is _FORWARD_SINGLE and type(nh).forward is _NECK_FORWARD
+
+
+_FORWARD_SINGLE = _NECK_FORWARD = None       # set by fcaf3d_neck_with_head at import: a subclass that overrides them falls back
+
+
+class NetProgram:
+    def __init__(self, det, training, wgrad_async, head_overlap):
+        self.det = det
+        self.training = training
+        self.wgrad_async = wgrad_async and training
+        bb, nh = det.backbone, det.neck_with_head
+        self.nl = min(bb.n_outs, 4)
+        self.head_overlap = head_overlap and self.nl > 1
+        self.dev = next(det.parameters()).device
+        self.ops_f, self.ops_b = [], []
+        self.n_addr = 0
+        self.static = []            # (addr index, address)
+        self.arena = {'f': [], 'b': []}     # (addr index, dims index of the row count, bytes per row)
+        self.alias = []             # (addr index, parent addr index, dims index of the row offset, bytes per row)
+        self.dyn = {}               # name -> addr index
+        self.dim_names = {}
+        self.map_names = {}
+        self.grad_refs = []         # (addr index, float offset into the gradient buffer)
+        self.keep = []              # tensors that must outlive the program build (persistent buffers)
+        self._params = [p for p in det.parameters() if p.requires_grad]
+        self._goff, off = {}, 0
+        flat = getattr(self._params[0], '_fc_flat', None)
+        self.flat = flat[0] if flat is not None else None
+        for p in self._params:
+            if self.flat is not None:
+                assert p._fc_flat[0] is self.flat
+                self._goff[id(p)] = p._fc_flat[1]
+            else:
+                self._goff[id(p)] = off
+                off += -(-p.numel() // 64) * 64
+        self._gtotal = self.flat.n if self.flat is not None else off
+        self._sig = self.signature(det)
+        self._build_weights()
+        self._build()
+        self._finalise()
+
+    @staticmethod
+    def signature(det):
+        ps = [p for p in det.parameters()]
+        return (len(ps), ps[0].data_ptr(), ps[-1].data_ptr(), getattr(ps[0], '_fc_flat', (None,))[0] is not None)
+
+    # ---- tables ------------------------------------------------------------------------------------------------------
+    def _new(self):
+        self.n_addr += 1
+        return self.n_addr - 1
+
+    def D(self, name):
+        if name not in self.dim_names:
+            self.dim_names[name] = len(self.dim_names)
+        return self.dim_names[name]
+
+    def M(self, name):
+        if name not in self.map_names:
+            self.map_names[name] = len(self.map_names)
+        return self.map_names[name]
+
+    def T(self, rows, cols, arena='f', elem=4):
+        i = self._new()
+        self.arena[arena].append((i, self.D(rows), cols * elem))
+        return i
+
+    def S(self, tensor):
+        """a static address: parameter data, module buffer, persistent scratch"""
+        i = self._new()
+        self.static.append((i, tensor.data_ptr()))
+        self.keep.append(tensor)
+        return i
+
+    def SA(self, address):
+        i = self._new()
+        self.static.append((i, int(address)))
+        return i
+
+    def DY(self, name):
+        if name not in self.dyn:
+            self.dyn[name] = self._new()
+        return self.dyn[name]
+
+    def AL(self, parent, off_dim, cols, elem=4):
+        i = self._new()
+        self.alias.append((i, parent, self.D(off_dim), cols * elem))
+        return i
+
+    def G(self, p):
+        i = self._new()
+        self.grad_refs.append((i, self._goff[id(p)]))
+        return i
+
+    def emit(self, lst, *words):
+        w = list(words) + [0] * (OPW - len(words))
+        assert len(w) == OPW, len(w)
+        lst.append(w)
+
+    # ---- weights: pre-split images of every kernel, incl. the packed head kernel and the generative convolutions' GEMM form ------
+    def _build_weights(self):
+        nh = self.det.neck_with_head
+        dev = self.dev
+        head = (nh.centerness_conv, nh.reg_conv, nh.cls_conv)
+        self.convs = [m for m in self.det.modules() if isinstance(m, MEnn.MinkowskiConvolution) and m not in head]
+        self.gents = [m for m in self.det.modules() if isinstance(m, MEnn.MinkowskiGenerativeConvolutionTranspose)]
+        C = nh.centerness_conv.in_channels
+        self.ncol = 1 + nh.n_reg_outs + nh.n_classes
+        self.packed = torch.zeros((1, C, 64), dtype=torch.float32, device=dev)       # [centerness | reg | cls | 0...]
+        self.gent_w = [torch.empty((1, m.in_channels, 8 * m.out_channels), dtype=torch.float32, device=dev) for m in self.gents]
+        ws = [m.kernel for m in self.convs] + [self.packed] + self.gent_w
+        self.images = Fn.WeightImages(ws)
+        self._img_of = {}
+        for w in ws:
+            K = 1 if w.dim() == 2 else w.shape[0]
+            self._img_of[w.data_ptr()] = self.images.table.get((w.data_ptr(), K, w.shape[-2], w.shape[-1]))
+        self.weights_fresh = False
+
+    @torch.no_grad()
+    def refresh_weights(self):
+        """pack the head kernels, permute the generative kernels into their GEMM form and rebuild every weight image (5-6 launches
+        on the CURRENT stream); the event other streams wait for is `self.images.event`"""
+        nh = self.det.neck_with_head
+        torch.cat((nh.centerness_conv.kernel, nh.reg_conv.kernel, nh.cls_conv.kernel), dim=1, out=self.packed[0][:, :self.ncol])
+        for m, w in zip(self.gents, self.gent_w):
+            w.view(m.in_channels, 8, m.out_channels).copy_(m.kernel.permute(1, 0, 2))
+        self.images.build()
+        self.weights_fresh = True
+
+    def IMG(self, w, transposed):
+        v = self._img_of[w.data_ptr()]
+        assert v is not None and v[1 if transposed else 0] is not None, 'no split-bf16 image for this kernel shape'
+        return self.S(v[1 if transposed else 0])
+
+    # ---- program ---------------------------------------------------------------------------------------------------------
+    def _build(self):
+        det = self.det
+        bb, nh = det.backbone, det.neck_with_head
+        tr = self.training
+        F, Bk = self.ops_f, self.ops_b
+        tape = []                        # (stream, backward emitter) in forward order
+        self.small = []                  # (sums address index or dyn name, nseg dim name or None, C, weight param, bias param)
+        relu, elu, none = Fn.ACT['relu'], Fn.ACT['elu'], Fn.ACT['none']
+        grad = {}                        # forward tensor -> gradient tensor (backward arena)
+        head_grads = {}                  # forward tensor -> (gradient from its head branch on the head stream, level)
+
+        def wstream(cur):
+            return S_WGRAD if self.wgrad_async else cur
+
+        def accumulate(t, g, rows, cols, stream):
+            """gradient `g` (a backward tensor) arrives for forward tensor t"""
+            if t not in grad:
+                grad[t] = g
+            else:
+                self.emit(Bk, OP_ADD, stream, grad[t], g, self.D(rows), cols)
+
+        def take(t, rows, cols):
+            """the complete gradient of forward tensor t, for the emitter of the operator that produced t (main stream)"""
+            if t in head_grads:
+                g, lvl = head_grads.pop(t)
+                self.emit(Bk, OP_WAIT, S_MAIN, EV_HB + lvl)          # the head branch of this level has delivered
+                accumulate(t, g, rows, cols, S_MAIN)
+            return grad[t]
+
+        def emit_wgrad(cur, *words):
+            if self.wgrad_async:
+                ev = EV_W0 if cur == S_MAIN else EV_W1
+                self.emit(Bk, OP_RECORD, cur, ev)
+                self.emit(Bk, OP_WAIT, S_WGRAD, ev)
+            self.emit(Bk, OP_WGRAD, wstream(cur), *words)
+
+        def conv(x, mod, mname, rows_in, rows_out, stream=S_MAIN):
+            """MinkowskiConvolution on a kernel map (functional._SparseConv)"""
+            Cin, Cout = mod.in_channels, mod.out_channels
+            y = self.T(rows_out, Cout)
+            m = self.M(mname)
+            self.emit(F, OP_CONV, stream, x, self.IMG(mod.kernel, False), m, 0, y, -1, Cin, Cout)
+            if tr:
+                def bwd():
+                    gy = take(y, rows_out, Cout) if stream == S_MAIN else grad[y]
+                    gx = self.T(rows_in, Cin, 'b')
+                    self.emit(Bk, OP_CONV, stream, gy, self.IMG(mod.kernel, True), m, 1, gx, -1, Cout, Cin)
+                    emit_wgrad(stream, x, gy, m, self.G(mod.kernel), -1, Cin, Cout)
+                    accumulate(x, gx, rows_in, Cin, stream)
+                tape.append((stream, bwd))
+            return y
+
+        def gemm(x, w_tensor, rows, Cin, Cout, gw_dst, stream=S_MAIN):
+            """dense GEMM (n, Cin) x (Cin, Cout): the generative transposed convolution, the fused 1x1 heads; gw_dst: the address
+            index the (Cin, Cout) weight gradient goes to"""
+            y = self.T(rows, Cout)
+            self.emit(F, OP_CONV, stream, x, self.IMG(w_tensor, False), -1, 0, y, self.D(rows), Cin, Cout)
+            if tr:
+                def bwd():
+                    gy = take(y, rows, Cout) if stream == S_MAIN else grad[y]
+                    gx = self.T(rows, Cin, 'b')
+                    self.emit(Bk, OP_CONV, stream, gy, self.IMG(w_tensor, True), -1, 1, gx, self.D(rows), Cout, Cin)
+                    emit_wgrad(stream, x, gy, -1, gw_dst, self.D(rows), Cin, Cout)
+                    accumulate(x, gx, rows, Cin, stream)
+                tape.append((stream, bwd))
+            return y
+
+        def bn(x, mod, act, rows, res=None, stream=S_MAIN):
+            """MinkowskiBatchNorm (+ residual) + activation (functional.bn_train / norm_act)"""
+            b = mod.bn
+            C = b.num_features
+            y = self.T(rows, C)
+            mean, var, cnt = (self.T('one', C), self.T('one', C), self.T('one', 1)) if tr else (-1, -1, -1)
+            self.emit(F, OP_BN_FWD, stream, x, self.D(rows), C, _f(b.eps), self.S(b.weight), self.S(b.bias), -1 if res is None else res, act,
+                      _f(b.momentum), y, mean, var, cnt, self.S(b.running_mean), self.S(b.running_var), self.S(b.num_batches_tracked),
+                      1 if tr else 0)
+            if tr:
+                sums = torch.zeros((2, C), dtype=torch.float32, device=self.dev)
+                si = self.S(sums)
+                self.small.append((sums.data_ptr(), None, C, b.weight, b.bias))
+
+                def bwd():
+                    gy = take(y, rows, C) if stream == S_MAIN else grad[y]
+                    gx = self.T(rows, C, 'b')
+                    gres = self.T(rows, C, 'b') if res is not None else -1
+                    self.emit(Bk, OP_BN_BWD, stream, x, y if res is not None else -1, gy, self.D(rows), C, mean, var, cnt, _f(b.eps),
+                              self.S(b.weight), self.S(b.bias), act, gx, gres, si)
+                    accumulate(x, gx, rows, C, stream)
+                    if res is not None:
+                        accumulate(res, gres, rows, C, stream)
+                tape.append((stream, bwd))
+            return y
+
+        # ---- backbone (me_resnet.py:14-50) ----
+        x0 = self.DY('x0')
+        seg1 = self.DY('seg1')
+        stem, inorm = bb.conv1[0], bb.conv1[1]
+        t_stem = self.T('n1', 64)
+        col = self.T('n1', 84) if tr else -1
+        self.emit(F, OP_STEM_FWD, S_MAIN, x0, self.S(stem.kernel), self.M('stem'), t_stem, col)
+        mean_in, var_in, cnt_in = self.T('B', 64), self.T('B', 64), self.T('B', 1)
+        self.emit(F, OP_COL_STATS, S_MAIN, t_stem, seg1, self.D('n1'), 64, self.D('B'), mean_in, var_in, cnt_in)
+        t_in = self.T('n1', 64)
+        self.emit(F, OP_NORM_FWD, S_MAIN, t_stem, seg1, self.D('n1'), 64, mean_in, var_in, _f(inorm.eps), self.S(inorm.weight),
+                  self.S(inorm.bias), -1, relu, t_in)
+        t_pool, arg = self.T('n2', 64), self.T('n2', 64)
+        self.emit(F, OP_MAXPOOL_FWD, S_MAIN, t_in, self.M('pool'), 64, t_pool, arg)
+        if tr:
+            in_sums = self.T('B', 2 * 64, 'b')
+            self.in_sums = in_sums
+            self.small.append((None, 'B', 64, inorm.weight, inorm.bias))
+
+            def bwd_stem():
+                g_pool = take(t_pool, 'n2', 64)
+                g_in = self.T('n1', 64, 'b')
+                self.emit(Bk, OP_MAXPOOL_BWD, S_MAIN, g_pool, arg, self.M('pool'), 64, g_in)
+                g_stem = self.T('n1', 64, 'b')
+                # instance norm + ReLU without a residual: y is not read (norm.hip bn_pre recomputes act')
+                self.emit(Bk, OP_NORM_BWD, S_MAIN, t_stem, -1, g_in, seg1, self.D('n1'), 64, self.D('B'), mean_in, var_in, cnt_in,
+                          _f(inorm.eps), self.S(inorm.weight), self.S(inorm.bias), relu, g_stem, -1, in_sums)
+                if self.wgrad_async:
+                    self.emit(Bk, OP_RECORD, S_MAIN, EV_W0)
+                    self.emit(Bk, OP_WAIT, S_WGRAD, EV_W0)
+                self.emit(Bk, OP_STEM_WGRAD, wstream(S_MAIN), col, g_stem, self.M('stem'), self.G(stem.kernel))
+            tape.append((S_MAIN, bwd_stem))
+        cur, cur_rows, cur_C = t_pool, 'n2', 64
+        levels = []
+        for li in range(1, self.nl + 1):
+            rows = f'L{li}'
+            for j, blk in enumerate(getattr(bb, f'layer{li}')):
+                planes = blk.conv1.out_channels
+                if j == 0:
+                    assert blk.downsample is not None and blk.conv1.stride == 2
+                    t_ds = conv(cur, blk.downsample[0], f'ds{li}', cur_rows, rows)
+                    res = bn(t_ds, blk.downsample[1], none, rows)
+                    t1 = conv(cur, blk.conv1, f'down{li}', cur_rows, rows)
+                else:
+                    assert blk.downsample is None
+                    res = cur
+                    t1 = conv(cur, blk.conv1, f'same{li}', rows, rows)
+                t1 = bn(t1, blk.norm1, relu, rows)
+                t2 = conv(t1, blk.conv2, f'same{li}', rows, rows)
+                cur = bn(t2, blk.norm2, relu, rows, res=res)
+                cur_rows, cur_C = rows, planes
+            levels.append((cur, rows, cur_C))
+        # ---- neck + head (fcaf3d_neck_with_head.py:94-108, :256-279) ----
+        n_reg, n_cls = nh.n_reg_outs, nh.n_classes
+        Cn = nh.centerness_conv.in_channels
+        cent_all, bbox_all = self.T('Nall', 1), self.T('Nall', n_reg)
+        cls_all, cmax_all = self.T('Nall', n_cls), self.T('Nall', 1)
+        self.out_idx = (cent_all, bbox_all, cls_all, cmax_all)
+        head_part = None
+        if tr:
+            self.gout_idx = (self.DY('g_cent'), self.DY('g_bbox'), self.DY('g_cls'))
+            self.gs_idx = self.T('Nall', 1, 'b')
+            head_part = torch.zeros((self.nl, Cn, 64), dtype=torch.float32, device=self.dev)
+            self.keep.append(head_part)
+        x, x_rows, x_C = levels[-1]
+        for i in range(self.nl - 1, -1, -1):
+            if i < self.nl - 1:
+                up = getattr(nh, f'up_block_{i + 1}')
+                gi = self.gents.index(up[0])
+                g_rows = f'g{i}'
+                Ci = up[0].out_channels
+                # generative transposed convolution: one dense GEMM (n, Cin) x (Cin, 8 Cout) whose (n, 8 Cout) output IS the
+                # (8 n, Cout) children matrix (row 8 i + k); its weight gradient comes out in the GEMM's layout and is permuted
+                # into the layer's (8, Cin, Cout) kernel gradient afterwards
+                gw_tmp = torch.zeros((x_C, 8 * Ci), dtype=torch.float32, device=self.dev)
+                self.keep.append(gw_tmp)
+                gw_i = self.S(gw_tmp)
+                if tr:
+                    def bwd_perm(gw_i=gw_i, mod=up[0], Cin=x_C, Ci=Ci):
+                        self.emit(Bk, OP_PERMUTE_GENT, wstream(S_MAIN), gw_i, self.G(mod.kernel), Cin, Ci)
+                    tape.append((S_MAIN, bwd_perm))          # forward order: BEFORE the GEMM, so the reversed walk reaches it after
+                t = gemm(x, self.gent_w[gi], x_rows, x_C, 8 * Ci, gw_i)
+                t = bn(t, up[1], elu, g_rows)
+                t = conv(t, up[3], f'gsame{i}', g_rows, g_rows)
+                t = bn(t, up[4], elu, g_rows)
+                # x = inputs[i] + t: every backbone voxel lies in the generated set -> the union IS the generated set (sparse.CoordMap.union)
+                fb, fb_rows, fb_C = levels[i]
+                u = self.T(g_rows, Ci)
+                rows_i = self.DY(f'rows{i}')
+                self.emit(F, OP_UNION_FWD, S_MAIN, t, fb, rows_i, self.D(g_rows), self.D(fb_rows), self.D(g_rows), Ci, u)
+                if tr:
+                    def bwd_union(u=u, t=t, fb=fb, fb_rows=fb_rows, rows_i=rows_i, g_rows=g_rows, Ci=Ci):
+                        gu = take(u, g_rows, Ci)
+                        accumulate(t, gu, g_rows, Ci, S_MAIN)          # d out / d fa = identity on all rows (n_a == n_union)
+                        gfb = self.T(fb_rows, Ci, 'b')
+                        self.emit(Bk, OP_GATHER, S_MAIN, gu, rows_i, self.D(fb_rows), Ci, gfb)
+                        accumulate(fb, gfb, fb_rows, Ci, S_MAIN)
+                    tape.append((S_MAIN, bwd_union))
+                x, x_rows, x_C = u, g_rows, Ci
+                kname = f'gsame{i}'
+            else:
+                kname = f'same{self.nl}'
+            # out_block_i + forward_single: on the head stream for i > 0
+            hs = S_HEAD if (self.head_overlap and i > 0) else S_MAIN
+            if hs == S_HEAD:
+                self.emit(F, OP_RECORD, S_MAIN, EV_FORK + i)
+                self.emit(F, OP_WAIT, S_HEAD, EV_FORK + i)
+            ob = getattr(nh, f'out_block_{i}')
+            o = conv(x, ob[0], kname, x_rows, x_rows, stream=hs)
+            o = bn(o, ob[1], elu, x_rows, stream=hs)
+            gw_head = self.SA(head_part[i].data_ptr()) if tr else -1
+            y = gemm(o, self.packed, x_rows, Cn, 64, gw_head, stream=hs)
+            off = f'off{i}'
+            outs = [self.AL(cent_all, off, 1), self.AL(bbox_all, off, n_reg), self.AL(cls_all, off, n_cls), self.AL(cmax_all, off, 1)]
+            self.emit(F, OP_HEAD_FWD, hs, y, 64, self.S(nh.cls_conv.bias), self.S(nh.scales[i].scale), self.D(x_rows), n_reg, n_cls, *outs)
+            if tr:
+                def bwd_head(y=y, outs=outs, off=off, hs=hs, rows=x_rows, lvl=i):
+                    gy = self.T(rows, 64, 'b')
+                    gin = [self.AL(g, off, c) for g, c in zip(self.gout_idx, (1, n_reg, n_cls))]
+                    self.emit(Bk, OP_HEAD_BWD, hs, y, 64, self.S(nh.scales[lvl].scale), outs[1], gin[0], gin[1], gin[2], self.D(rows), n_reg,
+                              n_cls, gy, self.AL(self.gs_idx, off, 1))
+                    grad[y] = gy
+                tape.append((hs, bwd_head))
+                if hs == S_HEAD:
+                    tape.append((S_HEAD, ('join', x, x_rows, x_C, i)))      # marker: where this level's head branch begins in reverse
+        if self.head_overlap:
+            self.emit(F, OP_RECORD, S_HEAD, EV_HEAD_DONE)
+            self.emit(F, OP_WAIT, S_MAIN, EV_HEAD_DONE)
+        # ---- backward program -------------------------------------------------------------------------------------------
+        if tr:
+            if self.head_overlap:
+                # the head branches depend on the loss gradients only: their backward is enqueued first, on the head stream, finest
+                # forked level first (the main chain needs that one first); each leaves the gradient of its neck tensor behind an event
+                self.emit(Bk, OP_RECORD, S_MAIN, EV_BWD0)          # the loss gradients are ready on the caller's stream
+                self.emit(Bk, OP_WAIT, S_HEAD, EV_BWD0)
+                branches, cur_b = [], None
+                for s, e in reversed(tape):
+                    if s != S_HEAD:
+                        continue
+                    if isinstance(e, tuple):
+                        cur_b = [e, []]
+                        branches.append(cur_b)
+                    else:
+                        cur_b[1].append(e)
+                for (_, xt, rows, C, lvl), ems in sorted(branches, key=lambda b: b[0][4]):
+                    saved = grad.pop(xt, None)
+                    assert saved is None
+                    for e in ems:
+                        e()
+                    self.emit(Bk, OP_RECORD, S_HEAD, EV_HB + lvl)
+                    head_grads[xt] = (grad.pop(xt), lvl)
+            for s, e in reversed(tape):
+                if s == S_MAIN:
+                    e()
+            assert not head_grads, 'a head branch was never joined'
+            # per-level partials of the packed head kernel -> the three head kernels' gradients; normalisation sums -> their slices
+            self.emit(Bk, OP_HEAD_WFIN, wstream(S_MAIN), self.SA(head_part.data_ptr()), self.nl, Cn, 64, n_reg, n_cls,
+                      self.G(nh.centerness_conv.kernel), self.G(nh.reg_conv.kernel), self.G(nh.cls_conv.kernel))
+            self.emit(Bk, OP_SMALL_GRADS, S_MAIN, self.DY('small_desc'), 2 * len(self.small))
+            if self.wgrad_async:
+                self.emit(Bk, OP_RECORD, S_WGRAD, EV_WEND)
+                self.emit(Bk, OP_WAIT, S_MAIN, EV_WEND)
+
+    # ---- per-step tables ---------------------------------------------------------------------------------------------------
+    def _finalise(self):
+        self.ops_f = np.ascontiguousarray(np.asarray(self.ops_f, dtype=np.int64).reshape(-1, OPW))
+        self.ops_b = np.ascontiguousarray(np.asarray(self.ops_b, dtype=np.int64).reshape(-1, OPW)) if self.ops_b else np.zeros((0, OPW), np.int64)
+        self.addr0 = np.zeros(self.n_addr, dtype=np.int64)
+        for i, a in self.static:
+            self.addr0[i] = a
+        self._ar = {}
+        for k in ('f', 'b'):
+            a = self.arena[k]
+            self._ar[k] = (np.array([t[0] for t in a], dtype=np.int64), np.array([t[1] for t in a], dtype=np.int64),
+                           np.array([t[2] for t in a], dtype=np.int64))
+        self._al = (np.array([t[0] for t in self.alias], dtype=np.int64), np.array([t[1] for t in self.alias], dtype=np.int64),
+                    np.array([t[2] for t in self.alias], dtype=np.int64), np.array([t[3] for t in self.alias], dtype=np.int64))
+        self._gr = (np.array([t[0] for t in self.grad_refs], dtype=np.int64), np.array([t[1] for t in self.grad_refs], dtype=np.int64) * 4)
+        self.n_dims, self.n_maps = len(self.dim_names), len(self.map_names)
+        self._ws = [None, None, None]
+        self._need = np.zeros(3, dtype=np.int64)
+        self._cfg = np.array([Fn.BN_SMALL_ELEMS, Fn.FLAGS], dtype=np.int64)
+        self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
+        if self.training:
+            # small-gradient descriptor template: (src, dst, C, nseg, stride, 0, 0, 0) per (bias, weight) of every normalisation layer
+            n = len(self.small)
+            self._small = np.zeros((2 * n, 8), dtype=np.int64)
+            self._small_goff = np.zeros(2 * n, dtype=np.int64)
+            self._small_in = None
+            for k, (src, nseg, C, w, b) in enumerate(self.small):
+                for h, p in ((0, b), (1, w)):          # sums[0] = d beta, sums[1] = d gamma
+                    r = 2 * k + h
+                    self._small[r, 2], self._small[r, 3], self._small[r, 4] = C, 1, 2 * C
+                    self._small_goff[r] = self._goff[id(p)] * 4
+                    if src is not None:
+                        self._small[r, 0] = src + 4 * C * h
+                    else:
+                        self._small_in = (2 * k, C)
+
+    def _fill_arena(self, addr, dims, which, base):
+        idx, di, bpr = self._ar[which]
+        if len(idx) == 0:
+            return
+        sizes = (dims[di] * bpr + (ALIGN - 1)) // ALIGN * ALIGN
+        offs = np.cumsum(sizes) - sizes
+        addr[idx] = base + offs
+
+    def _arena_bytes(self, dims, which):
+        idx, di, bpr = self._ar[which]
+        return int(((dims[di] * bpr + (ALIGN - 1)) // ALIGN * ALIGN).sum()) + ALIGN
+
+    def bind(self, x, batch_size, backward):
+        """per-step tables from the input SparseTensor's coordinate maps (all cached lookups after plan_maps); None if this
+        step's maps do not fit the program (a union that is not the generated set)"""
+        nl = self.nl
+        cm0 = x.cmap
+        dims = np.zeros(self.n_dims, dtype=np.int64)
+        maps = np.zeros((self.n_maps, MAPW), dtype=np.int64)
+        dn, mn = self.dim_names, self.map_names
+
+        def setd(k, v):
+            if k in dn:
+                dims[dn[k]] = v
+        m1 = cm0.strided(2)
+        m2 = m1.strided(2)
+        maps[mn['stem']] = cm0.kernel_map(m1, 3).desc(conv=False)
+        maps[mn['pool']] = m1.kernel_map(m2, 2).desc(conv=False)
+        setd('n0', cm0.n); setd('n1', m1.n); setd('n2', m2.n); setd('B', batch_size); setd('one', 1)
+        prev, lv = m2, []
+        for li in range(1, nl + 1):
+            mi = prev.strided(2)
+            maps[mn[f'down{li}']] = prev.kernel_map(mi, 3).desc(True, backward)
+            maps[mn[f'ds{li}']] = prev.kernel_map(mi, 1).desc(True, backward)
+            maps[mn[f'same{li}']] = mi.kernel_map(mi, 3).desc(True, backward)
+            setd(f'L{li}', mi.n)
+            lv.append(mi)
+            prev = mi
+        xm = lv[-1]
+        head_maps = [xm]
+        dyn = {}
+        for i in range(nl - 2, -1, -1):
+            g = xm.generate()
+            u, rows, swapped = lv[i].union(g)
+            if not swapped or u is not g:
+                return None
+            maps[mn[f'gsame{i}']] = g.kernel_map(g, 3).desc(True, backward)
+            setd(f'g{i}', g.n)
+            dyn[f'rows{i}'] = rows
+            xm = g
+            head_maps.append(g)
+        head_maps = head_maps[::-1]                       # finest first
+        off = 0
+        for i, cm in enumerate(head_maps):
+            setd(f'off{i}', off)
+            off += cm.n
+        setd('Nall', off)
+        return dict(dims=dims, maps=maps, dyn=dyn, head_maps=head_maps, x=x, seg1=m1.coords, n_all=off)
+
+    def _streams(self):
+        dev = self.dev
+        nh = self.det.neck_with_head
+        main = L.stream()
+        head = nh._head_stream(dev).cuda_stream if self.head_overlap else main
+        wg = Fn.wgrad_stream(dev).cuda_stream if self.wgrad_async else main
+        return np.array([main, head, wg], dtype=np.int64)
+
+    def _run(self, ops, addr, st):
+        streams = self._streams()
+        while True:
+            ws = np.array([w.data_ptr() if w is not None else 0 for w in self._ws], dtype=np.int64)
+            wsb = np.array([w.numel() if w is not None else 0 for w in self._ws], dtype=np.int64)
+            rc = L.lib().fc_exec(ops.ctypes.data, 0, len(ops), addr.ctypes.data, st['dims'].ctypes.data, st['maps'].ctypes.data,
+                                 streams.ctypes.data, ws.ctypes.data, wsb.ctypes.data, self._need.ctypes.data, self._cfg.ctypes.data)
+            if rc == -2:                                  # nothing was launched: grow the scratch buffers and go again
+                for i in range(3):
+                    if self._need[i] > wsb[i]:
+                        self._ws[i] = torch.empty(int(self._need[i] * 5 // 4) + (1 << 20), dtype=torch.uint8, device=self.dev)
+                continue
+            if rc != 0:
+                raise RuntimeError(f'fc_exec failed: {"invalid argument" if rc == -1 else "hipError %d" % rc}')
+            return
+
+    def forward(self, st):
+        """-> (cent_all, bbox_all, cls_all, cmax_all) for all head locations (levels finest first), autograd-connected in training"""
+        if not self.weights_fresh:
+            self.refresh_weights()
+        ev = self.images.event
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)     # images may have been built on another stream (runner: after the optimizer step)
+        if self.training:
+            return _NetFn.apply(self._anchor, self, st)
+        return self._forward(st)
+
+    def _forward(self, st):
+        dims = st['dims']
+        fa = torch.empty(self._arena_bytes(dims, 'f'), dtype=torch.uint8, device=self.dev)
+        addr = self.addr0.copy()
+        base = (fa.data_ptr() + ALIGN - 1) // ALIGN * ALIGN
+        self._fill_arena(addr, dims, 'f', base)
+        addr[self.dyn['x0']] = st['x'].F.data_ptr()
+        addr[self.dyn['seg1']] = st['seg1'].data_ptr()
+        for k, t in st['dyn'].items():
+            addr[self.dyn[k]] = t.data_ptr()
+        ai, ap, ad, ab = self._al
+        fwd_alias = addr[ap] != 0                         # aliases of forward tensors (the backward ones are resolved later)
+        addr[ai[fwd_alias]] = addr[ap[fwd_alias]] + dims[ad[fwd_alias]] * ab[fwd_alias]
+        st['fa'], st['addr'] = fa, addr
+        self._run(self.ops_f, addr, st)
+        n = st['n_all']
+        nh = self.det.neck_with_head
+        outs = []
+        for idx, c in zip(self.out_idx, (1, nh.n_reg_outs, nh.n_classes, 1)):
+            o = int(addr[idx] - fa.data_ptr())
+            outs.append(fa[o:o + n * c * 4].view(torch.float32).view(n, c))
+        return tuple(outs)
+
+    def _backward(self, st, g_cent, g_bbox, g_cls):
+        dims, addr = st['dims'], st['addr']
+        n = st['n_all']
+        nh = self.det.neck_with_head
+        gs = []
+        for g, c in zip((g_cent, g_bbox, g_cls), (1, nh.n_reg_outs, nh.n_classes)):
+            gs.append(g.contiguous() if g is not None else torch.zeros((n, c), dtype=torch.float32, device=self.dev))
+        ba = torch.empty(self._arena_bytes(dims, 'b'), dtype=torch.uint8, device=self.dev)
+        base = (ba.data_ptr() + ALIGN - 1) // ALIGN * ALIGN
+        self._fill_arena(addr, dims, 'b', base)
+        for k, g in zip(('g_cent', 'g_bbox', 'g_cls'), gs):
+            addr[self.dyn[k]] = g.data_ptr()
+        ai, ap, ad, ab = self._al
+        addr[ai] = addr[ap] + dims[ad] * ab
+        if self.flat is not None:
+            gbuf = self.flat.grad
+        else:
+            gbuf = torch.zeros(self._gtotal, dtype=torch.float32, device=self.dev)
+        gi, go = self._gr
+        addr[gi] = gbuf.data_ptr() + go
+        desc = self._small.copy()
+        desc[:, 1] = gbuf.data_ptr() + self._small_goff
+        r, C = self._small_in
+        B = int(dims[self.dim_names['B']])
+        desc[r, 0], desc[r + 1, 0] = addr[self.in_sums], addr[self.in_sums] + 4 * C
+        desc[r:r + 2, 3] = B
+        desc_dev = L.upload(desc, self.dev)
+        addr[self.dyn['small_desc']] = desc_dev.data_ptr()
+        self._run(self.ops_b, addr, st)
+        # the head's bias and the per-level scales: plain reductions over the location rows
+        o = int(addr[self.gs_idx] - ba.data_ptr())
+        gs_all = ba[o:o + n * 4].view(torch.float32)
+        offs = [int(dims[self.dim_names[f'off{i}']]) for i in range(self.nl)] + [n]
+        gv = self._grad_views(gbuf)
+        gv[id(nh.cls_conv.bias)].copy_(gs[2].sum(0).view_as(nh.cls_conv.bias))
+        for i in range(self.nl):
+            gv[id(nh.scales[i].scale)].copy_(gs_all[offs[i]:offs[i + 1]].sum())
+        for p in self._params:
+            v = gv[id(p)]
+            if p.grad is None:
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                p.grad += v
+        if self.flat is not None:
+            self.flat.complete = True
+        st['ba'] = ba                                       # until the caller drops the step state
+
+    def _grad_views(self, gbuf):
+        key = gbuf.data_ptr()
+        cache = getattr(self, '_gv', None)
+        if cache is None or cache[0] != key:
+            views = {id(p): gbuf[self._goff[id(p)]:self._goff[id(p)] + p.numel()].view(p.shape) for p in self._params}
+            cache = self._gv = (key, views, gbuf)
+        return cache[1]
+
+
+class _NetFn(torch.autograd.Function):
+    """The whole network body as one autograd node: forward = one fc_exec call, backward = one fc_exec call that leaves every
+    parameter gradient in the (flat) gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, anchor, prog, st):
+        ctx.prog, ctx.st = prog, st
+        cent, bbox, cls, cmax = prog._forward(st)
+        ctx.mark_non_differentiable(cmax)
+        return cent, bbox, cls, cmax
+
+    @staticmethod
+    def backward(ctx, g_cent, g_bbox, g_cls, _g_max):
+        ctx.prog._backward(ctx.st, g_cent, g_bbox, g_cls)
+        ctx.st = None
+        return None, None, None
+
+
+def program_for(det, training):
+    """the cached NetProgram of this detector for the current mode / stream configuration (None: not covered -> module path)"""
+    if not supported(det):
+        return None
+    nh = det.neck_with_head
+    key = (bool(training), bool(Fn.WGRAD_ASYNC), bool(nh.head_overlap))
+    cache = det.__dict__.setdefault('_programs', {})
+    sig = NetProgram.signature(det)
+    prog = cache.get(key)
+    if prog is None or prog._sig != sig:
+        prog = cache[key] = NetProgram(det, *key)
+    return prog

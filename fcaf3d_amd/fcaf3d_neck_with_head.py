@@ -30,9 +30,17 @@ class SceneList:
     decomposition permutation, fcaf3d_neck_with_head.py:266-275), kept as ONE (N,C) tensor on its coordinate
     map; the per-scene tensors are materialised only when indexed.  `loss()` consumes `.full` directly."""
 
-    def __init__(self, full, cmap):
-        self.full, self.cmap = full, cmap
+    def __init__(self, full, cmap, parent=None):
+        """full: the (N, C) tensor, or a callable that makes it on first use; parent: the all-levels tensor this level is a row
+        range of (executor path: the loss then reads the parent instead of concatenating the levels)"""
+        self._full, self.cmap, self.parent = full, cmap, parent
         self._items = {}
+
+    @property
+    def full(self):
+        if callable(self._full):
+            self._full = self._full()
+        return self._full
 
     def __len__(self):
         return self.cmap.batch_size
@@ -159,6 +167,13 @@ class Fcaf3DNeckWithHead(nn.Module):
                 x = inputs[i] + x
                 x = self._prune(x, scores, (main, side))
             if side is not None and i > 0:
+                # Every table the two branches share is built HERE, on the main stream, before the fork: this level's k3
+                # kernel map (out_block_i reads it on the head stream; the next up_block derives the generated set's map
+                # from it on the main stream, sparse.CoordMap.kernel_map) and its derived tables (backward replays each
+                # branch on the stream of its forward).  Planned steps find them prefetched (a cache hit); with pruning
+                # live nothing was, and a table first built under the head stream would be read by the main stream
+                # without any ordering.
+                x.cmap.kernel_map(x.cmap, 3).prefetch(self.training and torch.is_grad_enabled())
                 side.wait_stream(main)                       # x is complete on the main stream
                 x.F.record_stream(side)
                 with torch.cuda.stream(side):
@@ -314,9 +329,12 @@ class Fcaf3DNeckWithHead(nn.Module):
             tg = self._targets(cmaps, gt_bboxes, gt_labels)
         pts, scene, ct, bt, labels, posf, inv_pos, inv_den = (tg[k] for k in ('pts', 'scene', 'ct', 'bt', 'labels', 'posf',
                                                                                'inv_pos', 'inv_den'))
-        centerness = torch.cat([c.full for c in centernesses])
-        bbox_pred = torch.cat([b.full for b in bbox_preds])
-        cls_score = torch.cat([c.full for c in cls_scores])
+        def cat(lists):
+            par = lists[0].parent
+            if par is not None and all(v.parent is par for v in lists) and par.shape[0] == sum(v.cmap.n for v in lists):
+                return par                                  # the levels ARE consecutive row ranges of one tensor (executor.py)
+            return torch.cat([v.full for v in lists])
+        centerness, bbox_pred, cls_score = cat(centernesses), cat(bbox_preds), cat(cls_scores)
         if self._fusable_loss(bbox_pred):
             # yaw-less head with the reference's default loss types: focal + centerness BCE + decode + axis-aligned IoU and
             # their weighted sums in 2 launches (1 backward) instead of ~40 (~40) tiny ones on the step's serial spine
@@ -662,3 +680,8 @@ class Fcaf3DAssigner:
         rows = torch.arange(n_points, device=dev)
         centerness_targets = compute_centerness(targets[rows, owner])
         return centerness_targets, boxes[owner], labels
+
+
+from . import executor as _executor                          # the native executor covers exactly these two methods
+_executor._FORWARD_SINGLE = Fcaf3DNeckWithHead.forward_single
+_executor._NECK_FORWARD = Fcaf3DNeckWithHead.forward

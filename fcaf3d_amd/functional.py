@@ -32,6 +32,16 @@ def join_wgrad_stream():
         torch.cuda.current_stream(s.device).wait_stream(s)
 
 
+_flat_handed = set()          # ids of the leaf kernels whose flat gradient slice this backward pass has handed out
+_flat_cb_queued = False
+
+
+def _flat_pass_done():
+    global _flat_cb_queued
+    _flat_cb_queued = False
+    _flat_handed.clear()
+
+
 def _chk(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -207,7 +217,15 @@ class _SparseConv(torch.autograd.Function):
             nbr, ridx = (kmap.nbr if kmap is not None else None), None      # wgrad walks rows in natural order (see conv.hip)
 
             col = ctx.saved_tensors[2] if ctx.has_col else None
-            flat = ctx.flat if (ctx.flat is not None and weight.grad is None) else None
+            # a kernel used by TWO convolutions of one graph (shared weights) gets its slice only once per backward pass: the
+            # second node would overwrite it and hand autograd an aliasing view (g2 + g2 instead of g1 + g2)
+            flat = ctx.flat if (ctx.flat is not None and weight.grad is None and id(weight) not in _flat_handed) else None
+            if flat is not None:
+                global _flat_cb_queued
+                _flat_handed.add(id(weight))
+                if not _flat_cb_queued:
+                    _flat_cb_queued = True
+                    torch.autograd.Variable._execution_engine.queue_callback(_flat_pass_done)
 
             def launch():
                 # flat storage: a FRESH view of the parameter's slice of the flat gradient buffer — autograd adopts it as

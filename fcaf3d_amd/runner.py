@@ -25,7 +25,10 @@ from .flat import FlatParams
 class FlatAdamW:
     """torch.optim.AdamW (betas 0.9 / 0.999, eps 1e-8, decoupled weight decay, no amsgrad) + clip_grad_norm_ over the flat
     buffers of a `FlatParams`: `step(max_norm)` = fc_grad_norm (global 2-norm and clip coefficient, on the device) +
-    fc_adamw_step (one pass; the coefficient is applied while the gradient is read).  Keeps the slice of torch's optimizer
+    fc_adamw_step (one pass; the coefficient is applied while the gradient is read).  One difference to torch.optim.AdamW:
+    a parameter that received NO gradient in a step has its slice zeroed by `FlatParams.gather` and is stepped with a zero
+    gradient (weight decay and moment decay apply) where torch skips it — every parameter of the FCAF3D detector receives a
+    gradient in every step.  Keeps the slice of torch's optimizer
     interface the runner and the LR hook use: `param_groups`, `defaults`, `zero_grad`, `state_dict` / `load_state_dict` in
     torch's own layout (per-parameter `step`, `exp_avg`, `exp_avg_sq`), so mmcv-style checkpoints round-trip."""
 
@@ -41,13 +44,14 @@ class FlatAdamW:
     def zero_grad(self, set_to_none=True):
         for p in self.flat.params:
             p.grad = None                        # the flat gradient buffer is overwritten, not accumulated into
+        self.flat.complete = False
 
     def step(self, max_norm=None, gathered=False):
         """-> the global gradient norm (0-d device tensor) when max_norm is given"""
         f = self.flat
         if not f.data.is_cuda:
             raise RuntimeError('FlatAdamW runs on the GPU only (HIP); CPU parameters take torch.optim.AdamW')
-        if not gathered:
+        if not gathered and not getattr(f, 'complete', False):      # complete: the executor's backward left every gradient in place
             f.gather()
         g = self.param_groups[0]
         self.steps += 1
@@ -60,7 +64,7 @@ class FlatAdamW:
         L.call('fc_adamw_step', L.ptr(f.data), L.ptr(f.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), f.n, float(g['lr']),
                float(b1), float(b2), float(g['eps']), float(g['weight_decay']), 1.0 - b1 ** self.steps, 1.0 - b2 ** self.steps,
                L.ptr(clip), L.stream())
-        return self.norm_clip[0] if clip is not None else None
+        return self.norm_clip[0].clone() if clip is not None else None      # a copy: norm_clip is rewritten by the next step
 
     def _views(self, buf):
         return [buf[o:o + p.numel()].view(p.shape) for p, o in zip(self.flat.params, self.flat.offsets)]
@@ -77,6 +81,8 @@ class FlatAdamW:
         m, v = self._views(self.exp_avg), self._views(self.exp_avg_sq)
         steps = 0
         with torch.no_grad():
+            self.exp_avg.zero_()                  # entries the loaded state does not hold start from zero moments, as a
+            self.exp_avg_sq.zero_()               # fresh torch.optim.AdamW state would
             for i, st in sd['state'].items():
                 m[int(i)].copy_(st['exp_avg'])
                 v[int(i)].copy_(st['exp_avg_sq'])
@@ -185,6 +191,15 @@ class TrainStep:
     def from_config(cls, model, cfg, **kw):
         return cls(model, cfg.optimizer, cfg.get('optimizer_config'), cfg.get('lr_config'), **kw)
 
+    def invalidate_images(self):
+        """Call after writing the weights in a way that does not move their version counters (`p.data.copy_`,
+        `dist.broadcast(p.data)`, EMA / weight surgery through `.data`): the next step rebuilds the pre-split weight images
+        (the module path's and the native executor's) before it uses them.  Writes through torch ops on the parameters
+        themselves (load_state_dict, `with no_grad(): p.copy_()`) are detected by the version counters."""
+        for pr in getattr(self.model, '_programs', {}).values():
+            pr.weights_fresh = False
+        self.images_version = None
+
     def _build_images(self, side_stream):
         from . import functional as Fn
         if side_stream:
@@ -196,10 +211,25 @@ class TrainStep:
             self.images.build()
         self.images_version = sum(w._version for w in self._image_ws)
 
+    def _program(self):
+        """the model's native-executor program for a training step, if this step will go through it (executor.py)"""
+        from . import executor
+        if self.flat is None or not hasattr(self.model, 'backbone') or not self.model.training:
+            return None
+        return executor.program_for(self.model, True)
+
     def __call__(self, batch):
         from . import functional as Fn
         self.optimizer.zero_grad(set_to_none=True)
-        if self.images is not None and self.images.n:
+        prog = self._program()
+        if prog is not None:
+            # the executor reads its own weight images (incl. the packed head kernel and the generative kernels' GEMM form); they
+            # are refreshed right after the optimizer step below, or here if something else has written the weights since
+            ver = sum(w._version for w in self._image_ws) if self.images is not None else None
+            if not prog.weights_fresh or getattr(self, '_prog_version', None) != ver:
+                prog.refresh_weights()
+                self._prog_version = ver
+        elif self.images is not None and self.images.n:
             if self.images_version != sum(w._version for w in self._image_ws):      # first step, or somebody wrote the weights through torch
                 self._build_images(side_stream=False)
             Fn.PREBUILT, Fn.PREBUILT_EVENT = self.images.table, self.images.event
@@ -213,7 +243,15 @@ class TrainStep:
         if isinstance(self.optimizer, FlatAdamW):
             # after finish() under data parallelism every gradient already sits (averaged) in the flat buffer
             self.last_grad_norm = self.optimizer.step(self.max_norm, gathered=bool(self.averager.buckets))
-            if self.images is not None and self.images.n:
+            for pr in getattr(self.model, '_programs', {}).values():
+                pr.weights_fresh = False
+            if prog is not None:
+                side, main = Fn.wgrad_stream(self.flat.data.device), torch.cuda.current_stream()
+                side.wait_stream(main)                   # the optimizer step (and every reader of the old images) is enqueued on main
+                with torch.cuda.stream(side):
+                    prog.refresh_weights()
+                self.images_version = None               # the module path's images are stale now; rebuilt if a step takes that path
+            elif self.images is not None and self.images.n:
                 self._build_images(side_stream=True)
             return loss, losses
         if self.max_norm is not None:
@@ -229,6 +267,7 @@ class TrainStep:
         return dict(optimizer=self.optimizer.state_dict(), epoch=self.lr.epoch if self.lr else 0)
 
     def load_state_dict(self, sd):
+        self.invalidate_images()
         self.optimizer.load_state_dict(sd['optimizer'])
         if self.lr is not None:
             self.lr.set_epoch(sd.get('epoch', 0))

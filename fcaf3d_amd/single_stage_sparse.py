@@ -70,6 +70,17 @@ class SingleStageSparse3DDetector(nn.Module):
         x = SparseTensor(features, coordinates=coordinates, batch_size=len(points))
         _rec(x.F)
         head_maps = self.plan_maps(x.cmap)
+        # the network body as one native call per direction (executor.py) when this step's maps fit its static operator list
+        self._bound = None
+        if head_maps is not None and x.F.is_cuda:
+            from . import executor
+            grad_on = torch.is_grad_enabled()
+            if self.training == grad_on:                   # training with gradients, or inference without: the two programs
+                prog = executor.program_for(self, self.training)
+                if prog is not None:
+                    st = prog.bind(x, len(points), backward=self.training)
+                    if st is not None:
+                        self._bound = (prog, st)
         if gt is not None and head_maps is not None and hasattr(self.neck_with_head, 'prepare_targets'):
             # training: the target assignment depends on the head's LOCATIONS (coordinate sets, known now) and the ground
             # truth only — it runs here, on the coordinate stream, instead of between forward and backward (r3)
@@ -116,9 +127,31 @@ class SingleStageSparse3DDetector(nn.Module):
                 x = self._sparse_input(points, gt)
         else:
             x = self._sparse_input(points, gt)
+        bound, self._bound = getattr(self, '_bound', None), None
+        if bound is not None:
+            return self._exec_forward(*bound)
         x = self.backbone(x)
         x = self.neck_with_head(x)
         return x
+
+    def _exec_forward(self, prog, st):
+        """backbone + neck + head through the native executor; returns what `neck_with_head(backbone(x))` returns"""
+        from .fcaf3d_neck_with_head import SceneList
+        cent, bbox, cls, _ = prog.forward(st)
+        vs = self.neck_with_head.voxel_size
+        outs, o = ([], [], [], []), 0
+        for cm in st['head_maps']:
+            n = cm.n
+            outs[0].append(SceneList(cent[o:o + n], cm, parent=cent))
+            outs[1].append(SceneList(bbox[o:o + n], cm, parent=bbox))
+            outs[2].append(SceneList(cls[o:o + n], cm, parent=cls))
+            outs[3].append(SceneList(lambda cm=cm: cm.coords[:, 1:].float() * vs, cm))      # voxel corners, made when asked for
+            o += n
+        return [tuple(v) for v in outs]
+
+    def _apply(self, fn, *a, **kw):
+        self.__dict__.pop('_programs', None)              # parameters / buffers may move: the executor's address tables are stale
+        return super()._apply(fn, *a, **kw)
 
     def forward_train(self, points, gt_bboxes_3d, gt_labels_3d, img_metas):
         x = self.extract_feat(points, img_metas, (gt_bboxes_3d, gt_labels_3d))

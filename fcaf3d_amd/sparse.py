@@ -222,6 +222,44 @@ class KernelMap:
             else:
                 self.sorted_bwd()
 
+    def desc(self, conv=True, backward=True):
+        """int64 descriptor of this map for the native executor (csrc/exec.hip, MAPW words): sizes, the tables the
+        convolution routes of functional._SparseConv would pick (built now if they are not yet: the same lazy tables, so a
+        planned step finds them prefetched) and the route bits.  conv=False: the plain table only (stem, pooling)."""
+        key = (conv, backward)
+        d = self._desc.get(key) if hasattr(self, '_desc') else None
+        if d is not None:
+            return d
+        if not hasattr(self, '_desc'):
+            self._desc = {}
+        d = np.zeros(20, dtype=np.int64)
+        d[0], d[1], d[2], d[3] = self.n_in, self.n_out, self.K, self.nbr.data_ptr()
+        if conv:
+            flags = 0
+            if self.use_pairs and self.n_out <= PAIR_CONV_ROWS:
+                pi, po, pos, cnt = self.pairs()
+                d[9:14] = (pi.data_ptr(), po.data_ptr(), pos.data_ptr(), cnt.data_ptr(), self.pair_tiles())
+                flags |= 1
+            else:
+                tab, idx = self.sorted_fwd()
+                d[5], d[6] = tab.data_ptr(), (idx.data_ptr() if idx is not None else 0)
+            if backward:
+                d[4] = self.nbr_t.data_ptr()
+                if self.use_pairs:
+                    pi, po, pos, cnt = self.pairs()
+                    d[9:13] = (pi.data_ptr(), po.data_ptr(), pos.data_ptr(), cnt.data_ptr())
+                    flags |= 4
+                if self.use_pairs and self.n_in <= PAIR_CONV_ROWS:
+                    pi, po, pos, cnt = self.pairs_t()
+                    d[14:19] = (pi.data_ptr(), po.data_ptr(), pos.data_ptr(), cnt.data_ptr(), self.pair_tiles(transposed=True))
+                    flags |= 2
+                else:
+                    tab, idx = self.sorted_bwd()
+                    d[7], d[8] = tab.data_ptr(), (idx.data_ptr() if idx is not None else 0)
+            d[19] = flags
+        self._desc[key] = d
+        return d
+
     def sorted_fwd(self):
         """(nbr permuted into mask order, order) for the forward / weight-gradient pass, or (nbr, None)."""
         if not self.sort_rows:

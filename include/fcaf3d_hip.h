@@ -349,6 +349,22 @@ int fc_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float
                   float weight_decay, float bias_correction1, float bias_correction2, const float* norm_and_clip,
                   hipStream_t stream);
 
+/* ---- launch-list executor (the network body in one call per direction) ------------------------------------ */
+
+/* SingleStageSparse3DDetector.extract_feat (mmdet3d/models/detectors/single_stage_sparse.py:43-50: backbone me_resnet.py:43-50 +
+ * Fcaf3DNeckWithHead.forward, fcaf3d_neck_with_head.py:94-108) and torch.autograd's backward over it, as a STATIC list of
+ * operators walked natively: every operator is one of the entry points above with operands taken from host tables of device
+ * addresses (`addr`), row counts (`dims`) and kernel-map descriptors (`maps`, fc_exec_map_words() int64 each) that the caller
+ * refreshes per step; `ops` holds fc_exec_op_words() int64 per operator (layouts: fcaf3d_amd/executor.py, csrc/exec.hip).
+ * Operators [op_begin, op_end) run on streams[0] (caller's), streams[1] (head branch of the neck), streams[2] (weight
+ * gradients), ordered by library-owned events.  ws / ws_bytes: one scratch buffer per stream; a sizing pass runs first: if a
+ * buffer is too small NOTHING is launched, ws_need[3] receives the sizes and the call returns -2.
+ * cfg[0]: the two-launch BatchNorm is used up to this many elements; cfg[1]: kernel-variant flags (as `flags` above). */
+int fc_exec_op_words(void);
+int fc_exec_map_words(void);
+int fc_exec(const int64_t* ops, int64_t op_begin, int64_t op_end, const int64_t* addr, const int64_t* dims, const int64_t* maps,
+            const int64_t* streams, const int64_t* ws, const int64_t* ws_bytes, int64_t* ws_need, const int64_t* cfg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,77 @@ BOTTLENECK = (50, 101)   # MinkowskiEngine.modules.resnet_block.Bottleneck (me_r
 TRAINING = True     # False: BatchNorm uses the running statistics of the state_dict (model.eval())
 
 
+class DecisionTape:
+    """The DISCRETE decisions of one forward pass of the backbone, in execution order: the sign pattern of every ReLU
+    (stem, norm1 / norm2 of every BasicBlock / Bottleneck) and the arg-max row of the stem's max-pooling.  With `TAPE` set
+    the oracle takes these decisions from the tape instead of from its own pre-activations (the forward value of a flipped
+    element changes by its pre-activation, ~1e-8 at fp32 rounding level; the BACKWARD pass then differentiates the same
+    piecewise-linear branch as the path the tape was recorded from) and counts where its own decision would have differed.
+    tests/test_gpu_model.py records the tape from the HIP forward: gradient parity with equal decisions is a statement about
+    the kernels' arithmetic, not about which side of zero a 1e-8 pre-activation fell on.  (The neck's ELU is C1: no decision.)"""
+
+    def __init__(self, relu_masks=None, pool_arg=None, prune_kept=None):
+        """no arguments: RECORD the oracle's own decisions (a tape to replay, e.g. into the fp64 oracle)"""
+        self.recording = relu_masks is None
+        self.relu = list(relu_masks or [])    # bool (N, C) tensors: output > 0
+        self.pool = pool_arg                  # int64 (n_out, C): input row each pooled value came from
+        self.prune = list(prune_kept or [])   # per pruned neck level, in execution order: (k, 4) int coordinates kept by the top-k
+        self.i = 0
+        self.ip = 0
+        self.flips = []                       # (site, disagreeing elements, elements, max |own pre-activation| among them)
+
+    def replay(self):
+        return DecisionTape(self.relu, self.pool, self.prune)
+
+    def prune_forced(self, coords, own_mask, site):
+        """the per-scene top-k selection of `_prune` (fcaf3d_neck_with_head.py:110-126): keep the recorded coordinate set"""
+        if self.recording:
+            self.prune.append(coords[own_mask].copy())
+            return own_mask
+        kept = self.prune[self.ip]
+        self.ip += 1
+        mask = np.isin(mo.pack_keys(coords), mo.pack_keys(kept))
+        assert int(mask.sum()) == len(kept), (site, 'a recorded voxel is not in the oracle\'s set')
+        self.flips.append((site, int((mask != own_mask).sum()), len(mask), 0.0))
+        return mask
+
+    def relu_forced(self, pre, site):
+        if self.recording:
+            self.relu.append(pre.detach() > 0)
+            self.i += 1
+            return torch.relu(pre)
+        mask = self.relu[self.i]
+        self.i += 1
+        assert mask.shape == pre.shape, (site, mask.shape, pre.shape)
+        own = pre.detach() > 0
+        diff = own != mask
+        n = int(diff.sum())
+        self.flips.append((site, n, pre.numel(), float(pre.detach().abs()[diff].max()) if n else 0.0))
+        return torch.where(mask, pre, torch.zeros_like(pre))
+
+    def pool_forced(self, feats, nbr, site):
+        if self.recording:
+            K, n_out = nbr.shape
+            neg = torch.full((1, feats.shape[1]), -float('inf'), dtype=feats.dtype)
+            idx = torch.from_numpy(np.where(nbr >= 0, nbr, len(feats)).astype(np.int64))
+            g = torch.cat([feats.detach(), neg])[idx.reshape(-1)].reshape(K, n_out, -1)
+            self.pool = idx.t().gather(1, g.max(0).indices)               # (n_out, C): the row that holds the maximum
+            return mo.max_pool(feats, nbr)
+        own = mo.max_pool(feats.detach(), nbr)
+        arg = self.pool.long()
+        out = feats.gather(0, arg)
+        diff = out.detach() != own
+        n = int(diff.sum())
+        self.flips.append((site, n, out.numel(), float((out.detach() - own).abs()[diff].max()) if n else 0.0))
+        return out
+
+    def total_flips(self):
+        return sum(f[1] for f in self.flips)
+
+
+TAPE = None          # a DecisionTape: take the backbone's ReLU / arg-max decisions from it
+
+
 class SP:
     """coords (N,4) numpy int32, feats (N,C) torch, tensor stride, kernel-map cache shared per coordinate set"""
 
@@ -56,7 +127,7 @@ def bn(x, P, pre, act=None, residual=None):
     if residual is not None:
         f = f + residual
     if act == 'relu':
-        f = torch.relu(f)
+        f = TAPE.relu_forced(f, pre) if TAPE is not None else torch.relu(f)
     elif act == 'elu':
         f = torch.nn.functional.elu(f)
     return SP(x.C, f, x.stride, x.cache)
@@ -65,9 +136,11 @@ def bn(x, P, pre, act=None, residual=None):
 def backbone(x, P, depth=34, n_outs=4):
     x = conv(x, P['backbone.conv1.0.kernel'], 3, 2)
     f = mo.instance_norm(x.F, x.C[:, 0], P['backbone.conv1.1.weight'], P['backbone.conv1.1.bias'])
-    x = SP(x.C, torch.relu(f), x.stride, x.cache)
+    x = SP(x.C, TAPE.relu_forced(f, 'backbone.conv1.1') if TAPE is not None else torch.relu(f), x.stride, x.cache)
     oc, ocache = _strided(x, 2)
-    x = SP(oc, mo.max_pool(x.F, _kmap(x, oc, 2, 'down')), x.stride * 2, ocache)
+    pool_nbr = _kmap(x, oc, 2, 'down')
+    x = SP(oc, TAPE.pool_forced(x.F, pool_nbr, 'backbone.conv1.3') if TAPE is not None else mo.max_pool(x.F, pool_nbr),
+           x.stride * 2, ocache)
     outs = []
     def k3d(w):                      # ME stores a kernel_size = 1, stride = 1 kernel as (Cin, Cout)
         return w if w.dim() == 3 else w.unsqueeze(0)
@@ -121,6 +194,8 @@ def neck_head(inputs, P, voxel_size, pts_threshold, n_reg_outs):
                         k = min(len(rows), pts_threshold)
                         ids = torch.topk(sc[torch.from_numpy(rows)], k, sorted=False).indices.numpy()
                         mask[rows[ids]] = True
+                    if TAPE is not None and (TAPE.recording or TAPE.ip < len(TAPE.prune)) and not mask.all():
+                        mask = TAPE.prune_forced(uc, mask, f'prune level {i}')
                 if not mask.all():
                     pc, pf = mo.prune(uc, uf, mask)
                     x = SP(pc, pf, g.stride)

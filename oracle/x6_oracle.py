@@ -1,18 +1,37 @@
 """ORACLE — test infrastructure only.  The arithmetic of the split-bf16 convolution kernels (fcaf3d_amd/csrc/conv_x6.h,
-wgrad_x6.h) restated in numpy: an fp32 value as three bf16 pieces by truncation, an fp32 product as the six bf16 x bf16
-products the kernels keep, accumulated in fp32 in blocks of 16 products (one v_mfma_f32_32x32x16_bf16 per piece pair).
+wgrad_x6.h) restated in numpy: an fp32 value as three bf16 pieces, an fp32 product as the six bf16 x bf16 products the
+kernels keep, accumulated in fp32 in blocks of 16 products (one v_mfma_f32_32x32x16_bf16 per piece pair).
 Pins the properties the kernels rely on (tests/test_oracle_golden.py):
   * x == x1 + x2 + x3 exactly for every finite fp32 (24 = 8 + 8 + 8 significand bits, bf16 has the fp32 exponent range);
   * every piece product is exact in fp32 (8 x 8 = 16 bits);
-  * |x2| < 2^-7 |x|, |x3| < 2^-15 |x| (truncation), so the three dropped products (x2 y3, x3 y2, x3 y3) sum to at most
-    2^-21 |x y| (2^-25 on average); a round-to-nearest split would make that 2^-25 / unbiased at the same instruction count
-    (v_cvt_pk_bf16_f32) — not done: inside a convolution's sum both are below the fp32 accumulation's own rounding.
+  * r4, the kernels' split: pieces by ROUND-TO-NEAREST-EVEN (v_cvt_pk_bf16_f32): |x2| <= 2^-8 |x|, |x3| <= 2^-17 |x|, residuals
+    of either sign, so the three dropped products (x2 y3, x3 y2, x3 y3) sum to at most 2^-24 |x y| and are unbiased;
+  * r3 (`split3_trunc`, the kernels built with -DFC_X6_TRUNC): pieces by truncation, |x2| < 2^-7 |x|, |x3| < 2^-15 |x|, dropped
+    products <= 2^-21 |x y|, all with the sign of x y.
 There is no reference counterpart: the reference computes the same convolutions in fp32 on ME's kernels (me_resnet.py:56-62)."""
 import numpy as np
 
 
+def _rn_bf16(x):
+    """fp32 -> nearest bf16 (ties to even), returned as fp32 (finite inputs)"""
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    return u.astype(np.uint32).view(np.float32)
+
+
 def split3(x):
-    """fp32 array -> (x1, x2, x3) fp32 arrays, each representable in bf16 (low 16 bits zero), x1 + x2 + x3 == x"""
+    """fp32 array -> (x1, x2, x3) fp32 arrays, each representable in bf16 (low 16 bits zero), x1 + x2 + x3 == x; pieces
+    rounded to nearest even (the kernels' split since r4)"""
+    x = np.asarray(x, dtype=np.float32)
+    x1 = _rn_bf16(x)
+    r = x - x1
+    x2 = _rn_bf16(r)
+    x3 = _rn_bf16(r - x2)
+    return x1, x2, x3
+
+
+def split3_trunc(x):
+    """the truncating split of r3 (-DFC_X6_TRUNC)"""
     x = np.asarray(x, dtype=np.float32)
     mask = np.uint32(0xffff0000)
     x1 = (x.view(np.uint32) & mask).view(np.float32)

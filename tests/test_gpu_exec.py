@@ -1,0 +1,174 @@
+"""-m gpu: the native launch-list executor (fcaf3d_amd/executor.py + csrc/exec.hip: the network body as one C-ABI call per
+direction) against the per-operator module path — the SAME kernels with the SAME arguments, so the forward pass must agree bit
+for bit and the gradients to rounding (where a tensor has two consumers the two paths add the contributions in a different
+order).  The module path itself is what tests/test_gpu_model.py holds against the CPU oracle."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import fcaf3d_amd as fa
+import fcaf3d_amd.functional as Fn
+from fcaf3d_amd import executor as E
+from fcaf3d_amd.synthetic import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _build(name='fcaf3d_scannet-3d-18class', levels=4, seed=0):
+    torch.manual_seed(seed)
+    cfg = fa.get_config(name, voxel_size=0.02)
+    m = cfg.model
+    m.backbone['n_outs'] = levels
+    m.neck_with_head['in_channels'] = (64, 128, 256, 512)[:levels]
+    m.neck_with_head.assigner['n_scales'] = levels
+    return fa.build_detector(m, train_cfg=m.get('train_cfg'), test_cfg=m.get('test_cfg')), cfg
+
+
+def _batch(seeds, dev, n_points=30000, **kw):
+    sc = [make_scene(s, n_points=n_points, **kw) for s in seeds]
+    return dict(points=[torch.from_numpy(s[0]).to(dev) for s in sc],
+                gt_bboxes_3d=[fa.DepthInstance3DBoxes(torch.from_numpy(s[1]), origin=(.5, .5, .5)) for s in sc],
+                gt_labels_3d=[torch.from_numpy(s[2]).to(dev) for s in sc],
+                img_metas=[dict(box_type_3d=fa.DepthInstance3DBoxes) for _ in sc])
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max()) / max(1e-12, float(b.abs().max()))
+
+
+def _run(model, batch, use_exec):
+    E.ENABLED = use_exec
+    try:
+        model.zero_grad(set_to_none=True)
+        taken = []
+        orig = type(model)._exec_forward
+
+        def spy(self, prog, st):
+            taken.append(1)
+            return orig(self, prog, st)
+        type(model)._exec_forward = spy
+        try:
+            feats = [list(v) for v in model.extract_feat(batch['points'], batch['img_metas'])]
+            outs = [[lvl.full.detach().clone() for lvl in kind] for kind in feats]
+            losses = model(return_loss=True, **batch)
+            sum(losses.values()).backward()
+        finally:
+            type(model)._exec_forward = orig
+        torch.cuda.synchronize()
+        assert bool(taken) == use_exec, 'the path under test did not run'
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        bufs = {k: v.detach().clone() for k, v in model.named_buffers()}
+        return outs, {k: float(v) for k, v in losses.items()}, grads, bufs
+    finally:
+        E.ENABLED = True
+
+
+@pytest.mark.parametrize('levels,seeds,kw,overlap', [
+    (4, (11, 12), {}, False),
+    (4, (11, 12), {}, True),                       # head branch + weight gradients on their own streams (bench mode)
+    (2, (13,), {}, True),
+    (1, (14,), {}, False),                         # BASELINE config 1: one level, no neck fork
+    (3, (15, 16, 17), dict(rotated=True, n_boxes=6, n_classes=10), True),      # SUN RGB-D head: 8 regression outputs, rotated IoU loss
+])
+def test_executor_equals_module_path_training(levels, seeds, kw, overlap):
+    dev = _dev()
+    name = 'fcaf3d_sunrgbd-3d-10class' if kw else 'fcaf3d_scannet-3d-18class'
+    model, _ = _build(name, levels)
+    model = model.to(dev).train()
+    batch = _batch(seeds, dev, **kw)
+    state = copy.deepcopy(model.state_dict())
+    Fn.WGRAD_ASYNC = overlap
+    model.neck_with_head.head_overlap = overlap
+    model.async_maps = overlap
+    try:
+        ref = _run(model, batch, False)
+        model.load_state_dict(state)               # same running statistics at the start of both runs
+        got = _run(model, batch, True)
+    finally:
+        Fn.WGRAD_ASYNC = False
+    for kind in range(4):
+        for l in range(levels):
+            assert torch.equal(got[0][kind][l], ref[0][kind][l]), f'forward output {kind} of level {l} differs'
+    assert got[1] == ref[1], (got[1], ref[1])
+    for k, b in ref[3].items():
+        assert torch.equal(got[3][k], b), f'buffer {k} (running statistics) differs'
+    errs = {k: _rel(got[2][k], g) for k, g in ref[2].items()}
+    worst = max(errs, key=errs.get)
+    print(f'levels={levels} overlap={overlap}: worst gradient difference executor vs module path {errs[worst]:.2e} ({worst})')
+    assert errs[worst] < 2e-5, (worst, errs[worst])
+
+
+def test_executor_equals_module_path_inference():
+    dev = _dev()
+    model, _ = _build(levels=4)
+    model = model.to(dev).eval()
+    batch = _batch((21, 22), dev)
+    res = {}
+    for use in (False, True):
+        E.ENABLED = use
+        try:
+            with torch.no_grad():
+                feats = [list(v) for v in model.extract_feat(batch['points'], batch['img_metas'])]
+                res[use] = ([[lvl.full.clone() for lvl in kind] for kind in feats],
+                            model(return_loss=False, points=batch['points'], img_metas=batch['img_metas']))
+        finally:
+            E.ENABLED = True
+    for kind in range(4):
+        for l in range(4):
+            assert torch.equal(res[True][0][kind][l], res[False][0][kind][l]), (kind, l)
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a['boxes_3d'].tensor, b['boxes_3d'].tensor) and torch.equal(a['scores_3d'], b['scores_3d'])
+
+
+def test_train_step_through_the_executor_equals_module_path():
+    """runner.TrainStep (flat buffers, fused clip + AdamW, weight images refreshed after the optimizer step) for 3 steps with the
+    executor and without it: the same losses and the same parameters to rounding."""
+    from fcaf3d_amd.runner import TrainStep
+    dev = _dev()
+    batches = [_batch((31, 32), dev), _batch((33, 34), dev)]
+    out = {}
+    for use in (False, True):
+        E.ENABLED = use
+        Fn.WGRAD_ASYNC = True
+        try:
+            model, cfg = _build(levels=4)
+            model = model.to(dev).train()
+            model.async_maps = True
+            tr = TrainStep.from_config(model, cfg)
+            losses = [float(tr(batches[i % 2])[0]) for i in range(3)]
+            torch.cuda.synchronize()
+            out[use] = (losses, {k: p.detach().clone() for k, p in model.named_parameters()}, float(tr.last_grad_norm))
+        finally:
+            E.ENABLED = True
+            Fn.WGRAD_ASYNC = False
+    print('losses', out[False][0], out[True][0], 'grad norms', out[False][2], out[True][2])
+    for a, b in zip(out[True][0], out[False][0]):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (out[True][0], out[False][0])
+    errs = {k: _rel(out[True][1][k], p) for k, p in out[False][1].items()}
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 2e-3, (worst, errs[worst])          # three AdamW steps of lr 1e-3 amplify rounding-level gradient differences
+
+
+def test_pruning_falls_back_to_the_module_path():
+    dev = _dev()
+    torch.manual_seed(0)
+    cfg = fa.get_config('fcaf3d_scannet-3d-18class', voxel_size=0.02)
+    m = cfg.model
+    m.backbone['n_outs'] = 3
+    m.neck_with_head['in_channels'] = (64, 128, 256)
+    m.neck_with_head.assigner['n_scales'] = 3
+    m.neck_with_head['pts_threshold'] = 1500
+    model = fa.build_detector(m, train_cfg=m.get('train_cfg'), test_cfg=m.get('test_cfg')).to(dev).train()
+    batch = _batch((41,), dev, n_points=20000)
+    losses = model(return_loss=True, **batch)
+    sum(losses.values()).backward()
+    assert getattr(model, '_bound', None) is None
+    assert all(np.isfinite(float(v)) for v in losses.values())

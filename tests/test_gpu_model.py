@@ -62,68 +62,152 @@ def _oracle_params(model):
 SUNRGBD_KW = dict(rotated=True, single_view=True, rgb_unit=True, n_boxes=6, n_classes=10)
 
 
-@pytest.mark.parametrize('name,levels,B,n_points,kw', [
-    ('fcaf3d_scannet-3d-18class', 1, 1, 20000, {}),                       # BASELINE config 1 (plumbing)
-    ('fcaf3d_scannet-3d-18class', 4, 2, 30000, {}),                       # 4 levels, 2 scenes
-    ('fcaf3d_sunrgbd-3d-10class', 2, 1, 20000, dict(rotated=True, n_boxes=6, n_classes=10)),   # rotated IoU loss
-    ('fcaf3d_scannet-3d-18class', 4, 1, 100000, {}),                      # BASELINE config 2 at FULL size
-    ('fcaf3d_sunrgbd-3d-10class', 4, 1, 100000, SUNRGBD_KW),              # BASELINE config 3 at FULL size (4 levels, rotated)
+class _RecordDecisions:
+    """Context manager: record the discrete decisions of the HIP forward pass (oracle.model_oracle.DecisionTape) — the sign
+    pattern of every fused norm + ReLU output and the arg-max rows of the stem's max-pooling, in execution order."""
+
+    def __enter__(self):
+        import fcaf3d_amd.functional as Fn
+        self.Fn = Fn
+        import fcaf3d_amd.nn as MEnn
+        self.relu, self.pool, self.prune = [], [], []
+        self.saved = (Fn._NormAct.forward, Fn._BNTrainSmall.forward, Fn._MaxPool.forward)
+        self.prune0 = MEnn.MinkowskiPruning.forward
+        na0, bs0, mp0 = self.saved
+        rec = self
+
+        def pr(mod, x, mask):
+            if not bool(mask.all()):
+                rec.prune.append(x.C[mask].cpu().numpy())
+            return rec.prune0(mod, x, mask)
+        MEnn.MinkowskiPruning.forward = pr
+
+        def na(ctx, x, gamma, beta, residual, seg, nseg, eps, act, *rest):
+            y = na0(ctx, x, gamma, beta, residual, seg, nseg, eps, act, *rest)
+            if act == Fn.ACT['relu']:
+                rec.relu.append((y > 0).cpu())
+            return y
+
+        def bs(ctx, x, gamma, beta, residual, eps, act, *rest):
+            out = bs0(ctx, x, gamma, beta, residual, eps, act, *rest)
+            if act == Fn.ACT['relu']:
+                rec.relu.append((out[0] > 0).cpu())
+            return out
+
+        def mp(ctx, feats, kmap):
+            out = mp0(ctx, feats, kmap)
+            rec.pool.append(ctx.to_save[0].cpu())          # the arg-max rows (saved for backward)
+            return out
+        Fn._NormAct.forward, Fn._BNTrainSmall.forward, Fn._MaxPool.forward = staticmethod(na), staticmethod(bs), staticmethod(mp)
+        return self
+
+    def __exit__(self, *a):
+        Fn = self.Fn
+        Fn._NormAct.forward, Fn._BNTrainSmall.forward, Fn._MaxPool.forward = (staticmethod(f) for f in self.saved)
+        import fcaf3d_amd.nn as MEnn
+        MEnn.MinkowskiPruning.forward = self.prune0
+
+    def tape(self):
+        assert len(self.pool) == 1
+        return MO.DecisionTape(self.relu, self.pool[0], self.prune)
+
+
+# rows of the deepest stage: a (scene, level-4) set of 109-862 voxels — BatchNorm statistics over so few rows amplify
+# rounding differences of the same arithmetic by the conditioning of 1 / sigma; the bound there is 1e-3 (BASELINE.md section 3)
+DEEP = ('backbone.layer4.', 'neck_with_head.up_block_3.', 'neck_with_head.out_block_3.')
+
+
+@pytest.mark.parametrize('name,levels,B,n_points,kw,x6', [
+    ('fcaf3d_scannet-3d-18class', 1, 1, 20000, {}, True),                       # BASELINE config 1 (plumbing)
+    ('fcaf3d_scannet-3d-18class', 4, 2, 30000, {}, True),                       # 4 levels, 2 scenes
+    ('fcaf3d_scannet-3d-18class', 4, 2, 30000, {}, False),                      # ... on the fp32 MFMA route (FC_X6=0)
+    ('fcaf3d_sunrgbd-3d-10class', 2, 1, 20000, dict(rotated=True, n_boxes=6, n_classes=10), True),   # rotated IoU loss
+    ('fcaf3d_scannet-3d-18class', 4, 1, 100000, {}, True),                      # BASELINE config 2 at FULL size
+    ('fcaf3d_scannet-3d-18class', 4, 1, 100000, {}, False),                     # ... on the fp32 MFMA route
+    ('fcaf3d_sunrgbd-3d-10class', 4, 1, 100000, SUNRGBD_KW, True),              # BASELINE config 3 at FULL size (4 levels, rotated)
+    ('fcaf3d_sunrgbd-3d-10class', 4, 1, 100000, SUNRGBD_KW, False),
 ])
-def test_forward_train_parity(name, levels, B, n_points, kw):
+def test_forward_train_parity(name, levels, B, n_points, kw, x6):
+    """Forward outputs, losses and EVERY parameter gradient of the detector against the CPU oracle on identical scenes and
+    weights, for the split-bf16 route (default) and the fp32 MFMA route.
+
+    Gradients are compared with EQUAL DISCRETE DECISIONS: the HIP forward's ReLU signs and max-pool
+    arg-max rows are recorded and the fp32 oracle is run with those decisions (oracle.model_oracle.DecisionTape), so that both
+    sides differentiate the same piecewise-smooth function.  Then every gradient must agree to 1e-4 of the tensor's scale
+    (1e-3 in the deepest stage, DEEP) — no envelope.  r3 compared gradients across DIFFERENT decisions (a pre-activation of
+    +-1e-8 falls on either side of zero in any two fp32 implementations) and needed a 6e-2 envelope for it, which a 5 %
+    defect in one weight-gradient variant would have passed; what was attributed to flips then is counted here: the number of
+    elements where the oracle's own pre-activation has the other sign is printed and bounded, with the magnitude of those
+    pre-activations (fp32 rounding level)."""
+    import fcaf3d_amd.functional as Fn
     dev = _dev()
     model, m = _build(name, 0.02, levels)
     P = _oracle_params(model)
     model = model.to(dev).train()
     pts, gts, labs = _scenes(range(10, 10 + B), n_points=n_points, **kw)
-    # forward outputs
-    out_o = MO.extract_feat(P, m, pts)
-    out_g = [list(x) for x in model.extract_feat([torch.from_numpy(p).to(dev) for p in pts], None)]
-    for kind in range(4):
-        for l in range(levels):
-            for b in range(B):
-                if kind == 3:
-                    assert torch.equal(out_g[kind][l][b].cpu(), out_o[kind][l][b]), 'points (voxel corners) must be exact'
-                else:
-                    assert _rel(out_g[kind][l][b], out_o[kind][l][b]) < 1e-4, (kind, l, b)
-    # losses + gradients (fresh forward so that BN running stats are touched once per path)
-    model.zero_grad()
-    losses_g = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
-    losses_o = MO.forward_train(P, m, pts, gts, labs)
+    x6_0 = Fn.X6
+    Fn.X6 = x6
+    try:
+        # forward outputs
+        out_o = MO.extract_feat(P, m, pts)
+        out_g = [list(x) for x in model.extract_feat([torch.from_numpy(p).to(dev) for p in pts], None)]
+        for kind in range(4):
+            for l in range(levels):
+                for b in range(B):
+                    if kind == 3:
+                        assert torch.equal(out_g[kind][l][b].cpu(), out_o[kind][l][b]), 'points (voxel corners) must be exact'
+                    else:
+                        assert _rel(out_g[kind][l][b], out_o[kind][l][b]) < 1e-4, (kind, l, b)
+        # losses + gradients (fresh forward so that BN running stats are touched once per path)
+        model.zero_grad()
+        with _RecordDecisions() as rec:
+            losses_g = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
+        sum(losses_g.values()).backward()
+        torch.cuda.synchronize()
+    finally:
+        Fn.X6 = x6_0
+    tape = rec.tape()
+    MO.TAPE = tape
+    try:
+        losses_o = MO.forward_train(P, m, pts, gts, labs)
+    finally:
+        MO.TAPE = None
+    assert tape.i == len(tape.relu), 'the oracle must have consumed every recorded ReLU'
     for k in ('loss_centerness', 'loss_bbox', 'loss_cls'):
         assert _rel(losses_g[k], losses_o[k]) < 1e-4, (k, float(losses_g[k]), float(losses_o[k]))
-    sum(losses_g.values()).backward()
     sum(losses_o.values()).backward()
-    # Gradient yardsticks (r3, tests/diag_grad.py on the MI355X, 4 levels x 2 scenes x 30k points): tensor by tensor the HIP
-    # path sits at the SAME distance from the fp64 oracle as the fp32 oracle does (backbone.layer4.2.conv1.kernel 9.19e-2 vs
-    # 9.19e-2, layer3.0.conv1.kernel 5.32e-2 vs 5.31e-2, layer4.2.norm1.bn.bias 4.64e-2 vs 4.64e-2, ...) and within 1.05e-3
-    # of the fp32 oracle itself: what separates fp32 from fp64 is not round-off of the kernels but the discrete decisions
-    # both fp32 paths take alike (a ReLU / max-pool argmax / top-k on a pre-activation that is +1e-8 in fp32 and -1e-9 in
-    # fp64; in the deepest stage, 109-862 rows, one flipped row is several percent of a weight gradient).  So:
-    #   (1) against the fp32 oracle: the MEDIAN tensor within 1e-3 of its scale, every tensor within the flip envelope
-    #       6e-2 (which of two fp32 implementations sides with fp64 on such a decision is chance: with another rounding of
-    #       the BatchNorm pre-activation the HIP path sat at 3.0e-6 median from fp64 and 3.7e-2 from the fp32 oracle on
-    #       backbone.layer3.0.conv1.kernel — exactly the fp32 oracle's own distance from fp64 there);
-    #   (2) against the fp64 oracle: every tensor within the same flip envelope, the median tensor of the same order as the
-    #       fp32 oracle's own median distance (5x, or 1e-3: ScanNet 100k points with the split-bf16 convolutions 5.7e-4 vs
-    #       1.3e-4 — which decisions flip is chance), and at most 5 % of the tensors farther than 2x the fp32 oracle's distance
-    #       + 2e-3 (the mirror case of (1) occurs too: SUN RGB-D 100k points, backbone.conv1.0.kernel 1.3e-2 from fp64 where
-    #       the fp32 oracle is at 7e-4 — 3 of 250 tensors on that input).
-    P64 = {k: (v.detach().double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in P.items()}
-    sum(MO.forward_train(P64, m, pts, gts, labs).values()).backward()
-    errs, errs_o, errs_32 = {}, {}, {}
-    for k, p in model.named_parameters():
-        errs[k], errs_o[k], errs_32[k] = _rel(p.grad, P64[k].grad), _rel(P[k].grad, P64[k].grad), _rel(p.grad, P[k].grad)
-    worst, worst32 = max(errs, key=errs.get), max(errs_32, key=errs_32.get)
-    print(f'{name} L={levels} B={B} n={n_points}: gradient error vs the fp32 oracle: worst {errs_32[worst32]:.2e} ({worst32}), '
-          f'median {np.median(list(errs_32.values())):.2e}; vs the fp64 oracle: HIP worst {errs[worst]:.2e} ({worst}), fp32 oracle '
-          f'on the same tensor {errs_o[worst]:.2e}; medians {np.median(list(errs.values())):.2e} / {np.median(list(errs_o.values())):.2e}')
-    assert errs_32[worst32] < 6e-2, (worst32, errs_32[worst32])
-    assert np.median(list(errs_32.values())) < 1e-3
-    over = {k: (errs[k], errs_o[k]) for k in errs if errs[k] > 2.0 * errs_o[k] + 2e-3}
-    assert errs[worst] < 6e-2, (worst, errs[worst])
-    assert len(over) <= 0.05 * len(errs), over
-    assert np.median(list(errs.values())) <= max(5.0 * np.median(list(errs_o.values())), 1e-3)
-    assert np.median(list(errs.values())) < 5e-3
+    flips = [f for f in tape.flips if f[1]]
+    n_dec = sum(f[2] for f in tape.flips)
+    print(f'{name} L={levels} B={B} n={n_points} x6={x6}: {tape.total_flips()} of {n_dec} decisions differ between the HIP forward '
+          f'and the fp32 oracle\'s own pre-activations: ' + ', '.join(f'{s}: {n} (|pre| <= {mx:.1e})' for s, n, _, mx in flips))
+    # a flipped decision sits on a pre-activation at fp32 rounding level of the layer's scale (values are O(1) after a norm)
+    assert all(mx < 1e-4 for _, _, _, mx in flips), flips
+    assert tape.total_flips() <= 1e-5 * n_dec + 8, tape.total_flips()
+    errs = {k: _rel(p.grad, P[k].grad) for k, p in model.named_parameters()}
+    worst = max(errs, key=errs.get)
+    shallow = {k: v for k, v in errs.items() if not k.startswith(DEEP)}
+    deep = {k: v for k, v in errs.items() if k.startswith(DEEP)}
+    ws, wd = max(shallow, key=shallow.get), (max(deep, key=deep.get) if deep else None)
+    print(f'   gradients vs the fp32 oracle with equal decisions: worst {errs[worst]:.2e} ({worst}); outside the deepest stage '
+          f'{shallow[ws]:.2e} ({ws}); deepest stage {deep[wd] if wd else 0:.2e} ({wd}); median {np.median(list(errs.values())):.2e}')
+    over = [k for k, v in shallow.items() if v >= 1e-4] + [k for k, v in deep.items() if v >= 1e-3]
+    if over:
+        # A tensor beyond the bound with equal decisions: is it the HIP path, or is the fp32 ORACLE itself that far from the exact
+        # gradient there?  (The head's 1x1 kernels sum mixed-sign products over every location of the batch: 1.6e-4 on
+        # cls_conv.kernel at 2 x 30k points, the same on both convolution routes.)  The fp64 oracle with the same decisions
+        # settles it: the HIP gradient must be as close to it as the fp32 oracle's own gradient is (within 2x), or within the bound.
+        P64 = {k: (v.detach().double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in P.items()}
+        MO.TAPE = tape.replay()
+        try:
+            sum(MO.forward_train(P64, m, pts, gts, labs).values()).backward()
+        finally:
+            MO.TAPE = None
+        named = dict(model.named_parameters())
+        for k in over:
+            bound = 1e-3 if k.startswith(DEEP) else 1e-4
+            e_hip, e_o = _rel(named[k].grad, P64[k].grad), _rel(P[k].grad, P64[k].grad)
+            print(f'   {k}: vs the fp64 oracle (same decisions): HIP {e_hip:.2e}, fp32 oracle {e_o:.2e}')
+            assert e_hip < max(bound, 2.0 * e_o), (k, e_hip, e_o)
 
 
 def test_bottleneck_backbone_parity_depth50():
@@ -143,16 +227,22 @@ def test_bottleneck_backbone_parity_depth50():
     P = _oracle_params(model)
     model = model.to(dev).train()
     pts, gts, labs = _scenes([91], n_points=12000)
-    losses_g = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
-    losses_o = MO.forward_train(P, m, pts, gts, labs)
+    with _RecordDecisions() as rec:
+        losses_g = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
+    MO.TAPE = tape = rec.tape()
+    try:
+        losses_o = MO.forward_train(P, m, pts, gts, labs)          # with the HIP forward's ReLU / arg-max decisions
+    finally:
+        MO.TAPE = None
     for k in ('loss_centerness', 'loss_bbox', 'loss_cls'):
         assert _rel(losses_g[k], losses_o[k]) < 1e-4, (k, float(losses_g[k]), float(losses_o[k]))
     sum(losses_g.values()).backward()
     sum(losses_o.values()).backward()
     errs = {k: _rel(p.grad, P[k].grad) for k, p in model.named_parameters()}
     worst = max(errs, key=errs.get)
-    print(f'depth 50: gradient error vs the fp32 oracle: worst {errs[worst]:.2e} ({worst}), median {np.median(list(errs.values())):.2e}')
-    assert errs[worst] < 6e-2 and np.median(list(errs.values())) < 1e-3, (worst, errs[worst])
+    print(f'depth 50: {tape.total_flips()} decisions differ; gradient error vs the fp32 oracle with equal decisions: worst '
+          f'{errs[worst]:.2e} ({worst}), median {np.median(list(errs.values())):.2e}')
+    assert errs[worst] < 1e-3 and np.median(list(errs.values())) < 1e-4, (worst, errs[worst])
 
 
 def test_async_map_stream_is_bitwise_equivalent():
@@ -480,45 +570,51 @@ def test_full_size_config5_s3dis_pruning_live():
             assert _rel(out_g[kind][l][0][torch.from_numpy(sg).to(dev)], out_o[kind][l][0][torch.from_numpy(so)]) < 1e-4, (kind, l)
 
 
-def test_full_size_config5_backward_vs_oracle_digest():
-    """BASELINE config 5 at FULL size, forward_train + BACKWARD (r2 checked extract_feat only): one 500 000-point S3DIS-shaped
-    scene, pruning live at the real pts_threshold, so the gradients flow through MinkowskiPruning's gather / scatter
-    (fcaf3d_neck_with_head.py:110-126), the interpolation-selected rows and the 100 000-row level-0 maps.  The yardstick is
-    the CPU oracle in fp32 (the reference's precision; see the generator's header for why not fp64), run once in the build
-    container (tests/golden/make_config5_golden.py, ~90 s) and stored as a digest per parameter tensor: 2-norm, largest
-    magnitude, 256 entries at seeded positions.  Bounds: losses 1e-4; every tensor's sampled entries within 6e-2 of the
-    tensor's largest magnitude (two fp32 implementations take a few ReLU / top-k decisions differently on 420k voxels: the deep,
-    few-row stages feel single rows), the median tensor within 5e-3."""
-    import importlib.util
+def test_full_size_config5_backward_with_equal_decisions():
+    """BASELINE config 5 at FULL size, forward_train + BACKWARD: one 500 000-point S3DIS-shaped scene, pruning live at the real
+    pts_threshold, so the gradients flow through MinkowskiPruning's gather / scatter (fcaf3d_neck_with_head.py:110-126), the
+    interpolation-selected rows and the 100 000-row level-0 maps.  The fp32 CPU oracle runs HERE (~2 minutes) with the HIP
+    forward's discrete decisions — ReLU signs, max-pool arg-max rows and the top-k kept set of `_prune` — so every parameter
+    gradient is held to 1e-4 of its scale (1e-3 in the deepest stage).  r3 compared against a stored digest of an oracle run
+    with its OWN decisions and needed a 6e-2 envelope for the flips; that digest is gone."""
     from fcaf3d_amd.synthetic import WORKLOADS
-    spec = importlib.util.spec_from_file_location('make_config5_golden', os.path.join(G, 'make_config5_golden.py'))
-    mk = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mk)
-    d = np.load(os.path.join(G, 'config5_backward.npz'))
     dev = _dev()
-    model, m = mk.build()
-    chk = float(sum(v.detach().double().abs().sum() for v in model.state_dict().values() if v.dtype.is_floating_point))
-    assert abs(chk - float(d['weight_checksum'][0])) <= 1e-9 * chk, 'initial weights differ from the ones the digest was made with'
+    torch.manual_seed(0)
+    cfg = fa.get_config('fcaf3d_s3dis-3d-5class', voxel_size=0.02)
+    m = cfg.model
+    model = fa.build_detector(m, train_cfg=m.get('train_cfg'), test_cfg=m.get('test_cfg'))
+    with torch.no_grad():                                     # spread the scores so that top-k has no near-ties
+        model.neck_with_head.cls_conv.kernel.normal_(0, 0.5)
+    P = _oracle_params(model)
     model = model.to(dev).train()
-    pts, gts, labs = _scenes([mk.SEED_SCENE], **WORKLOADS['s3dis-500k']['scene'])
-    losses = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
-    sum(losses.values()).backward()
-    for j, k in enumerate(('loss_centerness', 'loss_bbox', 'loss_cls')):
-        assert abs(float(losses[k]) - d['losses'][j]) <= 1e-4 * max(1.0, abs(d['losses'][j])), (k, float(losses[k]), d['losses'][j])
-    names = [k for k, _ in model.named_parameters()]
-    assert names == list(d['names'])
-    errs = {}
-    for i, (k, p) in enumerate(model.named_parameters()):
-        ref = d[f'g{i}']
-        gnorm, gmax, samples = ref[0], ref[1], ref[2:]
-        g = p.grad.detach().double().reshape(-1).cpu()
-        got = g[torch.from_numpy(mk.sample_index(i, g.numel()))].numpy()
-        scale = max(gmax, 1e-12)
-        errs[k] = max(float(np.abs(got - samples).max()) / scale, abs(float(g.norm()) - gnorm) / max(gnorm, 1e-12) / 3.0)
-    worst = max(errs, key=errs.get)
-    print(f'config 5 backward vs fp32 oracle digest: worst {errs[worst]:.2e} ({worst}), median {np.median(list(errs.values())):.2e}')
-    assert errs[worst] < 6e-2, (worst, errs[worst])           # measured 3.6e-2 (backbone.layer3.5.conv1.kernel), median 1.9e-3
-    assert np.median(list(errs.values())) < 5e-3
+    pts, gts, labs = _scenes([51], **WORKLOADS['s3dis-500k']['scene'])
+    with _RecordDecisions() as rec:
+        losses_g = model(return_loss=True, **_to_gpu_batch(pts, gts, labs, dev))
+    sum(losses_g.values()).backward()
+    torch.cuda.synchronize()
+    tape = rec.tape()
+    assert len(tape.prune) >= 1, 'pruning must be live at the config\'s pts_threshold'
+    MO.TAPE = tape
+    try:
+        losses_o = MO.forward_train(P, m, pts, gts, labs)
+    finally:
+        MO.TAPE = None
+    assert tape.i == len(tape.relu) and tape.ip == len(tape.prune)
+    for k in ('loss_centerness', 'loss_bbox', 'loss_cls'):
+        assert _rel(losses_g[k], losses_o[k]) < 1e-4, (k, float(losses_g[k]), float(losses_o[k]))
+    sum(losses_o.values()).backward()
+    flips = [f for f in tape.flips if f[1]]
+    print(f'config 5: {tape.total_flips()} of {sum(f[2] for f in tape.flips)} decisions differ: '
+          + ', '.join(f'{s}: {n} (|pre| <= {mx:.1e})' for s, n, _, mx in flips))
+    assert all(mx < 1e-4 for _, _, _, mx in flips), flips
+    errs = {k: _rel(p.grad, P[k].grad) for k, p in model.named_parameters()}
+    shallow = {k: v for k, v in errs.items() if not k.startswith(DEEP)}
+    deep = {k: v for k, v in errs.items() if k.startswith(DEEP)}
+    ws, wd = max(shallow, key=shallow.get), max(deep, key=deep.get)
+    print(f'   gradients vs the fp32 oracle with equal decisions: outside the deepest stage {shallow[ws]:.2e} ({ws}); deepest stage '
+          f'{deep[wd]:.2e} ({wd}); median {np.median(list(errs.values())):.2e}')
+    assert shallow[ws] < 1e-4, (ws, shallow[ws])
+    assert deep[wd] < 1e-3, (wd, deep[wd])
 
 
 def test_out_of_range_coordinates_raise():

@@ -1,4 +1,13 @@
-"""Diagnostic: where does the HOST spend its time in one training step? (cProfile + phase timers with syncs)"""
+"""Diagnostic (tools/, not product): where does the HOST spend its time in one training step of bench.py?
+
+For every --batches entry B: the step exactly as bench.py runs it (runner.TrainStep, coordinate work on its side stream,
+weight gradients on theirs, priority main stream), measured three ways over the same steps:
+  * enqueue-only  — host wall time until all work of a step is ENQUEUED (no synchronisation inside), per phase;
+  * drained       — wall time per step including the final synchronise (= what bench.py reports);
+  * serial phases — each phase followed by a synchronise (GPU time of a phase with nothing overlapping it);
+plus the number of C-ABI calls per step and, with --cprofile B, the cProfile listing for that batch size.
+
+    python tools/hostprof.py --batches 2,4,8 [--cprofile 2] [bench.py flags ...]"""
 import cProfile
 import os
 import pstats
@@ -11,66 +20,114 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 
-def main():
-    sys.argv = [sys.argv[0]] + sys.argv[1:]
-    args = bench.parse()
-    dev = torch.device('cuda:0')
+def pop_flag(name, default):
+    if name in sys.argv:
+        i = sys.argv.index(name)
+        v = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+        return v
+    return default
+
+
+def run_one(args, B, dev, do_cprofile, steps=8):
+    import fcaf3d_amd._lib as L
+    import fcaf3d_amd.functional as Fn
+    from fcaf3d_amd.runner import TrainStep, parse_losses
+    args.batch = B
     model, cfg = bench.build_model(args)
     model = model.to(dev).train()
     model.async_maps = True
     model.inputs_resident = True
+    Fn.WGRAD_ASYNC = not args.no_wgrad_overlap
+    tr = TrainStep.from_config(model, cfg)
     batches = bench.make_batches(args, 0, dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+    ncalls = [0]
+    orig = L.call
 
-    def step(i, timers=None):
+    def counting(name, *a):
+        ncalls[0] += 1
+        return orig(name, *a)
+
+    def step(i, marks=None, sync=False):
         b = batches[i % 2]
-        t = [time.perf_counter()]
 
         def mark():
-            if timers is not None:
-                torch.cuda.synchronize()
-            t.append(time.perf_counter())
-        opt.zero_grad(set_to_none=True)
-        x = model.extract_feat(b['points'], b['img_metas'])
+            if marks is not None:
+                if sync:
+                    torch.cuda.synchronize()
+                marks.append(time.perf_counter())
+        mark()
+        tr.optimizer.zero_grad(set_to_none=True)
+        if tr.images is not None and tr.images.n:
+            if tr.images_version != sum(w._version for w in tr._image_ws):
+                tr._build_images(side_stream=False)
+            Fn.PREBUILT, Fn.PREBUILT_EVENT = tr.images.table, tr.images.event
+        x = model.extract_feat(b['points'], b['img_metas'], (b['gt_bboxes_3d'], b['gt_labels_3d']))
         x = [list(v) for v in x]
         mark()
         losses = model.neck_with_head.loss(*x, b['gt_bboxes_3d'], b['gt_labels_3d'], b['img_metas'])
-        loss = sum(losses.values())
+        loss = parse_losses(losses)
         mark()
         loss.backward()
+        Fn.PREBUILT, Fn.PREBUILT_EVENT = {}, None
+        tr.averager.finish()
         mark()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
-        opt.step()
+        tr.optimizer.step(tr.max_norm)
+        if tr.images is not None and tr.images.n:
+            tr._build_images(side_stream=True)
         mark()
-        if timers is not None:
-            for j in range(4):
-                timers[j] += t[j + 1] - t[j]
 
-    for i in range(3):
-        step(i)
-    torch.cuda.synchronize()
-    timers = [0.0] * 4
-    for i in range(4):
-        step(i, timers)
-    print('synced phase ms/step: extract_feat %.1f | loss %.1f | backward %.1f | clip+adamw %.1f' % tuple(1e3 * v / 4 for v in timers))
-    # pure host time (no syncs inside): how long until all work is ENQUEUED
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    names = ['forward (extract_feat)', 'loss', 'backward', 'clip + AdamW + images']
     for i in range(4):
         step(i)
-    t1 = time.perf_counter()
     torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    print('enqueue-only ms/step %.1f ; drained ms/step %.1f' % (1e3 * (t1 - t0) / 4, 1e3 * (t2 - t0) / 4))
-    pr = cProfile.Profile()
-    pr.enable()
-    for i in range(3):
-        step(i)
+    out = {}
+    for label, sync in (('enqueue-only', False), ('serial phases', True)):
+        tot = [0.0] * 4
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            m = []
+            step(i, m, sync)
+            for k in range(4):
+                tot[k] += m[k + 1] - m[k]
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        out[label] = ([1e3 * v / steps for v in tot], 1e3 * (t1 - t0) / steps, 1e3 * (t2 - t0) / steps)
+    L.call = counting
+    step(0)
+    L.call = orig
     torch.cuda.synchronize()
-    pr.disable()
-    st = pstats.Stats(pr)
-    st.sort_stats('cumulative').print_stats(45)
-    st.sort_stats('tottime').print_stats(25)
+    print(f'=== B = {B} scenes per step ({args.workload}) ===')
+    for label in ('enqueue-only', 'serial phases'):
+        ph, enq, drained = out[label]
+        print(f'{label:14s}: ' + ' | '.join(f'{n} {v:.2f}' for n, v in zip(names, ph)) + f'  || sum {sum(ph):.2f} ms/step')
+        if label == 'enqueue-only':
+            print(f'{"":14s}  host enqueue {enq:.2f} ms/step ; drained {drained:.2f} ms/step ({B / drained * 1e3:.1f} scenes/s)')
+    print(f'C-ABI calls per step: {ncalls[0]}')
+    if do_cprofile:
+        pr = cProfile.Profile()
+        pr.enable()
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        pr.disable()
+        st = pstats.Stats(pr)
+        st.sort_stats('cumulative').print_stats(60)
+        st.sort_stats('tottime').print_stats(40)
+    sys.stdout.flush()
+
+
+def main():
+    bs = [int(v) for v in pop_flag('--batches', '2,4,8').split(',')]
+    cp = int(pop_flag('--cprofile', '0'))
+    args = bench.parse()
+    dev = torch.device('cuda:0')
+    if args.priority_stream:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
+    for B in bs:
+        run_one(args, B, dev, cp == B)
 
 
 if __name__ == '__main__':
