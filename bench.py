@@ -50,7 +50,10 @@ def parse():
                     help='default: the step\'s dependent chain runs on a high-priority HIP stream (r3, beside the split kernels: 23.41 -> 23.25 ms)')
     ap.add_argument('--infer-steps', type=int, default=4, help='untimed-region extra: simple_test batches for the inference scenes/s line (0 = skip)')
     ap.add_argument('--cpu-reps', type=int, default=3, help='repetitions of the conv-only part of the cpu_baseline (median)')
+    ap.add_argument('--no-fp32-route', action='store_true', help='skip the untimed FC_X6=0 extra')
     ap.add_argument('--no-force-dp', action='store_true', help='skip the untimed N=1-through-the-averager extra')
+    ap.add_argument('--no-executor', action='store_true', help='per-operator module path for every step (default: the network body through the '
+                    'native launch-list executor, fcaf3d_amd/executor.py; FC_EXEC=0 does the same)')
     ap.add_argument('--breakdown', action='store_true', help='diagnostic: HIP-event time per C-ABI entry point and per conv shape (stderr)')
     return ap.parse_args()
 
@@ -178,11 +181,19 @@ class ConvProbe:
         self.pool_n_in = 0
         self.timed = {}        # batch index -> list of per-step lists of (start, end)
         self.counted = {}      # batch index -> list of (pairs_dev | None, flops_per_pair, n_out, bytes)
+        self.shapes = {}       # batch index -> list of (entry point, n_in, n_out, K, Cin, Cout, has map)
         self.mode = None
         self._cur = None
+        self.exec_steps = []   # executor.PROBE entries of the probed steps that went through the native executor
 
     def begin_step(self, batch_index, mode):
         self.mode = mode
+        self._bi = batch_index
+        if mode == 'hbm':
+            self._cur = None
+            return
+        if mode != 'time':
+            self.shapes[batch_index] = []
         if mode == 'time':
             self._cur = []
             self.timed.setdefault(batch_index, []).append(self._cur)
@@ -195,7 +206,7 @@ class ConvProbe:
         orig = L.call
 
         def call(name, *a):
-            if probe.mode == 'time' and name in HBM_BYTES:
+            if probe.mode in ('time', 'hbm') and name in HBM_BYTES:
                 try:
                     nbytes = HBM_BYTES[name](a, probe)
                 except Exception:
@@ -208,7 +219,7 @@ class ConvProbe:
                     e.record()
                     probe.hbm.append((name if not (name in ('fc_conv_fwd', 'fc_conv_wgrad') and a[8] == 3) else name + '(stem)', nbytes, s, e))
                     return
-            if name not in ('fc_conv_fwd', 'fc_conv_fwd_pairs', 'fc_conv_fwd_pairs_tiles') or probe.mode is None:
+            if name not in ('fc_conv_fwd', 'fc_conv_fwd_pairs', 'fc_conv_fwd_pairs_tiles') or probe.mode in (None, 'hbm'):
                 return orig(name, *a)
             if name == 'fc_conv_fwd':
                 # (in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream)
@@ -229,6 +240,7 @@ class ConvProbe:
                 orig(name, *a)
                 nbytes = 4.0 * (n_in * Cin + n_out * Cout + K * Cin * Cout) + (4.0 * K * n_out if has_map else 0.0)
                 probe._cur.append((probe._pairs, 2.0 * Cin * Cout, n_out, nbytes))
+                probe.shapes.setdefault(probe._bi, []).append((name, n_in, n_out, K, Cin, Cout, int(has_map)))
         L.call = call
         self._pairs = None
         import fcaf3d_amd.functional as Fn
@@ -273,13 +285,44 @@ class ConvProbe:
                              avg_us=round(ms * 1e3 / n, 2), GBps=round(gbs, 1), frac_of_hbm_peak=round(gbs / PEAK_HBM_GBS, 4)))
         return rows
 
+    def exec_records(self):
+        """probed steps that went through the native executor: (FLOPs, bytes, ms) per convolution launch from the event brackets
+        inside fc_exec (csrc/exec.hip) and the pair counts bound with each step"""
+        import ctypes
+        import fcaf3d_amd._lib as L
+        torch.cuda.synchronize()
+        cap = sum(e['nf'] + e['nb'] for e in self.exec_steps) + 16
+        ms = (ctypes.c_float * cap)()
+        meta = (ctypes.c_int64 * (8 * cap))()
+        n = L.lib().fc_exec_probe_read(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(meta, ctypes.c_void_p), cap)
+        assert n == cap - 16, (n, cap)
+        out, i = [], 0
+        for e in self.exec_steps:
+            pairs = {k: float(v.item()) for k, v in e['pairs'].items()}
+            for _ in range(e['nf'] + e['nb']):
+                mp, _dir, n_in, n_out, K, Cin, Cout, _pm = (int(meta[8 * i + j]) for j in range(8))
+                P = pairs[mp] if mp >= 0 else float(n_out)
+                nbytes = 4.0 * (n_in * Cin + n_out * Cout + K * Cin * Cout) + (4.0 * K * n_out if mp >= 0 else 0.0)
+                out.append((2.0 * P * Cin * Cout, nbytes, float(ms[i])))
+                i += 1
+        return out
+
     def summary(self):
-        if not self.timed:
+        if not any(ev for st_ in self.timed.values() for ev in st_) and not self.exec_steps:
             return None
         torch.cuda.synchronize()
         flops = ms = alg_bytes = 0.0
         n = 0
+        if self.exec_steps:
+            for f, nb, t in self.exec_records():
+                flops += f
+                alg_bytes += nb
+                ms += t
+                n += 1
         for bi, steps in self.timed.items():
+            steps = [ev for ev in steps if ev]             # (steps that went through the executor left no per-call brackets)
+            if not steps:
+                continue
             counted = self.counted[bi]
             per_launch = [((float(p.item()) if p is not None else float(n_out)) * fpp, nb) for p, fpp, n_out, nb in counted]
             for ev in steps:
@@ -290,6 +333,15 @@ class ConvProbe:
                     alg_bytes += nb
                     n += 1
         achieved = flops / (ms * 1e-3) / 1e12
+        if os.environ.get('FC_PROBE_DUMP') and self.timed:          # diagnostic: every probed launch (shape, pairs, FLOPs, microseconds) as JSON lines
+            with open(os.environ['FC_PROBE_DUMP'], 'w') as fh:
+                for bi, steps in self.timed.items():
+                    for ev in steps:
+                        if not ev:
+                            continue
+                        for (s_, e_), (p_, fpp, n_out, nb), shp in zip(ev, self.counted[bi], self.shapes[bi]):
+                            pr = float(p_.item()) if p_ is not None else float(n_out)
+                            fh.write(json.dumps(dict(shape=shp, pairs=pr, gflop=pr * fpp / 1e9, us=s_.elapsed_time(e_) * 1e3)) + '\n')
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, 'profiles', 'r3_traffic.json')
         if os.path.exists(tj):          # PMC passes cannot run inside the timed region: committed rocprofv3 result
@@ -419,6 +471,8 @@ def main():
     model.inputs_resident = True      # ... without waiting for the main stream (nothing enqueued there produces them)
     model.spatial_sort = args.spatial_sort
     import fcaf3d_amd.functional as Fn
+    import fcaf3d_amd.executor as EX
+    exec_on = EX.ENABLED and not args.no_executor
     Fn.WGRAD_ASYNC = not args.no_wgrad_overlap
     head_overlap = model.neck_with_head.head_overlap and not args.no_wgrad_overlap
     if world > 1:
@@ -449,9 +503,17 @@ def main():
                 probe.mode = None
         # probed steps keep every kernel on the main stream: a HIP-event bracket is only a kernel's own duration when
         # nothing else shares the GPU (the overlapped weight-gradient stream would inflate every bracket it touches)
-        Fn.WGRAD_ASYNC = (not args.no_wgrad_overlap) and probe_mode != 'time'
-        model.neck_with_head.head_overlap = head_overlap and probe_mode != 'time'      # ... nor the head branch's stream
+        one_stream = probe_mode in ('time', 'hbm')
+        Fn.WGRAD_ASYNC = (not args.no_wgrad_overlap) and not one_stream
+        # probed steps of the timed region go through the native executor like every other step (its one-stream program), the
+        # brackets sit inside fc_exec around every convolution operator; the untimed extras (FLOP counts of the per-operator
+        # path, `hbm_kernels`) bracket individual C-ABI calls of the per-operator module path — the same calls with the same
+        # arguments (tests/test_gpu_exec.py: bit for bit)
+        EX.ENABLED = exec_on and probe_mode in (None, 'time') and bd is None
+        EX.PROBE = probe.exec_steps if (probe and probe_mode == 'time' and EX.ENABLED) else None
+        model.neck_with_head.head_overlap = head_overlap and not one_stream             # ... nor the head branch's stream
         loss, _ = trainer(batch)
+        EX.PROBE = None
         return loss
 
     for i in range(args.warmup):
@@ -468,10 +530,15 @@ def main():
     trainer.averager.log = None
     # untimed: FLOPs of every launch, one step per distinct batch.  EVERY rank steps (a step holds collectives: a
     # rank-0-only extra step deadlocks the job); only rank 0 carries the probe
-    for b in range(count_steps(args, len(batches))):
+    per_call = bool(probe) and any(ev for steps_ in probe.timed.values() for ev in steps_)
+    n_count = count_steps(args, len(batches)) if (not exec_on or per_call) else 0       # FLOPs of executor-probed steps
+    for b in range(n_count):                                                                           # come with the brackets
         step(b, 'count' if probe else None)
+    if exec_on and not (args.no_instrument or args.breakdown):
+        step(0, 'hbm' if probe else None)          # untimed, per-operator path: the bandwidth-bound entry points for `hbm_kernels`
     if probe:
         probe.mode = None
+    EX.ENABLED = exec_on
     if bd:
         bd.report(args.steps, dt * 1e3)
     assert np.isfinite(final_loss), 'loss diverged'
@@ -503,7 +570,7 @@ def main():
                         value=round(16 * 6 / dt4, 3), unit='scenes/s')
     # (b2) N = 1 through the data-parallel machinery (1-rank RCCL group: autograd hooks, bucket launches on the weight-gradient
     #      stream, in-place all-reduce of the flat gradient buffer) — what the DP path itself costs, without a second GPU
-    forced = None
+    forced = cfg4_1 = None
     if world == 1 and not args.no_force_dp and trainer.flat is not None:
         try:
             import socket
@@ -517,6 +584,26 @@ def main():
             dtf, _ = timed_region(lambda i: step(i), 10, 1, dev)
             forced = dict(steps=10, ms_per_step=round(dtf / 10 * 1e3, 3), value=round(args.batch * 10 / dtf, 3), unit='scenes/s',
                           buckets=len(trainer.averager.buckets), what='the same step with the gradient averager active in a 1-rank RCCL group')
+            if args.workload == 'scannet-100k' and args.batch >= 2:
+                # BASELINE config 4 as ONE of its 8 GPUs sees it: 2 scenes per step (global batch 16 / 8), through the data-parallel
+                # machinery (1-rank RCCL group: bucket launches, in-place all-reduce of the 282 MB flat gradient buffer)
+                small = [{k: v[:2] for k, v in b.items()} for b in batches]
+                for i in range(3):
+                    step(i, which=small)
+                dt2, _ = timed_region(lambda i: step(i, which=small), 12, 1, dev)
+                ms2 = dt2 / 12 * 1e3
+                gbytes = trainer.flat.n * 4
+                # prediction, not a measurement: ring all-reduce moves 2 (N-1)/N of the buffer per GPU; one xGMI link carries
+                # ~153 GB/s (MI355X_MICROARCH.md / task statement: 7 links x ~153 GB/s, ring collectives are per-link bound).
+                # Worst case = nothing of it hidden behind backward, one ring; best case = fully hidden.
+                t_ar = 2 * 7 / 8 * gbytes / 153e9 * 1e3
+                cfg4_1 = dict(scenes_per_gpu_per_step=2, steps=12, ms_per_step=round(ms2, 3), value=round(2 * 12 / dt2, 3), unit='scenes/s per GPU',
+                              what='N = 1, 2 scenes per step (what each of the 8 GPUs of BASELINE config 4 runs), gradient averager in a 1-rank RCCL group',
+                              gradient_MB=round(gbytes / 1e6, 1),
+                              predicted_8gpu=dict(note='PREDICTION from this N = 1 measurement, not measured on 8 GPUs',
+                                                  allreduce_ms_one_ring_153GBps=round(t_ar, 2),
+                                                  scenes_per_s_allreduce_hidden=round(16 / ms2 * 1e3, 1),
+                                                  scenes_per_s_allreduce_exposed=round(16 / (ms2 + t_ar) * 1e3, 1)))
             trainer.averager.close()
             trainer.averager = plain
         except Exception as e:                                   # an extra: never fails the bench line
@@ -525,6 +612,19 @@ def main():
             D.FORCE_AVERAGER = False
             if torch.distributed.is_initialized():
                 torch.distributed.destroy_process_group()
+    # (b3) the same step on the fp32 MFMA kernels (FC_X6=0: v_mfma_f32_32x32x2_f32, IEEE fp32 products) — the number to fall back on
+    #      if the split-bf16 route were not accepted as fp32-within-tolerance
+    fp32_route = None
+    if world == 1 and Fn.X6 and not args.no_fp32_route:
+        x6_0, Fn.X6 = Fn.X6, False
+        try:
+            for i in range(3):
+                step(i)
+            dt32, _ = timed_region(lambda i: step(i), 8, 1, dev)
+            fp32_route = dict(steps=8, ms_per_step=round(dt32 / 8 * 1e3, 3), value=round(args.batch * 8 / dt32, 3), unit='scenes/s',
+                              what='FC_X6=0: every convolution on v_mfma_f32_32x32x2_f32 (per-operator module path)')
+        finally:
+            Fn.X6 = x6_0
     # (c) inference: simple_test (eval-mode BatchNorm, decode, multi-class BEV NMS on the device) — the only quantity the
     #     reference publishes a speed for (README.md:91-93, scenes/s on one GPU)
     infer = None
@@ -553,7 +653,10 @@ def main():
                        'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
                        'fwd_bwd_only': {'protocol': 'SURVEY 8(d): forward_train + backward (+ all-reduce), synchronised per iteration, median of 5',
                                         'ms': round(fb_med * 1e3, 3), 'scenes_per_s': round(args.batch * world / fb_med, 3)},
-                       'config4_global_batch_16': cfg4, 'forced_dp_n1': forced, 'inference': infer},
+                       'config4_global_batch_16': cfg4, 'forced_dp_n1': forced, 'config4_per_gpu': cfg4_1,
+                       'fp32_mfma_route': fp32_route, 'inference': infer,
+                       'executor': bool(exec_on) and 'network body through the native launch-list executor (fcaf3d_amd/executor.py, '
+                                   'csrc/exec.hip); probed steps through the per-operator path'},
         }
         rl = probe.summary() if probe else None
         if rl:

@@ -16,6 +16,7 @@
 // single_stage_sparse.py:43-50 `extract_feat`, torch.autograd's backward over it).
 #include "fc_common.h"
 #include "../../include/fcaf3d_hip.h"
+#include <vector>
 
 namespace {
 
@@ -38,6 +39,18 @@ int ensure_events() {
   for (int i = 0; i < MAX_EVENTS; ++i) FC_HIP(hipEventCreateWithFlags(&g_events[i], hipEventDisableTiming));
   g_events_ready = true;
   return 0;
+}
+
+// ---- probe: HIP-event brackets around the convolution launches of a call (bench.py's roofline measurement) ----------------
+struct ProbeRec { hipEvent_t a, b; int64_t meta[8]; };
+std::vector<ProbeRec> g_probe;          // records since the last fc_exec_probe_read
+std::vector<hipEvent_t> g_probe_pool;   // timing events, reused
+
+hipEvent_t probe_event() {
+  if (!g_probe_pool.empty()) { hipEvent_t e = g_probe_pool.back(); g_probe_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
 }
 
 inline double as_double(int64_t v) { double d; __builtin_memcpy(&d, &v, 8); return d; }
@@ -100,9 +113,36 @@ struct Ctx {
   int64_t ws_bytes[NSTREAM];
   int64_t need[NSTREAM];
   bool dry;
+  bool probe;
   int64_t bn_small_elems;
   int flags;
 };
+
+int run_op_impl(Ctx& c, const int64_t* op);
+
+int run_op(Ctx& c, const int64_t* op) {
+  if (c.dry || !c.probe || op[0] != 5 /* OP_CONV */) return run_op_impl(c, op);
+  ProbeRec r;
+  r.a = probe_event(); r.b = probe_event();
+  if (!r.a || !r.b) return run_op_impl(c, op);
+  hipStream_t st = c.streams[op[1]];
+  const int64_t Cin = op[8], Cout = op[9];
+  if (op[4] < 0) {
+    const int64_t n = c.dims[op[7]];
+    const int64_t m[8] = {-1, op[5], n, n, 1, Cin, Cout, 0};
+    __builtin_memcpy(r.meta, m, sizeof m);
+  } else {
+    const int64_t* mp = c.maps + op[4] * MAPW;
+    const bool bwd = op[5] != 0;
+    const int64_t m[8] = {op[4], op[5], bwd ? mp[1] : mp[0], bwd ? mp[0] : mp[1], mp[2], Cin, Cout, (mp[19] & (bwd ? 2 : 1)) ? 1 : 0};
+    __builtin_memcpy(r.meta, m, sizeof m);
+  }
+  FC_HIP(hipEventRecord(r.a, st));
+  const int rc = run_op_impl(c, op);
+  FC_HIP(hipEventRecord(r.b, st));
+  g_probe.push_back(r);
+  return rc;
+}
 
 template <class T>
 inline T* P(const Ctx& c, int64_t idx) { return idx < 0 ? nullptr : reinterpret_cast<T*>(c.addr[idx]); }
@@ -112,7 +152,7 @@ inline bool want_ws(Ctx& c, int s, int64_t bytes) {     // true: the launch may 
   return !c.dry;
 }
 
-int run_op(Ctx& c, const int64_t* op) {
+int run_op_impl(Ctx& c, const int64_t* op) {
   const int s = (int)op[1];
   hipStream_t st = c.streams[s];
   switch (op[0]) {
@@ -345,6 +385,7 @@ int fc_exec(const int64_t* ops, int64_t op_begin, int64_t op_end, const int64_t*
   }
   c.bn_small_elems = cfg[0];
   c.flags = (int)cfg[1];
+  c.probe = cfg[2] != 0;
   c.dry = true;
   for (int64_t i = op_begin; i < op_end; ++i) {
     rc = run_op(c, ops + i * OPW);
@@ -362,6 +403,26 @@ int fc_exec(const int64_t* ops, int64_t op_begin, int64_t op_end, const int64_t*
     if (rc) return rc;
   }
   return 0;
+}
+
+// Probe read-out (cfg[2] != 0 in fc_exec: a HIP-event pair brackets every convolution operator, on the stream it is launched
+// on).  Call after the device has drained: ms[i] = duration of record i, meta[8 i ..] = {map index or -1, direction, n_in, n_out,
+// K, Cin, Cout, 1 if the per-offset pair-list route ran}; returns the number of records (at most cap are written) and forgets them.
+int64_t fc_exec_probe_read(float* ms, int64_t* meta, int64_t cap) {
+  const int64_t n = (int64_t)g_probe.size();
+  for (int64_t i = 0; i < n; ++i) {
+    ProbeRec& r = g_probe[i];
+    if (i < cap) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) t = -1.f;
+      ms[i] = t;
+      __builtin_memcpy(meta + 8 * i, r.meta, sizeof r.meta);
+    }
+    g_probe_pool.push_back(r.a);
+    g_probe_pool.push_back(r.b);
+  }
+  g_probe.clear();
+  return n;
 }
 
 }  // extern "C"

@@ -30,6 +30,9 @@ from . import functional as Fn
 from . import nn as MEnn
 
 ENABLED = os.environ.get('FC_EXEC', '1') != '0'
+# bench.py's live roofline measurement: a list -> every step bound while it is set has its convolution operators bracketed by
+# HIP events inside fc_exec (csrc/exec.hip, cfg[2]) and appends {pairs per kernel map (device scalars), operators per direction}
+PROBE = None
 
 (OP_STEM_FWD, OP_COL_STATS, OP_NORM_FWD, OP_MAXPOOL_FWD, OP_CONV, OP_BN_FWD, OP_UNION_FWD, OP_HEAD_FWD, OP_RECORD, OP_WAIT,
  OP_HEAD_BWD, OP_WGRAD, OP_BN_BWD, OP_NORM_BWD, OP_MAXPOOL_BWD, OP_STEM_WGRAD, OP_GATHER, OP_ADD, OP_SMALL_GRADS,
@@ -97,8 +100,10 @@ class NetProgram:
 
     @staticmethod
     def signature(det):
-        ps = [p for p in det.parameters()]
-        return (len(ps), ps[0].data_ptr(), ps[-1].data_ptr(), getattr(ps[0], '_fc_flat', (None,))[0] is not None)
+        """what the program's static address table depends on: cheap to compare per step (parameters are re-pointed only by
+        flat.FlatParams and by nn.Module._apply, which drops the detector's programs)"""
+        from .flat import GENERATION
+        return GENERATION[0]
 
     # ---- tables ------------------------------------------------------------------------------------------------------
     def _new(self):
@@ -462,7 +467,9 @@ class NetProgram:
         self.n_dims, self.n_maps = len(self.dim_names), len(self.map_names)
         self._ws = [None, None, None]
         self._need = np.zeros(3, dtype=np.int64)
-        self._cfg = np.array([Fn.BN_SMALL_ELEMS, Fn.FLAGS], dtype=np.int64)
+        self._cfg = np.array([Fn.BN_SMALL_ELEMS, Fn.FLAGS, 0], dtype=np.int64)
+        self.n_conv_f = int((self.ops_f[:, 0] == OP_CONV).sum())
+        self.n_conv_b = int((self.ops_b[:, 0] == OP_CONV).sum()) if len(self.ops_b) else 0
         self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
         if self.training:
             # small-gradient descriptor template: (src, dst, C, nseg, stride, 0, 0, 0) per (bias, weight) of every normalisation layer
@@ -508,13 +515,14 @@ class NetProgram:
         m2 = m1.strided(2)
         maps[mn['stem']] = cm0.kernel_map(m1, 3).desc(conv=False)
         maps[mn['pool']] = m1.kernel_map(m2, 2).desc(conv=False)
+        kms = {}
         setd('n0', cm0.n); setd('n1', m1.n); setd('n2', m2.n); setd('B', batch_size); setd('one', 1)
         prev, lv = m2, []
         for li in range(1, nl + 1):
             mi = prev.strided(2)
-            maps[mn[f'down{li}']] = prev.kernel_map(mi, 3).desc(True, backward)
-            maps[mn[f'ds{li}']] = prev.kernel_map(mi, 1).desc(True, backward)
-            maps[mn[f'same{li}']] = mi.kernel_map(mi, 3).desc(True, backward)
+            kms[f'down{li}'], kms[f'ds{li}'], kms[f'same{li}'] = prev.kernel_map(mi, 3), prev.kernel_map(mi, 1), mi.kernel_map(mi, 3)
+            for k in (f'down{li}', f'ds{li}', f'same{li}'):
+                maps[mn[k]] = kms[k].desc(True, backward)
             setd(f'L{li}', mi.n)
             lv.append(mi)
             prev = mi
@@ -526,7 +534,8 @@ class NetProgram:
             u, rows, swapped = lv[i].union(g)
             if not swapped or u is not g:
                 return None
-            maps[mn[f'gsame{i}']] = g.kernel_map(g, 3).desc(True, backward)
+            kms[f'gsame{i}'] = g.kernel_map(g, 3)
+            maps[mn[f'gsame{i}']] = kms[f'gsame{i}'].desc(True, backward)
             setd(f'g{i}', g.n)
             dyn[f'rows{i}'] = rows
             xm = g
@@ -537,7 +546,13 @@ class NetProgram:
             setd(f'off{i}', off)
             off += cm.n
         setd('Nall', off)
-        return dict(dims=dims, maps=maps, dyn=dyn, head_maps=head_maps, x=x, seg1=m1.coords, n_all=off)
+        st = dict(dims=dims, maps=maps, dyn=dyn, head_maps=head_maps, x=x, seg1=m1.coords, n_all=off)
+        if PROBE is not None:
+            # valid (input, output) pairs of every map, as device scalars (read back after the timed region): the FLOPs of a launch
+            from .sparse import _rec
+            st['pairs'] = {mn[k]: _rec(km._pairs[3].sum() if km._pairs is not None else (km.nbr >= 0).sum()) for k, km in kms.items()}
+            PROBE.append(dict(pairs=st['pairs'], nf=self.n_conv_f, nb=self.n_conv_b))
+        return st
 
     def _streams(self):
         dev = self.dev
@@ -549,6 +564,7 @@ class NetProgram:
 
     def _run(self, ops, addr, st):
         streams = self._streams()
+        self._cfg[2] = 1 if 'pairs' in st else 0
         while True:
             ws = np.array([w.data_ptr() if w is not None else 0 for w in self._ws], dtype=np.int64)
             wsb = np.array([w.numel() if w is not None else 0 for w in self._ws], dtype=np.int64)

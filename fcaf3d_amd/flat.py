@@ -14,6 +14,7 @@ The reference gets the same semantics from torch.optim.AdamW + clip_grad_norm_ +
 import torch
 
 ALIGN = 64          # floats: every tensor starts on a 256-byte boundary (16-byte vector accesses, no shared cache lines)
+GENERATION = [0]    # bumped whenever parameters are re-pointed (here; nn.Module._apply of the detector): address tables keyed on it
 
 
 class FlatParams:
@@ -35,6 +36,7 @@ class FlatParams:
                 v.copy_(p.data)
                 p.data = v                                                  # the Parameter object (and its name) is unchanged
                 p._fc_flat = (self, o)
+        GENERATION[0] += 1
 
     def grad_view(self, p):
         """a FRESH view of p's gradient slice (autograd adopts a gradient only if nobody else references the tensor object)"""

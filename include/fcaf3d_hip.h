@@ -359,8 +359,13 @@ int fc_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * Operators [op_begin, op_end) run on streams[0] (caller's), streams[1] (head branch of the neck), streams[2] (weight
  * gradients), ordered by library-owned events.  ws / ws_bytes: one scratch buffer per stream; a sizing pass runs first: if a
  * buffer is too small NOTHING is launched, ws_need[3] receives the sizes and the call returns -2.
- * cfg[0]: the two-launch BatchNorm is used up to this many elements; cfg[1]: kernel-variant flags (as `flags` above). */
+ * cfg[0]: the two-launch BatchNorm is used up to this many elements; cfg[1]: kernel-variant flags (as `flags` above);
+ * cfg[2] != 0: bracket every convolution operator with a HIP-event pair on its stream — fc_exec_probe_read(ms, meta, cap), called
+ * after the device has drained, returns the number of brackets since the last read-out and writes their durations (ms) and
+ * {map index | -1, direction, n_in, n_out, K, Cin, Cout, pair-list route} (8 int64 each): bench.py's live roofline measurement
+ * (the reference times whole iterations only: tools/analysis_tools/benchmark.py:64-91). */
 int fc_exec_op_words(void);
+int64_t fc_exec_probe_read(float* ms, int64_t* meta, int64_t cap);
 int fc_exec_map_words(void);
 int fc_exec(const int64_t* ops, int64_t op_begin, int64_t op_end, const int64_t* addr, const int64_t* dims, const int64_t* maps,
             const int64_t* streams, const int64_t* ws, const int64_t* ws_bytes, int64_t* ws_need, const int64_t* cfg);

@@ -58,7 +58,11 @@ def run_one(args, B, dev, do_cprofile, steps=8):
                 marks.append(time.perf_counter())
         mark()
         tr.optimizer.zero_grad(set_to_none=True)
-        if tr.images is not None and tr.images.n:
+        prog = tr._program()
+        if prog is not None:
+            if not prog.weights_fresh:
+                prog.refresh_weights()
+        elif tr.images is not None and tr.images.n:
             if tr.images_version != sum(w._version for w in tr._image_ws):
                 tr._build_images(side_stream=False)
             Fn.PREBUILT, Fn.PREBUILT_EVENT = tr.images.table, tr.images.event
@@ -73,7 +77,14 @@ def run_one(args, B, dev, do_cprofile, steps=8):
         tr.averager.finish()
         mark()
         tr.optimizer.step(tr.max_norm)
-        if tr.images is not None and tr.images.n:
+        for pr in getattr(model, '_programs', {}).values():
+            pr.weights_fresh = False
+        if prog is not None:
+            side, main = Fn.wgrad_stream(dev), torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                prog.refresh_weights()
+        elif tr.images is not None and tr.images.n:
             tr._build_images(side_stream=True)
         mark()
 
