@@ -321,7 +321,7 @@ class ConvProbe:
                 n += 1
         for bi, steps in self.timed.items():
             steps = [ev for ev in steps if ev]             # (steps that went through the executor left no per-call brackets)
-            if not steps:
+            if not steps or bi not in self.counted:
                 continue
             counted = self.counted[bi]
             per_launch = [((float(p.item()) if p is not None else float(n_out)) * fpp, nb) for p, fpp, n_out, nb in counted]
@@ -414,9 +414,16 @@ def cpu_baseline(args):
     return out
 
 
-def count_steps(args, n_batches):
-    """number of untimed FLOP-count steps after the timed region — a function of the flags only, never of the rank"""
-    return 0 if (args.no_instrument or args.breakdown) else n_batches      # every distinct batch a probed step may use
+def count_steps(args, n_batches, exec_on=False):
+    """number of untimed FLOP-count steps after the timed region — a function of the flags only, never of the rank.  With the
+    native executor the probed steps bring their FLOPs with them (pair counts bound with the step): no count steps"""
+    return 0 if (args.no_instrument or args.breakdown or exec_on) else n_batches      # every distinct batch a probed step may use
+
+
+def hbm_steps(args, exec_on):
+    """untimed per-operator steps for `roofline.hbm_kernels` when the timed region went through the executor — again a function
+    of the flags only"""
+    return 1 if (exec_on and not (args.no_instrument or args.breakdown)) else 0
 
 
 def timed_region(fn, n, world, dev):
@@ -530,12 +537,10 @@ def main():
     trainer.averager.log = None
     # untimed: FLOPs of every launch, one step per distinct batch.  EVERY rank steps (a step holds collectives: a
     # rank-0-only extra step deadlocks the job); only rank 0 carries the probe
-    per_call = bool(probe) and any(ev for steps_ in probe.timed.values() for ev in steps_)
-    n_count = count_steps(args, len(batches)) if (not exec_on or per_call) else 0       # FLOPs of executor-probed steps
-    for b in range(n_count):                                                                           # come with the brackets
+    for b in range(count_steps(args, len(batches), exec_on)):
         step(b, 'count' if probe else None)
-    if exec_on and not (args.no_instrument or args.breakdown):
-        step(0, 'hbm' if probe else None)          # untimed, per-operator path: the bandwidth-bound entry points for `hbm_kernels`
+    for b in range(hbm_steps(args, exec_on)):      # untimed, per-operator path: the bandwidth-bound entry points for `hbm_kernels`
+        step(b, 'hbm' if probe else None)
     if probe:
         probe.mode = None
     EX.ENABLED = exec_on

@@ -12,6 +12,7 @@
 // Replaces MinkowskiEngine's ConvolutionForward/Backward (and ConvolutionTranspose, 1x1 mm) called
 // from me_resnet.py:19-21,56-62, BasicBlock, fcaf3d_neck_with_head.py:52,60-69,83-85,257-263.
 #include "fc_common.h"
+#include <cstdlib>
 #ifdef FC_TRACE
 __device__ unsigned long long* g_trace_buf_lds;
 __device__ int g_trace_cap_lds;
@@ -1099,6 +1100,7 @@ __global__ void k_conv_fma(const float* __restrict__ in, const float* __restrict
 
 extern "C" {
 
+#define FC_CONV_APL (1 << 27)  // fc_conv_fwd / fc_conv_fwd_pairs(_tiles), with bits 24 and 26: `in` is the pre-split planes of fc_x6_planes
 #define FC_CONV_WT (1 << 23)   // fc_conv_fwd / fc_conv_fwd_pairs(_tiles): W[k] is stored transposed, (Cout, Cin) row-major
 // The deeper-pipelined LDS kernel (k_conv_mfma_p) holds 3 workgroups per CU (768 slots) where k_conv_mfma holds 4 (1024): it
 // wins on launches of many rounds and on launches that fit 768 slots anyway, and loses a round in between (r2: +5.5 / +7 %
@@ -1160,7 +1162,22 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
 // and LDS-padding occupancy caps all lose or are neutral — profiles/r1_conv_pmc.md — and were removed in r2)
 static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr,
                             const int* out_index, const int* cnt, float* dst, int64_t n_rows, int K, int Cin, int Cout,
-                            hipStream_t stream, bool wt = false) {
+                            hipStream_t stream, bool wt = false, bool apl = false) {
+  if (apl) {                                     // the input is pre-split planes (k_x6_planes): split-bf16 kernel with weight images only
+    if (pipe != 4 || bm < 128) return FC_EINVAL;
+    const u32x4* pl = reinterpret_cast<const u32x4*>(in);
+#define FC_LAUNCH_X6P(BM_, BN_, WM_)                                                                                   \
+  do {                                                                                                                 \
+    if (nbr) k_conv_x6p<BM_, BN_, true, WM_><<<grid, 256, 0, stream>>>(pl, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout);  \
+    else k_conv_x6p<BM_, BN_, false, WM_><<<grid, 256, 0, stream>>>(pl, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout);     \
+  } while (0)
+    if (bm == 256) FC_LAUNCH_X6P(256, 64, 4);
+    else if (bn == 128) FC_LAUNCH_X6P(128, 128, 2);
+    else FC_LAUNCH_X6P(128, 64, 2);
+#undef FC_LAUNCH_X6P
+    FC_CHECK_LAUNCH();
+    return FC_OK;
+  }
 #define FC_ARGS <<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout)
 #define FC_LAUNCH_MFMA(KERNEL, BM_, BN_, WM_)                                    \
   do {                                                                           \
@@ -1247,7 +1264,7 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
   bool mfma_ok; int bm, bn, S;
   conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S);
   if (!mfma_ok) {
-    if (out_index || (flags & (1 << 26))) return FC_EINVAL;      // sorted-row tables and weight images are MFMA-path features
+    if (out_index || (flags & ((1 << 26) | FC_CONV_APL))) return FC_EINVAL;      // sorted-row tables, weight images and planes are MFMA-path features
     k_conv_fma<<<(unsigned)fc_cdiv(n_out * Cout, 256), 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout, wt ? 1 : 0);
     FC_CHECK_LAUNCH();
     return FC_OK;
@@ -1255,7 +1272,8 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
   if (S > 1 && ws_bytes < (int64_t)S * n_out * Cout * (int64_t)sizeof(float)) return FC_EWS;
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
-  int rc = launch_conv_mfma(conv_pipe(flags, grid), bm, bn, grid, in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream, wt);
+  int rc = launch_conv_mfma(conv_pipe(flags, grid), bm, bn, grid, in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream, wt,
+                            (flags & FC_CONV_APL) != 0);
   if (rc != FC_OK) return rc;
   return S > 1 ? sum_parts(dst, out, n_out, Cout, S, stream) : FC_OK;
 }
@@ -1274,6 +1292,17 @@ int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int trans
   if (K < 1 || R < 32 || C < 64 || R % 32 != 0 || C % 64 != 0) return FC_EINVAL;
   const int64_t total = (int64_t)K * (R / 32) * (C / 64) * 256;
   k_x6_weight_image<<<(unsigned)fc_cdiv(total, 256), 256, 0, stream>>>(W, (u32x4*)img, K, R, C, transposed);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+int64_t fc_x6_planes_bytes(int64_t n, int C) { return n * (int64_t)C * 6; }
+
+int fc_x6_planes(const float* x, void* planes, int64_t n, int C, hipStream_t stream) {
+  if (n < 0 || C < 32 || C % 32) return FC_EINVAL;
+  if (n == 0) return FC_OK;
+  const int64_t t = n * (C / 32) * 4;
+  k_x6_planes<<<(unsigned)fc_cdiv(t, 256), 256, 0, stream>>>(x, reinterpret_cast<u32x4*>(planes), n, C);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
@@ -1305,7 +1334,7 @@ int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in,
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
   if (live_tiles > 0) grid = dim3((unsigned)live_tiles, Cout / bn, 1);       // linear list of the live (offset, tile) pairs
   {
-    int rc = launch_conv_mfma((live_tiles > 0 || (flags & (1 << 24))) ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt);
+    int rc = launch_conv_mfma((live_tiles > 0 || (flags & (1 << 24))) ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt, (flags & FC_CONV_APL) != 0);
     if (rc != FC_OK) return rc;
   }
   k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);
@@ -1817,7 +1846,11 @@ static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool 
     // uniform long workgroups: exactly one resident round (3 per CU), fewer partial gradients to write and re-read
     const bool wide = Cout % 128 == 0;
     tiles = (int64_t)(K / WGRAD_KO) * (Cin / 64) * (Cout / (wide ? 128 : 64));
-    s = (wide ? 512 : 768) / tiles;                     // the 128-column variant holds 2 workgroups per CU (registers)
+    // r4 A/B in the full step (weight gradients beside the dependent chain): 3/4 of a resident round 22.91 ms, a full round
+    // (r3) 23.34, half 23.70, a quarter 28.63, two rounds 23.25 — the main stream's kernels find a slot sooner
+    static const int round_wide = getenv("FC_WGRAD_ROUND_WIDE") ? atoi(getenv("FC_WGRAD_ROUND_WIDE")) : 384;
+    static const int round_narrow = getenv("FC_WGRAD_ROUND_NARROW") ? atoi(getenv("FC_WGRAD_ROUND_NARROW")) : 512;
+    s = (wide ? round_wide : round_narrow) / tiles;     // the 128-column variant holds 2 workgroups per CU (registers)
   }
   int64_t max_by_rows = fc_cdiv(n_out > 0 ? n_out : 1, mfma_ok ? 512 : 2048);
   if (s > max_by_rows) s = max_by_rows;

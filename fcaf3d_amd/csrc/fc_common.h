@@ -57,14 +57,34 @@ __device__ static inline int fc_floor_div(int a, int b) {
 }
 
 // Loads for data one launch hands to the next through a small table at a FIXED address (per-stream workspace, persistent
-// buffers): read it past the CU's vector L1.  r3 (csrc/assign.hip, tools/trace_det.py): with another stream's kernels keeping
-// the CUs busy, a consumer wave that lands on a CU late can still hit that CU's line from the previous use of the address —
-// the L2 is coherent, the L1 is not.  `nt` / agent-scope loads are served by the L2.
+// buffers): agent-scope relaxed atomic loads — `global_load ... sc1`, served by the L2, never by the CU's vector L1
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility").
+// r3 (csrc/assign.hip, tools/trace_det.py): with the target assignment on the coordinate stream while the main stream ran the
+// split-bf16 convolutions, ~30 % of the assignment calls returned a few dozen rows computed from the PREVIOUS call's kth / best
+// entries although stream order puts the consumer kernel after its producer.  r4: a stand-alone producer -> fixed-address
+// table -> consumer loop beside a busy second stream (tools/stale_repro.cpp: 13 configurations, 10^9-10^10 words each) never
+// returns a stale word with plain loads — the kernel boundary does invalidate the L1 there — so the mechanism behind the r3
+// symptom is NOT established; what is established is the symptom with the real kernels and its absence with L2-served loads
+// (tests/test_gpu_model.py::test_target_assignment_is_stable_beside_concurrent_convolutions; -DFC_LD_PLAIN builds the plain-load
+// library the A/B of profiles/r4_notes.md was run with).  The loads are therefore defined by SCOPE (r3 used the cache-policy
+// builtin __builtin_nontemporal_load, which happens to lower to the same instruction) and used for every cross-launch table a
+// kernel re-reads at a fixed address: assignment tables, optimizer clip coefficient, fused-loss partials, the normalisation
+// kernels' statistics / partial tables, the executor's small-gradient sums.
 typedef float fc_f4v __attribute__((ext_vector_type(4)));
-__device__ static inline float fc_ld(const float* p) { return __builtin_nontemporal_load(p); }
-__device__ static inline int fc_ld(const int* p) { return __builtin_nontemporal_load(p); }
-__device__ static inline double fc_ld(const double* p) { return __builtin_nontemporal_load(p); }
-__device__ static inline float4 fc_ld4(const float* p) {
-  const fc_f4v v = __builtin_nontemporal_load(reinterpret_cast<const fc_f4v*>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
+#ifdef FC_LD_PLAIN
+__device__ static inline float fc_ld(const float* p) { return *p; }
+__device__ static inline int fc_ld(const int* p) { return *p; }
+__device__ static inline double fc_ld(const double* p) { return *p; }
+__device__ static inline float4 fc_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+#else
+__device__ static inline float fc_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ static inline int fc_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ static inline double fc_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ static inline float4 fc_ld4(const float* p) {          // two 8-byte agent-scope loads (the widest atomic access)
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
+                     __uint_as_float((unsigned)(b >> 32)));
 }
+#endif

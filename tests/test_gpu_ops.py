@@ -657,3 +657,40 @@ def test_empty_and_degenerate_inputs():
                  torch.zeros((1, 0), dtype=torch.int32, device=dev))
     assert idx.shape == (1, 0, 9)
     torch.cuda.synchronize()
+
+
+def test_conv_on_presplit_planes_is_bit_identical():
+    """fc_x6_planes + flags bit27 (k_conv_x6p): the gathered operand arrives as pre-split bf16 planes instead of being split
+    in the kernel — the same pieces and products, so the dense-table, sorted-table and pair-list routes must agree BIT FOR BIT
+    with the in-kernel split (r4 A/B: profiles/r4_notes.md; the route is not the default, it is not faster)."""
+    dev = _dev()
+    import fcaf3d_amd._lib as L
+    import fcaf3d_amd.functional as Fn
+    from fcaf3d_amd.sparse import SparseTensor
+    torch.manual_seed(3)
+    pts = (torch.rand((60000, 3), device=dev) * torch.tensor([6.0, 5.0, 2.5], device=dev) / 0.02).floor().int()
+    coords = torch.cat([torch.randint(0, 2, (60000, 1), device=dev, dtype=torch.int32), pts], 1)
+    x = SparseTensor(torch.randn((60000, 3), device=dev), coordinates=coords, batch_size=2)
+    cm = x.cmap.strided(4)
+    fine = cm.kernel_map(cm, 3)
+    coarse_map = cm.strided(4)
+    coarse = coarse_map.kernel_map(coarse_map, 3)
+    APL = 1 << 27
+    for km, Cin, Cout in ((fine, 64, 128), (fine, 128, 64), (coarse, 128, 128)):
+        f = torch.randn((km.n_in, Cin), device=dev)
+        w = torch.randn((27, Cin, Cout), device=dev) * 0.05
+        img = Fn._x6_image(w, False)
+        planes = torch.empty(L.query('fc_x6_planes_bytes', km.n_in, Cin), dtype=torch.uint8, device=dev)
+        L.call('fc_x6_planes', L.ptr(f), L.ptr(planes), km.n_in, Cin, L.stream())
+        fl = Fn.CONV_X6
+        a = torch.empty((km.n_out, Cout), device=dev)
+        b = torch.empty_like(a)
+        if Fn._pair_conv(km, km.n_out, Cin, Cout):
+            Fn._conv_pairs(f, img, km.pairs(), a, km.n_in, km.n_out, 27, Cin, Cout, km.pair_tiles(), flags=fl)
+            Fn._conv_pairs(planes, img, km.pairs(), b, km.n_in, km.n_out, 27, Cin, Cout, km.pair_tiles(), flags=fl | APL)
+        else:
+            nbr, oidx = km.sorted_fwd()
+            Fn._conv_fwd(f, img, nbr, a, km.n_in, km.n_out, 27, Cin, Cout, oidx, flags=fl)
+            Fn._conv_fwd(planes, img, nbr, b, km.n_in, km.n_out, 27, Cin, Cout, oidx, flags=fl | APL)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (km.n_out, Cin, Cout)
