@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-points', type=int, default=0, help='points of the cpu_baseline sample scene (0 = same as workload)')
     ap.add_argument('--no-instrument', action='store_true', help='skip per-kernel HIP events (roofline = null)')
-    ap.add_argument('--probe-every', type=int, default=11, help='HIP events bracket the conv launches of every n-th timed step '
+    ap.add_argument('--probe-every', type=int, default=20, help='HIP events bracket the conv launches of every n-th timed step '
                     '(each event pair is a pipeline bubble: sampling keeps the probe from slowing the thing it measures)')
     ap.add_argument('--spatial-sort', action='store_true', help='Z-order sort of the collated points (measured: no gain, r1)')
     ap.add_argument('--no-wgrad-overlap', action='store_true', help='keep the weight-gradient kernels on the main stream (default: a second '

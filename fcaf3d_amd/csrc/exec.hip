@@ -23,7 +23,7 @@ namespace {
 enum : int64_t {
   OP_STEM_FWD = 1, OP_COL_STATS, OP_NORM_FWD, OP_MAXPOOL_FWD, OP_CONV, OP_BN_FWD, OP_UNION_FWD, OP_HEAD_FWD, OP_RECORD, OP_WAIT,
   OP_HEAD_BWD, OP_WGRAD, OP_BN_BWD, OP_NORM_BWD, OP_MAXPOOL_BWD, OP_STEM_WGRAD, OP_GATHER, OP_ADD, OP_SMALL_GRADS,
-  OP_PERMUTE_GENT, OP_HEAD_WFIN, OP_COPY
+  OP_PERMUTE_GENT, OP_HEAD_WFIN, OP_COPY, OP_COL_SUM, OP_ROW_SUM
 };
 constexpr int OPW = 20;            // int64 words per operator
 constexpr int MAPW = 20;           // int64 words per kernel-map descriptor
@@ -102,6 +102,26 @@ __global__ void k_head_wfin(const float* __restrict__ part, int nl, int R, int l
   if (c == 0) g_cent[r] = s;
   else if (c <= n_reg) g_reg[r * n_reg + c - 1] = s;
   else g_cls[r * n_cls + c - 1 - n_reg] = s;
+}
+
+// dst[c] = sum over n rows of x[r][c] (C columns, any C): one 1024-thread block per column, rows strided over the threads, fixed
+// tree order — the head's class-bias gradient (the column sums of d loss / d cls_score over every location of the batch)
+__global__ __launch_bounds__(1024) void k_col_sum(const float* __restrict__ x, int64_t n, int C, float* __restrict__ dst) {
+  __shared__ float red[1024];
+  const int c = blockIdx.x;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int64_t r = threadIdx.x;
+  for (; r + 3 * 1024 < n; r += 4 * 1024) {
+    a0 += x[r * C + c]; a1 += x[(r + 1024) * C + c]; a2 += x[(r + 2048) * C + c]; a3 += x[(r + 3072) * C + c];
+  }
+  for (; r < n; r += 1024) a0 += x[r * C + c];
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dst[c] = red[0];
 }
 
 struct Ctx {
@@ -327,9 +347,21 @@ int run_op_impl(Ctx& c, const int64_t* op) {
       FC_CHECK_LAUNCH();
       return 0;
     }
-    case OP_SMALL_GRADS: {  // desc (device), n
+    case OP_SMALL_GRADS: {  // desc (device), first entry, n entries
       if (c.dry) return 0;
-      if (op[3] > 0) k_small_grads<<<(unsigned)op[3], 128, 0, st>>>(P<const long long>(c, op[2]), (int)op[3]);
+      if (op[4] > 0) k_small_grads<<<(unsigned)op[4], 128, 0, st>>>(P<const long long>(c, op[2]) + 8 * op[3], (int)op[4]);
+      FC_CHECK_LAUNCH();
+      return 0;
+    }
+    case OP_COL_SUM: {  // x (n, C), n(dim), C, dst (C)
+      if (c.dry) return 0;
+      k_col_sum<<<(unsigned)op[4], 1024, 0, st>>>(P<const float>(c, op[2]), c.dims[op[3]], (int)op[4], P<float>(c, op[5]));
+      FC_CHECK_LAUNCH();
+      return 0;
+    }
+    case OP_ROW_SUM: {  // x (n), n(dim), dst (1)
+      if (c.dry) return 0;
+      k_col_sum<<<1, 1024, 0, st>>>(P<const float>(c, op[2]), c.dims[op[3]], 1, P<float>(c, op[4]));
       FC_CHECK_LAUNCH();
       return 0;
     }

@@ -19,6 +19,7 @@ def world_size():
 # bench.py --gpus 1: run the gradient averager (hooks, buckets, RCCL launches) in a 1-rank process group, so that the
 # overhead of the data-parallel path itself is measured without a second GPU
 FORCE_AVERAGER = False
+ACTIVE = None          # the GradientAverager that is averaging right now (the native executor hands it its buckets: executor.py)
 
 
 def _averaging():
@@ -87,6 +88,8 @@ class GradientAverager:
         self._ranges = [self.flat.range_of(b) for b in self.buckets]           # contiguous [begin, end) per bucket
         for (lo, hi), b in zip(self._ranges, self.buckets):
             assert hi - lo == sum(-(-p.numel() // 64) * 64 for p in b), 'a bucket must be a contiguous run of parameters'
+        global ACTIVE
+        ACTIVE = self
         self._avg = dist.get_backend() == 'nccl'   # RCCL averages in the collective; gloo: divide, then sum
         self._bucket_of = {}
         for bi, b in enumerate(self.buckets):
@@ -97,6 +100,9 @@ class GradientAverager:
 
     def close(self):
         """detach the autograd hooks (a second averager may then take over the same parameters)"""
+        global ACTIVE
+        if ACTIVE is self:
+            ACTIVE = None
         for h in self._hooks:
             h.remove()
         self._hooks, self.buckets = [], []
@@ -127,6 +133,21 @@ class GradientAverager:
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
         while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
+
+    def launch_next(self):
+        """the native executor's backward (executor.py) has enqueued every operator that writes the next bucket's gradients:
+        launch its all-reduce now (the per-operator path gets here through the autograd hooks)"""
+        if self._next < len(self.buckets):
+            if self.log is not None and self._t0 is None:
+                import time
+                self._t0 = time.perf_counter()
+            if self.flat.grad.is_cuda:
+                from . import _lib as L
+                raw = L.stream()
+                if raw not in self._streams:
+                    self._streams[raw] = torch.cuda.current_stream(self.flat.grad.device)
             self._launch(self._next)
             self._next += 1
 

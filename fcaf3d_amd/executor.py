@@ -36,7 +36,7 @@ PROBE = None
 
 (OP_STEM_FWD, OP_COL_STATS, OP_NORM_FWD, OP_MAXPOOL_FWD, OP_CONV, OP_BN_FWD, OP_UNION_FWD, OP_HEAD_FWD, OP_RECORD, OP_WAIT,
  OP_HEAD_BWD, OP_WGRAD, OP_BN_BWD, OP_NORM_BWD, OP_MAXPOOL_BWD, OP_STEM_WGRAD, OP_GATHER, OP_ADD, OP_SMALL_GRADS,
- OP_PERMUTE_GENT, OP_HEAD_WFIN, OP_COPY) = range(1, 23)
+ OP_PERMUTE_GENT, OP_HEAD_WFIN, OP_COPY, OP_COL_SUM, OP_ROW_SUM) = range(1, 25)
 OPW, MAPW = 20, 20
 ALIGN = 256
 S_MAIN, S_HEAD, S_WGRAD = 0, 1, 2
@@ -203,6 +203,24 @@ class NetProgram:
         relu, elu, none = Fn.ACT['relu'], Fn.ACT['elu'], Fn.ACT['none']
         grad = {}                        # forward tensor -> gradient tensor (backward arena)
         head_grads = {}                  # forward tensor -> (gradient from its head branch on the head stream, level)
+        self._pready = {}                # id(parameter) -> number of backward operators after which its gradient is final
+        small_rows = []                  # normalisation layers in BACKWARD emission order: (sums address | None, nseg dim, C, weight, bias)
+        flushed = [0]
+
+        def wrote(*params):
+            for prm in params:
+                self._pready[id(prm)] = len(Bk)
+
+        def flush_small(stream):
+            """the d gamma / d beta sums of the normalisation layers whose backward has been emitted since the last flush -> their
+            gradient slices (one launch); called where a group of layers ends, so that a data-parallel bucket is complete early"""
+            n = len(small_rows) - flushed[0]
+            if n:
+                self.emit(Bk, OP_SMALL_GRADS, stream, self.DY('small_desc'), 2 * flushed[0], 2 * n)
+                for _, _, _, w_, b_ in small_rows[flushed[0]:]:
+                    wrote(w_, b_)
+                flushed[0] = len(small_rows)
+        head_wgrads = [0]
 
         def wstream(cur):
             return S_WGRAD if self.wgrad_async else cur
@@ -241,6 +259,7 @@ class NetProgram:
                     gx = self.T(rows_in, Cin, 'b')
                     self.emit(Bk, OP_CONV, stream, gy, self.IMG(mod.kernel, True), m, 1, gx, -1, Cout, Cin)
                     emit_wgrad(stream, x, gy, m, self.G(mod.kernel), -1, Cin, Cout)
+                    wrote(mod.kernel)
                     accumulate(x, gx, rows_in, Cin, stream)
                 tape.append((stream, bwd))
             return y
@@ -256,6 +275,15 @@ class NetProgram:
                     gx = self.T(rows, Cin, 'b')
                     self.emit(Bk, OP_CONV, stream, gy, self.IMG(w_tensor, True), -1, 1, gx, self.D(rows), Cout, Cin)
                     emit_wgrad(stream, x, gy, -1, gw_dst, self.D(rows), Cin, Cout)
+                    if w_tensor is self.packed:
+                        head_wgrads[0] += 1
+                        if head_wgrads[0] == self.nl:      # every level's partial of the packed head kernel is on its way
+                            s_ = wstream(stream)
+                            if not self.wgrad_async and stream != S_MAIN:
+                                s_ = S_MAIN                 # (never reached: without the weight-gradient stream there is no head stream order to respect)
+                            self.emit(Bk, OP_HEAD_WFIN, s_, self.SA(head_part.data_ptr()), self.nl, Cn, 64, n_reg, n_cls,
+                                      self.G(nh.centerness_conv.kernel), self.G(nh.reg_conv.kernel), self.G(nh.cls_conv.kernel))
+                            wrote(nh.centerness_conv.kernel, nh.reg_conv.kernel, nh.cls_conv.kernel)
                     accumulate(x, gx, rows, Cin, stream)
                 tape.append((stream, bwd))
             return y
@@ -272,9 +300,9 @@ class NetProgram:
             if tr:
                 sums = torch.zeros((2, C), dtype=torch.float32, device=self.dev)
                 si = self.S(sums)
-                self.small.append((sums.data_ptr(), None, C, b.weight, b.bias))
 
                 def bwd():
+                    small_rows.append((sums.data_ptr(), None, C, b.weight, b.bias))
                     gy = take(y, rows, C) if stream == S_MAIN else grad[y]
                     gx = self.T(rows, C, 'b')
                     gres = self.T(rows, C, 'b') if res is not None else -1
@@ -303,9 +331,9 @@ class NetProgram:
         if tr:
             in_sums = self.T('B', 2 * 64, 'b')
             self.in_sums = in_sums
-            self.small.append((None, 'B', 64, inorm.weight, inorm.bias))
 
             def bwd_stem():
+                small_rows.append((None, 'B', 64, inorm.weight, inorm.bias))
                 g_pool = take(t_pool, 'n2', 64)
                 g_in = self.T('n1', 64, 'b')
                 self.emit(Bk, OP_MAXPOOL_BWD, S_MAIN, g_pool, arg, self.M('pool'), 64, g_in)
@@ -317,11 +345,14 @@ class NetProgram:
                     self.emit(Bk, OP_RECORD, S_MAIN, EV_W0)
                     self.emit(Bk, OP_WAIT, S_WGRAD, EV_W0)
                 self.emit(Bk, OP_STEM_WGRAD, wstream(S_MAIN), col, g_stem, self.M('stem'), self.G(stem.kernel))
+                wrote(stem.kernel)
             tape.append((S_MAIN, bwd_stem))
         cur, cur_rows, cur_C = t_pool, 'n2', 64
         levels = []
         for li in range(1, self.nl + 1):
             rows = f'L{li}'
+            if tr:
+                tape.append((S_MAIN, lambda: flush_small(S_MAIN)))       # reversed walk: reached after this layer's backward
             for j, blk in enumerate(getattr(bb, f'layer{li}')):
                 planes = blk.conv1.out_channels
                 if j == 0:
@@ -346,6 +377,7 @@ class NetProgram:
         self.out_idx = (cent_all, bbox_all, cls_all, cmax_all)
         head_part = None
         if tr:
+            tape.append((S_MAIN, lambda: flush_small(S_MAIN)))           # ... after the whole neck's backward
             self.gout_idx = (self.DY('g_cent'), self.DY('g_bbox'), self.DY('g_cls'))
             self.gs_idx = self.T('Nall', 1, 'b')
             head_part = torch.zeros((self.nl, Cn, 64), dtype=torch.float32, device=self.dev)
@@ -366,6 +398,8 @@ class NetProgram:
                 if tr:
                     def bwd_perm(gw_i=gw_i, mod=up[0], Cin=x_C, Ci=Ci):
                         self.emit(Bk, OP_PERMUTE_GENT, wstream(S_MAIN), gw_i, self.G(mod.kernel), Cin, Ci)
+                        wrote(mod.kernel)
+                        flush_small(S_MAIN)                     # ... and after every neck level's up-block
                     tape.append((S_MAIN, bwd_perm))          # forward order: BEFORE the GEMM, so the reversed walk reaches it after
                 t = gemm(x, self.gent_w[gi], x_rows, x_C, 8 * Ci, gw_i)
                 t = bn(t, up[1], elu, g_rows)
@@ -405,8 +439,11 @@ class NetProgram:
                 def bwd_head(y=y, outs=outs, off=off, hs=hs, rows=x_rows, lvl=i):
                     gy = self.T(rows, 64, 'b')
                     gin = [self.AL(g, off, c) for g, c in zip(self.gout_idx, (1, n_reg, n_cls))]
+                    gs_l = self.AL(self.gs_idx, off, 1)
                     self.emit(Bk, OP_HEAD_BWD, hs, y, 64, self.S(nh.scales[lvl].scale), outs[1], gin[0], gin[1], gin[2], self.D(rows), n_reg,
-                              n_cls, gy, self.AL(self.gs_idx, off, 1))
+                              n_cls, gy, gs_l)
+                    self.emit(Bk, OP_ROW_SUM, hs, gs_l, self.D(rows), self.G(nh.scales[lvl].scale))       # d loss / d scale of this level
+                    wrote(nh.scales[lvl].scale)
                     grad[y] = gy
                 tape.append((hs, bwd_head))
                 if hs == S_HEAD:
@@ -416,6 +453,9 @@ class NetProgram:
             self.emit(F, OP_WAIT, S_MAIN, EV_HEAD_DONE)
         # ---- backward program -------------------------------------------------------------------------------------------
         if tr:
+            # the class-bias gradient = column sums of d loss / d cls_score: needs nothing of the backward pass
+            self.emit(Bk, OP_COL_SUM, S_MAIN, self.gout_idx[2], self.D('Nall'), n_cls, self.G(nh.cls_conv.bias))
+            wrote(nh.cls_conv.bias)
             if self.head_overlap:
                 # the head branches depend on the loss gradients only: their backward is enqueued first, on the head stream, finest
                 # forked level first (the main chain needs that one first); each leaves the gradient of its neck tensor behind an event
@@ -435,16 +475,18 @@ class NetProgram:
                     assert saved is None
                     for e in ems:
                         e()
+                    flush_small(S_HEAD)                    # this branch's normalisation layer
                     self.emit(Bk, OP_RECORD, S_HEAD, EV_HB + lvl)
                     head_grads[xt] = (grad.pop(xt), lvl)
             for s, e in reversed(tape):
                 if s == S_MAIN:
                     e()
             assert not head_grads, 'a head branch was never joined'
-            # per-level partials of the packed head kernel -> the three head kernels' gradients; normalisation sums -> their slices
-            self.emit(Bk, OP_HEAD_WFIN, wstream(S_MAIN), self.SA(head_part.data_ptr()), self.nl, Cn, 64, n_reg, n_cls,
-                      self.G(nh.centerness_conv.kernel), self.G(nh.reg_conv.kernel), self.G(nh.cls_conv.kernel))
-            self.emit(Bk, OP_SMALL_GRADS, S_MAIN, self.DY('small_desc'), 2 * len(self.small))
+            flush_small(S_MAIN)                            # what is left: the stem's instance norm
+            assert head_wgrads[0] == self.nl
+            self.small = small_rows
+            missing = [n for n, prm in det.named_parameters() if prm.requires_grad and id(prm) not in self._pready]
+            assert not missing, missing
             if self.wgrad_async:
                 self.emit(Bk, OP_RECORD, S_WGRAD, EV_WEND)
                 self.emit(Bk, OP_WAIT, S_MAIN, EV_WEND)
@@ -562,13 +604,14 @@ class NetProgram:
         wg = Fn.wgrad_stream(dev).cuda_stream if self.wgrad_async else main
         return np.array([main, head, wg], dtype=np.int64)
 
-    def _run(self, ops, addr, st):
+    def _run(self, ops, addr, st, begin=0, end=None):
         streams = self._streams()
         self._cfg[2] = 1 if 'pairs' in st else 0
+        end = len(ops) if end is None else end
         while True:
             ws = np.array([w.data_ptr() if w is not None else 0 for w in self._ws], dtype=np.int64)
             wsb = np.array([w.numel() if w is not None else 0 for w in self._ws], dtype=np.int64)
-            rc = L.lib().fc_exec(ops.ctypes.data, 0, len(ops), addr.ctypes.data, st['dims'].ctypes.data, st['maps'].ctypes.data,
+            rc = L.lib().fc_exec(ops.ctypes.data, begin, end, addr.ctypes.data, st['dims'].ctypes.data, st['maps'].ctypes.data,
                                  streams.ctypes.data, ws.ctypes.data, wsb.ctypes.data, self._need.ctypes.data, self._cfg.ctypes.data)
             if rc == -2:                                  # nothing was launched: grow the scratch buffers and go again
                 for i in range(3):
@@ -627,7 +670,10 @@ class NetProgram:
             addr[self.dyn[k]] = g.data_ptr()
         ai, ap, ad, ab = self._al
         addr[ai] = addr[ap] + dims[ad] * ab
-        if self.flat is not None:
+        # gradients that are already there (a second backward pass without zero_grad: accumulation) are added to afterwards;
+        # then, and without flat storage, this pass writes into a buffer of its own (same layout)
+        accum = any(p.grad is not None for p in self._params)
+        if self.flat is not None and not accum:
             gbuf = self.flat.grad
         else:
             gbuf = torch.zeros(self._gtotal, dtype=torch.float32, device=self.dev)
@@ -641,24 +687,47 @@ class NetProgram:
         desc[r:r + 2, 3] = B
         desc_dev = L.upload(desc, self.dev)
         addr[self.dyn['small_desc']] = desc_dev.data_ptr()
-        self._run(self.ops_b, addr, st)
-        # the head's bias and the per-level scales: plain reductions over the location rows
-        o = int(addr[self.gs_idx] - ba.data_ptr())
-        gs_all = ba[o:o + n * 4].view(torch.float32)
-        offs = [int(dims[self.dim_names[f'off{i}']]) for i in range(self.nl)] + [n]
         gv = self._grad_views(gbuf)
-        gv[id(nh.cls_conv.bias)].copy_(gs[2].sum(0).view_as(nh.cls_conv.bias))
-        for i in range(self.nl):
-            gv[id(nh.scales[i].scale)].copy_(gs_all[offs[i]:offs[i + 1]].sum())
-        for p in self._params:
-            v = gv[id(p)]
-            if p.grad is None:
-                p.grad = v
-            elif p.grad.data_ptr() != v.data_ptr():
-                p.grad += v
-        if self.flat is not None:
+        if not accum:
+            for p in self._params:                          # before the operators run: a data-parallel bucket may leave mid-way
+                p.grad = gv[id(p)]
+        from . import dist as D
+        av = D.ACTIVE
+        if av is not None and av.buckets and av.flat is self.flat and self.flat is not None and not accum:
+            # data parallel: every gradient bucket leaves (all-reduce on the weight-gradient stream) as soon as the operators that
+            # write its parameters are enqueued — what the autograd hooks of the per-operator path do
+            pos = 0
+            for upto in self._bucket_ready(av):
+                if upto > pos:
+                    self._run(self.ops_b, addr, st, pos, upto)
+                    pos = upto
+                av.launch_next()
+            if pos < len(self.ops_b):
+                self._run(self.ops_b, addr, st, pos, len(self.ops_b))
+        else:
+            self._run(self.ops_b, addr, st)
+        if accum:
+            for p in self._params:
+                if p.grad is None:
+                    p.grad = gv[id(p)]
+                else:
+                    p.grad.add_(gv[id(p)])
+        elif self.flat is not None:
             self.flat.complete = True
         st['ba'] = ba                                       # until the caller drops the step state
+
+    def _bucket_ready(self, av):
+        """per bucket of the averager (in launch order): the number of backward operators after which all of its gradients are
+        written (non-decreasing: buckets leave strictly in order)"""
+        key = id(av)
+        c = getattr(self, '_br', None)
+        if c is None or c[0] != key:
+            out, run = [], 0
+            for b in av.buckets:
+                run = max(run, max(self._pready[id(p)] for p in b))
+                out.append(run)
+            c = self._br = (key, out)
+        return c[1]
 
     def _grad_views(self, gbuf):
         key = gbuf.data_ptr()

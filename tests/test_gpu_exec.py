@@ -172,3 +172,29 @@ def test_pruning_falls_back_to_the_module_path():
     sum(losses.values()).backward()
     assert getattr(model, '_bound', None) is None
     assert all(np.isfinite(float(v)) for v in losses.values())
+
+
+def test_gradient_accumulation_over_two_backward_passes():
+    """a second backward pass without zero_grad adds to the gradients that are there (torch semantics), on both paths"""
+    dev = _dev()
+    model, _ = _build(levels=2)
+    model = model.to(dev).train()
+    batch = _batch((51,), dev, n_points=12000)
+    state = copy.deepcopy(model.state_dict())
+    got = {}
+    for use in (False, True):
+        E.ENABLED = use
+        try:
+            model.load_state_dict(state)
+            model.zero_grad(set_to_none=True)
+            sum(model(return_loss=True, **batch).values()).backward()
+            once = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+            model.load_state_dict(state)
+            sum(model(return_loss=True, **batch).values()).backward()
+            torch.cuda.synchronize()
+            got[use] = (once, {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+        finally:
+            E.ENABLED = True
+    for k, g1 in got[True][0].items():
+        assert _rel(got[True][1][k], 2.0 * g1) < 1e-6, k
+        assert _rel(got[True][1][k], got[False][1][k]) < 2e-5, k
