@@ -343,10 +343,10 @@ class ConvProbe:
                             pr = float(p_.item()) if p_ is not None else float(n_out)
                             fh.write(json.dumps(dict(shape=shp, pairs=pr, gflop=pr * fpp / 1e9, us=s_.elapsed_time(e_) * 1e3)) + '\n')
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, 'profiles', 'r3_traffic.json')
+        tj = os.path.join(ROOT, 'profiles', 'r4_traffic.json')
         if os.path.exists(tj):          # PMC passes cannot run inside the timed region: committed rocprofv3 result
             t = json.load(open(tj))
-            traffic, traffic_src = t['hbm_bytes_per_launch'], 'profiles/r3_traffic.json (' + t['method'] + ')'
+            traffic, traffic_src = t['hbm_bytes_per_launch'], 'profiles/r4_traffic.json (' + t['method'] + ')'
         import fcaf3d_amd.functional as Fn
         x6 = bool(Fn.X6)
         peak = PEAK_X6_TFLOPS if x6 else PEAK_F32_MFMA_TFLOPS
