@@ -635,6 +635,7 @@ def main():
     infer = None
     if args.infer_steps > 0:
         model.eval()
+        model.static_weights = True                  # inference serving: the weights do not change between calls
         test_batches = [dict(points=b['points'], img_metas=b['img_metas']) for b in batches]
         with torch.no_grad():
             model(return_loss=False, **test_batches[0])

@@ -15,6 +15,10 @@ as rows of int64 (operand layouts: csrc/exec.hip `run_op`).  Operands are indice
 a few vectorised numpy operations: `addr` (device addresses: arena tensors = base + aligned prefix sum of rows x bytes per row;
 parameters, buffers, weight images: static), `dims` (row counts) and `maps` (KernelMap.desc()).
 
+Parameter gradients are delivered by `backward()` into `p.grad` (views of the gradient buffer; accumulated into if gradients
+are already there); `torch.autograd.grad(loss, parameters)` does not see the parameters behind the single autograd node of the
+body — use the module path (FC_EXEC=0) for that.
+
 The module path stays the general route (and the cross-check of the tests: forward bit for bit, gradients to rounding): the
 program covers BasicBlock backbones (depth 14 / 18 / 34) with the FCAF3D neck when no pruning bites (`plan_maps` succeeded), the
 split-bf16 convolution route (FC_X6=1) and heads of at most 64 fused columns; anything else falls back.
@@ -33,6 +37,13 @@ ENABLED = os.environ.get('FC_EXEC', '1') != '0'
 # bench.py's live roofline measurement: a list -> every step bound while it is set has its convolution operators bracketed by
 # HIP events inside fc_exec (csrc/exec.hip, cfg[2]) and appends {pairs per kernel map (device scalars), operators per direction}
 PROBE = None
+# TrainStep (runner.py) sets this to the program whose weight images it has just rebuilt, for the duration of its step: only then
+# (or for a detector that declares `static_weights` in eval mode) does a forward pass trust the images of the previous call.  Anyone
+# else who steps the weights (an optimizer of their own, EMA, surgery) gets fresh images at every call, as on the per-operator path.
+TRUSTED = None
+# tests: keep the bound state of the last forward pass on the detector (`det._last_exec = (program, state)`) so that the recorded
+# activations can be inspected (NetProgram.decisions)
+KEEP_STATE = False
 
 (OP_STEM_FWD, OP_COL_STATS, OP_NORM_FWD, OP_MAXPOOL_FWD, OP_CONV, OP_BN_FWD, OP_UNION_FWD, OP_HEAD_FWD, OP_RECORD, OP_WAIT,
  OP_HEAD_BWD, OP_WGRAD, OP_BN_BWD, OP_NORM_BWD, OP_MAXPOOL_BWD, OP_STEM_WGRAD, OP_GATHER, OP_ADD, OP_SMALL_GRADS,
@@ -199,6 +210,7 @@ class NetProgram:
         tr = self.training
         F, Bk = self.ops_f, self.ops_b
         tape = []                        # (stream, backward emitter) in forward order
+        self.relu_outs = []              # (tensor, rows dim, C) of every fused norm + ReLU output, forward order (NetProgram.decisions)
         self.small = []                  # (sums address index or dyn name, nseg dim name or None, C, weight param, bias param)
         relu, elu, none = Fn.ACT['relu'], Fn.ACT['elu'], Fn.ACT['none']
         grad = {}                        # forward tensor -> gradient tensor (backward arena)
@@ -294,6 +306,8 @@ class NetProgram:
             C = b.num_features
             y = self.T(rows, C)
             mean, var, cnt = (self.T('one', C), self.T('one', C), self.T('one', 1)) if tr else (-1, -1, -1)
+            if act == relu:
+                self.relu_outs.append((y, rows, C))
             self.emit(F, OP_BN_FWD, stream, x, self.D(rows), C, _f(b.eps), self.S(b.weight), self.S(b.bias), -1 if res is None else res, act,
                       _f(b.momentum), y, mean, var, cnt, self.S(b.running_mean), self.S(b.running_var), self.S(b.num_batches_tracked),
                       1 if tr else 0)
@@ -326,7 +340,9 @@ class NetProgram:
         t_in = self.T('n1', 64)
         self.emit(F, OP_NORM_FWD, S_MAIN, t_stem, seg1, self.D('n1'), 64, mean_in, var_in, _f(inorm.eps), self.S(inorm.weight),
                   self.S(inorm.bias), -1, relu, t_in)
+        self.relu_outs.append((t_in, 'n1', 64))
         t_pool, arg = self.T('n2', 64), self.T('n2', 64)
+        self.pool_arg = (arg, 'n2', 64)
         self.emit(F, OP_MAXPOOL_FWD, S_MAIN, t_in, self.M('pool'), 64, t_pool, arg)
         if tr:
             in_sums = self.T('B', 2 * 64, 'b')
@@ -622,9 +638,22 @@ class NetProgram:
                 raise RuntimeError(f'fc_exec failed: {"invalid argument" if rc == -1 else "hipError %d" % rc}')
             return
 
+    def decisions(self, st):
+        """(ReLU sign patterns in forward order, max-pool arg-max rows) of the forward pass bound in `st` — what
+        oracle.DecisionTape replays (test infrastructure reads it; needs KEEP_STATE)"""
+        fa, addr, dims = st['fa'], st['addr'], st['dims']
+
+        def view(idx, rows, C, dtype):
+            n = int(dims[self.dim_names[rows]])
+            o = int(addr[idx] - fa.data_ptr())
+            return fa[o:o + n * C * 4].view(dtype).view(n, C)
+        relu = [(view(t, r, C, torch.float32) > 0).cpu() for t, r, C in self.relu_outs]
+        return relu, view(*self.pool_arg, torch.int32).cpu()
+
     def forward(self, st):
         """-> (cent_all, bbox_all, cls_all, cmax_all) for all head locations (levels finest first), autograd-connected in training"""
-        if not self.weights_fresh:
+        trusted = TRUSTED is self or (not self.training and getattr(self.det, 'static_weights', False))
+        if not (self.weights_fresh and trusted):
             self.refresh_weights()
         ev = self.images.event
         if ev is not None:
@@ -751,8 +780,7 @@ class _NetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_cent, g_bbox, g_cls, _g_max):
-        ctx.prog._backward(ctx.st, g_cent, g_bbox, g_cls)
-        ctx.st = None
+        ctx.prog._backward(ctx.st, g_cent, g_bbox, g_cls)          # (the state is released with the graph; retain_graph keeps it)
         return None, None, None
 
 

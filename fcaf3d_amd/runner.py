@@ -233,12 +233,15 @@ class TrainStep:
             if self.images_version != sum(w._version for w in self._image_ws):      # first step, or somebody wrote the weights through torch
                 self._build_images(side_stream=False)
             Fn.PREBUILT, Fn.PREBUILT_EVENT = self.images.table, self.images.event
+        from . import executor
+        executor.TRUSTED = prog                      # this step's images were rebuilt after the last write of the weights
         try:
             losses = self.model(return_loss=True, **batch)
             loss = parse_losses(losses)
             loss.backward()
         finally:
             Fn.PREBUILT, Fn.PREBUILT_EVENT = {}, None
+            executor.TRUSTED = None
         self.averager.finish()
         if isinstance(self.optimizer, FlatAdamW):
             # after finish() under data parallelism every gradient already sits (averaged) in the flat buffer

@@ -136,8 +136,10 @@ class SingleStageSparse3DDetector(nn.Module):
 
     def _exec_forward(self, prog, st):
         """backbone + neck + head through the native executor; returns what `neck_with_head(backbone(x))` returns"""
+        from . import executor
         from .fcaf3d_neck_with_head import SceneList
         cent, bbox, cls, _ = prog.forward(st)
+        self._last_exec = (prog, st) if executor.KEEP_STATE else None
         vs = self.neck_with_head.voxel_size
         outs, o = ([], [], [], []), 0
         for cm in st['head_maps']:
@@ -148,6 +150,22 @@ class SingleStageSparse3DDetector(nn.Module):
             outs[3].append(SceneList(lambda cm=cm: cm.coords[:, 1:].float() * vs, cm))      # voxel corners, made when asked for
             o += n
         return [tuple(v) for v in outs]
+
+    # eval mode: True = the weights do not change between calls (inference serving): the executor keeps its pre-split weight images
+    # across calls instead of rebuilding them at every forward pass.  Switching train() / eval(), load_state_dict and .to() drop them.
+    static_weights = False
+
+    def _stale_images(self):
+        for pr in self.__dict__.get('_programs', {}).values():
+            pr.weights_fresh = False
+
+    def train(self, mode=True):
+        self._stale_images()
+        return super().train(mode)
+
+    def load_state_dict(self, *a, **kw):
+        self._stale_images()
+        return super().load_state_dict(*a, **kw)
 
     def _apply(self, fn, *a, **kw):
         self.__dict__.pop('_programs', None)              # parameters / buffers may move: the executor's address tables are stale

@@ -31,6 +31,7 @@ def pop_flag(name, default):
 
 def run_one(args, B, dev, do_cprofile, steps=8):
     import fcaf3d_amd._lib as L
+    import fcaf3d_amd.executor as EX
     import fcaf3d_amd.functional as Fn
     from fcaf3d_amd.runner import TrainStep, parse_losses
     args.batch = B
@@ -66,6 +67,7 @@ def run_one(args, B, dev, do_cprofile, steps=8):
             if tr.images_version != sum(w._version for w in tr._image_ws):
                 tr._build_images(side_stream=False)
             Fn.PREBUILT, Fn.PREBUILT_EVENT = tr.images.table, tr.images.event
+        EX.TRUSTED = prog
         x = model.extract_feat(b['points'], b['img_metas'], (b['gt_bboxes_3d'], b['gt_labels_3d']))
         x = [list(v) for v in x]
         mark()
@@ -74,6 +76,7 @@ def run_one(args, B, dev, do_cprofile, steps=8):
         mark()
         loss.backward()
         Fn.PREBUILT, Fn.PREBUILT_EVENT = {}, None
+        EX.TRUSTED = None
         tr.averager.finish()
         mark()
         tr.optimizer.step(tr.max_norm)

@@ -15,6 +15,7 @@ def main():
     dev = torch.device('cuda:0')
     model, cfg = bench.build_model(args)
     model = model.to(dev).eval()
+    model.static_weights = True
     model.async_maps = True
     model.inputs_resident = True
     batches = bench.make_batches(args, 0, dev)
@@ -63,6 +64,16 @@ def main():
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print('extract_feat only: host %.2f ms/batch, drained %.2f ms/batch' % (1e3 * (t1 - t0) / 4, 1e3 * (t2 - t0) / 4))
+    if os.environ.get('FC_CPROFILE'):
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for i in range(3):
+            run(i)
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr).sort_stats('cumulative').print_stats(70)
     n_det = [len(r[1]) for r in run(0)]
     print('detections per scene', n_det)
 
