@@ -467,7 +467,7 @@ class CoordMap:
         if self._perm is None:
             b = self.coords[:, 0].long()
             order = torch.argsort(b, stable=True)            # rows grouped by scene, ascending inside
-            counts_dev = torch.bincount(b, minlength=self.batch_size)
+            counts_dev = torch.zeros(self.batch_size, dtype=torch.int64, device=b.device).scatter_add_(0, b, torch.ones_like(b))   # (bincount syncs)
             counts = counts_dev.cpu().tolist()                                      # one read-back per map
             self._order, self._counts_dev = _rec(order, counts_dev)
             self._counts = counts
