@@ -310,6 +310,8 @@ class ConvProbe:
     def summary(self):
         if not any(ev for st_ in self.timed.values() for ev in st_) and not self.exec_steps:
             return None
+        if self.exec_steps and not any(e['nf'] for e in self.exec_steps):
+            self.exec_steps = []
         torch.cuda.synchronize()
         flops = ms = alg_bytes = 0.0
         n = 0
@@ -414,10 +416,11 @@ def cpu_baseline(args):
     return out
 
 
-def count_steps(args, n_batches, exec_on=False):
-    """number of untimed FLOP-count steps after the timed region — a function of the flags only, never of the rank.  With the
-    native executor the probed steps bring their FLOPs with them (pair counts bound with the step): no count steps"""
-    return 0 if (args.no_instrument or args.breakdown or exec_on) else n_batches      # every distinct batch a probed step may use
+def count_steps(args, n_batches):
+    """number of untimed FLOP-count steps after the timed region — a function of the flags only, never of the rank.  (A probed
+    step that went through the native executor brings its FLOPs with it; one that fell back to the per-operator path — pruning
+    that bites, as on the S3DIS workload — needs these counts.)"""
+    return 0 if (args.no_instrument or args.breakdown) else n_batches      # every distinct batch a probed step may use
 
 
 def hbm_steps(args, exec_on):
@@ -519,9 +522,12 @@ def main():
         EX.ENABLED = exec_on and probe_mode in (None, 'time') and bd is None
         EX.PROBE = probe.exec_steps if (probe and probe_mode == 'time' and EX.ENABLED) else None
         model.neck_with_head.head_overlap = head_overlap and not one_stream             # ... nor the head branch's stream
+        n_exec = len(probe.exec_steps) if probe else 0
         loss, _ = trainer(batch)
         EX.PROBE = None
-        return loss
+        if probe and probe_mode == 'time' and len(probe.exec_steps) > n_exec and probe._cur:
+            probe._cur.clear()       # the step went through the executor (its brackets are inside fc_exec); a pruned finest level's
+        return loss                  # per-operator tail (2 convolutions) is not double-booked
 
     for i in range(args.warmup):
         step(i)
@@ -544,7 +550,7 @@ def main():
     trainer.averager.log = None
     # untimed: FLOPs of every launch, one step per distinct batch.  EVERY rank steps (a step holds collectives: a
     # rank-0-only extra step deadlocks the job); only rank 0 carries the probe
-    for b in range(count_steps(args, len(batches), exec_on)):
+    for b in range(count_steps(args, len(batches))):
         step(b, 'count' if probe else None)
     for b in range(hbm_steps(args, exec_on)):      # untimed, per-operator path: the bandwidth-bound entry points for `hbm_kernels`
         step(b, 'hbm' if probe else None)

@@ -74,8 +74,12 @@ _FORWARD_SINGLE = _NECK_FORWARD = None       # set by fcaf3d_neck_with_head at i
 
 
 class NetProgram:
-    def __init__(self, det, training, wgrad_async, head_overlap):
+    def __init__(self, det, training, wgrad_async, head_overlap, tail0=False):
+        """tail0: the finest neck level is PRUNED this step (`pts_threshold` bites there, fcaf3d_neck_with_head.py:110-126): the
+        program ends at that level's union — `x0`, exported as a fourth differentiable output — and `_prune` + out_block_0 +
+        forward_single of level 0 run on the per-operator path, attached by autograd (single_stage_sparse._exec_forward)"""
         self.det = det
+        self.tail0 = tail0
         self.training = training
         self.wgrad_async = wgrad_async and training
         bb, nh = det.backbone, det.neck_with_head
@@ -168,38 +172,28 @@ class NetProgram:
         assert len(w) == OPW, len(w)
         lst.append(w)
 
-    # ---- weights: pre-split images of every kernel, incl. the packed head kernel and the generative convolutions' GEMM form ------
+    # ---- weights: pre-split images of every kernel, incl. the packed head kernel and the generative convolutions' GEMM form; ONE
+    # set per detector, shared by its programs (training / inference, stream configurations, pruned-tail variant)
     def _build_weights(self):
-        nh = self.det.neck_with_head
-        dev = self.dev
-        head = (nh.centerness_conv, nh.reg_conv, nh.cls_conv)
-        self.convs = [m for m in self.det.modules() if isinstance(m, MEnn.MinkowskiConvolution) and m not in head]
-        self.gents = [m for m in self.det.modules() if isinstance(m, MEnn.MinkowskiGenerativeConvolutionTranspose)]
-        C = nh.centerness_conv.in_channels
-        self.ncol = 1 + nh.n_reg_outs + nh.n_classes
-        self.packed = torch.zeros((1, C, 64), dtype=torch.float32, device=dev)       # [centerness | reg | cls | 0...]
-        self.gent_w = [torch.empty((1, m.in_channels, 8 * m.out_channels), dtype=torch.float32, device=dev) for m in self.gents]
-        ws = [m.kernel for m in self.convs] + [self.packed] + self.gent_w
-        self.images = Fn.WeightImages(ws)
-        self._img_of = {}
-        for w in ws:
-            K = 1 if w.dim() == 2 else w.shape[0]
-            self._img_of[w.data_ptr()] = self.images.table.get((w.data_ptr(), K, w.shape[-2], w.shape[-1]))
-        self.weights_fresh = False
+        holder = self.det.__dict__.get('_exec_weights')
+        if holder is None or holder.sig != self._sig:
+            holder = self.det.__dict__['_exec_weights'] = _Weights(self.det, self.dev, self._sig)
+        self.w = holder
+        self.packed, self.gent_w, self.gents, self.images, self.ncol = holder.packed, holder.gent_w, holder.gents, holder.images, holder.ncol
 
-    @torch.no_grad()
+    @property
+    def weights_fresh(self):
+        return self.w.fresh
+
+    @weights_fresh.setter
+    def weights_fresh(self, v):
+        self.w.fresh = v
+
     def refresh_weights(self):
-        """pack the head kernels, permute the generative kernels into their GEMM form and rebuild every weight image (5-6 launches
-        on the CURRENT stream); the event other streams wait for is `self.images.event`"""
-        nh = self.det.neck_with_head
-        torch.cat((nh.centerness_conv.kernel, nh.reg_conv.kernel, nh.cls_conv.kernel), dim=1, out=self.packed[0][:, :self.ncol])
-        for m, w in zip(self.gents, self.gent_w):
-            w.view(m.in_channels, 8, m.out_channels).copy_(m.kernel.permute(1, 0, 2))
-        self.images.build()
-        self.weights_fresh = True
+        self.w.refresh()
 
     def IMG(self, w, transposed):
-        v = self._img_of[w.data_ptr()]
+        v = self.w.img_of[w.data_ptr()]
         assert v is not None and v[1 if transposed else 0] is not None, 'no split-bf16 image for this kernel shape'
         return self.S(v[1 if transposed else 0])
 
@@ -233,6 +227,12 @@ class NetProgram:
                     wrote(w_, b_)
                 flushed[0] = len(small_rows)
         head_wgrads = [0]
+
+        def head_wfin(stream):
+            self.emit(Bk, OP_HEAD_WFIN, stream, self.SA(head_part[1 if self.tail0 else 0].data_ptr()),
+                      self.nl - (1 if self.tail0 else 0), Cn, 64, n_reg, n_cls,
+                      self.G(nh.centerness_conv.kernel), self.G(nh.reg_conv.kernel), self.G(nh.cls_conv.kernel))
+            wrote(nh.centerness_conv.kernel, nh.reg_conv.kernel, nh.cls_conv.kernel)
 
         def wstream(cur):
             return S_WGRAD if self.wgrad_async else cur
@@ -289,13 +289,10 @@ class NetProgram:
                     emit_wgrad(stream, x, gy, -1, gw_dst, self.D(rows), Cin, Cout)
                     if w_tensor is self.packed:
                         head_wgrads[0] += 1
-                        if head_wgrads[0] == self.nl:      # every level's partial of the packed head kernel is on its way
-                            s_ = wstream(stream)
-                            if not self.wgrad_async and stream != S_MAIN:
-                                s_ = S_MAIN                 # (never reached: without the weight-gradient stream there is no head stream order to respect)
-                            self.emit(Bk, OP_HEAD_WFIN, s_, self.SA(head_part.data_ptr()), self.nl, Cn, 64, n_reg, n_cls,
-                                      self.G(nh.centerness_conv.kernel), self.G(nh.reg_conv.kernel), self.G(nh.cls_conv.kernel))
-                            wrote(nh.centerness_conv.kernel, nh.reg_conv.kernel, nh.cls_conv.kernel)
+                        if head_wgrads[0] == self.nl - (1 if self.tail0 else 0) and self.wgrad_async:
+                            # every level's partial of the packed head kernel is on its way, all on the weight-gradient stream:
+                            # sum them there right away (the head's parameters sit in the first gradient bucket to leave)
+                            head_wfin(S_WGRAD)
                     accumulate(x, gx, rows, Cin, stream)
                 tape.append((stream, bwd))
             return y
@@ -438,6 +435,11 @@ class NetProgram:
                 kname = f'gsame{i}'
             else:
                 kname = f'same{self.nl}'
+            if i == 0 and self.tail0:
+                self.x0_idx = (x, x_rows, x_C)              # the pruned level's tail runs outside the program
+                if tr:
+                    grad[x] = self.DY('g_x0')               # ... and hands back d loss / d x0
+                continue
             # out_block_i + forward_single: on the head stream for i > 0
             hs = S_HEAD if (self.head_overlap and i > 0) else S_MAIN
             if hs == S_HEAD:
@@ -498,10 +500,16 @@ class NetProgram:
                 if s == S_MAIN:
                     e()
             assert not head_grads, 'a head branch was never joined'
+            if not self.wgrad_async:
+                # without the weight-gradient stream the partials were written on the streams of their levels (main, head): the
+                # main stream has joined every head branch by now
+                head_wfin(S_MAIN)
             flush_small(S_MAIN)                            # what is left: the stem's instance norm
-            assert head_wgrads[0] == self.nl
+            assert head_wgrads[0] == self.nl - (1 if self.tail0 else 0)
             self.small = small_rows
             missing = [n for n, prm in det.named_parameters() if prm.requires_grad and id(prm) not in self._pready]
+            if self.tail0:                                 # out_block_0 and scales.0 get their gradients on the per-operator path
+                missing = [n for n in missing if not (n.startswith('neck_with_head.out_block_0.') or n == 'neck_with_head.scales.0.scale')]
             assert not missing, missing
             if self.wgrad_async:
                 self.emit(Bk, OP_RECORD, S_WGRAD, EV_WEND)
@@ -601,6 +609,8 @@ class NetProgram:
         head_maps = head_maps[::-1]                       # finest first
         off = 0
         for i, cm in enumerate(head_maps):
+            if i == 0 and self.tail0:
+                continue                                  # (its head outputs come from the per-operator tail)
             setd(f'off{i}', off)
             off += cm.n
         setd('Nall', off)
@@ -652,7 +662,7 @@ class NetProgram:
 
     def forward(self, st):
         """-> (cent_all, bbox_all, cls_all, cmax_all) for all head locations (levels finest first), autograd-connected in training"""
-        trusted = TRUSTED is self or (not self.training and getattr(self.det, 'static_weights', False))
+        trusted = (TRUSTED is not None and TRUSTED.w is self.w) or (not self.training and getattr(self.det, 'static_weights', False))
         if not (self.weights_fresh and trusted):
             self.refresh_weights()
         ev = self.images.event
@@ -683,25 +693,42 @@ class NetProgram:
         for idx, c in zip(self.out_idx, (1, nh.n_reg_outs, nh.n_classes, 1)):
             o = int(addr[idx] - fa.data_ptr())
             outs.append(fa[o:o + n * c * 4].view(torch.float32).view(n, c))
+        if self.tail0:
+            t, rows, C = self.x0_idx
+            n0 = int(dims[self.dim_names[rows]])
+            o = int(addr[t] - fa.data_ptr())
+            outs.append(fa[o:o + n0 * C * 4].view(torch.float32).view(n0, C))
         return tuple(outs)
 
-    def _backward(self, st, g_cent, g_bbox, g_cls):
+    def _backward(self, st, g_cent, g_bbox, g_cls, g_x0=None):
         dims, addr = st['dims'], st['addr']
         n = st['n_all']
         nh = self.det.neck_with_head
         gs = []
         for g, c in zip((g_cent, g_bbox, g_cls), (1, nh.n_reg_outs, nh.n_classes)):
             gs.append(g.contiguous() if g is not None else torch.zeros((n, c), dtype=torch.float32, device=self.dev))
+        if self.tail0:
+            t, rows, C = self.x0_idx
+            n0 = int(dims[self.dim_names[rows]])
+            g_x0 = g_x0.contiguous() if g_x0 is not None else torch.zeros((n0, C), dtype=torch.float32, device=self.dev)
+            gs.append(g_x0)                                 # (kept alive until the operators have been enqueued)
         ba = torch.empty(self._arena_bytes(dims, 'b'), dtype=torch.uint8, device=self.dev)
         base = (ba.data_ptr() + ALIGN - 1) // ALIGN * ALIGN
         self._fill_arena(addr, dims, 'b', base)
-        for k, g in zip(('g_cent', 'g_bbox', 'g_cls'), gs):
+        for k, g in zip(('g_cent', 'g_bbox', 'g_cls', 'g_x0'), gs):
             addr[self.dyn[k]] = g.data_ptr()
         ai, ap, ad, ab = self._al
         addr[ai] = addr[ap] + dims[ad] * ab
         # gradients that are already there (a second backward pass without zero_grad: accumulation) are added to afterwards;
         # then, and without flat storage, this pass writes into a buffer of its own (same layout)
-        accum = any(p.grad is not None for p in self._params)
+        own = self._own_params()
+        # Parameters that already hold a gradient when this pass starts: (a) a few, in tensors of their own — the pruned level's
+        # per-operator tail has delivered the head kernels' share before this node ran: the program writes its share into the
+        # buffer as always and the earlier one is added there afterwards; (b) views of the very buffer this pass writes (a second
+        # backward without zero_grad): then, and without flat storage, the pass writes into a buffer of its own and is added on top
+        pre = [(p, p.grad) for p in own if p.grad is not None]
+        aliased = self.flat is not None and any(g.data_ptr() == self.flat.grad_view(p).data_ptr() for p, g in pre)
+        accum = bool(pre) and (self.flat is None or aliased or len(pre) > 16)
         if self.flat is not None and not accum:
             gbuf = self.flat.grad
         else:
@@ -718,11 +745,11 @@ class NetProgram:
         addr[self.dyn['small_desc']] = desc_dev.data_ptr()
         gv = self._grad_views(gbuf)
         if not accum:
-            for p in self._params:                          # before the operators run: a data-parallel bucket may leave mid-way
+            for p in own:                                   # before the operators run: a data-parallel bucket may leave mid-way
                 p.grad = gv[id(p)]
         from . import dist as D
         av = D.ACTIVE
-        if av is not None and av.buckets and av.flat is self.flat and self.flat is not None and not accum:
+        if av is not None and av.buckets and av.flat is self.flat and self.flat is not None and not accum and not self.tail0:
             # data parallel: every gradient bucket leaves (all-reduce on the weight-gradient stream) as soon as the operators that
             # write its parameters are enqueued — what the autograd hooks of the per-operator path do
             pos = 0
@@ -736,14 +763,24 @@ class NetProgram:
         else:
             self._run(self.ops_b, addr, st)
         if accum:
-            for p in self._params:
+            for p in own:
                 if p.grad is None:
                     p.grad = gv[id(p)]
                 else:
                     p.grad.add_(gv[id(p)])
-        elif self.flat is not None:
-            self.flat.complete = True
+        else:
+            for p, g0 in pre:                               # (a): the share that was there first
+                gv[id(p)].add_(g0)
+            if self.flat is not None and not self.tail0:
+                self.flat.complete = True
         st['ba'] = ba                                       # until the caller drops the step state
+
+    def _own_params(self):
+        """the parameters whose gradients this program writes (all of them, unless the pruned level's tail runs outside it)"""
+        c = getattr(self, '_own', None)
+        if c is None:
+            c = self._own = [p for p in self._params if id(p) in self._pready]
+        return c
 
     def _bucket_ready(self, av):
         """per bucket of the averager (in launch order): the number of backward operators after which all of its gradients are
@@ -767,6 +804,39 @@ class NetProgram:
         return cache[1]
 
 
+class _Weights:
+    """the executor's view of a detector's weights: pre-split images of every convolution kernel (functional.WeightImages), the
+    three 1x1 head kernels packed side by side (zero-padded to 64 columns), the generative transposed convolutions' kernels in
+    their GEMM form (Cin, 8 Cout) — persistent buffers, rebuilt by `refresh` (5-6 launches on the current stream)"""
+
+    def __init__(self, det, dev, sig):
+        nh = det.neck_with_head
+        self.det, self.sig = det, sig
+        head = (nh.centerness_conv, nh.reg_conv, nh.cls_conv)
+        convs = [m for m in det.modules() if isinstance(m, MEnn.MinkowskiConvolution) and m not in head]
+        self.gents = [m for m in det.modules() if isinstance(m, MEnn.MinkowskiGenerativeConvolutionTranspose)]
+        C = nh.centerness_conv.in_channels
+        self.ncol = 1 + nh.n_reg_outs + nh.n_classes
+        self.packed = torch.zeros((1, C, 64), dtype=torch.float32, device=dev)       # [centerness | reg | cls | 0...]
+        self.gent_w = [torch.empty((1, m.in_channels, 8 * m.out_channels), dtype=torch.float32, device=dev) for m in self.gents]
+        ws = [m.kernel for m in convs] + [self.packed] + self.gent_w
+        self.images = Fn.WeightImages(ws)
+        self.img_of = {}
+        for w in ws:
+            K = 1 if w.dim() == 2 else w.shape[0]
+            self.img_of[w.data_ptr()] = self.images.table.get((w.data_ptr(), K, w.shape[-2], w.shape[-1]))
+        self.fresh = False
+
+    @torch.no_grad()
+    def refresh(self):
+        nh = self.det.neck_with_head
+        torch.cat((nh.centerness_conv.kernel, nh.reg_conv.kernel, nh.cls_conv.kernel), dim=1, out=self.packed[0][:, :self.ncol])
+        for m, w in zip(self.gents, self.gent_w):
+            w.view(m.in_channels, 8, m.out_channels).copy_(m.kernel.permute(1, 0, 2))
+        self.images.build()
+        self.fresh = True
+
+
 class _NetFn(torch.autograd.Function):
     """The whole network body as one autograd node: forward = one fc_exec call, backward = one fc_exec call that leaves every
     parameter gradient in the (flat) gradient buffer."""
@@ -774,22 +844,24 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, prog, st):
         ctx.prog, ctx.st = prog, st
-        cent, bbox, cls, cmax = prog._forward(st)
-        ctx.mark_non_differentiable(cmax)
-        return cent, bbox, cls, cmax
+        outs = prog._forward(st)
+        ctx.mark_non_differentiable(outs[3])
+        return outs
 
     @staticmethod
-    def backward(ctx, g_cent, g_bbox, g_cls, _g_max):
-        ctx.prog._backward(ctx.st, g_cent, g_bbox, g_cls)          # (the state is released with the graph; retain_graph keeps it)
+    def backward(ctx, g_cent, g_bbox, g_cls, _g_max, g_x0=None):
+        ctx.prog._backward(ctx.st, g_cent, g_bbox, g_cls, g_x0)    # (the state is released with the graph; retain_graph keeps it)
         return None, None, None
 
 
-def program_for(det, training):
+def program_for(det, training, tail0=False):
     """the cached NetProgram of this detector for the current mode / stream configuration (None: not covered -> module path)"""
     if not supported(det):
         return None
     nh = det.neck_with_head
-    key = (bool(training), bool(Fn.WGRAD_ASYNC), bool(nh.head_overlap))
+    if tail0 and min(det.backbone.n_outs, 4) < 2:
+        return None
+    key = (bool(training), bool(Fn.WGRAD_ASYNC), bool(nh.head_overlap), bool(tail0))
     cache = det.__dict__.setdefault('_programs', {})
     sig = NetProgram.signature(det)
     prog = cache.get(key)

@@ -72,11 +72,12 @@ class SingleStageSparse3DDetector(nn.Module):
         head_maps = self.plan_maps(x.cmap)
         # the network body as one native call per direction (executor.py) when this step's maps fit its static operator list
         self._bound = None
-        if head_maps is not None and x.F.is_cuda:
+        tail0 = self._prune_level == 0                     # pruning bites at the finest level only: its tail runs per operator
+        if (head_maps is not None or tail0) and x.F.is_cuda:
             from . import executor
             grad_on = torch.is_grad_enabled()
             if self.training == grad_on:                   # training with gradients, or inference without: the two programs
-                prog = executor.program_for(self, self.training)
+                prog = executor.program_for(self, self.training, tail0)
                 if prog is not None:
                     st = prog.bind(x, len(points), backward=self.training)
                     if st is not None:
@@ -93,6 +94,7 @@ class SingleStageSparse3DDetector(nn.Module):
         on demand).  The data-dependent sizes are read back here, while the queue holds only these small
         integer kernels — no host sync is left inside the convolution sequence."""
         bb, nh = self.backbone, self.neck_with_head
+        self._prune_level = None                                   # the neck level where pts_threshold first bites (None: nowhere)
         m1 = cm0.strided(2); cm0.kernel_map(m1, 3)                 # stem conv k3 s2
         m2 = m1.strided(2); m1.kernel_map(m2, 2)                   # max-pool k2 s2
         prev, levels = m2, []
@@ -114,6 +116,7 @@ class SingleStageSparse3DDetector(nn.Module):
             g = x.generate(); g.kernel_map(g, 3).prefetch(bwd)
             u, _, _ = levels[i].union(g)
             if nh.pts_threshold >= 0 and any(c > nh.pts_threshold for c in u.scene_counts):
+                self._prune_level = i
                 return None
             u.kernel_map(u, 3).prefetch(bwd)
             x = u
@@ -137,12 +140,26 @@ class SingleStageSparse3DDetector(nn.Module):
     def _exec_forward(self, prog, st):
         """backbone + neck + head through the native executor; returns what `neck_with_head(backbone(x))` returns"""
         from . import executor
+        from . import nn as MEnn
         from .fcaf3d_neck_with_head import SceneList
-        cent, bbox, cls, _ = prog.forward(st)
+        from .sparse import SparseTensor
+        res = prog.forward(st)
+        cent, bbox, cls, cmax = res[:4]
         self._last_exec = (prog, st) if executor.KEEP_STATE else None
-        vs = self.neck_with_head.voxel_size
+        nh = self.neck_with_head
+        vs = nh.voxel_size
         outs, o = ([], [], [], []), 0
-        for cm in st['head_maps']:
+        for lvl, cm in enumerate(st['head_maps']):
+            if lvl == 0 and prog.tail0:
+                # the pruned finest level (fcaf3d_neck_with_head.py:104-108, :110-126): top-k of the parent level's interpolated
+                # scores, MinkowskiPruning, out_block_0 and forward_single on the per-operator path, differentiable through x0
+                n1 = st['head_maps'][1].n
+                scores = SparseTensor(cmax[:n1], coordinate_map_key=st['head_maps'][1])
+                x0 = nh._prune(SparseTensor(res[4], coordinate_map_key=cm), scores)
+                out = nh.forward_single(MEnn.run_sequential(nh.out_block_0, x0), nh.scales[0])
+                for k in range(4):
+                    outs[k].append(out[k])
+                continue
             n = cm.n
             outs[0].append(SceneList(cent[o:o + n], cm, parent=cent))
             outs[1].append(SceneList(bbox[o:o + n], cm, parent=bbox))

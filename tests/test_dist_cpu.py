@@ -100,21 +100,21 @@ def test_bench_step_count_is_rank_independent():
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    assert list(inspect.signature(bench.count_steps).parameters) == ['args', 'n_batches', 'exec_on']
+    assert list(inspect.signature(bench.count_steps).parameters) == ['args', 'n_batches']
     assert list(inspect.signature(bench.hbm_steps).parameters) == ['args', 'exec_on']
     src = inspect.getsource(bench.main)
-    assert 'for b in range(count_steps(args, len(batches), exec_on))' in src and 'for b in range(hbm_steps(args, exec_on))' in src
+    assert 'for b in range(count_steps(args, len(batches)))' in src and 'for b in range(hbm_steps(args, exec_on))' in src
     # `exec_on` itself is a function of the flags / environment only
     assert 'exec_on = EX.ENABLED and not args.no_executor' in src
     # the loops that run them are not nested under a rank / probe condition
-    for key in ('count_steps(args, len(batches), exec_on)', 'hbm_steps(args, exec_on)'):
+    for key in ('count_steps(args, len(batches))', 'hbm_steps(args, exec_on)'):
         line = [l for l in src.splitlines() if key in l][0]
         assert line.startswith('    for '), 'extra-step loops must sit at function level, outside any rank-dependent branch'
     argv = sys.argv
     try:
         sys.argv = ['bench.py']
         a = bench.parse()
-        assert bench.count_steps(a, 2) == 2 and bench.count_steps(a, 2, True) == 0
+        assert bench.count_steps(a, 2) == 2
         assert bench.hbm_steps(a, True) == 1 and bench.hbm_steps(a, False) == 0
         sys.argv = ['bench.py', '--no-instrument']
         assert bench.count_steps(bench.parse(), 2) == 0

@@ -198,3 +198,76 @@ def test_gradient_accumulation_over_two_backward_passes():
     for k, g1 in got[True][0].items():
         assert _rel(got[True][1][k], 2.0 * g1) < 1e-6, k
         assert _rel(got[True][1][k], got[False][1][k]) < 2e-5, k
+
+
+def test_pruned_finest_level_runs_as_a_tail_of_the_executor():
+    """pts_threshold bites at the finest neck level only (the S3DIS situation, BASELINE config 5): the executor covers the body up to
+    that level's union, `_prune` + out_block_0 + forward_single run per operator behind it.  Against the pure per-operator path:
+    forward outputs bit for bit, every gradient to rounding — through TrainStep's flat buffers too."""
+    from fcaf3d_amd.runner import TrainStep
+    dev = _dev()
+
+    def build():
+        torch.manual_seed(0)
+        cfg = fa.get_config('fcaf3d_scannet-3d-18class', voxel_size=0.02)
+        m = cfg.model
+        m.backbone['n_outs'] = 3
+        m.neck_with_head['in_channels'] = (64, 128, 256)
+        m.neck_with_head.assigner['n_scales'] = 3
+        m.neck_with_head['pts_threshold'] = 6000           # level 0 (8 x level 1's rows) exceeds it, levels 1 and 2 do not
+        det = fa.build_detector(m, train_cfg=m.get('train_cfg'), test_cfg=m.get('test_cfg')).to(dev).train()
+        with torch.no_grad():
+            det.neck_with_head.cls_conv.kernel.normal_(0, 0.5)         # spread the scores: no near-ties in the top-k
+        return det, cfg
+    batch = _batch((61, 62), dev, n_points=30000)
+    got = {}
+    for use in (False, True):
+        E.ENABLED = use
+        try:
+            model, _ = build()
+            taken = []
+            orig = type(model)._exec_forward
+
+            def spy(self, prog, st):
+                taken.append(prog.tail0)
+                return orig(self, prog, st)
+            type(model)._exec_forward = spy
+            try:
+                feats = [list(v) for v in model.extract_feat(batch['points'], batch['img_metas'])]
+                outs = [[lvl.full.detach().clone() for lvl in kind] for kind in feats]
+                model.zero_grad(set_to_none=True)
+                losses = model(return_loss=True, **batch)
+                sum(losses.values()).backward()
+            finally:
+                type(model)._exec_forward = orig
+            torch.cuda.synchronize()
+            assert taken == ([True, True] if use else []), taken
+            assert outs[0][0].shape[0] == 2 * 6000, 'the finest level must have been pruned to the threshold'
+            got[use] = (outs, {k: float(v) for k, v in losses.items()}, {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+        finally:
+            E.ENABLED = True
+    for kind in range(4):
+        for l in range(3):
+            assert torch.equal(got[True][0][kind][l], got[False][0][kind][l]), (kind, l)
+    assert got[True][1] == got[False][1]
+    errs = {k: _rel(got[True][2][k], g) for k, g in got[False][2].items()}
+    worst = max(errs, key=errs.get)
+    print(f'pruned tail: worst gradient difference executor vs module path {errs[worst]:.2e} ({worst})')
+    assert errs[worst] < 2e-5, (worst, errs[worst])
+    # ... and three optimizer steps through TrainStep (flat buffers): same losses
+    traj = {}
+    for use in (False, True):
+        E.ENABLED = use
+        Fn.WGRAD_ASYNC = True
+        try:
+            model, cfg = build()
+            model.async_maps = True
+            tr = TrainStep.from_config(model, cfg)
+            traj[use] = [float(tr(batch)[0]) for _ in range(3)]
+            torch.cuda.synchronize()
+        finally:
+            E.ENABLED = True
+            Fn.WGRAD_ASYNC = False
+    print('pruned tail, TrainStep losses', traj)
+    for a, b in zip(traj[True], traj[False]):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), traj
