@@ -645,7 +645,7 @@ def main():
             Fn.X6 = x6_0
     # (c) inference: simple_test (eval-mode BatchNorm, decode, multi-class BEV NMS on the device) — the only quantity the
     #     reference publishes a speed for (README.md:91-93, scenes/s on one GPU)
-    infer = None
+    infer = infer_pipe = None
     if args.infer_steps > 0:
         model.eval()
         model.static_weights = True                  # inference serving: the weights do not change between calls
@@ -654,7 +654,22 @@ def main():
             model(return_loss=False, **test_batches[0])
             dti, _ = timed_region(lambda i: model(return_loss=False, **test_batches[i % len(test_batches)]), args.infer_steps,
                                   world, dev)
+        # ... and with two batches in flight (simple_test_async): the next batch's coordinate phase on the host while this one's
+        # forward pass and decode run on the GPU
+        n_pipe = 2 * args.infer_steps
+        with torch.no_grad():
+            def pipelined(i, pending=[None]):
+                h = model.simple_test_async(**test_batches[i % len(test_batches)])
+                if pending[0] is not None:
+                    pending[0]()
+                pending[0] = h
+                if i == n_pipe - 1:
+                    pending[0]()
+                    pending[0] = None
+            dtp, _ = timed_region(pipelined, n_pipe, world, dev)
         model.train()
+        infer_pipe = dict(value=round(args.batch * world * n_pipe / dtp, 3), unit='scenes/s', steps=n_pipe,
+                          ms_per_batch=round(dtp / n_pipe * 1e3, 3), what='simple_test_async: two batches in flight')
         infer = dict(value=round(args.batch * world * args.infer_steps / dti, 3), unit='scenes/s', steps=args.infer_steps,
                      ms_per_batch=round(dti / args.infer_steps * 1e3, 3), what='simple_test: extract_feat + get_bboxes + multi-class BEV NMS')
 
@@ -673,7 +688,7 @@ def main():
                        'fwd_bwd_only': {'protocol': 'SURVEY 8(d): forward_train + backward (+ all-reduce), synchronised per iteration, median of 5',
                                         'ms': round(fb_med * 1e3, 3), 'scenes_per_s': round(args.batch * world / fb_med, 3)},
                        'config4_global_batch_16': cfg4, 'forced_dp_n1': forced, 'config4_per_gpu': cfg4_1,
-                       'fp32_mfma_route': fp32_route, 'inference': infer,
+                       'fp32_mfma_route': fp32_route, 'inference': infer, 'inference_pipelined': infer_pipe,
                        'executor': bool(exec_on) and 'network body through the native launch-list executor (fcaf3d_amd/executor.py, '
                                    'csrc/exec.hip), the probed step included (event brackets inside fc_exec)'},
         }

@@ -370,11 +370,18 @@ class Fcaf3DNeckWithHead(nn.Module):
         return loss_centerness, loss_bbox, loss_cls
 
     # ---- inference (reference :205-253, :332-374) --------------------------------------------------
-    def get_bboxes(self, centernesses, bbox_preds, cls_scores, points, img_metas, rescale=False):
+    def get_bboxes(self, centernesses, bbox_preds, cls_scores, points, img_metas, rescale=False, defer=False):
+        """defer=True (SingleStageSparse3DDetector.simple_test_async): everything up to the NMS is ENQUEUED and a callable is
+        returned that performs the read-backs and builds the per-scene results when called — the caller may enqueue the next
+        batch first (two batches in flight: the next one's coordinate phase runs on the host while this one's forward pass and
+        decode run on the GPU)"""
         assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) == len(points[0]) == len(img_metas)
         if self.batched_decode and self.test_cfg.nms_pre > 0 and all(
                 isinstance(v, SceneList) for group in (centernesses, bbox_preds, cls_scores, points) for v in group):
-            return self._get_bboxes_batched(centernesses, bbox_preds, cls_scores, points, img_metas)
+            return self._get_bboxes_batched(centernesses, bbox_preds, cls_scores, points, img_metas, defer=defer)
+        if defer:
+            res = self.get_bboxes(centernesses, bbox_preds, cls_scores, points, img_metas, rescale)
+            return lambda post=None: post(res) if post is not None else res
         results = []
         for i in range(len(img_metas)):
             results.append(self._get_bboxes_single(
@@ -385,7 +392,7 @@ class Fcaf3DNeckWithHead(nn.Module):
     batched_decode = True      # False: the reference's per-scene loop (_get_bboxes_single), kept as the cross-check
     NMS_WS_BUDGET = int(os.environ.get('FC_NMS_WS_MB', '512')) << 20      # bytes of suppression masks per NMS launch
 
-    def _get_bboxes_batched(self, centernesses, bbox_preds, cls_scores, points, img_metas):
+    def _get_bboxes_batched(self, centernesses, bbox_preds, cls_scores, points, img_metas, defer=False):
         """get_bboxes for ALL scenes at once (r2: the per-scene, per-level loop of the reference issued ~1 500 tiny launches
         and 8 read-backs per batch of 8 scenes, 8.9 ms): scores, decode and the per-(scene, level) top-`nms_pre` selection run
         on the whole batch (one segmented sort), then every (scene, class) segment goes through ONE pair of NMS launches and
@@ -406,15 +413,23 @@ class Fcaf3DNeckWithHead(nn.Module):
         N, C = scores.shape
         yaw_flag = boxes.shape[1] == 7
         boxes7 = boxes if yaw_flag else torch.cat((boxes, torch.zeros_like(boxes[:, :1])), dim=1)
-        sel = segmented_topk(seg, maxs, B * Lv, cfg.nms_pre)   # (scene, level, rank) order == the per-scene loop's cat order
-        scene = seg[sel] // Lv
-        per_scene = count_ids(scene, B)
-        pos = torch.arange(sel.numel(), device=dev) - (torch.cumsum(per_scene, 0) - per_scene)[scene]
+        # the rows the per-scene loop keeps, gathered into the places it would put them — WITHOUT compacting them first (r4:
+        # `order[keep]` is a boolean-mask gather, i.e. a device -> host synchronisation in the middle of the decode; everything
+        # here is fixed-size, so the whole decode is enqueued while the forward pass still runs).  Candidate slot j of scene b
+        # belongs to level l = #levels whose kept rows end at or before j, rank r inside it: source = order[start(b, l) + r]
+        order, _, kept_counts = segmented_topk(seg, maxs, B * Lv, cfg.nms_pre, compact=False)
         n_max = min(Lv * cfg.nms_pre, N)                    # static bound: no read-back
-        P = scores.new_full((B, n_max, C), -1.0)
-        P[scene, pos] = scores[sel]
-        PB = boxes7.new_zeros((B, n_max, 7))
-        PB[scene, pos] = boxes7[sel]
+        kc = kept_counts.view(B, Lv)
+        ends = torch.cumsum(kc, 1)                          # (B, Lv): where each level's kept rows end in the scene's list
+        counts = count_ids(seg, B * Lv)
+        starts = (torch.cumsum(counts, 0) - counts).view(B, Lv)
+        j = torch.arange(n_max, device=dev)[None, :].expand(B, n_max)
+        lvl = (j[:, :, None] >= ends[:, None, :]).sum(-1).clamp(max=Lv - 1)
+        rank = j - (ends - kc).gather(1, lvl)
+        valid = j < ends[:, -1:]
+        src = order[(starts.gather(1, lvl) + rank).clamp(min=0, max=N - 1)]
+        P = torch.where(valid[:, :, None], scores[src], scores.new_full((), -1.0))
+        PB = torch.where(valid[:, :, None], boxes7[src], boxes7.new_zeros(()))
         # ---- every (scene, class) segment through one NMS ---------------------------------------------------------------
         masked = torch.where(P > cfg.score_thr, P, P.new_full((1,), -1.0)).permute(0, 2, 1).reshape(B * C, n_max)
         sorted_scores, ordr = masked.sort(dim=1, descending=True, stable=True)
@@ -437,23 +452,43 @@ class Fcaf3DNeckWithHead(nn.Module):
         kept = kept_l[0] if len(kept_l) == 1 else torch.cat(kept_l)
         kcount = kcount_l[0] if len(kcount_l) == 1 else torch.cat(kcount_l)
         valid = torch.arange(n_max, device=dev)[None, :] < kcount[:, None]
-        sc_seg, p = torch.nonzero(valid, as_tuple=True)     # (scene, class)-major, ascending position = descending score
-        idx = ordr[sc_seg, kept[sc_seg, p].long()]
-        out_scene, out_cls = sc_seg // C, sc_seg % C
-        out_boxes = PB[out_scene, idx]
-        out_scores = P[out_scene, idx, out_cls]
-        sizes = count_ids(out_scene, B).tolist()          # the one read-back
-        results, o = [], 0
-        for i, n in enumerate(sizes):
-            b = out_boxes[o:o + n]
-            if yaw_flag:
-                box_dim, with_yaw = 7, True
-            else:
-                box_dim, with_yaw, b = 6, False, b[:, :6]
-            results.append((img_metas[i]['box_type_3d'](b, box_dim=box_dim, with_yaw=with_yaw, origin=(.5, .5, .5)),
-                            out_scores[o:o + n], out_cls[o:o + n]))
-            o += n
-        return results
+        done = None
+        if defer:
+            done = torch.cuda.Event()
+            done.record()                                  # everything this batch needs is enqueued up to here
+
+        def finish(post=None):
+            # from here on the sizes are data: `nonzero` and `tolist` wait for everything enqueued above.  Deferred (two batches
+            # in flight): on the read-back stream behind THIS batch's event — a synchronisation of the main stream would wait for
+            # the next batch's forward pass, which is already enqueued there
+            if done is not None:
+                rb = _readback_stream(dev)
+                rb.wait_event(done)
+                with torch.cuda.stream(rb):
+                    res = collect()
+                    return post(res) if post is not None else res
+            res = collect()
+            return post(res) if post is not None else res
+
+        def collect():
+            sc_seg, p = torch.nonzero(valid, as_tuple=True)     # (scene, class)-major, ascending position = descending score
+            idx = ordr[sc_seg, kept[sc_seg, p].long()]
+            out_scene, out_cls = sc_seg // C, sc_seg % C
+            out_boxes = PB[out_scene, idx]
+            out_scores = P[out_scene, idx, out_cls]
+            sizes = count_ids(out_scene, B).tolist()          # the one read-back
+            results, o = [], 0
+            for i, n in enumerate(sizes):
+                b = out_boxes[o:o + n]
+                if yaw_flag:
+                    box_dim, with_yaw = 7, True
+                else:
+                    box_dim, with_yaw, b = 6, False, b[:, :6]
+                results.append((img_metas[i]['box_type_3d'](b, box_dim=box_dim, with_yaw=with_yaw, origin=(.5, .5, .5)),
+                                out_scores[o:o + n], out_cls[o:o + n]))
+                o += n
+            return results
+        return finish if defer else finish()
 
     def _get_bboxes_single(self, centernesses, bbox_preds, cls_scores, points, img_meta):
         mlvl_bboxes, mlvl_scores = [], []
@@ -545,6 +580,16 @@ class Fcaf3DNeckWithHead(nn.Module):
         return nms_bboxes, nms_scores, nms_labels
 
 
+_rb_streams = {}
+
+
+def _readback_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _rb_streams:
+        _rb_streams[idx] = torch.cuda.Stream(device=idx, priority=-1)
+    return _rb_streams[idx]
+
+
 def count_ids(ids, n):
     """torch.bincount(ids, minlength=n) for ids known to lie in [0, n), WITHOUT the device -> host synchronisation bincount
     makes to size its output (r4: in `get_bboxes` that sync made the host wait for the whole forward pass in the middle of the
@@ -552,7 +597,7 @@ def count_ids(ids, n):
     return torch.zeros(n, dtype=torch.int64, device=ids.device).scatter_add_(0, ids, torch.ones_like(ids))
 
 
-def segmented_topk(seg, score, n_seg, k):
+def segmented_topk(seg, score, n_seg, k, compact=True):
     """Indices of the rows the reference's per-(scene, level) loop keeps (fcaf3d_neck_with_head.py:238-243: `if len(scores) >
     nms_pre: topk(nms_pre)`), for every segment at once: segments in ascending id; inside a segment with more than k rows the k
     best by descending score (ties: row order), inside a smaller one ALL rows in row order.  Two STABLE sorts (by descending
@@ -567,8 +612,12 @@ def segmented_topk(seg, score, n_seg, k):
     o1 = torch.sort(key, stable=True).indices
     order = o1[torch.sort(seg[o1], stable=True).indices]
     starts = torch.cumsum(counts, 0) - counts
-    keep = (row - starts[seg[order]]) < k
-    return order[keep]
+    rank = row - starts[seg[order]]
+    if not compact:
+        # (order, rank of every row inside its segment, rows kept per segment): the caller keeps rank < k — no boolean-mask
+        # gather, hence no device -> host synchronisation
+        return order, rank, counts.clamp(max=k)
+    return order[rank < k]
 
 
 def compute_centerness(bbox_targets):

@@ -197,6 +197,16 @@ class SingleStageSparse3DDetector(nn.Module):
         bbox_list = self.neck_with_head.get_bboxes(*x, img_metas, rescale=rescale)
         return bbox3d2result_batch(bbox_list)
 
+    def simple_test_async(self, points, img_metas, imgs=None, rescale=False):
+        """`simple_test` in two halves for a serving loop that keeps two batches in flight: this call ENQUEUES the forward pass,
+        the decode and the NMS of the batch and returns a callable; calling it performs the read-backs and returns what
+        `simple_test` returns.  Enqueue the next batch before collecting this one: its coordinate phase (5 ms of host time per 8
+        scenes, mostly count read-backs on the coordinate stream) then runs while the GPU is busy with this batch.  The reference's
+        loop (tools/test.py -> mmdet3d/apis/test.py single_gpu_test) is synchronous per batch behind DataLoader workers."""
+        x = self.extract_feat(points, img_metas)
+        finish = self.neck_with_head.get_bboxes(*x, img_metas, rescale=rescale, defer=True)
+        return lambda: finish(bbox3d2result_batch)
+
     def aug_test(self, points, img_metas, imgs=None, rescale=False):
         pass
 

@@ -27,7 +27,10 @@ _record_to = None
 def map_stream(device):
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _side:
-        _side[key] = torch.cuda.Stream(device=key)
+        # HIGH priority (r4): the coordinate kernels are microseconds long and the host waits for their counts; at normal priority
+        # they queue behind whatever the dependent chain has in flight (FC_MAP_PRIO=0: the r3 behaviour)
+        prio = -1 if os.environ.get('FC_MAP_PRIO', '-1') != '0' else 0
+        _side[key] = torch.cuda.Stream(device=key, priority=prio)
     return _side[key]
 
 

@@ -271,3 +271,22 @@ def test_pruned_finest_level_runs_as_a_tail_of_the_executor():
     print('pruned tail, TrainStep losses', traj)
     for a, b in zip(traj[True], traj[False]):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), traj
+
+
+def test_simple_test_async_equals_simple_test():
+    """two batches in flight (enqueue batch 2 before collecting batch 1) return exactly what the synchronous calls return"""
+    dev = _dev()
+    model, _ = _build(levels=4)
+    model = model.to(dev).eval()
+    model.static_weights = True
+    b1, b2 = _batch((71, 72), dev), _batch((73, 74), dev)
+    with torch.no_grad():
+        ref = [model(return_loss=False, points=b['points'], img_metas=b['img_metas']) for b in (b1, b2)]
+        h1 = model.simple_test_async(b1['points'], b1['img_metas'])
+        h2 = model.simple_test_async(b2['points'], b2['img_metas'])
+        got = [h1(), h2()]
+    for r, g in zip(ref, got):
+        assert len(r) == len(g)
+        for a, b in zip(r, g):
+            assert torch.equal(a['boxes_3d'].tensor, b['boxes_3d'].tensor) and torch.equal(a['scores_3d'], b['scores_3d'])
+            assert torch.equal(a['labels_3d'], b['labels_3d'])
