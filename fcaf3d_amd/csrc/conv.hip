@@ -1098,6 +1098,25 @@ __global__ void k_conv_fma(const float* __restrict__ in, const float* __restrict
   out[t] = acc;
 }
 
+// Split-bf16 convolution with BOTH operands by LDS-DMA (k_conv_x6d): `planes` = fc_x6_planes of the input, `img` = the weight
+// image of the direction; neighbour-table launches (out_index: mask-sorted rows, may be NULL), no offset split.  bm = 128 / 256.
+template <int BM, int BN, int TM>
+static int launch_x6d(const u32x4* planes, const u32x4* img, const int* nbr, const int* out_index, const int* cnt, float* out,
+                      int64_t n_rows, int K, int Cin, int Cout, dim3 grid, hipStream_t stream) {
+  constexpr int NW = (BM / (32 * TM)) * (BN / 64);
+  constexpr size_t smem = 2 * (size_t)(3 * BM * 4 + (BN / 64) * X6_GROUP_U16) * 16;
+  static bool set_t = false, set_f = false;
+  if (nbr) {
+    if (!set_t) { FC_HIP(hipFuncSetAttribute((const void*)k_conv_x6d<BM, BN, TM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); set_t = true; }
+    k_conv_x6d<BM, BN, TM, true><<<grid, 64 * NW, smem, stream>>>(planes, img, nbr, out_index, cnt, out, n_rows, K, Cin, Cout);
+  } else {
+    if (!set_f) { FC_HIP(hipFuncSetAttribute((const void*)k_conv_x6d<BM, BN, TM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); set_f = true; }
+    k_conv_x6d<BM, BN, TM, false><<<grid, 64 * NW, smem, stream>>>(planes, img, nbr, out_index, cnt, out, n_rows, K, Cin, Cout);
+  }
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
 extern "C" {
 
 #define FC_CONV_APL (1 << 27)  // fc_conv_fwd / fc_conv_fwd_pairs(_tiles), with bits 24 and 26: `in` is the pre-split planes of fc_x6_planes
@@ -1305,6 +1324,20 @@ int fc_x6_planes(const float* x, void* planes, int64_t n, int C, hipStream_t str
   k_x6_planes<<<(unsigned)fc_cdiv(t, 256), 256, 0, stream>>>(x, reinterpret_cast<u32x4*>(planes), n, C);
   FC_CHECK_LAUNCH();
   return FC_OK;
+}
+
+int fc_conv_x6d(const void* planes, const void* img, const int* nbr, const int* out_index, float* out, int64_t n_out, int K, int Cin,
+                int Cout, int bm, hipStream_t stream) {
+  if (n_out < 0 || K < 1 || K > 32 || Cin % 32 || Cout % 64 || (bm != 128 && bm != 256)) return FC_EINVAL;
+  if (n_out == 0) return FC_OK;
+  const u32x4* pl = reinterpret_cast<const u32x4*>(planes);
+  const u32x4* im = reinterpret_cast<const u32x4*>(img);
+  const int bn = Cout % 128 == 0 ? 128 : 64;
+  dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, 1);
+  if (bm == 256 && bn == 128) return launch_x6d<256, 128, 2>(pl, im, nbr, out_index, nullptr, out, n_out, K, Cin, Cout, grid, stream);
+  if (bm == 128 && bn == 128) return launch_x6d<128, 128, 2>(pl, im, nbr, out_index, nullptr, out, n_out, K, Cin, Cout, grid, stream);
+  if (bm == 256) return launch_x6d<256, 64, 1>(pl, im, nbr, out_index, nullptr, out, n_out, K, Cin, Cout, grid, stream);
+  return launch_x6d<128, 64, 1>(pl, im, nbr, out_index, nullptr, out, n_out, K, Cin, Cout, grid, stream);
 }
 
 int fc_x6_weight_images(const int64_t* desc, int n, int64_t total_blocks, hipStream_t stream) {
@@ -1822,6 +1855,17 @@ static void wgrad_tiles(int Cin, int Cout, int flags, int* bm, int* bn) {
 // 55k rows 128->128 504 -> 446 us, 6.9k rows 256->256 278 -> 247, 256->128 148 -> 135, 441k rows 128->64 2121 -> 2003, 64->64
 // 1086 -> 1051); flags bit29 disables it, bit30 restricts it to its first rule (Cin = 64, >= 32768 rows)
 #define WGRAD_KO 3
+// split-bf16 weight gradients: rows loaded 16 B per lane and transposed by ds_read_b64_tr_b16 (k_wgrad_x6t, r4) or the register
+// transposition of r3 (k_wgrad_x6; FC_WGRAD_TR=0) — bit-identical results
+static int g_wgrad_tr = -1;                    // -1: not decided yet (environment at first use)
+static inline bool wgrad_tr() {
+  if (g_wgrad_tr < 0) g_wgrad_tr = !(getenv("FC_WGRAD_TR") && atoi(getenv("FC_WGRAD_TR")) == 0);
+  return g_wgrad_tr != 0;
+}
+extern "C" int fc_debug_set_wgrad_tr(int on) {   // A/B and the bit-identity test (tests/test_gpu_ops.py); not a C-ABI entry point
+  g_wgrad_tr = on ? 1 : 0;
+  return FC_OK;
+}
 static inline bool wgrad_multi_ok(int64_t n_out, int K, int Cin, int Cout, int flags, bool dense_table) {
   return dense_table && !(flags & 1) && !(flags & (1 << 29)) && K % WGRAD_KO == 0 &&
          Cin % 64 == 0 && Cout % 64 == 0 && n_out >= 4096 && (!(flags & (1 << 30)) || (Cin == 64 && n_out >= 32768));
@@ -1954,7 +1998,9 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     const int bn = (Cout % 128 == 0) ? 128 : 64;
     dim3 grid((unsigned)S, (unsigned)((K / WGRAD_KO) * (Cin / 64) * (Cout / bn)));
     if (flags & (1 << 24)) {                     // split-bf16 (wgrad_x6.h)
-      if (bn == 128) k_wgrad_x6<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+      if (wgrad_tr() && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+      else if (wgrad_tr()) k_wgrad_x6t<64, 64, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+      else if (bn == 128) k_wgrad_x6<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
       else k_wgrad_x6<64, 64, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
     } else
     if (bn == 128) k_wgrad_multi<128, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
@@ -1968,7 +2014,11 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     int bm = (Cin % 128 == 0) ? 128 : 64;
     if (bm == 128 && bn == 128 && (int64_t)S * K * (Cin / 128) * (Cout / 128) < 512) bm = 64;
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
-#define FC_WX6(BM_, BN_) k_wgrad_x6<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps)
+#define FC_WX6(BM_, BN_)                                                                                                             \
+  do {                                                                                                                               \
+    if (wgrad_tr()) k_wgrad_x6t<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); \
+    else k_wgrad_x6<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);    \
+  } while (0)
     if (bm == 128 && bn == 128) FC_WX6(128, 128);
     else if (bm == 128) FC_WX6(128, 64);
     else FC_WX6(64, 128);

@@ -617,3 +617,216 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
       }
     }
 }
+
+// ---- r4: planes AND weight image by LDS-DMA --------------------------------------------------------------------------------
+// k_conv_x6p showed that taking the split out of the stage loop is not enough: its stage still moves every byte through VGPRs
+// (12 loads + 12 ds_write_b128 per thread) and single-buffers the LDS, so the MFMA block waits for the write pass.  Here both
+// operands go from L2 STRAIGHT into LDS (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging registers, no
+// ds_write), into one of TWO stage buffers, ONE barrier per stage:
+//     wait for my DMAs of stage s -> barrier -> issue stage s+1's DMAs into the other buffer -> multiply stage s.
+// The LDS image of a DMA is lane-linear (wave-uniform base + lane x 16 B), the images of k_conv_x6 are kept by swizzling on the
+// SOURCE side: a plane row is 4 x 16 B, the lane that fills slot c' of tile row j fetches the row's chunk c' ^ ((j >> 2) & 3);
+// the weight image already is the LDS image (contiguous).  Wave tile 32 TM x 64, NW = (BM / 32 TM)(BN / 64) waves; a wave loads
+// two 16-row blocks of every plane (6 DMAs) and its share of the weight units per stage.
+template <int BM, int BN, int TM, bool HAS_NBR>
+__global__ __launch_bounds__(64 * (BM / (32 * TM)) * (BN / 64), 1) void k_conv_x6d(
+    const u32x4* __restrict__ planes, const u32x4* __restrict__ img, const int* __restrict__ nbr,
+    const int* __restrict__ out_index, const int* __restrict__ cnt, float* __restrict__ out, int64_t n_out, int K, int Cin,
+    int Cout) {
+  constexpr int NWC = BN / 64, NWR = BM / (32 * TM), NW = NWR * NWC;
+  constexpr int A_U = 3 * BM * 4, B_U = NWC * X6_GROUP_U16, STAGE_U = A_U + B_U;      // 16-byte units
+  constexpr int NBI = B_U / 64;                                                          // weight DMAs per stage
+  constexpr int BPW = (NBI + NW - 1) / NW;
+  static_assert(BM / 16 == 2 * NW, "a wave loads two 16-row blocks");
+  extern __shared__ __attribute__((aligned(1024))) u32x4 x6d_smem[];
+  __shared__ unsigned int kmask_s;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / NWC, wc = wave % NWC;
+  const int r = lane & 31, h = lane >> 5;
+  int64_t bx = blockIdx.x;
+  const int n0 = blockIdx.y * BN;
+  int S = gridDim.z, z = blockIdx.z;
+  int kbase = 0;
+  if (cnt) {                                     // pair mode: see k_conv_mfma
+    if (gridDim.z == 1 && K > 1) {
+      int k = 0;
+      for (; k < K - 1; ++k) {
+        const int64_t t = ((int64_t)cnt[k] + BM - 1) / BM;
+        if (bx < t) break;
+        bx -= t;
+      }
+      z = k;
+    }
+    const int64_t stride = n_out;
+    n_out = cnt[z];
+    if (bx * BM >= n_out) return;
+    nbr += (int64_t)z * stride;
+    kbase = z;
+    out += (int64_t)z * stride * Cout;
+    K = 1; S = 1; z = 0;
+  }
+  const int64_t m0 = bx * BM;
+
+  f32x16 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  unsigned int kmask;
+  {
+    if (tid == 0) kmask_s = 0u;
+    __syncthreads();
+    for (int t = tid; t < BM; t += 64 * NW) {
+      unsigned int mk = 0u;
+      int64_t row = m0 + t;
+      if (row < n_out) {
+        if (HAS_NBR) {
+          for (int k = z; k < K; k += S)
+            if (nbr[(int64_t)k * n_out + row] >= 0) mk |= 1u << k;
+        } else {
+          mk = 1u;
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) mk |= __shfl_xor(mk, off, 64);
+      if (lane == 0 && mk) atomicOr(&kmask_s, mk);
+    }
+    __syncthreads();
+    kmask = kmask_s;
+  }
+
+  if (kmask) {
+    const int nslab = Cin / 32, ngrp = Cout / 64;
+    const int nst = __popc(kmask) * nslab;
+    unsigned int rem = kmask;
+    int lk = __ffs(rem) - 1;
+    rem &= rem - 1;
+    int lnk = rem ? __ffs(rem) - 1 : lk;
+    if (rem) rem &= rem - 1;
+    int ls = 0;
+    bool sw = false;
+    // this lane's part of the row DMAs: tile rows (2 wave + q) 16 + lane / 4, LDS slot lane % 4, source chunk swizzled
+    int64_t arow[2];
+    bool aok[2];
+    int a_chunk[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int lrow = (2 * wave + q) * 16 + (lane >> 2);
+      const int64_t row = m0 + lrow;
+      aok[q] = row < n_out;
+      arow[q] = aok[q] ? row : 0;
+      a_chunk[q] = (lane & 3) ^ ((lrow >> 2) & 3);
+    }
+    int vcur[2], vnxt[2];
+    auto fetch_idx = [&](int kk, int (&v)[2]) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) v[q] = HAS_NBR ? nbr[(int64_t)kk * n_out + arow[q]] : (int)arow[q];
+    };
+    fetch_idx(lk, vcur);
+    fetch_idx(lnk, vnxt);
+    const u32x4* zero = reinterpret_cast<const u32x4*>(g_zero_planes);
+    auto issue_stage = [&](int buf) {
+      if (sw) {
+        sw = false;
+        lk = lnk;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) vcur[q] = vnxt[q];
+        if (rem) {
+          lnk = __ffs(rem) - 1;
+          rem &= rem - 1;
+        }
+        fetch_idx(lnk, vnxt);
+      }
+      u32x4* As = x6d_smem + buf * STAGE_U;
+      u32x4* Bs = As + A_U;
+      // every source address first (consumes the index registers while nothing is in flight), then the DMAs back to back
+      const u32x4* asrc[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const bool ok = vcur[q] >= 0 && aok[q];
+        asrc[q] = ok ? planes + ((int64_t)vcur[q] * nslab + ls) * 12 + a_chunk[q] : zero + (lane & 1);
+      }
+      const u32x4* bsrc = img + (((int64_t)(kbase + lk) * nslab + ls) * ngrp + n0 / 64) * X6_GROUP_U16 + lane;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < BPW; ++i) {
+        const int j = wave + NW * i;
+        if (NBI % NW == 0 || j < NBI)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + 64 * j),
+                                           (__attribute__((address_space(3))) void*)(Bs + 64 * j), 16, 0, 0);
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const bool ok = vcur[q] >= 0 && aok[q];
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[q] + (ok ? pl * 4 : 0)),
+                                           (__attribute__((address_space(3))) void*)(As + pl * BM * 4 + (2 * wave + q) * 64), 16, 0, 0);
+        }
+    };
+    issue_stage(0);
+    const int swz = (r >> 2) & 3;
+    int a_slot[2], b_slot[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      a_slot[b] = (wr * 32 * TM + r) * 4 + ((2 * b + h) ^ swz);
+      b_slot[b] = A_U + wc * X6_GROUP_U16 + r * 4 + ((2 * b + h) ^ swz);
+    }
+    for (int st = 0; st < nst; ++st) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my DMAs of stage st have landed ...
+      __syncthreads();                                      // ... and everyone's; stage st-1 is fully consumed
+      if (st + 1 < nst) {
+        if (++ls >= nslab) {
+          ls = 0;
+          sw = true;
+        }
+        issue_stage((st + 1) & 1);
+      }
+      const u32x4* Sb = x6d_smem + (st & 1) * STAGE_U;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        u32x4 fa[3][TM];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[pl][i] = Sb[pl * BM * 4 + a_slot[b] + i * 32 * 4];
+#pragma unroll
+        for (int pb = 2; pb >= 0; --pb) {
+          u32x4 fb[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) fb[j] = Sb[pb * 64 * 4 + b_slot[b] + j * 32 * 4];
+#pragma unroll
+          for (int pa = 2 - pb; pa >= 0; --pa)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][j] = X6_MFMA(fa[pa][i], fb[j], acc[i][j]);
+        }
+      }
+    }
+  }
+  float* dst = out + (int64_t)z * n_out * Cout + n0 + wc * 64 + 2 * r;
+  int orow[TM][16];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = m0 + wr * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      int o = -1;
+      if (row < n_out) o = out_index ? out_index[row] : (int)row;
+      orow[i][e] = o;
+    }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (orow[i][e] >= 0) {
+        f32x2 v = {acc[i][0][e], acc[i][1][e]};
+        *reinterpret_cast<f32x2*>(dst + (int64_t)orow[i][e] * Cout) = v;
+      }
+    }
+}

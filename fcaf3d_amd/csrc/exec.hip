@@ -175,6 +175,17 @@ inline bool want_ws(Ctx& c, int s, int64_t bytes) {     // true: the launch may 
 int run_op_impl(Ctx& c, const int64_t* op) {
   const int s = (int)op[1];
   hipStream_t st = c.streams[s];
+#ifdef FC_KO_EXEC
+  // knock-out build (tools/knockout.sh FC_KO_EXEC; never the product library): FC_KO_OPS = bit mask of op families NOT launched
+  // (1 weight gradients, 2 convolutions, 4 normalisation) — what the step costs without them (results are garbage)
+  {
+    static const int ko = getenv("FC_KO_OPS") ? atoi(getenv("FC_KO_OPS")) : 0;
+    const int64_t o = op[0];
+    if (!c.dry && (((ko & 1) && (o == OP_WGRAD || o == OP_STEM_WGRAD)) || ((ko & 2) && o == OP_CONV) ||
+                   ((ko & 4) && (o == OP_BN_FWD || o == OP_BN_BWD || o == OP_NORM_FWD || o == OP_NORM_BWD || o == OP_COL_STATS))))
+      return 0;
+  }
+#endif
   switch (op[0]) {
     case OP_STEM_FWD: {   // in, W, map, out, col
       const int64_t* m = c.maps + op[4] * MAPW;

@@ -11,10 +11,33 @@ import bench  # noqa: E402
 
 
 def main():
+    # --train-first N: N training steps before the measurement (trained-looking scores: many more NMS candidates than at
+    # initialisation); --save-state / --load-state PATH: hand that state to a second process (e.g. one under rocprofv3)
+    opts = {}
+    for flag in ('--train-first', '--save-state', '--load-state'):
+        if flag in sys.argv:
+            k = sys.argv.index(flag)
+            opts[flag] = sys.argv[k + 1]
+            del sys.argv[k:k + 2]
     args = bench.parse()
     dev = torch.device('cuda:0')
     model, cfg = bench.build_model(args)
-    model = model.to(dev).eval()
+    model = model.to(dev)
+    if '--load-state' in opts:
+        model.load_state_dict(torch.load(opts['--load-state'], map_location=dev))
+    if '--train-first' in opts:
+        from fcaf3d_amd.runner import TrainStep
+        model.train()
+        model.async_maps = True
+        model.inputs_resident = True
+        tr = TrainStep.from_config(model, cfg)
+        bt = bench.make_batches(args, 0, dev)
+        for i in range(int(opts['--train-first'])):
+            tr(bt[i % len(bt)])
+        torch.cuda.synchronize()
+    if '--save-state' in opts:
+        torch.save(model.state_dict(), opts['--save-state'])
+    model = model.eval()
     model.static_weights = True
     model.async_maps = True
     model.inputs_resident = True

@@ -54,7 +54,7 @@ def main():
               ('g0 64->64', g0.kernel_map(g0, 3), 64, 64), ('g0 64->128', g0.kernel_map(g0, 3), 64, 128),
               ('g0 128->64 (dgrad shape)', g0.kernel_map(g0, 3), 128, 64)]
     torch.manual_seed(0)
-    print(f'{"case":28s} {"rows":>8s} {"route":>6s} {"in-kernel us":>13s} {"planes us":>10s} {"to_planes us":>12s} {"GFLOP":>8s} {"TF in-k":>8s} {"TF planes":>9s}  equal')
+    print(f'{"case":28s} {"rows":>8s} {"route":>6s} {"in-kernel us":>13s} {"planes us":>10s} {"dma128 us":>10s} {"dma256 us":>10s} {"to_planes us":>12s} {"GFLOP":>8s} {"TF in-k":>8s} {"TF dma":>9s}  equal')
     for name, km, Cin, Cout in cases:
         n_in, n_out = km.n_in, km.n_out
         f = torch.relu(torch.randn((n_in, Cin), device=dev))
@@ -81,8 +81,17 @@ def main():
             P = float((km.nbr >= 0).sum().item())
         ta, tb, tp = timed(run_a), timed(run_b), timed(to_planes)
         gf = 2 * P * Cin * Cout / 1e9
-        print(f'{name:28s} {n_out:8d} {"pairs" if pairs else "table":>6s} {ta:13.1f} {tb:10.1f} {tp:12.1f} {gf:8.2f} {gf / ta * 1e3:8.1f} {gf / tb * 1e3:9.1f}  '
-              f'{bool(torch.equal(out_a, out_b))}')
+        td, eq = [float('nan')] * 2, [None] * 2
+        if not pairs:
+            for q, bm in enumerate((128, 256)):
+                out_c = torch.empty((n_out, Cout), device=dev)
+                run_c = lambda: L.call('fc_conv_x6d', L.ptr(planes), L.ptr(img), L.ptr(nbr), L.ptr(oidx) if oidx is not None else None,
+                                       L.ptr(out_c), n_out, km.K, Cin, Cout, bm, L.stream())
+                td[q] = timed(run_c)
+                eq[q] = bool(torch.equal(out_a, out_c))
+        best = min(t for t in td + [float('inf')] if t == t)
+        print(f'{name:28s} {n_out:8d} {"pairs" if pairs else "table":>6s} {ta:13.1f} {tb:10.1f} {td[0]:10.1f} {td[1]:10.1f} {tp:12.1f} {gf:8.2f} {gf / ta * 1e3:8.1f} {gf / best * 1e3:9.1f}  '
+              f'{bool(torch.equal(out_a, out_b))} {eq}')
 
 
 if __name__ == '__main__':

@@ -4,7 +4,7 @@
       --infer-steps 0 --no-instrument
   python tools/timeline.py <dir>/<host>/t_kernel_trace.csv [--steps 6]
 
-Splits the trace into steps at the optimizer's multi-tensor AdamW kernel, each step into forward (up to k_focal_fwd),
+Splits the trace into steps at the optimizer's AdamW kernel (k_adamw), each step into forward (up to the loss kernel),
 backward (up to the first optimizer kernel) and optimizer, and prints per phase: wall time, time with >= 1 kernel
 running (union of intervals), idle time, the sum of kernel durations per stream/queue, and the kernels that follow the
 largest gaps — i.e. where the dependent chain of small launches leaves the chip empty."""
@@ -46,7 +46,7 @@ def main():
     path = sys.argv[1]
     rows = load(path)
     # step boundaries: the LAST optimizer kernel of a step (fused AdamW = multi_tensor_apply with FusedAdam functor)
-    opt = [i for i, r in enumerate(rows) if 'FusedAdam' in r[2] or 'fused_adam' in r[2].lower()]
+    opt = [i for i, r in enumerate(rows) if r[2].startswith('k_adamw') or 'FusedAdam' in r[2] or 'fused_adam' in r[2].lower()]
     if not opt:
         opt = [i for i, r in enumerate(rows) if 'multi_tensor_apply' in r[2]]
     bounds, prev = [], None
@@ -70,8 +70,8 @@ def main():
     gapn = collections.Counter()
     per_stream = collections.defaultdict(float)
     for st in steps:
-        t_f = next((r[0] for r in st if 'k_focal_fwd' in r[2]), None)
-        t_o = next((r[0] for r in st if 'multi_tensor_apply' in r[2] or 'FusedAdam' in r[2]), None)
+        t_f = next((r[0] for r in st if 'k_focal_fwd' in r[2] or 'k_fcaf3d_loss_fwd' in r[2]), None)
+        t_o = next((r[0] for r in st if r[2].startswith('k_sqsum_partial') or 'multi_tensor_apply' in r[2] or 'FusedAdam' in r[2]), None)
         t0, t1 = st[0][0], max(r[1] for r in st)
         phases = {'forward': (t0, t_f), 'backward': (t_f, t_o), 'optimizer': (t_o, t1)}
         for ph, (a, b) in phases.items():
