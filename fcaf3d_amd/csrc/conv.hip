@@ -1891,8 +1891,10 @@ static void wgrad_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool 
     const bool wide = Cout % 128 == 0;
     tiles = (int64_t)(K / WGRAD_KO) * (Cin / 64) * (Cout / (wide ? 128 : 64));
     // r4 A/B in the full step (weight gradients beside the dependent chain): 3/4 of a resident round 22.91 ms, a full round
-    // (r3) 23.34, half 23.70, a quarter 28.63, two rounds 23.25 — the main stream's kernels find a slot sooner
-    static const int round_wide = getenv("FC_WGRAD_ROUND_WIDE") ? atoi(getenv("FC_WGRAD_ROUND_WIDE")) : 384;
+    // (r3) 23.34, half 23.70, a quarter 28.63, two rounds 23.25 — the main stream's kernels find a slot sooner.  With the
+    // transposing-read kernel (k_wgrad_x6t, 1.4x faster per launch) half a round of the wide variant is ahead: 256 / 512
+    // 22.26-22.35 ms, 192 / 512 22.41, 384 / 512 22.65, 128 / 512 23.36 (same box)
+    static const int round_wide = getenv("FC_WGRAD_ROUND_WIDE") ? atoi(getenv("FC_WGRAD_ROUND_WIDE")) : 256;
     static const int round_narrow = getenv("FC_WGRAD_ROUND_NARROW") ? atoi(getenv("FC_WGRAD_ROUND_NARROW")) : 512;
     s = (wide ? round_wide : round_narrow) / tiles;     // the 128-column variant holds 2 workgroups per CU (registers)
   }

@@ -116,13 +116,21 @@ __device__ static inline float iou_bev_aligned(const float* a, const float* b) {
   return inter / fmaxf(a[3] * a[4] + b[3] * b[4] - inter, NMS_EPS);
 }
 
-// grid (col blocks, row blocks, classes), 64 threads
+// grid (block pairs of the UPPER triangle, 1, classes), 64 threads.  The greedy scan only reads the words of column blocks at or
+// after a row's own block (a box can only suppress boxes that come later), so the lower triangle is never computed (r4: half
+// the IoU work and half the workgroups of the r1-r3 (col blocks, row blocks) grid; the reference computes the full matrix,
+// iou3d_nms_kernel.cu:267-313, and its host scan likewise only acts on later boxes).  Pair t = cb (cb + 1) / 2 + rb, rb <= cb.
 __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ counts,
                                                  int stride, float thresh, int rotated,
                                                  unsigned long long* __restrict__ mask) {
   const int seg = blockIdx.z;
   const int n = counts[seg];
-  const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+  const int t = blockIdx.x;
+  int cb = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+  while ((cb + 1) * (cb + 2) / 2 <= t) ++cb;           // float rounding: settle on cb (cb + 1) / 2 <= t < (cb + 1)(cb + 2) / 2
+  while (cb * (cb + 1) / 2 > t) --cb;
+  const int rblk = t - cb * (cb + 1) / 2;
+  const int row0 = rblk * 64, col0 = cb * 64;
   if (row0 >= n || col0 >= n) return;
   const int words = (stride + 63) / 64;
   const float* sb = boxes + (int64_t)seg * stride * 7;
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes
     float v = rotated ? iou_bev_rotated(rb, cbox + j * 7) : iou_bev_aligned(rb, cbox + j * 7);
     if (v > thresh) bits |= 1ull << j;
   }
-  mask[((int64_t)seg * stride + row) * words + blockIdx.x] = bits;
+  mask[((int64_t)seg * stride + row) * words + cb] = bits;
 }
 
 // grid (classes), 64 threads: lane j holds removed-words j, j+64, ...
@@ -193,7 +201,7 @@ int fc_nms_bev(const float* boxes, const int* counts_dev, int nseg, int stride, 
   if (nseg < 1 || stride < 1 || stride > 65536 || nseg > 65535) return FC_EINVAL;
   if (ws_bytes < fc_nms_bev_ws_bytes(nseg, stride)) return FC_EWS;
   int nb = (stride + 63) / 64;
-  dim3 grid(nb, nb, nseg);
+  dim3 grid(nb * (nb + 1) / 2, 1, nseg);
   k_nms_mask<<<grid, 64, 0, stream>>>(boxes, counts_dev, stride, thresh, rotated, mask_ws);
   FC_CHECK_LAUNCH();
   k_nms_greedy<<<nseg, 64, 0, stream>>>(mask_ws, counts_dev, stride, keep, keep_count);

@@ -123,7 +123,7 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
 /* flags bit24 (fc_conv_fwd, fc_conv_fwd_pairs, fc_conv_fwd_pairs_tiles): the same fp32 convolution (torch.float32 in and
  * out, as ME.MinkowskiConvolution computes it, me_resnet.py:56-62) on the bf16 matrix pipe by EXACT operand splitting —
  * x = x1 + x2 + x3 with three 8-bit pieces, six bf16 x bf16 products (each exact in the fp32 accumulator) per fp32 product
- * (the three dropped ones: <= 2^-21 of the product, 2^-25 on average);
+ * (the three dropped ones: <= 2^-24 of the product with the round-to-nearest split of r4);
  * results sit at fp32 rounding level against fp64, like the fp32 MFMA's (csrc/conv_x6.h, tests/test_gpu_ops.py).  128- and 256-row tiles.
  * flags bit26 (with bit24): `W` is not the fp32 kernel but its pre-split image built by fc_x6_weight_image — for the
  * backward-data pass the image of the transposed operator (then bit23 is not needed).
@@ -136,8 +136,8 @@ int64_t fc_x6_weight_image_bytes(int K, int R, int C);
  * offset that gathers it; same pieces, same products, bit-identical results.  fc_x6_planes_bytes(n, C) = 6 n C; C % 32 == 0. */
 int64_t fc_x6_planes_bytes(int64_t n, int C);
 int fc_x6_planes(const float* x, void* planes, int64_t n, int C, hipStream_t stream);
-/* The same convolution with BOTH operands copied from L2 straight into LDS (global_load_lds_dwordx4, two stage buffers, one
- * barrier per stage; csrc/conv_x6.h k_conv_x6d): `planes` of fc_x6_planes, `img` of fc_x6_weight_image(s); neighbour-table
+/* The same convolution (ME.MinkowskiConvolution, me_resnet.py:56-62) with BOTH operands copied from L2 straight into LDS
+ * (global_load_lds_dwordx4, two stage buffers, one barrier per stage; csrc/conv_x6.h k_conv_x6d): `planes` of fc_x6_planes, `img` of fc_x6_weight_image(s); neighbour-table
  * launches (out_index: the mask-sorted row order or NULL); bm = 128 or 256 tile rows.  Bit-identical to fc_conv_fwd with
  * bits 24 | 26 on the same operands. */
 int fc_conv_x6d(const void* planes, const void* img, const int* nbr, const int* out_index, float* out, int64_t n_out, int K,
