@@ -20,7 +20,7 @@ _join_queued = False
 def wgrad_stream(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _wg_streams:
-        _wg_streams[idx] = torch.cuda.Stream(device=idx)
+        _wg_streams[idx] = torch.cuda.Stream(device=idx, priority=int(os.environ.get('FC_WGRAD_PRIO', '0')))
     return _wg_streams[idx]
 
 

@@ -25,13 +25,21 @@ _record_to = None
 
 
 def map_stream(device):
+    """The coordinate stream of `device`.  Priority (r4): its kernels are microseconds long and the host waits for their counts, so
+    they should overtake whatever the dependent chain has in flight — HIGH priority — but ONLY when the caller's stream is not a
+    high-priority stream itself: two streams of one priority level can be multiplexed onto ONE hardware queue, and then the
+    coordinate phase of the next step queues behind the whole backlog of this one (measured: bench.py's high-priority training
+    stream + a high-priority coordinate stream fall into a 31 ms mode instead of 22.5 on some process layouts, always beside an
+    RCCL communicator: 2 scenes per step through the averager 22 ms instead of 10).  FC_MAP_PRIO = -1 / 0 forces one."""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    if key not in _side:
-        # HIGH priority (r4): the coordinate kernels are microseconds long and the host waits for their counts; at normal priority
-        # they queue behind whatever the dependent chain has in flight (FC_MAP_PRIO=0: the r3 behaviour)
-        prio = -1 if os.environ.get('FC_MAP_PRIO', '-1') != '0' else 0
-        _side[key] = torch.cuda.Stream(device=key, priority=prio)
-    return _side[key]
+    env = os.environ.get('FC_MAP_PRIO', 'auto')
+    if env in ('-1', '0'):
+        prio = int(env)
+    else:
+        prio = -1 if torch.cuda.current_stream(key).priority >= 0 else 0
+    if (key, prio) not in _side:
+        _side[(key, prio)] = torch.cuda.Stream(device=key, priority=prio)
+    return _side[(key, prio)]
 
 
 _inputs_ready = {}
