@@ -48,7 +48,7 @@ def parse():
                     'stream, so that they overlap the backward-data chain: +3 % measured r2)')
     ap.add_argument('--no-priority-stream', dest='priority_stream', action='store_false',
                     help='default: the step\'s dependent chain runs on a high-priority HIP stream (r3, beside the split kernels: 23.41 -> 23.25 ms)')
-    ap.add_argument('--infer-steps', type=int, default=4, help='untimed-region extra: simple_test batches for the inference scenes/s line (0 = skip)')
+    ap.add_argument('--infer-steps', type=int, default=8, help='untimed-region extra: simple_test batches for the inference scenes/s line (0 = skip)')
     ap.add_argument('--cpu-reps', type=int, default=3, help='repetitions of the conv-only part of the cpu_baseline (median)')
     ap.add_argument('--no-fp32-route', action='store_true', help='skip the untimed FC_X6=0 extra')
     ap.add_argument('--no-force-dp', action='store_true', help='skip the untimed N=1-through-the-averager extra')

@@ -290,3 +290,24 @@ def test_simple_test_async_equals_simple_test():
         for a, b in zip(r, g):
             assert torch.equal(a['boxes_3d'].tensor, b['boxes_3d'].tensor) and torch.equal(a['scores_3d'], b['scores_3d'])
             assert torch.equal(a['labels_3d'], b['labels_3d'])
+
+
+def test_coordinate_stream_priority_follows_the_callers_stream():
+    """sparse.map_stream: HIGH priority under a normal-priority caller (its kernels overtake the forward pass in flight: two
+    inference batches overlap), NORMAL under a high-priority caller — two streams of one priority level can share a hardware
+    queue, which put bench.py's training loop into a 31 ms mode (profiles/r4_notes.md section 12).  FC_MAP_PRIO forces one."""
+    import os
+    from fcaf3d_amd import sparse
+    dev = _dev()
+    assert os.environ.get('FC_MAP_PRIO', 'auto') == 'auto'
+    with torch.cuda.stream(torch.cuda.Stream(device=dev, priority=0)):
+        lo = sparse.map_stream(dev)
+    with torch.cuda.stream(torch.cuda.Stream(device=dev, priority=-1)):
+        hi = sparse.map_stream(dev)
+    assert lo.priority == -1 and hi.priority == 0 and lo.cuda_stream != hi.cuda_stream
+    os.environ['FC_MAP_PRIO'] = '0'
+    try:
+        with torch.cuda.stream(torch.cuda.Stream(device=dev, priority=0)):
+            assert sparse.map_stream(dev).priority == 0
+    finally:
+        del os.environ['FC_MAP_PRIO']
