@@ -662,10 +662,12 @@ def main():
             # one's forward pass and decode run on the GPU
             n_pipe = 2 * args.infer_steps
 
-            def pipelined(i, pending=[None]):
+            pending = [None]                     # the batch enqueued last, its read-backs still to be done
+
+            def pipelined(i):
                 h = model.simple_test_async(**test_batches[i % len(test_batches)])
                 if pending[0] is not None:
-                    pending[0]()
+                    pending[0]()                     # results of batch i - 1 while batch i runs on the GPU
                 pending[0] = h
                 if i == n_pipe - 1:
                     pending[0]()
