@@ -1,6 +1,6 @@
 """Run-to-run determinism of forward_train + backward on the GPU (tools/, not product): the same batch twice through the
 same model must give bitwise the same losses and gradients (no float atomics anywhere in the path).
-    python tools/determinism.py [--points 30000] [--scenes 2] [--levels 4] [--reps 3]"""
+    python tools/determinism.py [--points 30000] [--scenes 2] [--levels 4] [--reps 3] [--bench-streams]"""
 import argparse
 import os
 import sys
@@ -18,6 +18,7 @@ def main():
     ap.add_argument('--scenes', type=int, default=2)
     ap.add_argument('--levels', type=int, default=4)
     ap.add_argument('--reps', type=int, default=3)
+    ap.add_argument('--bench-streams', action='store_true', help="bench.py's stream layout: weight gradients and coordinates on their own streams")
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
@@ -27,6 +28,11 @@ def main():
     m.neck_with_head['in_channels'] = (64, 128, 256, 512)[:a.levels]
     m.neck_with_head.assigner['n_scales'] = a.levels
     model = fa.build_detector(m, train_cfg=m.get('train_cfg'), test_cfg=m.get('test_cfg')).to(dev).train()
+    if a.bench_streams:
+        import fcaf3d_amd.functional as Fn
+        Fn.WGRAD_ASYNC = True
+        model.async_maps = True
+        model.inputs_resident = True
     sc = [make_scene(100 + i, n_points=a.points) for i in range(a.scenes)]
     batch = dict(points=[torch.from_numpy(s[0]).to(dev) for s in sc],
                  gt_bboxes_3d=[fa.DepthInstance3DBoxes(torch.from_numpy(s[1]), origin=(.5, .5, .5)) for s in sc],
