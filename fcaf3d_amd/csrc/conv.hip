@@ -1862,6 +1862,13 @@ static inline bool wgrad_tr() {
   if (g_wgrad_tr < 0) g_wgrad_tr = !(getenv("FC_WGRAD_TR") && atoi(getenv("FC_WGRAD_TR")) == 0);
   return g_wgrad_tr != 0;
 }
+// 64 x 64-channel pair-list launches and the table-free dense GEMMs (generative transposed convolution, heads) on k_wgrad_x6t
+// as well (r4: one accumulator per wave lost to the fp32 kernel with the r3 kernel's loads, with 16-byte loads it is ahead:
+// 64.5k rows 64->64 pair lists 131 -> 90 us, stride-2 map 93.5 -> 69 us).  FC_WGRAD_TR64=0: those stay on the fp32 pipe.
+static inline bool wgrad_tr64() {
+  static const bool on = !(getenv("FC_WGRAD_TR64") && atoi(getenv("FC_WGRAD_TR64")) == 0);
+  return on && wgrad_tr();
+}
 extern "C" int fc_debug_set_wgrad_tr(int on) {   // A/B and the bit-identity test (tests/test_gpu_ops.py); not a C-ABI entry point
   g_wgrad_tr = on ? 1 : 0;
   return FC_OK;
@@ -2007,7 +2014,7 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     } else
     if (bn == 128) k_wgrad_multi<128, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
     else k_wgrad_multi<64, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
-  } else if (mfma_ok && cnt && (flags & (1 << 24)) && (Cin % 128 == 0 || Cout % 128 == 0)) {
+  } else if (mfma_ok && cnt && (flags & (1 << 24)) && (Cin % 128 == 0 || Cout % 128 == 0 || wgrad_tr64())) {
     // split-bf16 over the pair lists (r3 nbench: 128 x 128 tiles 119 -> 95 us on 15k rows 128->128, 111 -> 89 / 109 -> 87 on
     // the 256- and 512-channel levels; 64 x 64 tiles — one accumulator per wave, a dependent MFMA chain — lose to the fp32
     // kernel and stay there).  128-channel Cin tiles only while they still fill the chip (862 rows, 512->128: 216 workgroups
@@ -2023,8 +2030,21 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
   } while (0)
     if (bm == 128 && bn == 128) FC_WX6(128, 128);
     else if (bm == 128) FC_WX6(128, 64);
-    else FC_WX6(64, 128);
+    else if (bn == 128) FC_WX6(64, 128);
+    else k_wgrad_x6t<64, 64, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
 #undef FC_WX6
+  } else if (mfma_ok && !nbr && !cnt && (flags & (1 << 24)) && wgrad_tr64()) {
+    // table-free dense GEMM gW = in^T gout over the rows (K = 1): the same kernel with the row itself as the index
+    const int bn = (Cout % 128 == 0) ? 128 : 64;
+    int bm = (Cin % 128 == 0) ? 128 : 64;
+    if (bm == 128 && bn == 128 && (int64_t)S * (Cin / 128) * (Cout / 128) < 512) bm = 64;
+    dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
+#define FC_WX6D(BM_, BN_) k_wgrad_x6t<BM_, BN_, 1, false><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps)
+    if (bm == 128 && bn == 128) FC_WX6D(128, 128);
+    else if (bm == 128) FC_WX6D(128, 64);
+    else if (bn == 128) FC_WX6D(64, 128);
+    else FC_WX6D(64, 64);
+#undef FC_WX6D
   } else if (mfma_ok) {
     int bm, bn;
     wgrad_tiles(Cin, Cout, flags, &bm, &bn);

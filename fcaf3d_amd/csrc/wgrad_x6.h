@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
 #pragma unroll
       for (int o = 0; o < KO; ++o) {
         const int kk = k0 + o < K ? k0 + o : K - 1;
-        const int t = nbr[(int64_t)kk * n_out + rc];
+        const int t = nbr ? nbr[(int64_t)kk * n_out + rc] : (int)rc;        // no table: the dense GEMM over the rows themselves
         ia[o] = (row < r_end && k0 + o < K) ? t : -1;
       }
       ig = row < r_end ? (PAIRS ? row_index[(int64_t)k0 * n_out + rc] : (int)rc) : -1;

@@ -750,31 +750,48 @@ def test_wgrad_transposing_read_is_bit_identical():
     c2 = cm.strided(4)
     coarse = c2.kernel_map(c2, 3)                   # pair-list route
     try:
-        for km, Cin, Cout in ((fine, 64, 128), (fine, 128, 64), (fine, 64, 64), (coarse, 128, 128), (coarse, 256, 128), (coarse, 64, 128)):
+        for km, Cin, Cout in ((fine, 64, 128), (fine, 128, 64), (fine, 64, 64), (coarse, 128, 128), (coarse, 256, 128), (coarse, 64, 128), (coarse, 64, 64)):
             f = torch.randn((km.n_in, Cin), device=dev)
             g = torch.randn((km.n_out, Cout), device=dev) * 1e-3
-            res = []
             fl = Fn.FLAGS | Fn.WGRAD_X6
             ws = L.workspace(L.query('fc_conv_wgrad_ws_bytes', km.n_out, 27, Cin, Cout, fl), dev)
+            pi, po, _, cnt = km.pairs()
+            res = {'table': [], 'pairs': []}
             for tr in (0, 1):
                 L.lib().fc_debug_set_wgrad_tr(tr)
-                gw = torch.full((27, Cin, Cout), float('nan'), device=dev)
-                if km.use_pairs:
-                    pi, po, _, cnt = km.pairs()
-                    L.call('fc_conv_wgrad_pairs', L.ptr(f), L.ptr(g), L.ptr(pi), L.ptr(po), L.ptr(cnt), L.ptr(gw), km.n_in, km.n_out, 27, Cin,
-                           Cout, fl, L.ptr(ws), ws.numel(), L.stream())
-                else:
-                    L.call('fc_conv_wgrad', L.ptr(f), L.ptr(g), L.ptr(km.nbr), None, L.ptr(gw), km.n_in, km.n_out, 27, Cin, Cout, fl,
-                           L.ptr(ws), ws.numel(), L.stream())
-                res.append(gw)
+                for route in res:
+                    gw = torch.full((27, Cin, Cout), float('nan'), device=dev)
+                    if route == 'pairs':
+                        L.call('fc_conv_wgrad_pairs', L.ptr(f), L.ptr(g), L.ptr(pi), L.ptr(po), L.ptr(cnt), L.ptr(gw), km.n_in, km.n_out, 27,
+                               Cin, Cout, fl, L.ptr(ws), ws.numel(), L.stream())
+                    else:
+                        L.call('fc_conv_wgrad', L.ptr(f), L.ptr(g), L.ptr(km.nbr), None, L.ptr(gw), km.n_in, km.n_out, 27, Cin, Cout, fl,
+                               L.ptr(ws), ws.numel(), L.stream())
+                    res[route].append(gw)
             torch.cuda.synchronize()
-            assert torch.equal(res[0], res[1]), (km.n_out, Cin, Cout, float((res[0] - res[1]).abs().max()))
+            for route, (a, b) in res.items():
+                if route == 'pairs' and Cin == 64 and Cout == 64:
+                    continue      # the r3 side of the switch keeps 64 x 64 pair lists on the fp32 pipe: checked against fp64 below
+                assert torch.equal(a, b), (route, km.n_out, Cin, Cout, float((a - b).abs().max()))
+            res = [res['table'][1], res['pairs'][1]]
             # fp64 evaluation of three offsets
             for k in (0, 13, 26):
                 idx = km.nbr[k].long()
                 ok = idx >= 0
                 ref = f[idx[ok]].double().t() @ g[ok].double()
-                err = float((res[1][k].double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
-                assert err < 2e-5, (km.n_out, Cin, Cout, k, err)
+                for gw in res:
+                    err = float((gw[k].double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+                    assert err < 2e-5, (km.n_out, Cin, Cout, k, err)
+        # the table-free dense GEMM (generative transposed convolution, heads): fp32 pipe on the r3 side of the switch — against fp64
+        L.lib().fc_debug_set_wgrad_tr(1)
+        fl = Fn.FLAGS | Fn.WGRAD_X6
+        for n, Cin, Cout in ((5000, 128, 512), (777, 64, 64), (20000, 256, 64)):
+            f = torch.randn((n, Cin), device=dev)
+            g = torch.randn((n, Cout), device=dev) * 1e-3
+            ws = L.workspace(L.query('fc_conv_wgrad_ws_bytes', n, 1, Cin, Cout, fl), dev)
+            gw = torch.full((1, Cin, Cout), float('nan'), device=dev)
+            L.call('fc_conv_wgrad', L.ptr(f), L.ptr(g), None, None, L.ptr(gw), n, n, 1, Cin, Cout, fl, L.ptr(ws), ws.numel(), L.stream())
+            ref = f.double().t() @ g.double()
+            assert float((gw[0].double() - ref).abs().max() / ref.abs().max()) < 2e-5, (n, Cin, Cout)
     finally:
         L.lib().fc_debug_set_wgrad_tr(1)
