@@ -292,12 +292,24 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
     auto load_rows = [&]() {                     // rows of the stage whose indices sit in ia / ig
       const float* gp = ig >= 0 ? gout + (int64_t)ig * Cout + co0 + s_c4 : g_zero_row + s_c4;
 #pragma unroll
-      for (int p = 0; p < SG; ++p) gv[p] = *reinterpret_cast<const f32x4*>(gp + (ig >= 0 ? p * 32 : 0));
+      for (int p = 0; p < SG; ++p) {
+#ifdef FC_KO_WG_NOLOAD
+        gv[p] = f32x4{(float)lane, 1.f, 2.f, (float)p};
+#else
+        gv[p] = *reinterpret_cast<const f32x4*>(gp + (ig >= 0 ? p * 32 : 0));
+#endif
+      }
 #pragma unroll
       for (int o = 0; o < KO; ++o) {
         const float* ap = ia[o] >= 0 ? in + (int64_t)ia[o] * Cin + ci0 + s_c4 : g_zero_row + s_c4;
 #pragma unroll
-        for (int p = 0; p < SA; ++p) av[o][p] = *reinterpret_cast<const f32x4*>(ap + (ia[o] >= 0 ? p * 32 : 0));
+        for (int p = 0; p < SA; ++p) {
+#ifdef FC_KO_WG_NOLOAD
+          av[o][p] = f32x4{(float)lane, 1.f, (float)o, (float)p};
+#else
+          av[o][p] = *reinterpret_cast<const f32x4*>(ap + (ia[o] >= 0 ? p * 32 : 0));
+#endif
+        }
       }
     };
     fetch_idx(r_begin);
@@ -358,7 +370,13 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
 #pragma unroll
               for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[o][i][j] = X6_MFMA(fa[o][pa][i], fb[pb][j], acc[o][i][j]);
+                for (int j = 0; j < TN; ++j) {
+#ifdef FC_KO_WG_NOMFMA
+                  acc[o][i][j][0] += __uint_as_float((fa[o][pa][i][0] ^ fb[pb][j][0]) & 0x3fffffu);
+#else
+                  acc[o][i][j] = X6_MFMA(fa[o][pa][i], fb[pb][j], acc[o][i][j]);
+#endif
+                }
       }
     }
   }
