@@ -220,3 +220,22 @@ def test_weight_image_table_layout():
     # images never overlap
     spans = sorted((r[1], r[1] + 6 * r[2] * r[3] * r[4]) for r in d)
     assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_nms_upper_triangle_block_enumeration():
+    """csrc/nms.hip k_nms_mask (r4): block t of the grid works on the block pair (rb, cb), rb <= cb, t = cb (cb + 1) / 2 + rb, found
+    from t with a float32 square root and two correcting loops.  The same arithmetic here in numpy float32: a bijection onto the
+    upper triangle for every grid the entry point accepts (up to 1 024 column blocks = 65 536 boxes per segment)."""
+    nb = 1024
+    t = np.arange(nb * (nb + 1) // 2, dtype=np.int64)
+    cb = ((np.sqrt(np.float32(8.0) * t.astype(np.float32) + np.float32(1.0)) - np.float32(1.0)) * np.float32(0.5)).astype(np.int64)
+    for _ in range(4):                                   # the kernel's while loops: at most one step each way is ever needed
+        cb = np.where((cb + 1) * (cb + 2) // 2 <= t, cb + 1, cb)
+    for _ in range(4):
+        cb = np.where(cb * (cb + 1) // 2 > t, cb - 1, cb)
+    rb = t - cb * (cb + 1) // 2
+    assert (rb >= 0).all() and (rb <= cb).all() and (cb < nb).all()
+    assert np.unique(cb * nb + rb).size == t.size
+    # one correcting step suffices
+    cb0 = ((np.sqrt(np.float32(8.0) * t.astype(np.float32) + np.float32(1.0)) - np.float32(1.0)) * np.float32(0.5)).astype(np.int64)
+    assert np.abs(cb0 - cb).max() <= 1
