@@ -2016,9 +2016,9 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     else k_wgrad_multi<64, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
   } else if (mfma_ok && cnt && (flags & (1 << 24)) && (Cin % 128 == 0 || Cout % 128 == 0 || wgrad_tr64())) {
     // split-bf16 over the pair lists (r3 nbench: 128 x 128 tiles 119 -> 95 us on 15k rows 128->128, 111 -> 89 / 109 -> 87 on
-    // the 256- and 512-channel levels; 64 x 64 tiles — one accumulator per wave, a dependent MFMA chain — lose to the fp32
-    // kernel and stay there).  128-channel Cin tiles only while they still fill the chip (862 rows, 512->128: 216 workgroups
-    // of 128 x 128 tiles 49 us, fp32 36 us)
+    // the 256- and 512-channel levels; 64 x 64 tiles — one accumulator per wave, a dependent MFMA chain — lost to the fp32
+    // kernel with the r3 kernel and win with k_wgrad_x6t: wgrad_tr64()).  128-channel Cin tiles only while they still fill the
+    // chip (862 rows, 512->128: 216 workgroups of 128 x 128 tiles 49 us, fp32 36 us)
     const int bn = (Cout % 128 == 0) ? 128 : 64;
     int bm = (Cin % 128 == 0) ? 128 : 64;
     if (bm == 128 && bn == 128 && (int64_t)S * K * (Cin / 128) * (Cout / 128) < 512) bm = 64;
