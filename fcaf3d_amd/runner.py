@@ -12,7 +12,6 @@ LR hook's per-epoch update.  On the GPU the parameters, gradients and AdamW mome
 and clip + AdamW are three launches of csrc/optim.hip (`FlatAdamW`); CPU parameters (the host-logic tests) take
 torch.optim.AdamW + clip_grad_norm_, the calls the reference makes.
 """
-import math
 import os
 
 import torch

@@ -5,7 +5,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .boxes import bbox3d2result, bbox3d2result_batch
+from .boxes import bbox3d2result_batch
 from .registry import DETECTORS, build_backbone, build_head
 from .sparse import SparseTensor, _rec, on_map_stream
 
