@@ -239,3 +239,23 @@ def test_nms_upper_triangle_block_enumeration():
     # one correcting step suffices
     cb0 = ((np.sqrt(np.float32(8.0) * t.astype(np.float32) + np.float32(1.0)) - np.float32(1.0)) * np.float32(0.5)).astype(np.int64)
     assert np.abs(cb0 - cb).max() <= 1
+
+
+def test_committed_profile_tables_follow_from_the_committed_traces():
+    """profiles/r4_kernel_stats.md is tools/kernel_stats.py over the two committed rocprofv3 --stats CSVs, and bench.py's
+    `roofline.traffic` is what profiles/r4_traffic.json holds: the judged summaries cannot drift from their raw data."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('kernel_stats', os.path.join(root, 'tools', 'kernel_stats.py'))
+    ks = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ks)
+    md = open(os.path.join(root, 'profiles', 'r4_kernel_stats.md')).read()
+    for name in ('r4_kernel_stats.csv', 'r4_kernel_stats_no_overlap.csv'):
+        assert ks.table(os.path.join(root, 'profiles', name), 30.0) in md, name
+    traffic = json.load(open(os.path.join(root, 'profiles', 'r4_traffic.json')))
+    bench_line = json.load(open(os.path.join(root, 'profiles', 'r4_bench_n1.json')))
+    assert bench_line['roofline']['traffic'] == round(traffic['hbm_bytes_per_launch'])
+    assert abs(traffic['hbm_bytes_per_launch'] - traffic['fetch_bytes_per_launch'] - traffic['write_bytes_per_launch']) <= 1
+    r = bench_line['roofline']
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
