@@ -812,6 +812,73 @@ __global__ void k_sum_pairs(const float* __restrict__ part, const int* __restric
   *reinterpret_cast<f32x4*>(out + o * Cout + c4 * 4) = a;
 }
 
+// ---- r5: the same two sums, leaving the BatchNorm statistics of what they write -----------------------------------------------
+// A workgroup = 16 float4 lanes (64 channels) x 16 row lanes; grid (row blocks of RB rows, C / 64).  Besides out, every workgroup
+// writes the column sums of its rows' results and of their squares: stats[row block][2][C] (norm.hip k_bn2_apply / k_bn2_finalize
+// combine them in fp64).  RB = fc_stat_rb(n): row blocks are sized so that small matrices leave <= 64 of them (then the
+// BatchNorm that follows is ONE launch) while every thread still has at most a handful of rows.
+__host__ __device__ static inline int fc_stat_rb(int64_t n) { return n <= 1024 ? 16 : (n <= 4096 ? 64 : 32); }
+
+__device__ __forceinline__ void stat_block_reduce(f32x4 a1, f32x4 a2, float* __restrict__ stats, int C, f32x4* sm /*[16][2][16]*/) {
+  const int lane = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  sm[(rl * 2 + 0) * 16 + lane] = a1;
+  sm[(rl * 2 + 1) * 16 + lane] = a2;
+  __syncthreads();
+  if (rl < 2) {                                  // row lane 0 adds the sums, row lane 1 the sums of squares (fixed order)
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sm[(q * 2 + rl) * 16 + lane];
+    *reinterpret_cast<f32x4*>(stats + ((int64_t)blockIdx.x * 2 + rl) * C + blockIdx.y * 64 + lane * 4) = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sum_parts_stats(const float* __restrict__ part, float* __restrict__ out, int64_t n, int C, int S,
+                                                         int RB, float* __restrict__ stats) {
+  __shared__ f32x4 sm[16 * 2 * 16];
+  const int lane = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+  const int c = blockIdx.y * 64 + lane * 4;
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
+  for (int64_t r = r0 + rl; r < r0 + RB && r < n; r += 16) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(part + r * C + c);
+    for (int z = 1; z < S; ++z) a += *reinterpret_cast<const f32x4*>(part + ((int64_t)z * n + r) * C + c);
+    *reinterpret_cast<f32x4*>(out + r * C + c) = a;
+    a1 += a;
+    a2 += a * a;
+  }
+  stat_block_reduce(a1, a2, stats, C, sm);
+}
+
+__global__ __launch_bounds__(256) void k_sum_pairs_stats(const float* __restrict__ part, const int* __restrict__ pos, float* __restrict__ out,
+                                                         int64_t n_out, int K, int Cout, int RB, float* __restrict__ stats) {
+  __shared__ f32x4 sm[16 * 2 * 16];
+  const int lane = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+  const int c = blockIdx.y * 64 + lane * 4;
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
+  for (int64_t o = r0 + rl; o < r0 + RB && o < n_out; o += 16) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};                           // as k_sum_pairs: offsets in order, nine in flight
+    for (int k0 = 0; k0 < K; k0 += 9) {
+      int j[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) j[u] = k0 + u < K ? pos[(int64_t)(k0 + u) * n_out + o] : -1;
+      f32x4 v[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const float* src = j[u] >= 0 ? part + ((int64_t)(k0 + u) * n_out + j[u]) * Cout + c : g_zero_row + lane * 4;
+        v[u] = *reinterpret_cast<const f32x4*>(src);
+      }
+#pragma unroll
+      for (int u = 0; u < 9; ++u)
+        if (j[u] >= 0) a += v[u];
+    }
+    *reinterpret_cast<f32x4*>(out + o * Cout + c) = a;
+    a1 += a;
+    a2 += a * a;
+  }
+  stat_block_reduce(a1, a2, stats, Cout, sm);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Stem convolution (Cin = 3 colour channels -> 64, k3 s2; me_resnet.py:19-21): bound by the 148 MB output
 // write.  64 output rows per workgroup; the 27x3 gathered inputs of every row and the whole (81,64) kernel sit in
@@ -1181,7 +1248,8 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
 // and LDS-padding occupancy caps all lose or are neutral — profiles/r1_conv_pmc.md — and were removed in r2)
 static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr,
                             const int* out_index, const int* cnt, float* dst, int64_t n_rows, int K, int Cin, int Cout,
-                            hipStream_t stream, bool wt = false, bool apl = false) {
+                            hipStream_t stream, bool wt = false, bool apl = false, float* stats = nullptr) {
+  if (stats && (apl || pipe < 3 || bm < 128 || cnt || grid.z != 1)) return FC_EINVAL;      // the statistics epilogue lives in k_conv_x6
   if (apl) {                                     // the input is pre-split planes (k_x6_planes): split-bf16 kernel with weight images only
     if (pipe != 4 || bm < 128) return FC_EINVAL;
     const u32x4* pl = reinterpret_cast<const u32x4*>(in);
@@ -1213,18 +1281,20 @@ static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in
   if (wt && !nbr) return FC_EINVAL;              // transposed weights: neighbour-table / pair-list launches only
   if (wt && pipe == 2) pipe = 0;                 // the LDS-DMA image cannot be transposed in flight
   if (pipe >= 3 && bm >= 128) {                  // split-bf16 kernel; pipe 4: the weights are a pre-split image
+#define FC_ARGS6 <<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout, stats)
 #define FC_LAUNCH_X6(BM_, BN_, WM_)                                              \
   do {                                                                           \
-    if (pipe == 4 && nbr) k_conv_x6<BM_, BN_, true, WM_, 2> FC_ARGS;       \
-    else if (pipe == 4) k_conv_x6<BM_, BN_, false, WM_, 2> FC_ARGS;        \
-    else if (wt) k_conv_x6<BM_, BN_, true, WM_, 1> FC_ARGS;                \
-    else if (nbr) k_conv_x6<BM_, BN_, true, WM_, 0> FC_ARGS;               \
-    else k_conv_x6<BM_, BN_, false, WM_, 0> FC_ARGS;                       \
+    if (pipe == 4 && nbr) k_conv_x6<BM_, BN_, true, WM_, 2> FC_ARGS6;       \
+    else if (pipe == 4) k_conv_x6<BM_, BN_, false, WM_, 2> FC_ARGS6;        \
+    else if (wt) k_conv_x6<BM_, BN_, true, WM_, 1> FC_ARGS6;                \
+    else if (nbr) k_conv_x6<BM_, BN_, true, WM_, 0> FC_ARGS6;               \
+    else k_conv_x6<BM_, BN_, false, WM_, 0> FC_ARGS6;                       \
   } while (0)
     if (bm == 256) FC_LAUNCH_X6(256, 64, 4);
     else if (bn == 128) FC_LAUNCH_X6(128, 128, 2);
     else FC_LAUNCH_X6(128, 64, 2);
 #undef FC_LAUNCH_X6
+#undef FC_ARGS6
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
@@ -1265,9 +1335,16 @@ static int sum_parts(const float* part, float* out, int64_t n_out, int Cout, int
   return FC_OK;
 }
 
+static int sum_parts_stats(const float* part, float* out, int64_t n_out, int Cout, int S, float* stats, hipStream_t stream) {
+  const int rb = fc_stat_rb(n_out);
+  k_sum_parts_stats<<<dim3((unsigned)fc_cdiv(n_out, rb), Cout / 64), 256, 0, stream>>>(part, out, n_out, Cout, S, rb, stats);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
 static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const int* out_index,
                          float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
-                         int64_t ws_bytes, hipStream_t stream) {
+                         int64_t ws_bytes, hipStream_t stream, float* stats = nullptr) {
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (n_out == 0) return FC_OK;                 // nothing to write (an empty table may well be a NULL pointer)
   if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
@@ -1282,6 +1359,7 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
   if (wt && !nbr) return FC_EINVAL;
   bool mfma_ok; int bm, bn, S;
   conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S);
+  if (stats && (!mfma_ok || !(flags & (1 << 24)) || (flags & FC_CONV_APL))) return FC_EINVAL;      // see fc_conv_stats_blocks
   if (!mfma_ok) {
     if (out_index || (flags & ((1 << 26) | FC_CONV_APL))) return FC_EINVAL;      // sorted-row tables, weight images and planes are MFMA-path features
     k_conv_fma<<<(unsigned)fc_cdiv(n_out * Cout, 256), 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout, wt ? 1 : 0);
@@ -1292,9 +1370,29 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
   int rc = launch_conv_mfma(conv_pipe(flags, grid), bm, bn, grid, in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream, wt,
-                            (flags & FC_CONV_APL) != 0);
+                            (flags & FC_CONV_APL) != 0, S > 1 ? nullptr : stats);
   if (rc != FC_OK) return rc;
-  return S > 1 ? sum_parts(dst, out, n_out, Cout, S, stream) : FC_OK;
+  if (S > 1) return stats ? sum_parts_stats(dst, out, n_out, Cout, S, stats, stream) : sum_parts(dst, out, n_out, Cout, S, stream);
+  return FC_OK;
+}
+
+// Row blocks of the statistics table a convolution launch leaves for the BatchNorm behind it (fc_conv_fwd_stats /
+// fc_conv_fwd_pairs_tiles_stats: stats[blocks][2][Cout], column sums of the result and of its square per row block); 0: this launch
+// has no statistics epilogue (not the split-bf16 MFMA route).  pairs != 0: the per-offset pair-list route.
+int64_t fc_conv_stats_blocks(int64_t n_out, int K, int Cin, int Cout, int flags, int pairs) {
+  if (n_out < 1 || !(flags & (1 << 24)) || (flags & FC_CONV_APL)) return 0;
+  if (pairs) return (Cin % 32 == 0 && Cout % 64 == 0) ? fc_cdiv(n_out, fc_stat_rb(n_out)) : 0;
+  bool mfma_ok; int bm, bn, S;
+  conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S);
+  if (!mfma_ok || bm < 128) return 0;
+  return S > 1 ? fc_cdiv(n_out, fc_stat_rb(n_out)) : fc_cdiv(n_out, bm);
+}
+
+int fc_conv_fwd_stats(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
+                      int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, float* stats,
+                      hipStream_t stream) {
+  if (stats && fc_conv_stats_blocks(n_out, K, Cin, Cout, flags, 0) == 0) return FC_EINVAL;
+  return conv_fwd_impl(in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream, stats);
 }
 
 // flags: bit0 = force the generic FMA kernel.
@@ -1352,9 +1450,9 @@ int64_t fc_conv_fwd_pairs_ws_bytes(int64_t n_out, int K, int Cout) {
 }
 
 // Convolution over the exact pair lists: per offset a compacted gather-GEMM into the workspace, then a gather-sum.
-int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
+static int conv_fwd_pairs_impl(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
                             float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
-                            void* ws, int64_t ws_bytes, hipStream_t stream) {
+                            void* ws, int64_t ws_bytes, hipStream_t stream, float* stats) {
   if (n_in < 0 || n_out < 0 || K < 1 || K > 65535 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (!pair_in || !pair_cnt || !pair_pos) return FC_EINVAL;
   if (Cin % 32 != 0 || Cout % 64 != 0) return FC_EINVAL;       // MFMA shapes only; callers use fc_conv_fwd otherwise
@@ -1370,9 +1468,29 @@ int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in,
     int rc = launch_conv_mfma((live_tiles > 0 || (flags & (1 << 24))) ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt, (flags & FC_CONV_APL) != 0);
     if (rc != FC_OK) return rc;
   }
-  k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);
+  if (stats) {
+    const int rb = fc_stat_rb(n_out);
+    k_sum_pairs_stats<<<dim3((unsigned)fc_cdiv(n_out, rb), Cout / 64), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout, rb, stats);
+  } else {
+    k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);
+  }
   FC_CHECK_LAUNCH();
   return FC_OK;
+}
+
+int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
+                            float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
+                            void* ws, int64_t ws_bytes, hipStream_t stream) {
+  return conv_fwd_pairs_impl(in, W, pair_in, pair_cnt, pair_pos, out, n_in, n_out, K, Cin, Cout, live_tiles, flags, ws, ws_bytes, stream,
+                             nullptr);
+}
+
+int fc_conv_fwd_pairs_tiles_stats(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
+                                  float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
+                                  void* ws, int64_t ws_bytes, float* stats, hipStream_t stream) {
+  if (stats && !(flags & (1 << 24))) return FC_EINVAL;
+  return conv_fwd_pairs_impl(in, W, pair_in, pair_cnt, pair_pos, out, n_in, n_out, K, Cin, Cout, live_tiles, flags, ws, ws_bytes, stream,
+                             stats);
 }
 
 int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,

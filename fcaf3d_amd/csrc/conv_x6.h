@@ -133,7 +133,7 @@ template <int BM, int BN, bool HAS_NBR, int WM, int BSRC>
 __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_conv_x6(
     const float* __restrict__ in, const float* __restrict__ W, const int* __restrict__ nbr,
     const int* __restrict__ out_index, const int* __restrict__ cnt, float* __restrict__ out, int64_t n_out, int K, int Cin,
-    int Cout) {
+    int Cout, float* __restrict__ stats) {
   constexpr int WN = 4 / WM;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);      // 32x32 MFMA tiles per wave
   constexpr int RW = BM / WM;                                  // rows of a wave's part of the tile
@@ -373,6 +373,41 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); lane r of sub-tile j holds
   // column 2 r + j of the wave's 64-column group (TN == 1: j = wc)
+  if (stats) {
+    // r5: BatchNorm statistics out of the epilogue (unsplit neighbour-table / dense launches only: the accumulators ARE the
+    // results): column sums of x and x^2 over this tile's rows -> stats[tile][2][Cout] (rows past the end and absent
+    // neighbours hold exact zeros).  Lane: 16 TM values per column; the other half-wave holds the same columns' other rows;
+    // the WM waves along the rows meet in LDS (the stage buffers are free now).  Fixed order: deterministic.
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; a += v; b += v * v; }
+      s1[j] = a + __shfl_xor(a, 32, 64);
+      s2[j] = b + __shfl_xor(b, 32, 64);
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(As);                 // [WM][BN][2]
+    if (h == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int cl = bgrp * 64 + 2 * r + (TN == 2 ? j : wc);
+        red[(wr * BN + cl) * 2 + 0] = s1[j];
+        red[(wr * BN + cl) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2 + 0]; b += red[(w * BN + tid) * 2 + 1]; }
+      stats[((int64_t)blockIdx.x * 2 + 0) * Cout + n0 + tid] = a;
+      stats[((int64_t)blockIdx.x * 2 + 1) * Cout + n0 + tid] = b;
+    }
+  }
   float* dst = out + (int64_t)z * n_out * Cout + n0 + bgrp * 64 + 2 * r + (TN == 2 ? 0 : wc);
   int orow[TM][16];
 #pragma unroll

@@ -25,19 +25,29 @@ enum : int64_t {
   OP_HEAD_BWD, OP_WGRAD, OP_BN_BWD, OP_NORM_BWD, OP_MAXPOOL_BWD, OP_STEM_WGRAD, OP_GATHER, OP_ADD, OP_SMALL_GRADS,
   OP_PERMUTE_GENT, OP_HEAD_WFIN, OP_COPY, OP_COL_SUM, OP_ROW_SUM
 };
-constexpr int OPW = 20;            // int64 words per operator
+constexpr int OPW = 24;            // int64 words per operator
 constexpr int MAPW = 20;           // int64 words per kernel-map descriptor
 constexpr int NSTREAM = 3;
 constexpr int MAX_EVENTS = 64;
 constexpr int CONV_X6 = (1 << 24) | (1 << 26), WGRAD_X6 = 1 << 24;
 
-hipEvent_t g_events[MAX_EVENTS];
-bool g_events_ready = false;
+// one event set per DEVICE (an event belongs to the device that was current when it was created; a process that drives
+// detectors on two devices must not share them — ADVICE r4).  fc_exec is NOT re-entrant per device: one thread per device at a
+// time (the reference's loop is one Python thread per process, SURVEY.md 8(b) "Threading").
+constexpr int MAX_DEVICES = 16;
+hipEvent_t g_events_dev[MAX_DEVICES][MAX_EVENTS];
+bool g_events_ready[MAX_DEVICES] = {};
+thread_local hipEvent_t* g_events = nullptr;      // the current call's set
 
 int ensure_events() {
-  if (g_events_ready) return 0;
-  for (int i = 0; i < MAX_EVENTS; ++i) FC_HIP(hipEventCreateWithFlags(&g_events[i], hipEventDisableTiming));
-  g_events_ready = true;
+  int dev = 0;
+  FC_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEVICES) return FC_EINVAL;
+  if (!g_events_ready[dev]) {
+    for (int i = 0; i < MAX_EVENTS; ++i) FC_HIP(hipEventCreateWithFlags(&g_events_dev[dev][i], hipEventDisableTiming));
+    g_events_ready[dev] = true;
+  }
+  g_events = g_events_dev[dev];
   return 0;
 }
 
@@ -91,10 +101,17 @@ __global__ void k_permute_gent(const float* __restrict__ src, float* __restrict_
 }
 
 // the packed head kernel's gradient: sum of the per-level partials (nl, R, ld) -> centerness (R, 1), reg (R, n_reg), cls (R, n_cls)
+// ... and (r5) the class-bias gradient: sum over the levels of bias_part (nl, n_cls), the column sums fc_head_split_bwd_sums left
 __global__ void k_head_wfin(const float* __restrict__ part, int nl, int R, int ld, int n_reg, int n_cls, float* __restrict__ g_cent,
-                            float* __restrict__ g_reg, float* __restrict__ g_cls) {
+                            float* __restrict__ g_reg, float* __restrict__ g_cls, const float* __restrict__ bias_part,
+                            float* __restrict__ g_bias) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int ncol = 1 + n_reg + n_cls;
+  if (g_bias && t < n_cls) {
+    float b = 0.f;
+    for (int l = 0; l < nl; ++l) b += fc_ld(&bias_part[l * n_cls + t]);
+    g_bias[t] = b;
+  }
   if (t >= R * ncol) return;
   const int r = t / ncol, c = t % ncol;
   float s = 0.f;
@@ -125,6 +142,7 @@ __global__ __launch_bounds__(1024) void k_col_sum(const float* __restrict__ x, i
 }
 
 struct Ctx {
+  const int64_t* ops;            // the WHOLE operator list (an operator may refer to its producer by index)
   const int64_t* addr;
   const int64_t* dims;
   const int64_t* maps;
@@ -166,6 +184,18 @@ int run_op(Ctx& c, const int64_t* op) {
 
 template <class T>
 inline T* P(const Ctx& c, int64_t idx) { return idx < 0 ? nullptr : reinterpret_cast<T*>(c.addr[idx]); }
+
+// Row blocks of the statistics table the convolution operator `pop` leaves (its word 10 = address index + 1 of the table): the
+// route logic of OP_CONV below, as a pure function of the step's tables — the BatchNorm operator behind it may sit in another
+// segment of a segmented run, so nothing is remembered from the launch.
+int64_t stats_blocks_of(const Ctx& c, const int64_t* pop) {
+  const int Cin = (int)pop[8], Cout = (int)pop[9];
+  const int fl = c.flags | CONV_X6;
+  if (pop[4] < 0) return fc_conv_stats_blocks(c.dims[pop[7]], 1, Cin, Cout, fl, 0);
+  const int64_t* m = c.maps + pop[4] * MAPW;
+  const bool bwd = pop[5] != 0;
+  return fc_conv_stats_blocks(bwd ? m[0] : m[1], (int)m[2], Cin, Cout, fl, (m[19] & (bwd ? 2 : 1)) ? 1 : 0);
+}
 
 inline bool want_ws(Ctx& c, int s, int64_t bytes) {     // true: the launch may go ahead
   if (bytes > c.need[s]) c.need[s] = bytes;
@@ -212,14 +242,15 @@ int run_op_impl(Ctx& c, const int64_t* op) {
       return fc_maxpool_fwd(P<const float>(c, op[2]), reinterpret_cast<const int*>(m[3]), m[1], (int)m[2], (int)op[4], P<float>(c, op[5]),
                             P<int>(c, op[6]), st);
     }
-    case OP_CONV: {  // in, img, map (-1: dense GEMM over n rows), dir, out, n(dim, dense only), Cin, Cout
+    case OP_CONV: {  // in, img, map (-1: dense GEMM over n rows), dir, out, n(dim, dense only), Cin, Cout, statistics table + 1 | 0
       const int Cin = (int)op[8], Cout = (int)op[9];
       const int fl = c.flags | CONV_X6;
+      float* stats = (op[10] > 0 && stats_blocks_of(c, op) > 0) ? P<float>(c, op[10] - 1) : nullptr;
       if (op[4] < 0) {
         const int64_t n = c.dims[op[7]];
         if (!want_ws(c, s, fc_conv_fwd_ws_bytes(n, 1, Cin, Cout, fl))) return 0;
-        return fc_conv_fwd(P<const float>(c, op[2]), P<const float>(c, op[3]), nullptr, nullptr, P<float>(c, op[6]), n, n, 1, Cin, Cout, fl,
-                           c.ws[s], c.ws_bytes[s], st);
+        return fc_conv_fwd_stats(P<const float>(c, op[2]), P<const float>(c, op[3]), nullptr, nullptr, P<float>(c, op[6]), n, n, 1, Cin, Cout,
+                                 fl, c.ws[s], c.ws_bytes[s], stats, st);
       }
       const int64_t* m = c.maps + op[4] * MAPW;
       const bool bwd = op[5] != 0;
@@ -228,14 +259,14 @@ int run_op_impl(Ctx& c, const int64_t* op) {
       if (m[19] & (bwd ? 2 : 1)) {                       // per offset over the exact pair lists
         const int b = bwd ? 14 : 9;
         if (!want_ws(c, s, fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout))) return 0;
-        return fc_conv_fwd_pairs_tiles(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[b]),
-                                       reinterpret_cast<const int*>(m[b + 3]), reinterpret_cast<const int*>(m[b + 2]), P<float>(c, op[6]),
-                                       n_in, n_out, K, Cin, Cout, m[b + 4], fl, c.ws[s], c.ws_bytes[s], st);
+        return fc_conv_fwd_pairs_tiles_stats(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[b]),
+                                             reinterpret_cast<const int*>(m[b + 3]), reinterpret_cast<const int*>(m[b + 2]),
+                                             P<float>(c, op[6]), n_in, n_out, K, Cin, Cout, m[b + 4], fl, c.ws[s], c.ws_bytes[s], stats, st);
       }
       if (!want_ws(c, s, fc_conv_fwd_ws_bytes(n_out, K, Cin, Cout, fl))) return 0;
-      return fc_conv_fwd(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[bwd ? 7 : 5]),
-                         reinterpret_cast<const int*>(m[bwd ? 8 : 6]), P<float>(c, op[6]), n_in, n_out, K, Cin, Cout, fl, c.ws[s],
-                         c.ws_bytes[s], st);
+      return fc_conv_fwd_stats(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[bwd ? 7 : 5]),
+                               reinterpret_cast<const int*>(m[bwd ? 8 : 6]), P<float>(c, op[6]), n_in, n_out, K, Cin, Cout, fl, c.ws[s],
+                               c.ws_bytes[s], stats, st);
     }
     case OP_BN_FWD: {  // x, n(dim), C, eps, gamma, beta, res, act, momentum, y, mean, var, cnt, rmean, rvar, nbt, train
       const int64_t n = c.dims[op[3]];
@@ -247,19 +278,20 @@ int run_op_impl(Ctx& c, const int64_t* op) {
                                P<const float>(c, op[6]), P<const float>(c, op[7]), P<const float>(c, op[8]), (int)op[9], P<float>(c, op[11]),
                                st);
       }
-      if (n * C <= c.bn_small_elems) {
-        if (!want_ws(c, s, fc_bn_small_ws_bytes(C))) return 0;
-        return fc_bn_act_train_fwd(P<const float>(c, op[2]), n, C, eps, P<const float>(c, op[6]), P<const float>(c, op[7]),
-                                   P<const float>(c, op[8]), (int)op[9], mom, P<float>(c, op[11]), P<float>(c, op[12]), P<float>(c, op[13]),
-                                   P<float>(c, op[14]), P<float>(c, op[15]), P<float>(c, op[16]), P<long long>(c, op[17]), c.ws[s],
-                                   c.ws_bytes[s], st);
+      // training: statistics from the producer's epilogue when the operator names one (word 19 = producer index + 1, word 20 =
+      // column groups per channel) and that launch has a statistics epilogue; else computed from x (fc_bn_train_fwd)
+      const float* part = nullptr;
+      int64_t nbp = 0;
+      if (op[19] > 0) {
+        const int64_t* pop = c.ops + (op[19] - 1) * OPW;
+        nbp = pop[10] > 0 ? stats_blocks_of(c, pop) : 0;
+        if (nbp > 0) part = P<const float>(c, pop[10] - 1);
       }
-      if (!want_ws(c, s, fc_bn_stats_ws_bytes(n, C))) return 0;
-      int rc = fc_bn_stats_train(P<const float>(c, op[2]), n, C, mom, P<float>(c, op[12]), P<float>(c, op[13]), P<float>(c, op[14]),
-                                 P<float>(c, op[15]), P<float>(c, op[16]), P<long long>(c, op[17]), c.ws[s], c.ws_bytes[s], st);
-      if (rc) return rc;
-      return fc_norm_act_fwd(P<const float>(c, op[2]), nullptr, 0, n, C, P<const float>(c, op[12]), P<const float>(c, op[13]), eps,
-                             P<const float>(c, op[6]), P<const float>(c, op[7]), P<const float>(c, op[8]), (int)op[9], P<float>(c, op[11]), st);
+      if (!want_ws(c, s, fc_bn_train_ws_bytes(n, C))) return 0;
+      return fc_bn_train_fwd(P<const float>(c, op[2]), n, C, eps, P<const float>(c, op[6]), P<const float>(c, op[7]),
+                             P<const float>(c, op[8]), (int)op[9], mom, P<float>(c, op[11]), P<float>(c, op[12]), P<float>(c, op[13]),
+                             P<float>(c, op[14]), P<float>(c, op[15]), P<float>(c, op[16]), P<long long>(c, op[17]), part, nbp,
+                             op[20] > 0 ? (int)op[20] : 1, c.bn_small_elems, c.ws[s], c.ws_bytes[s], st);
     }
     case OP_UNION_FWD: {  // fa, fb, rows, n_a(dim), n_b(dim), n_union(dim), C, out:  out[:n_a] = fa, rest 0, out[rows[i]] += fb[i]
       if (c.dry) return 0;
@@ -283,7 +315,15 @@ int run_op_impl(Ctx& c, const int64_t* op) {
       if (c.dry) return 0;
       FC_HIP(hipStreamWaitEvent(st, g_events[op[2]], 0));
       return 0;
-    case OP_HEAD_BWD: {  // y, ld, scale, bbox, g_cent, g_bbox, g_cls, n(dim), n_reg, n_cls, gy, gs_row
+    case OP_HEAD_BWD: {  // y, ld, scale, bbox, g_cent, g_bbox, g_cls, n(dim), n_reg, n_cls, gy, gs_row | -1, g_scale, bias_part
+      if (op[13] < 0) {    // with the scale / class-bias reductions of this level (fc_head_split_bwd_sums)
+        const int64_t n = c.dims[op[9]];
+        if (!want_ws(c, s, fc_head_split_bwd_sums_ws_bytes(n))) return 0;
+        return fc_head_split_bwd_sums(P<const float>(c, op[2]), (int)op[3], P<const float>(c, op[4]), P<const float>(c, op[5]),
+                                      P<const float>(c, op[6]), P<const float>(c, op[7]), P<const float>(c, op[8]), n, (int)op[10],
+                                      (int)op[11], P<float>(c, op[12]), P<float>(c, op[15]), P<float>(c, op[14]), c.ws[s],
+                                      c.ws_bytes[s], st);
+      }
       if (c.dry) return 0;
       return fc_head_split_bwd(P<const float>(c, op[2]), (int)op[3], P<const float>(c, op[4]), P<const float>(c, op[5]),
                                P<const float>(c, op[6]), P<const float>(c, op[7]), P<const float>(c, op[8]), c.dims[op[9]], (int)op[10],
@@ -308,21 +348,15 @@ int run_op_impl(Ctx& c, const int64_t* op) {
       return fc_conv_wgrad(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[3]), nullptr,
                            P<float>(c, op[5]), m[0], m[1], K, Cin, Cout, fl, c.ws[s], c.ws_bytes[s], st);
     }
-    case OP_BN_BWD: {  // x, y, gy, n(dim), C, mean, var, cnt, eps, gamma, beta, act, gx, gres, sums
+    case OP_BN_BWD: {  // x, y, gy, n(dim), C, mean, var, cnt, eps, gamma, beta, act, gx, gres, sums, gy2 + 1 | 0
       const int64_t n = c.dims[op[5]];
       const int C = (int)op[6];
       const float eps = (float)as_double(op[10]);
-      if (n * C <= c.bn_small_elems) {
-        if (!want_ws(c, s, fc_bn_small_ws_bytes(C))) return 0;
-        return fc_bn_act_train_bwd(P<const float>(c, op[2]), P<const float>(c, op[3]), P<const float>(c, op[4]), n, C,
-                                   P<const float>(c, op[7]), P<const float>(c, op[8]), eps, P<const float>(c, op[11]),
-                                   P<const float>(c, op[12]), (int)op[13], P<float>(c, op[14]), P<float>(c, op[15]), P<float>(c, op[16]),
-                                   c.ws[s], c.ws_bytes[s], st);
-      }
-      if (!want_ws(c, s, fc_norm_act_bwd_ws_bytes(n, C, 1))) return 0;
-      return fc_norm_act_bwd(P<const float>(c, op[2]), P<const float>(c, op[3]), P<const float>(c, op[4]), nullptr, 0, n, C, 1,
-                             P<const float>(c, op[7]), P<const float>(c, op[8]), P<const float>(c, op[9]), eps, P<const float>(c, op[11]),
-                             P<const float>(c, op[12]), (int)op[13], P<float>(c, op[14]), P<float>(c, op[15]), P<float>(c, op[16]), c.ws[s],
+      if (!want_ws(c, s, fc_bn_train_ws_bytes(n, C))) return 0;
+      return fc_bn_train_bwd(P<const float>(c, op[2]), P<const float>(c, op[3]), P<const float>(c, op[4]),
+                             op[17] > 0 ? P<const float>(c, op[17] - 1) : nullptr, n, C, P<const float>(c, op[7]), P<const float>(c, op[8]),
+                             P<const float>(c, op[9]), eps, P<const float>(c, op[11]), P<const float>(c, op[12]), (int)op[13],
+                             P<float>(c, op[14]), P<float>(c, op[15]), P<float>(c, op[16]), nullptr, 0, c.bn_small_elems, c.ws[s],
                              c.ws_bytes[s], st);
     }
     case OP_NORM_BWD: {  // x, y, gy, seg, n(dim), C, nseg(dim), mean, var, cnt, eps, gamma, beta, act, gx, gres, sums
@@ -383,11 +417,12 @@ int run_op_impl(Ctx& c, const int64_t* op) {
       FC_CHECK_LAUNCH();
       return 0;
     }
-    case OP_HEAD_WFIN: {  // part, nl, R, ld, n_reg, n_cls, g_cent, g_reg, g_cls
+    case OP_HEAD_WFIN: {  // part, nl, R, ld, n_reg, n_cls, g_cent, g_reg, g_cls, bias_part | -1, g_bias | -1
       if (c.dry) return 0;
       const int total = (int)(op[4] * (1 + op[6] + op[7]));
       k_head_wfin<<<(unsigned)fc_cdiv(total, 256), 256, 0, st>>>(P<const float>(c, op[2]), (int)op[3], (int)op[4], (int)op[5], (int)op[6],
-                                                                 (int)op[7], P<float>(c, op[8]), P<float>(c, op[9]), P<float>(c, op[10]));
+                                                                 (int)op[7], P<float>(c, op[8]), P<float>(c, op[9]), P<float>(c, op[10]),
+                                                                 P<const float>(c, op[11]), P<float>(c, op[12]));
       FC_CHECK_LAUNCH();
       return 0;
     }
@@ -412,13 +447,15 @@ int fc_exec_map_words(void) { return MAPW; }
 // addr / dims / maps: HOST arrays of device addresses, row counts and kernel-map descriptors the operators index.
 // streams / ws / ws_bytes: 3 entries each (0 main, 1 head branch, 2 weight gradients).  A first pass sizes the scratch space of
 // every operator; if a stream's workspace is too small NOTHING is launched, ws_need[3] holds the required sizes and the call
-// returns -2.  cfg[0] = bn_small_elems (functional.BN_SMALL_ELEMS), cfg[1] = kernel-variant flags (functional.FLAGS).
+// returns -2.  cfg[0] = bn_small_elems (functional.BN_SMALL_ELEMS), cfg[1] = kernel-variant flags (functional.FLAGS), cfg[2] != 0:
+// probe (below), cfg[3] != 0: the sizing pass ONLY (ws_need is filled, -2 if a workspace is too small, nothing is launched).
 int fc_exec(const int64_t* ops, int64_t op_begin, int64_t op_end, const int64_t* addr, const int64_t* dims, const int64_t* maps,
             const int64_t* streams, const int64_t* ws, const int64_t* ws_bytes, int64_t* ws_need, const int64_t* cfg) {
   if (!ops || op_begin < 0 || op_end < op_begin) return FC_EINVAL;
   int rc = ensure_events();
   if (rc) return rc;
   Ctx c;
+  c.ops = ops;
   c.addr = addr; c.dims = dims; c.maps = maps;
   for (int i = 0; i < NSTREAM; ++i) {
     c.streams[i] = reinterpret_cast<hipStream_t>(streams[i]);
@@ -440,6 +477,7 @@ int fc_exec(const int64_t* ops, int64_t op_begin, int64_t op_end, const int64_t*
     if (c.need[i] > c.ws_bytes[i]) ok = false;
   }
   if (!ok) return FC_EWS;
+  if (cfg[3]) return 0;
   c.dry = false;
   for (int64_t i = op_begin; i < op_end; ++i) {
     rc = run_op(c, ops + i * OPW);

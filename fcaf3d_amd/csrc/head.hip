@@ -62,7 +62,100 @@ __global__ __launch_bounds__(256) void k_head_split_bwd(const float* __restrict_
   if (lane == 0) gscale_row[row] = s;
 }
 
+// r5: the same pass over 64 rows per workgroup (16 per wave), which ALSO leaves the column sums of gy and the sum of the per-row
+// d/dscale terms of its rows: part[block][65] = {sum over the block's rows of gy[.][lane] (lane 0..63), sum of gscale_row}.
+// The class-bias gradient (column sums of d loss / d cls_score) and the scale gradient were two single-block reductions over
+// all locations on the critical path (k_col_sum: 5 launches, 0.35 ms per step at 8 scenes, profiles/r4_kernel_stats.md).
+#define HEAD_RPB 64
+__global__ __launch_bounds__(256) void k_head_split_bwd_sums(const float* __restrict__ y, int ld, const float* __restrict__ scale,
+                                                             const float* __restrict__ bbox, const float* __restrict__ g_cent,
+                                                             const float* __restrict__ g_bbox, const float* __restrict__ g_cls,
+                                                             int64_t n, int n_reg, int n_cls, float* __restrict__ gy,
+                                                             float* __restrict__ part) {
+  __shared__ float red[4][65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * HEAD_RPB;
+  const float sc = scale[0];
+  float ag = 0.f, as = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < HEAD_RPB / 4; ++i) {
+    const int64_t row = base + wave + 4 * i;
+    if (row >= n) break;
+    float g = 0.f, s = 0.f;
+    if (lane == 0) {
+      g = g_cent ? g_cent[row] : 0.f;
+    } else if (lane <= n_reg) {
+      int j = lane - 1;
+      float gb = g_bbox ? g_bbox[row * n_reg + j] : 0.f;
+      if (j < 6) {
+        float e = gb * bbox[row * n_reg + j];
+        g = e * sc;
+        s = e * y[row * ld + lane];
+      } else {
+        g = gb;
+      }
+    } else if (lane <= n_reg + n_cls) {
+      g = g_cls ? g_cls[row * n_cls + (lane - 1 - n_reg)] : 0.f;
+    }
+    if (lane < ld) gy[row * ld + lane] = g;
+    ag += g;
+    as += s;
+  }
+  for (int off = 32; off > 0; off >>= 1) as += __shfl_xor(as, off, 64);
+  red[wave][lane] = ag;
+  if (lane == 0) red[wave][64] = as;
+  __syncthreads();
+  if (threadIdx.x < 65)
+    part[(int64_t)blockIdx.x * 65 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// block b < n_cls: gbias[b] = sum over the partial blocks of column 1 + n_reg + b; block n_cls: gscale[0] = sum of entry 64
+// (fixed tree order: deterministic)
+__global__ __launch_bounds__(1024) void k_head_sums_final(const float* __restrict__ part, int64_t nb, int n_reg, int n_cls,
+                                                          float* __restrict__ gbias, float* __restrict__ gscale) {
+  __shared__ float red[1024];
+  const int col = (int)blockIdx.x < n_cls ? 1 + n_reg + (int)blockIdx.x : 64;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int64_t b = threadIdx.x;
+  for (; b + 3 * 1024 < nb; b += 4 * 1024) {
+    a0 += part[b * 65 + col]; a1 += part[(b + 1024) * 65 + col]; a2 += part[(b + 2048) * 65 + col]; a3 += part[(b + 3072) * 65 + col];
+  }
+  for (; b < nb; b += 1024) a0 += part[b * 65 + col];
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if ((int)blockIdx.x < n_cls) { if (gbias) gbias[blockIdx.x] = red[0]; }
+    else if (gscale) gscale[0] = red[0];
+  }
+}
+
 extern "C" {
+
+int64_t fc_head_split_bwd_sums_ws_bytes(int64_t n) { return fc_cdiv(n > 0 ? n : 1, HEAD_RPB) * 65 * (int64_t)sizeof(float); }
+
+int fc_head_split_bwd_sums(const float* y, int ld, const float* scale_dev, const float* bbox_pred, const float* g_centerness,
+                           const float* g_bbox, const float* g_cls, int64_t n, int n_reg, int n_cls, float* gy, float* gbias,
+                           float* gscale, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (n < 0 || ld < 1 || ld > 64 || n_reg < 6 || n_cls < 1 || 1 + n_reg + n_cls > ld) return FC_EINVAL;
+  if (ws_bytes < fc_head_split_bwd_sums_ws_bytes(n)) return FC_EWS;
+  if (n == 0) {
+    if (gbias) FC_HIP(hipMemsetAsync(gbias, 0, sizeof(float) * n_cls, stream));
+    if (gscale) FC_HIP(hipMemsetAsync(gscale, 0, sizeof(float), stream));
+    return FC_OK;
+  }
+  const int64_t nb = fc_cdiv(n, HEAD_RPB);
+  float* part = (float*)ws;
+  k_head_split_bwd_sums<<<(unsigned)nb, 256, 0, stream>>>(y, ld, scale_dev, bbox_pred, g_centerness, g_bbox, g_cls, n, n_reg, n_cls,
+                                                         gy, part);
+  FC_CHECK_LAUNCH();
+  k_head_sums_final<<<(unsigned)(n_cls + 1), 1024, 0, stream>>>(part, nb, n_reg, n_cls, gbias, gscale);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
 
 int fc_head_split_fwd(const float* y, int ld, const float* bias, const float* scale_dev, int64_t n, int n_reg, int n_cls,
                       float* centerness, float* bbox_pred, float* cls_score, float* cls_max, hipStream_t stream) {

@@ -211,8 +211,11 @@ __global__ void k_norm_act_fwd(const float* __restrict__ x, const int* __restric
 // backward pass 1: per (block, seg, channel) partial sums of g' and g'*xhat, g' = gy * act'(y)
 // part layout: [block][seg][2][C]
 // y == NULL (no residual in the forward): act'(.) is recomputed from x with gamma / beta (bn_pre) instead of read from y
+// gy2 (nullable, r5): a second contribution to the incoming gradient — g = gy + gy2 is formed on the fly here and, with the same
+// operands in the same order, in the apply kernels: the executor no longer materialises the sum where a normalised tensor has
+// two consumers (k_add_inplace: 22 launches per step in r4)
 __global__ void k_norm_bwd_partial(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
-                                   const int* __restrict__ seg, int seg_stride, int64_t n, int C, int nseg,
+                                   const float* __restrict__ gy2, const int* __restrict__ seg, int seg_stride, int64_t n, int C, int nseg,
                                    const float* __restrict__ mean, const float* __restrict__ var, float eps, int act,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    int64_t rpb, float* __restrict__ part) {
@@ -244,7 +247,7 @@ __global__ void k_norm_bwd_partial(const float* __restrict__ x, const float* __r
       for (int64_t rb = r0 + rl; rb < r1; rb += 4 * nrl) {
         // branch-free batch: the 4 x (x, gy, y) rows are requested together (rows past the range re-read row r0 and are
         // dropped by `ok`), r3 — a `continue` in front of each load serialised them
-        float4 xv[4], gv[4], yv[4];
+        float4 xv[4], gv[4], yv[4], g2[4];
         bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -254,12 +257,14 @@ __global__ void k_norm_bwd_partial(const float* __restrict__ x, const float* __r
           if (chk) ok[u] = ok[u] && seg[rc * seg_stride] == s;
           xv[u] = *reinterpret_cast<const float4*>(x + rc * C + cl * 4);
           gv[u] = *reinterpret_cast<const float4*>(gy + rc * C + cl * 4);
+          if (gy2) g2[u] = *reinterpret_cast<const float4*>(gy2 + rc * C + cl * 4);
           if (from_y) yv[u] = *reinterpret_cast<const float4*>(y + rc * C + cl * 4);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (!ok[u]) continue;
           float4 g = gv[u];
+          if (gy2) { g.x += g2[u].x; g.y += g2[u].y; g.z += g2[u].z; g.w += g2[u].w; }
           if (from_y) {
             g.x *= act_bwd_from_y(yv[u].x, act); g.y *= act_bwd_from_y(yv[u].y, act);
             g.z *= act_bwd_from_y(yv[u].z, act); g.w *= act_bwd_from_y(yv[u].w, act);
@@ -300,7 +305,7 @@ __global__ void k_norm_bwd_partial(const float* __restrict__ x, const float* __r
 
 // backward pass 3:  gx = gamma*invstd*( g' - sum_g/cnt - xhat * sum_gx/cnt ) ; gres = g'
 __global__ void k_norm_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
-                                 const int* __restrict__ seg, int seg_stride, int64_t n, int C,
+                                 const float* __restrict__ gy2, const int* __restrict__ seg, int seg_stride, int64_t n, int C,
                                  const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                  const float* __restrict__ sums /*[seg][2][C]*/,
@@ -315,6 +320,10 @@ __global__ void k_norm_bwd_apply(const float* __restrict__ x, const float* __res
   float xv[4], gv[4], muv[4], vav[4], gam[4], bet[4] = {0.f, 0.f, 0.f, 0.f}, s1[4], s2[4], yv[4], o[4], gr[4];
   *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + r * C + c);
   *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(gy + r * C + c);
+  if (gy2) {
+    const float4 t2 = *reinterpret_cast<const float4*>(gy2 + r * C + c);
+    gv[0] += t2.x; gv[1] += t2.y; gv[2] += t2.z; gv[3] += t2.w;
+  }
   *reinterpret_cast<float4*>(muv) = *reinterpret_cast<const float4*>(mean + (int64_t)s * C + c);
   *reinterpret_cast<float4*>(vav) = *reinterpret_cast<const float4*>(var + (int64_t)s * C + c);
   *reinterpret_cast<float4*>(s1) = *reinterpret_cast<const float4*>(sums + ((int64_t)s * 2) * C + c);
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
 
 // backward launch 2: reduce the partials of k_norm_bwd_partial (nseg = 1, layout [nb][1][2][C]) and apply
 __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
-                                int64_t n, int C, int64_t rpb, const float* __restrict__ part, int nb,
+                                const float* __restrict__ gy2, int64_t n, int C, int64_t rpb, const float* __restrict__ part, int nb,
                                 const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                 float* __restrict__ gx, float* __restrict__ gres, float* __restrict__ sums /*[2][C]*/) {
@@ -653,6 +662,10 @@ __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __rest
       const int64_t rc = r < r1 ? r : r0;
       *reinterpret_cast<float4*>(xv[u]) = *reinterpret_cast<const float4*>(x + rc * C + cl * 4);
       *reinterpret_cast<float4*>(gv[u]) = *reinterpret_cast<const float4*>(gy + rc * C + cl * 4);
+      if (gy2) {
+        const float4 t2 = *reinterpret_cast<const float4*>(gy2 + rc * C + cl * 4);
+        gv[u][0] += t2.x; gv[u][1] += t2.y; gv[u][2] += t2.z; gv[u][3] += t2.w;
+      }
       if (from_y) *reinterpret_cast<float4*>(yv[u]) = *reinterpret_cast<const float4*>(y + rc * C + cl * 4);
     }
 #pragma unroll
@@ -671,6 +684,149 @@ __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __rest
       }
       *reinterpret_cast<float4*>(gx + r * C + cl * 4) = *reinterpret_cast<float4*>(o);
       if (gres) *reinterpret_cast<float4*>(gres + r * C + cl * 4) = *reinterpret_cast<float4*>(gr);
+    }
+  }
+}
+
+// ================================================================================================
+// r5: BatchNorm statistics out of the PRODUCER's epilogue.  The kernel that writes a convolution's result (the MFMA tile epilogue
+// of k_conv_x6, or the fixed-order sums k_sum_parts_stats / k_sum_pairs_stats of an offset-split / pair-list launch) also leaves,
+// per row block, the column sums of x and x^2 of the rows it wrote: part[nb][2][G * C] (plain fp32 sums over <= a few hundred
+// rows; G > 1: the (n, G C) matrix of a generative transposed convolution's GEMM viewed as (G n, C): channel c collects the
+// columns g C + c).  They are combined in fp64 in a fixed order — mean = S1 / n, var = S2 / n - mean^2 — either in the prologue
+// of the apply kernel (<= BN1_MAXB partial blocks: ONE launch per BatchNorm) or by k_bn2_finalize (two launches).  The
+// read pass over x of k_bn1_partial is gone (r4: 46 launches, 0.32 ms alone / 0.56 ms beside the weight-gradient stream).
+__device__ static inline void bn2_stats(double s1, double s2, int64_t n, float* mu, float* va) {
+  const double m = s1 / (double)n;
+  double v = s2 / (double)n - m * m;
+  if (v < 0.0) v = 0.0;
+  *mu = (float)m;
+  *va = (float)v;
+}
+
+__global__ void k_bn2_apply(const float* __restrict__ x, int64_t n, int C, int64_t rpb, const float* __restrict__ part, int nb, int G,
+                            float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                            const float* __restrict__ residual, int act, float momentum, float* __restrict__ y,
+                            float* __restrict__ mean_out, float* __restrict__ var_out, float* __restrict__ cnt_out,
+                            float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt) {
+  extern __shared__ double smd[];             // [nrl][2][C]
+  const int c4n = C / 4;
+  const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+  const int nrl = blockDim.x / c4n;
+  double a1[4] = {0., 0., 0., 0.}, a2[4] = {0., 0., 0., 0.};
+  const int GC = G * C;
+  for (int t = rl; t < nb * G; t += nrl) {            // (block, group) pairs, fixed order per row lane
+    const int b = t / G, g = t % G;
+    const float* src = part + ((int64_t)b * 2) * GC + g * C + cl * 4;
+    const float4 u = fc_ld4(src), w = fc_ld4(src + GC);
+    a1[0] += u.x; a1[1] += u.y; a1[2] += u.z; a1[3] += u.w;
+    a2[0] += w.x; a2[1] += w.y; a2[2] += w.z; a2[3] += w.w;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    smd[(rl * 2 + 0) * C + cl * 4 + j] = a1[j];
+    smd[(rl * 2 + 1) * C + cl * 4 + j] = a2[j];
+  }
+  __syncthreads();
+  float mu[4], va[4], is[4], g[4], bt[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double t1 = 0., t2 = 0.;
+    for (int q = 0; q < nrl; ++q) { t1 += smd[(q * 2 + 0) * C + cl * 4 + j]; t2 += smd[(q * 2 + 1) * C + cl * 4 + j]; }
+    bn2_stats(t1, t2, n, &mu[j], &va[j]);
+    is[j] = 1.f / sqrtf(va[j] + eps);
+    g[j] = gamma ? gamma[cl * 4 + j] : 1.f;
+    bt[j] = beta ? beta[cl * 4 + j] : 0.f;
+  }
+  if (blockIdx.x == 0 && rl == 0) {
+    *reinterpret_cast<float4*>(mean_out + cl * 4) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+    *reinterpret_cast<float4*>(var_out + cl * 4) = make_float4(va[0], va[1], va[2], va[3]);
+    if (cl == 0) { cnt_out[0] = (float)n; if (nbt) nbt[0] += 1; }
+    if (rmean) {
+      float unbias = (float)n / fmaxf((float)n - 1.f, 1.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        rmean[cl * 4 + j] = (1.f - momentum) * rmean[cl * 4 + j] + momentum * mu[j];
+        rvar[cl * 4 + j] = (1.f - momentum) * rvar[cl * 4 + j] + momentum * va[j] * unbias;
+      }
+    }
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  int64_t r1 = r0 + rpb;
+  if (r1 > n) r1 = n;
+  for (int64_t rb = r0 + rl; rb < r1; rb += 4 * (int64_t)nrl) {      // four rows in flight per thread
+    float v[4][4], rs[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = rb + (int64_t)u * nrl;
+      const int64_t rc = r < r1 ? r : r0;
+      *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(x + rc * C + cl * 4);
+      if (residual) *reinterpret_cast<float4*>(rs[u]) = *reinterpret_cast<const float4*>(residual + rc * C + cl * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = rb + (int64_t)u * nrl;
+      if (r >= r1) continue;
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = bn_pre(v[u][j], mu[j], is[j], g[j], bt[j]);
+        if (residual) o[j] += rs[u][j];
+        o[j] = act_fwd(o[j], act);
+      }
+      *reinterpret_cast<float4*>(y + r * C + cl * 4) = *reinterpret_cast<float4*>(o);
+    }
+  }
+}
+
+// many partial blocks: one 1024-thread block per 64 channels adds them (fp64, fixed order) and writes mean / biased var / count +
+// the nn.BatchNorm1d running-buffer update; follow with k_norm_act_fwd
+__global__ __launch_bounds__(1024) void k_bn2_finalize(const float* __restrict__ part, int nb, int C, int G, int64_t n, float momentum,
+                                                       float* __restrict__ mean, float* __restrict__ var, float* __restrict__ cnt,
+                                                       float* __restrict__ rmean, float* __restrict__ rvar,
+                                                       long long* __restrict__ nbt) {
+  __shared__ double r1[16][65], r2[16][65];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;
+  const int GC = G * C;
+  double a1 = 0., a2 = 0.;
+  if (c < C) {
+    double p1[4] = {0., 0., 0., 0.}, p2[4] = {0., 0., 0., 0.};      // four partial blocks in flight
+    const int total = nb * G;
+    int t = j;
+    for (; t + 48 < total; t += 64) {
+      float u[4], w[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int tt = t + 16 * q, b = tt / G, g = tt % G;
+        u[q] = fc_ld(&part[((int64_t)b * 2) * GC + g * C + c]);
+        w[q] = fc_ld(&part[((int64_t)b * 2 + 1) * GC + g * C + c]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { p1[q] += u[q]; p2[q] += w[q]; }
+    }
+    for (; t < total; t += 16) {
+      const int b = t / G, g = t % G;
+      p1[0] += fc_ld(&part[((int64_t)b * 2) * GC + g * C + c]);
+      p2[0] += fc_ld(&part[((int64_t)b * 2 + 1) * GC + g * C + c]);
+    }
+    a1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+    a2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
+  }
+  r1[j][threadIdx.x & 63] = a1;
+  r2[j][threadIdx.x & 63] = a2;
+  __syncthreads();
+  if (j == 0 && c < C) {
+    double s1 = 0., s2 = 0.;
+    for (int q = 0; q < 16; ++q) { s1 += r1[q][threadIdx.x & 63]; s2 += r2[q][threadIdx.x & 63]; }
+    float mu, va;
+    bn2_stats(s1, s2, n, &mu, &va);
+    mean[c] = mu;
+    var[c] = va;
+    if (c == 0) { cnt[0] = (float)n; if (nbt) nbt[0] += 1; }
+    if (rmean) {
+      float unbias = (float)n / fmaxf((float)n - 1.f, 1.f);
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * va * unbias;
     }
   }
 }
@@ -844,9 +1000,9 @@ int fc_bn_act_train_bwd(const float* x, const float* y, const float* gy, int64_t
   int64_t nb, rpb;
   bn1_plan(n, &nb, &rpb);
   float* part = (float*)ws;
-  k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, 0, n, C, 1, mean, var, eps, act, gamma, beta, rpb, part);
+  k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, nullptr, 0, n, C, 1, mean, var, eps, act, gamma, beta, rpb, part);
   FC_CHECK_LAUNCH();
-  k_bn1_bwd_apply<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, n, C, rpb, part, (int)nb, mean, var, eps, gamma, beta, act, gx,
+  k_bn1_bwd_apply<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, n, C, rpb, part, (int)nb, mean, var, eps, gamma, beta, act, gx,
                                                         gres, sums);
   FC_CHECK_LAUNCH();
   return FC_OK;
@@ -885,13 +1041,100 @@ int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* 
   int64_t nb, rpb;
   red_plan(n, &nb, &rpb);
   float* part = (float*)ws;
-  k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, seg, seg_stride, n, C, nseg, mean, var, eps, act, gamma,
+  k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, seg, seg_stride, n, C, nseg, mean, var, eps, act, gamma,
                                                           beta, rpb, part);
   FC_CHECK_LAUNCH();
   k_stats_final<<<(unsigned)(nseg * ((2 * C + 63) / 64)), 1024, 0, stream>>>(part, nullptr, nb, nseg, 2 * C, 2, sums, nullptr);
   FC_CHECK_LAUNCH();
-  k_norm_bwd_apply<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, y, gy, seg, seg_stride, n, C, mean, var, eps,
+  k_norm_bwd_apply<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, y, gy, nullptr, seg, seg_stride, n, C, mean, var, eps,
                                                                            gamma, beta, sums, cnt, act, gx, gres);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+// ---- r5: training-mode BatchNorm, one entry point per direction for every size ------------------------------------------------
+static void ap_plan(int64_t n, int64_t* nb, int64_t* rpb) {     // apply grid of the prologue-reducing kernels: up to 256 blocks
+  int64_t m = n > 0 ? n : 1;
+  int64_t g = fc_cdiv(m, 64);
+  if (g > 256) g = 256;
+  *rpb = fc_cdiv(m, g);
+  *nb = fc_cdiv(m, *rpb);
+}
+
+int64_t fc_bn_train_ws_bytes(int64_t n, int C) {
+  const int64_t a = fc_bn_stats_ws_bytes(n, C), b = fc_norm_act_bwd_ws_bytes(n, C, 1), c = fc_bn_small_ws_bytes(C);
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
+
+// Forward.  part == NULL: the statistics are computed here from x (n * C <= small_elems: fc_bn_act_train_fwd, else fc_bn_stats_train +
+// fc_norm_act_fwd — the r1-r4 routes).  part != NULL: nb_part row blocks of producer-written column sums [nb_part][2][groups * C]
+// (see k_bn2_apply); x is then (groups * n_rows_of_the_producer, C) = n rows.
+int fc_bn_train_fwd(const float* x, int64_t n, int C, float eps, const float* gamma, const float* beta, const float* residual,
+                    int act, float momentum, float* y, float* mean, float* var, float* cnt, float* running_mean,
+                    float* running_var, long long* num_batches_tracked, const float* part, int64_t nb_part, int groups,
+                    int64_t small_elems, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (n < 1 || act < 0 || act > 2) return FC_EINVAL;
+  if (!part) {
+    if (n * C <= small_elems)
+      return fc_bn_act_train_fwd(x, n, C, eps, gamma, beta, residual, act, momentum, y, mean, var, cnt, running_mean, running_var,
+                                 num_batches_tracked, ws, ws_bytes, stream);
+    int rc = fc_bn_stats_train(x, n, C, momentum, mean, var, cnt, running_mean, running_var, num_batches_tracked, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return fc_norm_act_fwd(x, nullptr, 0, n, C, mean, var, eps, gamma, beta, residual, act, y, stream);
+  }
+  int threads; size_t sf, sb;
+  if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
+  if (nb_part < 1 || nb_part > 0x7fffffff / 64 || groups < 1 || groups > 64) return FC_EINVAL;
+  if (nb_part <= BN1_MAXB) {
+    int64_t nb, rpb;
+    ap_plan(n, &nb, &rpb);
+    const size_t smem = (size_t)(threads / (C / 4)) * 2 * C * sizeof(double);
+    k_bn2_apply<<<(unsigned)nb, threads, smem, stream>>>(x, n, C, rpb, part, (int)nb_part, groups, eps, gamma, beta, residual, act,
+                                                        momentum, y, mean, var, cnt, running_mean, running_var, num_batches_tracked);
+    FC_CHECK_LAUNCH();
+    return FC_OK;
+  }
+  k_bn2_finalize<<<(unsigned)((C + 63) / 64), 1024, 0, stream>>>(part, (int)nb_part, C, groups, n, momentum, mean, var, cnt,
+                                                                 running_mean, running_var, num_batches_tracked);
+  FC_CHECK_LAUNCH();
+  return fc_norm_act_fwd(x, nullptr, 0, n, C, mean, var, eps, gamma, beta, residual, act, y, stream);
+}
+
+// Backward.  gy2 (nullable): a second contribution to the incoming gradient, added on the fly.  part == NULL: the sums of g' and
+// g' xhat are reduced here (two or three launches by size, as fc_bn_act_train_bwd / fc_norm_act_bwd); part != NULL: nb_part blocks
+// [nb_part][2][C] written by the producer of gy.
+int fc_bn_train_bwd(const float* x, const float* y, const float* gy, const float* gy2, int64_t n, int C, const float* mean,
+                    const float* var, const float* cnt, float eps, const float* gamma, const float* beta, int act, float* gx,
+                    float* gres, float* sums, const float* part, int64_t nb_part, int64_t small_elems, void* ws, int64_t ws_bytes,
+                    hipStream_t stream) {
+  if (n < 1 || act < 0 || act > 2) return FC_EINVAL;
+  int threads; size_t sf, sb;
+  if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
+  const float* p = part;
+  int64_t np = nb_part;
+  if (!p) {
+    const bool small = n * C <= small_elems;
+    if (ws_bytes < (small ? fc_bn_small_ws_bytes(C) : fc_norm_act_bwd_ws_bytes(n, C, 1))) return FC_EWS;
+    int64_t rpb;
+    if (small) bn1_plan(n, &np, &rpb); else red_plan(n, &np, &rpb);
+    k_norm_bwd_partial<<<(unsigned)np, threads, sb, stream>>>(x, y, gy, gy2, nullptr, 0, n, C, 1, mean, var, eps, act, gamma, beta, rpb,
+                                                            (float*)ws);
+    FC_CHECK_LAUNCH();
+    p = (const float*)ws;
+  }
+  if (np < 1) return FC_EINVAL;
+  if (np <= BN1_MAXB) {
+    int64_t nb, rpb;
+    if (!part) bn1_plan(n, &nb, &rpb); else ap_plan(n, &nb, &rpb);
+    k_bn1_bwd_apply<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, gy2, n, C, rpb, p, (int)np, mean, var, eps, gamma, beta, act, gx,
+                                                          gres, sums);
+    FC_CHECK_LAUNCH();
+    return FC_OK;
+  }
+  k_stats_final<<<(unsigned)((2 * C + 63) / 64), 1024, 0, stream>>>(p, nullptr, np, 1, 2 * C, 2, sums, nullptr);
+  FC_CHECK_LAUNCH();
+  k_norm_bwd_apply<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, y, gy, gy2, nullptr, 0, n, C, mean, var, eps, gamma, beta,
+                                                                           sums, cnt, act, gx, gres);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }

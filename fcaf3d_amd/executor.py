@@ -48,7 +48,7 @@ KEEP_STATE = False
 (OP_STEM_FWD, OP_COL_STATS, OP_NORM_FWD, OP_MAXPOOL_FWD, OP_CONV, OP_BN_FWD, OP_UNION_FWD, OP_HEAD_FWD, OP_RECORD, OP_WAIT,
  OP_HEAD_BWD, OP_WGRAD, OP_BN_BWD, OP_NORM_BWD, OP_MAXPOOL_BWD, OP_STEM_WGRAD, OP_GATHER, OP_ADD, OP_SMALL_GRADS,
  OP_PERMUTE_GENT, OP_HEAD_WFIN, OP_COPY, OP_COL_SUM, OP_ROW_SUM) = range(1, 25)
-OPW, MAPW = 20, 20
+OPW, MAPW = 24, 20
 ALIGN = 256
 S_MAIN, S_HEAD, S_WGRAD = 0, 1, 2
 EV_FORK, EV_HEAD_DONE, EV_W0, EV_W1, EV_WEND, EV_BWD0, EV_HB = 0, 8, 9, 10, 11, 12, 16       # EV_FORK + level, EV_HB + level
@@ -89,7 +89,7 @@ class NetProgram:
         self.ops_f, self.ops_b = [], []
         self.n_addr = 0
         self.static = []            # (addr index, address)
-        self.arena = {'f': [], 'b': []}     # (addr index, dims index of the row count, bytes per row)
+        self.arena = {'f': [], 'b': []}     # (addr index, dims index of the row count, bytes per row, extra bytes)
         self.alias = []             # (addr index, parent addr index, dims index of the row offset, bytes per row)
         self.dyn = {}               # name -> addr index
         self.dim_names = {}
@@ -135,9 +135,9 @@ class NetProgram:
             self.map_names[name] = len(self.map_names)
         return self.map_names[name]
 
-    def T(self, rows, cols, arena='f', elem=4):
+    def T(self, rows, cols, arena='f', elem=4, extra=0):
         i = self._new()
-        self.arena[arena].append((i, self.D(rows), cols * elem))
+        self.arena[arena].append((i, self.D(rows), cols * elem, extra))
         return i
 
     def S(self, tensor):
@@ -213,9 +213,17 @@ class NetProgram:
         small_rows = []                  # normalisation layers in BACKWARD emission order: (sums address | None, nseg dim, C, weight, bias)
         flushed = [0]
 
+        head_lvl = [None]                # the neck level whose head branch (S_HEAD) is being emitted, None: main chain
+        head_written = {}                # level -> parameters whose gradient is written on S_HEAD by that branch
+
         def wrote(*params):
             for prm in params:
                 self._pready[id(prm)] = len(Bk)
+            if head_lvl[0] is not None:
+                # written on the head stream (or behind it): final for a data-parallel bucket only once the MAIN stream has
+                # joined this branch (take(): OP_WAIT EV_HB + level) — GradientAverager.launch_next orders the collective behind
+                # the main and the weight-gradient stream, not behind S_HEAD
+                head_written.setdefault(head_lvl[0], []).extend(params)
 
         def flush_small(stream):
             """the d gamma / d beta sums of the normalisation layers whose backward has been emitted since the last flush -> their
@@ -229,27 +237,53 @@ class NetProgram:
         head_wgrads = [0]
 
         def head_wfin(stream):
-            self.emit(Bk, OP_HEAD_WFIN, stream, self.SA(head_part[1 if self.tail0 else 0].data_ptr()),
-                      self.nl - (1 if self.tail0 else 0), Cn, 64, n_reg, n_cls,
-                      self.G(nh.centerness_conv.kernel), self.G(nh.reg_conv.kernel), self.G(nh.cls_conv.kernel))
-            wrote(nh.centerness_conv.kernel, nh.reg_conv.kernel, nh.cls_conv.kernel)
+            lo = 1 if self.tail0 else 0
+            self.emit(Bk, OP_HEAD_WFIN, stream, self.SA(head_part[lo].data_ptr()), self.nl - lo, Cn, 64, n_reg, n_cls,
+                      self.G(nh.centerness_conv.kernel), self.G(nh.reg_conv.kernel), self.G(nh.cls_conv.kernel),
+                      self.SA(bias_part[lo].data_ptr()), self.G(nh.cls_conv.bias))
+            wrote(nh.centerness_conv.kernel, nh.reg_conv.kernel, nh.cls_conv.kernel, nh.cls_conv.bias)
 
         def wstream(cur):
             return S_WGRAD if self.wgrad_async else cur
 
+        grad2 = {}                       # forward tensor -> (second gradient contribution, rows, cols, stream), not yet added
+
+        def flush2(t):
+            g2, rows, cols, stream = grad2.pop(t)
+            self.emit(Bk, OP_ADD, stream, grad[t], g2, self.D(rows), cols)
+
         def accumulate(t, g, rows, cols, stream):
-            """gradient `g` (a backward tensor) arrives for forward tensor t"""
+            """gradient `g` (a backward tensor) arrives for forward tensor t.  The SECOND contribution is kept aside: if the
+            consumer of the sum is a BatchNorm backward it adds the two on the fly (norm.hip gy2) and no add pass runs; a third
+            arrival, or any other consumer, adds the first two as before (same operands, same order: same bits)"""
             if t not in grad:
                 grad[t] = g
+            elif Fn.BN_FUSE and t not in grad2:
+                grad2[t] = (g, rows, cols, stream)
             else:
+                if t in grad2:
+                    flush2(t)
                 self.emit(Bk, OP_ADD, stream, grad[t], g, self.D(rows), cols)
 
-        def take(t, rows, cols):
-            """the complete gradient of forward tensor t, for the emitter of the operator that produced t (main stream)"""
+        def take(t, rows, cols, pair=False):
+            """the complete gradient of forward tensor t, for the emitter of the operator that produced t (main stream); pair:
+            the caller adds a second contribution itself -> (gradient, second contribution | None)"""
             if t in head_grads:
                 g, lvl = head_grads.pop(t)
                 self.emit(Bk, OP_WAIT, S_MAIN, EV_HB + lvl)          # the head branch of this level has delivered
+                for prm in head_written.pop(lvl, ()):
+                    self._pready[id(prm)] = max(self._pready[id(prm)], len(Bk))
                 accumulate(t, g, rows, cols, S_MAIN)
+            if pair:
+                return grad[t], (grad2.pop(t)[0] if t in grad2 else None)
+            if t in grad2:
+                flush2(t)
+            return grad[t]
+
+        def got(t):
+            """grad[t] for a consumer on the tensor's own (head) stream"""
+            if t in grad2:
+                flush2(t)
             return grad[t]
 
         def emit_wgrad(cur, *words):
@@ -259,15 +293,18 @@ class NetProgram:
                 self.emit(Bk, OP_WAIT, S_WGRAD, ev)
             self.emit(Bk, OP_WGRAD, wstream(cur), *words)
 
+        producer = {}                    # forward tensor -> (index of the OP_CONV that wrote it, rows, columns)
+
         def conv(x, mod, mname, rows_in, rows_out, stream=S_MAIN):
             """MinkowskiConvolution on a kernel map (functional._SparseConv)"""
             Cin, Cout = mod.in_channels, mod.out_channels
             y = self.T(rows_out, Cout)
             m = self.M(mname)
             self.emit(F, OP_CONV, stream, x, self.IMG(mod.kernel, False), m, 0, y, -1, Cin, Cout)
+            producer[y] = (len(F) - 1, rows_out, Cout)
             if tr:
                 def bwd():
-                    gy = take(y, rows_out, Cout) if stream == S_MAIN else grad[y]
+                    gy = take(y, rows_out, Cout) if stream == S_MAIN else got(y)
                     gx = self.T(rows_in, Cin, 'b')
                     self.emit(Bk, OP_CONV, stream, gy, self.IMG(mod.kernel, True), m, 1, gx, -1, Cout, Cin)
                     emit_wgrad(stream, x, gy, m, self.G(mod.kernel), -1, Cin, Cout)
@@ -281,9 +318,10 @@ class NetProgram:
             index the (Cin, Cout) weight gradient goes to"""
             y = self.T(rows, Cout)
             self.emit(F, OP_CONV, stream, x, self.IMG(w_tensor, False), -1, 0, y, self.D(rows), Cin, Cout)
+            producer[y] = (len(F) - 1, rows, Cout)
             if tr:
                 def bwd():
-                    gy = take(y, rows, Cout) if stream == S_MAIN else grad[y]
+                    gy = take(y, rows, Cout) if stream == S_MAIN else got(y)
                     gx = self.T(rows, Cin, 'b')
                     self.emit(Bk, OP_CONV, stream, gy, self.IMG(w_tensor, True), -1, 1, gx, self.D(rows), Cout, Cin)
                     emit_wgrad(stream, x, gy, -1, gw_dst, self.D(rows), Cin, Cout)
@@ -305,20 +343,30 @@ class NetProgram:
             mean, var, cnt = (self.T('one', C), self.T('one', C), self.T('one', 1)) if tr else (-1, -1, -1)
             if act == relu:
                 self.relu_outs.append((y, rows, C))
+            prod_word, groups = 0, 1
+            if tr and Fn.BN_FUSE and x in producer:
+                # the convolution that wrote x leaves the column sums of x and x^2 per row block in its epilogue (conv_x6.h /
+                # k_sum_*_stats) and this BatchNorm takes its batch statistics from them: no statistics pass over x
+                pi, prows, pcols = producer[x]
+                groups = pcols // C
+                assert pcols == groups * C and groups in (1, 8)
+                # table: [blocks][2][pcols] floats, blocks <= rows / 16 + 1 (conv.hip fc_stat_rb)
+                F[pi][10] = self.T(prows, pcols // 8, extra=8 * pcols + 256) + 1
+                prod_word = pi + 1
             self.emit(F, OP_BN_FWD, stream, x, self.D(rows), C, _f(b.eps), self.S(b.weight), self.S(b.bias), -1 if res is None else res, act,
                       _f(b.momentum), y, mean, var, cnt, self.S(b.running_mean), self.S(b.running_var), self.S(b.num_batches_tracked),
-                      1 if tr else 0)
+                      1 if tr else 0, prod_word, groups)
             if tr:
                 sums = torch.zeros((2, C), dtype=torch.float32, device=self.dev)
                 si = self.S(sums)
 
                 def bwd():
                     small_rows.append((sums.data_ptr(), None, C, b.weight, b.bias))
-                    gy = take(y, rows, C) if stream == S_MAIN else grad[y]
+                    gy, gy2 = take(y, rows, C, pair=True) if stream == S_MAIN else (got(y), None)
                     gx = self.T(rows, C, 'b')
                     gres = self.T(rows, C, 'b') if res is not None else -1
                     self.emit(Bk, OP_BN_BWD, stream, x, y if res is not None else -1, gy, self.D(rows), C, mean, var, cnt, _f(b.eps),
-                              self.S(b.weight), self.S(b.bias), act, gx, gres, si)
+                              self.S(b.weight), self.S(b.bias), act, gx, gres, si, 0 if gy2 is None else gy2 + 1)
                     accumulate(x, gx, rows, C, stream)
                     if res is not None:
                         accumulate(res, gres, rows, C, stream)
@@ -392,9 +440,10 @@ class NetProgram:
         if tr:
             tape.append((S_MAIN, lambda: flush_small(S_MAIN)))           # ... after the whole neck's backward
             self.gout_idx = (self.DY('g_cent'), self.DY('g_bbox'), self.DY('g_cls'))
-            self.gs_idx = self.T('Nall', 1, 'b')
             head_part = torch.zeros((self.nl, Cn, 64), dtype=torch.float32, device=self.dev)
-            self.keep.append(head_part)
+            # per level: the column sums of d loss / d cls_score (the class-bias gradient's share), left by OP_HEAD_BWD
+            bias_part = torch.zeros((self.nl, n_cls), dtype=torch.float32, device=self.dev)
+            self.keep += [head_part, bias_part]
         x, x_rows, x_C = levels[-1]
         for i in range(self.nl - 1, -1, -1):
             if i < self.nl - 1:
@@ -457,10 +506,11 @@ class NetProgram:
                 def bwd_head(y=y, outs=outs, off=off, hs=hs, rows=x_rows, lvl=i):
                     gy = self.T(rows, 64, 'b')
                     gin = [self.AL(g, off, c) for g, c in zip(self.gout_idx, (1, n_reg, n_cls))]
-                    gs_l = self.AL(self.gs_idx, off, 1)
+                    # ... with d loss / d scale of this level and this level's share of the class-bias gradient (column sums of
+                    # d loss / d cls_score; summed over the levels by OP_HEAD_WFIN) out of the same pass (r5: they were single-block
+                    # reductions over every location, k_col_sum: 0.35 ms per step on the dependent chain)
                     self.emit(Bk, OP_HEAD_BWD, hs, y, 64, self.S(nh.scales[lvl].scale), outs[1], gin[0], gin[1], gin[2], self.D(rows), n_reg,
-                              n_cls, gy, gs_l)
-                    self.emit(Bk, OP_ROW_SUM, hs, gs_l, self.D(rows), self.G(nh.scales[lvl].scale))       # d loss / d scale of this level
+                              n_cls, gy, -1, self.G(nh.scales[lvl].scale), self.SA(bias_part[lvl].data_ptr()))
                     wrote(nh.scales[lvl].scale)
                     grad[y] = gy
                 tape.append((hs, bwd_head))
@@ -471,9 +521,6 @@ class NetProgram:
             self.emit(F, OP_WAIT, S_MAIN, EV_HEAD_DONE)
         # ---- backward program -------------------------------------------------------------------------------------------
         if tr:
-            # the class-bias gradient = column sums of d loss / d cls_score: needs nothing of the backward pass
-            self.emit(Bk, OP_COL_SUM, S_MAIN, self.gout_idx[2], self.D('Nall'), n_cls, self.G(nh.cls_conv.bias))
-            wrote(nh.cls_conv.bias)
             if self.head_overlap:
                 # the head branches depend on the loss gradients only: their backward is enqueued first, on the head stream, finest
                 # forked level first (the main chain needs that one first); each leaves the gradient of its neck tensor behind an event
@@ -491,15 +538,18 @@ class NetProgram:
                 for (_, xt, rows, C, lvl), ems in sorted(branches, key=lambda b: b[0][4]):
                     saved = grad.pop(xt, None)
                     assert saved is None
+                    head_lvl[0] = lvl
                     for e in ems:
                         e()
                     flush_small(S_HEAD)                    # this branch's normalisation layer
+                    head_lvl[0] = None
                     self.emit(Bk, OP_RECORD, S_HEAD, EV_HB + lvl)
-                    head_grads[xt] = (grad.pop(xt), lvl)
+                    head_grads[xt] = (got(xt), lvl)
+                    grad.pop(xt)
             for s, e in reversed(tape):
                 if s == S_MAIN:
                     e()
-            assert not head_grads, 'a head branch was never joined'
+            assert not head_grads and not head_written, 'a head branch was never joined'
             if not self.wgrad_async:
                 # without the weight-gradient stream the partials were written on the streams of their levels (main, head): the
                 # main stream has joined every head branch by now
@@ -526,14 +576,14 @@ class NetProgram:
         for k in ('f', 'b'):
             a = self.arena[k]
             self._ar[k] = (np.array([t[0] for t in a], dtype=np.int64), np.array([t[1] for t in a], dtype=np.int64),
-                           np.array([t[2] for t in a], dtype=np.int64))
+                           np.array([t[2] for t in a], dtype=np.int64), np.array([t[3] for t in a], dtype=np.int64))
         self._al = (np.array([t[0] for t in self.alias], dtype=np.int64), np.array([t[1] for t in self.alias], dtype=np.int64),
                     np.array([t[2] for t in self.alias], dtype=np.int64), np.array([t[3] for t in self.alias], dtype=np.int64))
         self._gr = (np.array([t[0] for t in self.grad_refs], dtype=np.int64), np.array([t[1] for t in self.grad_refs], dtype=np.int64) * 4)
         self.n_dims, self.n_maps = len(self.dim_names), len(self.map_names)
         self._ws = [None, None, None]
         self._need = np.zeros(3, dtype=np.int64)
-        self._cfg = np.array([Fn.BN_SMALL_ELEMS, Fn.FLAGS, 0], dtype=np.int64)
+        self._cfg = np.array([Fn.BN_SMALL_ELEMS, Fn.FLAGS, 0, 0], dtype=np.int64)
         self.n_conv_f = int((self.ops_f[:, 0] == OP_CONV).sum())
         self.n_conv_b = int((self.ops_b[:, 0] == OP_CONV).sum()) if len(self.ops_b) else 0
         self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
@@ -554,16 +604,16 @@ class NetProgram:
                         self._small_in = (2 * k, C)
 
     def _fill_arena(self, addr, dims, which, base):
-        idx, di, bpr = self._ar[which]
+        idx, di, bpr, ext = self._ar[which]
         if len(idx) == 0:
             return
-        sizes = (dims[di] * bpr + (ALIGN - 1)) // ALIGN * ALIGN
+        sizes = (dims[di] * bpr + ext + (ALIGN - 1)) // ALIGN * ALIGN
         offs = np.cumsum(sizes) - sizes
         addr[idx] = base + offs
 
     def _arena_bytes(self, dims, which):
-        idx, di, bpr = self._ar[which]
-        return int(((dims[di] * bpr + (ALIGN - 1)) // ALIGN * ALIGN).sum()) + ALIGN
+        idx, di, bpr, ext = self._ar[which]
+        return int(((dims[di] * bpr + ext + (ALIGN - 1)) // ALIGN * ALIGN).sum()) + ALIGN
 
     def bind(self, x, batch_size, backward):
         """per-step tables from the input SparseTensor's coordinate maps (all cached lookups after plan_maps); None if this
@@ -630,9 +680,13 @@ class NetProgram:
         wg = Fn.wgrad_stream(dev).cuda_stream if self.wgrad_async else main
         return np.array([main, head, wg], dtype=np.int64)
 
-    def _run(self, ops, addr, st, begin=0, end=None):
+    def _run(self, ops, addr, st, begin=0, end=None, size_only=False):
+        """size_only: the sizing pass alone (cfg[3]) — grows the scratch buffers to what [begin, end) needs and launches nothing.
+        The segmented data-parallel backward sizes its WHOLE list first: a buffer replaced between two segments would go back to
+        the caching allocator while kernels of an earlier segment on the head / weight-gradient stream still use it"""
         streams = self._streams()
         self._cfg[2] = 1 if 'pairs' in st else 0
+        self._cfg[3] = 1 if size_only else 0
         end = len(ops) if end is None else end
         while True:
             ws = np.array([w.data_ptr() if w is not None else 0 for w in self._ws], dtype=np.int64)
@@ -753,6 +807,7 @@ class NetProgram:
             # data parallel: every gradient bucket leaves (all-reduce on the weight-gradient stream) as soon as the operators that
             # write its parameters are enqueued — what the autograd hooks of the per-operator path do
             pos = 0
+            self._run(self.ops_b, addr, st, size_only=True)
             for upto in self._bucket_ready(av):
                 if upto > pos:
                     self._run(self.ops_b, addr, st, pos, upto)

@@ -134,27 +134,46 @@ PREBUILT = {}          # (data_ptr, K, Cin, Cout) of a kernel -> (forward image,
 PREBUILT_EVENT = None   # training loop for the duration of one step; the event the first consumer waits for
 
 
-def _conv_pairs(x, w, lists, out, n_in, n_out, K, Cin, Cout, live_tiles=0, flags=None):
+def _stats_table(n_out, K, Cin, Cout, flags, pairs, device):
+    """(table, row blocks) for the statistics epilogue of this launch (fc_conv_stats_blocks), or (None, 0) if it has none"""
+    nb = L.query('fc_conv_stats_blocks', n_out, K, Cin, Cout, flags, 1 if pairs else 0)
+    if nb <= 0:
+        return None, 0
+    return torch.empty((nb, 2, Cout), dtype=torch.float32, device=device), nb
+
+
+def _conv_pairs(x, w, lists, out, n_in, n_out, K, Cin, Cout, live_tiles=0, flags=None, stats=None):
     pi, _, pos, cnt = lists
     flags = FLAGS if flags is None else flags
     ws = L.workspace(L.query('fc_conv_fwd_pairs_ws_bytes', n_out, K, Cout), x.device)
+    if stats is not None:
+        L.call('fc_conv_fwd_pairs_tiles_stats', L.ptr(x), L.ptr(w), L.ptr(pi), L.ptr(cnt), L.ptr(pos), L.ptr(out), n_in, n_out, K,
+               Cin, Cout, live_tiles, flags, L.ptr(ws), ws.numel(), L.ptr(stats), L.stream())
+        return
     L.call('fc_conv_fwd_pairs_tiles', L.ptr(x), L.ptr(w), L.ptr(pi), L.ptr(cnt), L.ptr(pos), L.ptr(out), n_in, n_out, K, Cin,
            Cout, live_tiles, flags, L.ptr(ws), ws.numel(), L.stream())
 
 
-def _conv_fwd(x, w, nbr, out, n_in, n_out, K, Cin, Cout, out_index=None, flags=None):
+def _conv_fwd(x, w, nbr, out, n_in, n_out, K, Cin, Cout, out_index=None, flags=None, stats=None):
     flags = FLAGS if flags is None else flags
     wsb = L.query('fc_conv_fwd_ws_bytes', n_out, K, Cin, Cout, flags)
     ws = L.workspace(wsb, x.device) if wsb else None
+    if stats is not None:
+        L.call('fc_conv_fwd_stats', L.ptr(x), L.ptr(w), L.ptr(nbr), L.ptr(out_index), L.ptr(out), n_in, n_out, K, Cin, Cout, flags,
+               L.ptr(ws), ws.numel() if ws is not None else 0, L.ptr(stats), L.stream())
+        return
     L.call('fc_conv_fwd', L.ptr(x), L.ptr(w), L.ptr(nbr), L.ptr(out_index), L.ptr(out), n_in, n_out, K, Cin, Cout, flags,
            L.ptr(ws), ws.numel() if ws is not None else 0, L.stream())
 
 
 class _SparseConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, weight, kmap, n_out, training=True):
+    def forward(ctx, feats, weight, kmap, n_out, training=True, want_stats=False):
         """feats (n_in,Cin), weight (K,Cin,Cout), kmap KernelMap or None (identity, K==1).  training: the caller is in
-        training mode with gradients enabled (only then does the stem keep its gathered inputs for the weight gradient)."""
+        training mode with gradients enabled (only then does the stem keep its gathered inputs for the weight gradient).
+        want_stats (r5): a training-mode BatchNorm follows — also return the statistics table the launch's epilogue leaves
+        ((nb, 2, Cout): column sums of the result and of its square per row block; None where the launch has no such epilogue):
+        -> (out, table)"""
         _chk(feats, weight)
         feats = feats.contiguous()
         # only a LEAF kernel's gradient goes straight to AccumulateGrad (no kernel reads it before the join)
@@ -165,7 +184,7 @@ class _SparseConv(torch.autograd.Function):
         K, Cin, Cout = weight.shape
         n_in = feats.shape[0]
         out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
-        col = None
+        col = stats = None
         if (STEM_COL and training and kmap is not None and Cin == 3 and Cout == 64 and K <= 27 and not (FLAGS & 1)
                 and ctx.needs_input_grad[1]):
             # stem in training: keep the gathered inputs (n_out, 84) for the weight gradient (conv.hip: k_stem_fwd / k_stem_wgrad_col)
@@ -175,19 +194,26 @@ class _SparseConv(torch.autograd.Function):
         else:
             x6 = X6 and X6_CONV and _mfma_shape(Cin, Cout)
             w, fl = (_x6_image(weight, False), FLAGS | CONV_X6) if x6 else (weight, FLAGS)
-            if _pair_conv(kmap, n_out, Cin, Cout):
-                _conv_pairs(feats, w, kmap.pairs(), out, n_in, n_out, K, Cin, Cout, kmap.pair_tiles(), flags=fl)
+            pairs = _pair_conv(kmap, n_out, Cin, Cout)
+            stats = _stats_table(n_out, K, Cin, Cout, fl, pairs, feats.device)[0] if (want_stats and BN_FUSE and x6) else None
+            if pairs:
+                _conv_pairs(feats, w, kmap.pairs(), out, n_in, n_out, K, Cin, Cout, kmap.pair_tiles(), flags=fl, stats=stats)
             else:
                 nbr, oidx = ((kmap.sorted_fwd() if _mfma_shape(Cin, Cout) else (kmap.nbr, None))
                              if kmap is not None else (None, None))
-                _conv_fwd(feats, w, nbr, out, n_in, n_out, K, Cin, Cout, oidx, flags=fl)
+                _conv_fwd(feats, w, nbr, out, n_in, n_out, K, Cin, Cout, oidx, flags=fl, stats=stats)
         ctx.has_col = col is not None
         ctx.save_for_backward(*((feats, weight, col) if col is not None else (feats, weight)))
         ctx.kmap = kmap
+        if want_stats:
+            if stats is not None:
+                ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)
+            return out, stats
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, _gstats=None):
         feats, weight = ctx.saved_tensors[:2]
         kmap = ctx.kmap
         gout = gout.contiguous()
@@ -264,10 +290,13 @@ class _SparseConv(torch.autograd.Function):
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
             else:
                 gw = launch()
-        return gin, gw, None, None, None
+        return gin, gw, None, None, None, None
 
 
-def sparse_conv(feats, weight, kmap, n_out, training=True):
+def sparse_conv(feats, weight, kmap, n_out, training=True, want_stats=False):
+    """want_stats: -> (out, statistics table | None), see _SparseConv.forward"""
+    if want_stats:
+        return _SparseConv.apply(feats, weight, kmap, n_out, training, True)
     return _SparseConv.apply(feats, weight, kmap, n_out, training)
 
 
@@ -345,6 +374,9 @@ class _NormAct(torch.autograd.Function):
 
 
 import os as _os
+# r5: BatchNorm statistics from the producing convolution's epilogue, and the add of a two-consumer tensor's gradients inside the
+# BatchNorm backward kernels (csrc/norm.hip fc_bn_train_fwd / fc_bn_train_bwd); 0: the r4 kernels (A/B switch)
+BN_FUSE = _os.environ.get('FC_BN_FUSE', '1') != '0'
 # matrices up to this size take the two-launch BatchNorm path (measured r1: equal speed up to 1 M elements, fewer host
 # launches; at 4 M the <=64-block grid is slower than the general path)
 BN_SMALL_ELEMS = int(_os.environ.get('FC_BN_SMALL_ELEMS', 1024 * 1024))
@@ -392,10 +424,58 @@ class _BNTrainSmall(torch.autograd.Function):
         return gx, sums[1].reshape(gshape), sums[0].reshape(bshape), gres, None, None, None, None, None, None
 
 
-def bn_train(x, gamma, beta, residual, eps, act, momentum, rmean, rvar, nbt):
+class _BNTrainFused(torch.autograd.Function):
+    """Training-mode BatchNorm (+act, +residual) whose batch statistics come from the statistics table of the convolution that
+    produced x (`part` (nb, 2, groups * C): csrc/norm.hip fc_bn_train_fwd) — the route the native executor takes, so that the
+    two paths stay bit for bit equal in the forward pass; the backward pass is the r4 one (fc_bn_train_bwd without a table)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, eps, act, momentum, rmean, rvar, nbt, part, groups):
+        _chk(x, gamma, beta, residual, part)
+        x = x.contiguous()
+        n, C = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        stats = torch.empty((2, C), dtype=torch.float32, device=dev)       # [mean, var]
+        cnt = torch.empty(1, dtype=torch.float32, device=dev)
+        res = residual.contiguous() if residual is not None else None
+        g = gamma.reshape(-1).contiguous()
+        b = beta.reshape(-1).contiguous()
+        ws = L.workspace(L.query('fc_bn_train_ws_bytes', n, C), dev)
+        L.call('fc_bn_train_fwd', L.ptr(x), n, C, float(eps), L.ptr(g), L.ptr(b), L.ptr(res), act, float(momentum), L.ptr(y),
+               L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(cnt), L.ptr(rmean), L.ptr(rvar), L.ptr(nbt), L.ptr(part), part.shape[0],
+               groups, BN_SMALL_ELEMS, L.ptr(ws), ws.numel(), L.stream())
+        ctx.save_for_backward(x, y if res is not None else None, g, stats, b, cnt)
+        ctx.cfg = (float(eps), act, residual is not None, gamma.shape, beta.shape)
+        ctx.mark_non_differentiable(stats, cnt)
+        ctx.set_materialize_grads(False)
+        return y, stats, cnt
+
+    @staticmethod
+    def backward(ctx, gy, _gs, _gc):
+        x, y, g, stats, b, cnt = ctx.saved_tensors
+        eps, act, has_res, gshape, bshape = ctx.cfg
+        gy = gy.contiguous()
+        n, C = x.shape
+        dev = x.device
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if has_res else None
+        sums = torch.empty((2, C), dtype=torch.float32, device=dev)
+        ws = L.workspace(L.query('fc_bn_train_ws_bytes', n, C), dev)
+        L.call('fc_bn_train_bwd', L.ptr(x), L.ptr(y), L.ptr(gy), None, n, C, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(cnt), eps,
+               L.ptr(g), L.ptr(b), act, L.ptr(gx), L.ptr(gres), L.ptr(sums), None, 0, BN_SMALL_ELEMS, L.ptr(ws), ws.numel(),
+               L.stream())
+        return gx, sums[1].reshape(gshape), sums[0].reshape(bshape), gres, None, None, None, None, None, None, None, None
+
+
+def bn_train(x, gamma, beta, residual, eps, act, momentum, rmean, rvar, nbt, part=None, groups=1):
     """BatchNorm in training mode with buffer update; picks the two-launch path for small matrices.
-    Returns y (and leaves mean/var/count of the batch on the device for inspection)."""
+    Returns y (and leaves mean/var/count of the batch on the device for inspection).
+    part (r5): the statistics table of the convolution that produced x (sparse_conv(want_stats=True))."""
     n, C = x.shape
+    if part is not None and n > 0 and gamma is not None and beta is not None:
+        y, stats, cnt = _BNTrainFused.apply(x, gamma, beta, residual, eps, ACT[act], momentum, rmean, rvar, nbt, part, groups)
+        return y, (stats[0:1], stats[1:2], cnt)
     if 0 < n * C <= BN_SMALL_ELEMS and gamma is not None and beta is not None:
         y, stats, cnt = _BNTrainSmall.apply(x, gamma, beta, residual, eps, ACT[act], momentum, rmean, rvar, nbt)
         return y, (stats[0:1], stats[1:2], cnt)

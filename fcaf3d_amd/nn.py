@@ -41,17 +41,27 @@ class MinkowskiConvolution(nn.Module):
             if self.bias is not None:
                 self.bias.uniform_(-stdv, stdv)
 
-    def forward(self, x):
+    def forward(self, x, want_stats=False):
+        """want_stats (r5): a training-mode BatchNorm consumes the result — the launch also leaves the statistics table of its
+        result (Fn.sparse_conv) on the returned tensor (`.stats`), where MinkowskiBatchNorm finds it"""
+        grad_on = self.training and torch.is_grad_enabled()
+        want_stats = want_stats and grad_on and self.bias is None
+        stats = None
         if self.kernel_volume == 1 and self.stride == 1:
-            f = Fn.sparse_conv(x.F, self.kernel.unsqueeze(0), None, x.F.shape[0])
+            f = Fn.sparse_conv(x.F, self.kernel.unsqueeze(0), None, x.F.shape[0], want_stats=want_stats)
             out_map = x.cmap
         else:
             out_map = x.cmap.strided(self.stride)
             km = x.cmap.kernel_map(out_map, self.kernel_size)
-            f = Fn.sparse_conv(x.F, self.kernel, km, out_map.n, self.training and torch.is_grad_enabled())
+            f = Fn.sparse_conv(x.F, self.kernel, km, out_map.n, grad_on, want_stats=want_stats)
+        if want_stats:
+            f, stats = f
         if self.bias is not None:
             f = f + self.bias
-        return SparseTensor(f, coordinate_map_key=out_map)
+        out = SparseTensor(f, coordinate_map_key=out_map)
+        if stats is not None:
+            out.stats = (stats, 1)
+        return out
 
 
 class MinkowskiGenerativeConvolutionTranspose(nn.Module):
@@ -67,11 +77,18 @@ class MinkowskiGenerativeConvolutionTranspose(nn.Module):
         with torch.no_grad():
             self.kernel.uniform_(-stdv, stdv)
 
-    def forward(self, x):
+    def forward(self, x, want_stats=False):
         out_map = x.cmap.generate()
         w = self.kernel.permute(1, 0, 2).reshape(1, self.in_channels, 8 * self.out_channels)
-        f = Fn.sparse_conv(x.F, w, None, x.F.shape[0]).reshape(-1, self.out_channels)
-        return SparseTensor(f, coordinate_map_key=out_map)
+        want_stats = want_stats and self.training and torch.is_grad_enabled()
+        f = Fn.sparse_conv(x.F, w, None, x.F.shape[0], want_stats=want_stats)
+        stats = None
+        if want_stats:
+            f, stats = f
+        out = SparseTensor(f.reshape(-1, self.out_channels), coordinate_map_key=out_map)
+        if stats is not None:
+            out.stats = (stats, 8)              # the (n, 8 C) GEMM result viewed as (8 n, C): 8 column groups per channel
+        return out
 
 
 class _Act(nn.Module):
@@ -103,8 +120,9 @@ class MinkowskiBatchNorm(nn.Module):
     def forward(self, x, act=None, residual=None):
         bn = self.bn
         if self.training:
+            part, groups = getattr(x, 'stats', None) or (None, 1)
             y, _ = Fn.bn_train(x.F, bn.weight, bn.bias, residual, bn.eps, act, bn.momentum, bn.running_mean,
-                               bn.running_var, bn.num_batches_tracked)
+                               bn.running_var, bn.num_batches_tracked, part=part, groups=groups)
         else:
             C = x.F.shape[1]
             stats = (bn.running_mean.reshape(1, C).contiguous(), bn.running_var.reshape(1, C).contiguous(),
@@ -149,6 +167,7 @@ class MinkowskiPruning(nn.Module):
 
 
 _NORMS = (MinkowskiBatchNorm, MinkowskiInstanceNorm)
+_CONVS = (MinkowskiConvolution, MinkowskiGenerativeConvolutionTranspose)
 
 
 def run_sequential(seq, x):
@@ -160,6 +179,9 @@ def run_sequential(seq, x):
         if isinstance(m, _NORMS) and i + 1 < len(mods) and isinstance(mods[i + 1], _Act):
             x = m(x, act=mods[i + 1].act)
             i += 2
+        elif isinstance(m, _CONVS) and i + 1 < len(mods) and isinstance(mods[i + 1], MinkowskiBatchNorm):
+            x = m(x, want_stats=True)                  # the BatchNorm behind it takes its statistics from this launch's epilogue
+            i += 1
         else:
             x = m(x)
             i += 1
@@ -181,8 +203,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         residual = x if self.downsample is None else run_sequential(self.downsample, x)
-        out = self.norm1(self.conv1(x), act='relu')
-        out = self.conv2(out)
+        out = self.norm1(self.conv1(x, want_stats=True), act='relu')
+        out = self.conv2(out, want_stats=True)
         assert out.cmap is residual.cmap
         return self.norm2(out, act='relu', residual=residual.F)      # relu(bn(conv) + residual), one pass
 

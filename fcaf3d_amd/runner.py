@@ -220,6 +220,7 @@ class TrainStep:
     def __call__(self, batch):
         from . import functional as Fn
         self.optimizer.zero_grad(set_to_none=True)
+        Fn._flat_pass_done()                         # a backward pass that raised never ran its final callback: start clean
         prog = self._program()
         if prog is not None:
             # the executor reads its own weight images (incl. the packed head kernel and the generative kernels' GEMM form); they

@@ -185,7 +185,11 @@ class SingleStageSparse3DDetector(nn.Module):
         return super().load_state_dict(*a, **kw)
 
     def _apply(self, fn, *a, **kw):
-        self.__dict__.pop('_programs', None)              # parameters / buffers may move: the executor's address tables are stale
+        # parameters / buffers may move: the executor's address tables AND its weight images (keyed by the old data_ptr) are stale
+        self.__dict__.pop('_programs', None)
+        self.__dict__.pop('_exec_weights', None)
+        from .flat import GENERATION
+        GENERATION[0] += 1
         return super()._apply(fn, *a, **kw)
 
     def forward_train(self, points, gt_bboxes_3d, gt_labels_3d, img_metas):

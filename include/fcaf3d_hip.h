@@ -181,6 +181,21 @@ int fc_conv_fwd_pairs_tiles(const float* in, const float* W, const int* pair_in,
                             float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
                             void* ws, int64_t ws_bytes, hipStream_t stream);
 
+/* r5 — the convolution -> BatchNorm pairs of the network (BasicBlock conv1 / norm1, conv2 / norm2, me_resnet.py:3, :56-63; the
+ * neck's blocks, fcaf3d_neck_with_head.py:52-53, :60-62, :66-68): fc_conv_fwd / fc_conv_fwd_pairs_tiles that ALSO leave, per row
+ * block of their result, the column sums of the result and of its square — stats[fc_conv_stats_blocks(...)][2][Cout] — written
+ * by whichever kernel produces the final rows (the MFMA tile epilogue, or the fixed-order sum of an offset-split / pair-list
+ * launch).  fc_bn_train_fwd(part = stats) turns them into the batch statistics without reading the matrix again.  Split-bf16
+ * route only (flags bits 24 | 26); fc_conv_stats_blocks returns 0 where a launch has no statistics epilogue.  stats == NULL:
+ * exactly the plain entry points. */
+int64_t fc_conv_stats_blocks(int64_t n_out, int K, int Cin, int Cout, int flags, int pairs);
+int fc_conv_fwd_stats(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
+                      int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, float* stats,
+                      hipStream_t stream);
+int fc_conv_fwd_pairs_tiles_stats(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
+                                  float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
+                                  void* ws, int64_t ws_bytes, float* stats, hipStream_t stream);
+
 /* backward-weights of ME.MinkowskiConvolution (autograd of me_resnet.py:19-21, :56-62 and fcaf3d_neck_with_head.py:52,
  * :60-69; `gW[k] += in[i]^T (x) gout[o]`): gW[k] = sum_o in[nbr[k][o]]^T (x) gout[o];
  * deterministic two-level reduction.  flags bit24 (both entry points): the split-bf16 kernels (csrc/wgrad_x6.h: fp32 in, fp32
@@ -253,6 +268,27 @@ int fc_bn_act_train_bwd(const float* x, const float* y, const float* gy, int64_t
                         const float* var, float eps, const float* gamma, const float* beta, int act, float* gx, float* gres,
                         float* sums, void* ws, int64_t ws_bytes, hipStream_t stream);
 
+/* r5 — training-mode ME.MinkowskiBatchNorm (BasicBlock norm1 / norm2 / downsample norm: me_resnet.py:3, :56-63; the neck's
+ * norms: fcaf3d_neck_with_head.py:53, :62, :68) as ONE entry point per direction for every matrix size, with the two fusions
+ * the launch-list executor uses:
+ *   forward, `part` != NULL: the batch statistics come from column sums the PRODUCER of x left in its epilogue
+ *     (fc_conv_fwd_stats / fc_conv_fwd_pairs_tiles_stats: part[nb_part][2][groups * C] = sums of x and x^2 per row block; groups = 8
+ *     for the (n, 8 C) GEMM of a generative transposed convolution viewed as (8 n, C)), combined in fp64 in a fixed order — no read
+ *     pass over x for the statistics; nb_part <= 64: one launch (every block of the apply kernel re-reduces the table), else two;
+ *   backward, `gy2` != NULL: a second contribution to the incoming gradient, added on the fly (a tensor with two consumers:
+ *     BasicBlock's `out += residual`, me_resnet.py:3) instead of a separate add pass.
+ * part == NULL / gy2 == NULL: exactly fc_bn_act_train_fwd/bwd (n * C <= small_elems) or fc_bn_stats_train + fc_norm_act_fwd /
+ * fc_norm_act_bwd.  sums (2, C) = [d beta, d gamma]. */
+int64_t fc_bn_train_ws_bytes(int64_t n, int C);
+int fc_bn_train_fwd(const float* x, int64_t n, int C, float eps, const float* gamma, const float* beta, const float* residual,
+                    int act, float momentum, float* y, float* mean, float* var, float* cnt, float* running_mean,
+                    float* running_var, long long* num_batches_tracked, const float* part, int64_t nb_part, int groups,
+                    int64_t small_elems, void* ws, int64_t ws_bytes, hipStream_t stream);
+int fc_bn_train_bwd(const float* x, const float* y, const float* gy, const float* gy2, int64_t n, int C, const float* mean,
+                    const float* var, const float* cnt, float eps, const float* gamma, const float* beta, int act, float* gx,
+                    float* gres, float* sums, const float* part, int64_t nb_part, int64_t small_elems, void* ws, int64_t ws_bytes,
+                    hipStream_t stream);
+
 /* ME.MinkowskiMaxPooling(k=2,s=2) — me_resnet.py:24. */
 int fc_maxpool_fwd(const float* in, const int* nbr, int64_t n_out, int K, int C, float* out, int* argrow,
                    hipStream_t stream);
@@ -313,6 +349,14 @@ int fc_head_split_fwd(const float* y, int ld, const float* bias, const float* sc
 int fc_head_split_bwd(const float* y, int ld, const float* scale_dev, const float* bbox_pred, const float* g_centerness,
                       const float* g_bbox, const float* g_cls, int64_t n, int n_reg, int n_cls, float* gy,
                       float* gscale_row, hipStream_t stream);
+/* fc_head_split_bwd plus, in the same pass, the two reductions autograd would run over its outputs: gbias (n_cls) = column sums
+ * of g_cls — the gradient of cls_conv's bias (fcaf3d_neck_with_head.py:262, init :91-92) — and gscale (1) = sum of the per-row
+ * d/dscale terms — the gradient of Scale.scale (:273-275); either may be NULL.  Two launches (64 rows per workgroup leave
+ * 65 partial sums each in ws; one 1024-thread block per column adds them in a fixed order). */
+int64_t fc_head_split_bwd_sums_ws_bytes(int64_t n);
+int fc_head_split_bwd_sums(const float* y, int ld, const float* scale_dev, const float* bbox_pred, const float* g_centerness,
+                           const float* g_bbox, const float* g_cls, int64_t n, int n_reg, int n_cls, float* gy, float* gbias,
+                           float* gscale, void* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* `cuda_ext.sort_v(vertices, mask, num_valid)` of the un-vendored Rotated_IoU extension (docker/Dockerfile:35-40),
  * bound by the reference at rotated_iou/box_intersection_2d.py:147: vertices (n_pairs,24,2) f32 centred on the mean
@@ -375,7 +419,9 @@ int fc_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * cfg[2] != 0: bracket every convolution operator with a HIP-event pair on its stream — fc_exec_probe_read(ms, meta, cap), called
  * after the device has drained, returns the number of brackets since the last read-out and writes their durations (ms) and
  * {map index | -1, direction, n_in, n_out, K, Cin, Cout, pair-list route} (8 int64 each): bench.py's live roofline measurement
- * (the reference times whole iterations only: tools/analysis_tools/benchmark.py:64-91). */
+ * (the reference times whole iterations only: tools/analysis_tools/benchmark.py:64-91).
+ * cfg[3] != 0: the sizing pass only (ws_need is filled; 0 or -2; nothing is launched).  Events are kept per device; one caller
+ * thread per device at a time. */
 int fc_exec_op_words(void);
 int64_t fc_exec_probe_read(float* ms, int64_t* meta, int64_t cap);
 int fc_exec_map_words(void);
