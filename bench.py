@@ -55,7 +55,43 @@ def parse():
     ap.add_argument('--no-executor', action='store_true', help='per-operator module path for every step (default: the network body through the '
                     'native launch-list executor, fcaf3d_amd/executor.py; FC_EXEC=0 does the same)')
     ap.add_argument('--breakdown', action='store_true', help='diagnostic: HIP-event time per C-ABI entry point and per conv shape (stderr)')
+    ap.add_argument('--no-extras', action='store_true', help='skip the untimed BASELINE.md section 2 "also report" configurations '
+                    '(literal 1 cm, two scales, SUN RGB-D, S3DIS: 5 steps each, N = 1 only) and the bf16 fast-mode number')
+    ap.add_argument('--extra-steps', type=int, default=5)
     return ap.parse_args()
+
+
+# BASELINE.md section 2 "also report": the reference's other FCAF3D configurations, as flagged extras of the default line
+# (configs/fcaf3d/fcaf3d.py:1 literal 1 cm voxels, fcaf3d_2scales_scannet-3d-18class.py:2, fcaf3d_sunrgbd-3d-10class.py,
+# fcaf3d_s3dis-3d-5class.py).  key -> (workload, voxel size, levels, scenes per step)
+EXTRAS = {'literal_1cm': ('scannet-100k', 0.01, 4, 4), 'two_scales': ('scannet-100k', 0.02, 2, 8),
+          'sunrgbd': ('sunrgbd-100k', 0.02, 4, 8), 's3dis': ('s3dis-500k', 0.02, 4, 2)}
+
+
+def run_extra(args, key, dev, steps):
+    """one BASELINE.md 'also report' configuration: its own model, scenes and TrainStep; `steps` timed steps after 2 warm-ups,
+    with the stream configuration of the main line (nothing of it is probed)"""
+    import copy
+    import fcaf3d_amd.functional as Fn
+    from fcaf3d_amd.runner import TrainStep
+    wl, vs, lv, bs = EXTRAS[key]
+    a = copy.copy(args)
+    a.workload, a.voxel_size, a.levels, a.batch = wl, vs, lv, bs
+    model, cfg = build_model(a)
+    model = model.to(dev).train()
+    model.async_maps = True
+    model.inputs_resident = True
+    Fn.WGRAD_ASYNC = not args.no_wgrad_overlap
+    tr = TrainStep.from_config(model, cfg)
+    batches = make_batches(a, 0, dev)
+    for i in range(2):
+        tr(batches[i % 2])
+    dt, loss = timed_region(lambda i: tr(batches[i % 2])[0], steps, 1, dev)
+    out = dict(workload=f'{wl}, voxel {vs} m, {lv} levels', scenes_per_step=bs, steps=steps, ms_per_step=round(dt / steps * 1e3, 3),
+               value=round(bs * steps / dt, 3), unit='scenes/s', final_loss=round(float(loss), 4))
+    del tr, model, batches
+    torch.cuda.empty_cache()
+    return out
 
 
 CONFIG_OF = {'plumbing-20k': 'fcaf3d_scannet-3d-18class', 'scannet-100k': 'fcaf3d_scannet-3d-18class',
@@ -160,6 +196,11 @@ HBM_BYTES = {
     'fc_bn_act_train_fwd': lambda a, pr: 4.0 * a[1] * a[2] * (2 + (1 if a[6] else 0)),
     # (x, y, gy, n, C, mean, var, eps, gamma, beta, act, gx, gres, ..)
     'fc_bn_act_train_bwd': lambda a, pr: 4.0 * a[3] * a[4] * (3 + (1 if a[1] else 0) + (1 if a[12] else 0)),
+    # r5 (x, n, C, eps, gamma, beta, residual, act, momentum, y, mean, var, cnt, rmean, rvar, nbt, part, ..): with a statistics table
+    # from the producing convolution x is read once and y written; without one x is read twice
+    'fc_bn_train_fwd': lambda a, pr: 4.0 * a[1] * a[2] * ((2 if a[16] else 3) + (1 if a[6] else 0)),
+    # (x, y, gy, gy2, n, C, mean, var, cnt, eps, gamma, beta, act, gx, gres, ..)
+    'fc_bn_train_bwd': lambda a, pr: 4.0 * a[4] * a[5] * (3 + (1 if a[1] else 0) + (1 if a[3] else 0) + (1 if a[14] else 0)),
     # (coords, n, q, keys, vals, cap, out_coords, ..): 16 B coordinate read + 16 B key/value insert per row
     'fc_hash_unique': lambda a, pr: 32.0 * a[1],
     # (out_coords, n_out, keys, vals, cap, offsets, K, nbr): 16 B coordinate + K x (12 B probe + 4 B write) per row
@@ -206,6 +247,13 @@ class ConvProbe:
         orig = L.call
 
         def call(name, *a):
+            full_name = name
+            if name in ('fc_conv_fwd_stats', 'fc_conv_fwd_pairs_tiles_stats'):
+                name = name[:-6]          # (r5: the same launch + the statistics epilogue for the BatchNorm behind it; same argument positions)
+            return call_(name, full_name, *a)
+
+        def call_(name, full_name, *a):
+            orig_ = orig
             if probe.mode in ('time', 'hbm') and name in HBM_BYTES:
                 try:
                     nbytes = HBM_BYTES[name](a, probe)
@@ -215,12 +263,12 @@ class ConvProbe:
                     s = torch.cuda.Event(enable_timing=True)
                     e = torch.cuda.Event(enable_timing=True)
                     s.record()
-                    orig(name, *a)
+                    orig_(full_name, *a)
                     e.record()
                     probe.hbm.append((name if not (name in ('fc_conv_fwd', 'fc_conv_wgrad') and a[8] == 3) else name + '(stem)', nbytes, s, e))
                     return
             if name not in ('fc_conv_fwd', 'fc_conv_fwd_pairs', 'fc_conv_fwd_pairs_tiles') or probe.mode in (None, 'hbm'):
-                return orig(name, *a)
+                return orig_(full_name, *a)
             if name == 'fc_conv_fwd':
                 # (in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream)
                 n_in, n_out, K, Cin, Cout, has_map = a[5], a[6], a[7], a[8], a[9], bool(a[2])
@@ -228,16 +276,16 @@ class ConvProbe:
                 # (in, W, pair_in, pair_cnt, pair_pos, out, n_in, n_out, K, Cin, Cout, [live_tiles,] flags, ws, ws_bytes, stream)
                 n_in, n_out, K, Cin, Cout, has_map = a[6], a[7], a[8], a[9], a[10], True
             if Cin % 32 or Cout % 64:
-                return orig(name, *a)          # generic FMA / stem path: not the kernel under the probe
+                return orig_(full_name, *a)          # generic FMA / stem path: not the kernel under the probe
             if probe.mode == 'time':
                 s = torch.cuda.Event(enable_timing=True)
                 e = torch.cuda.Event(enable_timing=True)
                 s.record()
-                orig(name, *a)
+                orig_(full_name, *a)
                 e.record()
                 probe._cur.append((s, e))
             else:
-                orig(name, *a)
+                orig_(full_name, *a)
                 nbytes = 4.0 * (n_in * Cin + n_out * Cout + K * Cin * Cout) + (4.0 * K * n_out if has_map else 0.0)
                 probe._cur.append((probe._pairs, 2.0 * Cin * Cout, n_out, nbytes))
                 probe.shapes.setdefault(probe._bi, []).append((name, n_in, n_out, K, Cin, Cout, int(has_map)))
@@ -257,9 +305,9 @@ class ConvProbe:
             probe._pairs = pairs_of(kmap)
             return fwd0(ctx, feats, weight, kmap, n_out, *rest)
 
-        def bwd(ctx, gout):
+        def bwd(ctx, gout, *rest):
             probe._pairs = pairs_of(ctx.kmap)
-            return bwd0(ctx, gout)
+            return bwd0(ctx, gout, *rest)
         Fn._SparseConv.forward = staticmethod(fwd)
         Fn._SparseConv.backward = staticmethod(bwd)
         pool0 = Fn._MaxPool.forward
@@ -345,10 +393,12 @@ class ConvProbe:
                             pr = float(p_.item()) if p_ is not None else float(n_out)
                             fh.write(json.dumps(dict(shape=shp, pairs=pr, gflop=pr * fpp / 1e9, us=s_.elapsed_time(e_) * 1e3)) + '\n')
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, 'profiles', 'r4_traffic.json')
-        if os.path.exists(tj):          # PMC passes cannot run inside the timed region: committed rocprofv3 result
-            t = json.load(open(tj))
-            traffic, traffic_src = t['hbm_bytes_per_launch'], 'profiles/r4_traffic.json (' + t['method'] + ')'
+        for tname in ('r5_traffic.json', 'r4_traffic.json'):          # PMC passes cannot run inside the timed region: committed rocprofv3 result
+            tj = os.path.join(ROOT, 'profiles', tname)
+            if os.path.exists(tj):
+                t = json.load(open(tj))
+                traffic, traffic_src = t['hbm_bytes_per_launch'], f'profiles/{tname} (' + t['method'] + ')'
+                break
         import fcaf3d_amd.functional as Fn
         x6 = bool(Fn.X6)
         peak = PEAK_X6_TFLOPS if x6 else PEAK_F32_MFMA_TFLOPS
@@ -643,6 +693,35 @@ def main():
                               what='FC_X6=0: every convolution on v_mfma_f32_32x32x2_f32 (per-operator module path)')
         finally:
             Fn.X6 = x6_0
+    # (b4) SURVEY.md 8(f) rank 4: bf16 fast mode — the split-bf16 launches multiply the operands rounded to bf16 only (one MFMA
+    #      product instead of six).  NOT a parity route (tests/test_gpu_ops.py bounds it at 2e-2); a flagged extra, never `value`
+    bf16_fast = None
+    if world == 1 and Fn.X6 and not args.no_extras:
+        import fcaf3d_amd._lib as L
+        try:
+            torch.cuda.synchronize()
+            L.lib().fc_set_bf16_fast(1)
+            for i in range(3):
+                step(i)
+            dtb, lb = timed_region(lambda i: step(i), 8, 1, dev)
+            bf16_fast = dict(parity=False, steps=8, ms_per_step=round(dtb / 8 * 1e3, 3), value=round(args.batch * 8 / dtb, 3), unit='scenes/s',
+                             loss_after=round(float(lb), 4),
+                             what='fc_set_bf16_fast(1): forward / backward-data / weight-gradient MFMA launches on bf16-rounded operands '
+                                  '(1 of the 6 products), fp32 accumulate; everything else unchanged')
+        except Exception as e:
+            bf16_fast = dict(error=repr(e)[:200])
+        finally:
+            torch.cuda.synchronize()
+            L.lib().fc_set_bf16_fast(0)
+    # (b5) BASELINE.md section 2 "also report" configurations (their own models; 5 steps each)
+    extras = {}
+    if world == 1 and not args.no_extras and args.workload == 'scannet-100k' and args.levels == 4 and args.voxel_size == 0.02:
+        for key in EXTRAS:
+            try:
+                extras[key] = run_extra(args, key, dev, args.extra_steps)
+            except Exception as e:                               # an extra never fails the bench line
+                extras[key] = dict(error=repr(e)[:200])
+        Fn.WGRAD_ASYNC = not args.no_wgrad_overlap
     # (c) inference: simple_test (eval-mode BatchNorm, decode, multi-class BEV NMS on the device) — the only quantity the
     #     reference publishes a speed for (README.md:91-93, scenes/s on one GPU)
     infer = infer_pipe = None
@@ -695,7 +774,9 @@ def main():
                        'fwd_bwd_only': {'protocol': 'SURVEY 8(d): forward_train + backward (+ all-reduce), synchronised per iteration, median of 5',
                                         'ms': round(fb_med * 1e3, 3), 'scenes_per_s': round(args.batch * world / fb_med, 3)},
                        'config4_global_batch_16': cfg4, 'forced_dp_n1': forced, 'config4_per_gpu': cfg4_1,
-                       'fp32_mfma_route': fp32_route, 'inference': infer, 'inference_pipelined': infer_pipe,
+                       'fp32_mfma_route': fp32_route, 'bf16_fast_mode': bf16_fast, 'inference': infer, 'inference_pipelined': infer_pipe,
+                       **extras,
+                       'kernel_source_sha16': __import__('fcaf3d_amd.build', fromlist=['source_hash']).source_hash(),
                        'executor': bool(exec_on) and 'network body through the native launch-list executor (fcaf3d_amd/executor.py, '
                                    'csrc/exec.hip), the probed step included (event brackets inside fc_exec)'},
         }

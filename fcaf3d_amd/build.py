@@ -15,6 +15,19 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
 
 
+def source_hash():
+    """sha256[:16] over the kernel sources (csrc/*.hip, csrc/*.h, in name order) — recorded with every profile under profiles/ and
+    in bench.py's line, so that a committed kernel table can be told from one taken on other kernels
+    (tests/test_host_logic.py::test_r5_profiles_were_taken_on_the_committed_kernels)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

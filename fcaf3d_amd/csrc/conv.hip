@@ -45,6 +45,16 @@ extern "C" int fc_debug_set_prio(int mode) {
   return FC_OK;
 }
 
+// r5, SURVEY.md 8(f) rank 4 "bf16 fast mode" — a flagged NON-PARITY extra, never the benchmark's `value`: with the switch on,
+// the split-bf16 launches that read a weight image (k_conv_x6 BSRC 2, 128-row tiles) and k_wgrad_x6t run their FAST variants:
+// ONLY plane 0 of either operand = the operand rounded to nearest bf16 (x6_rn2), fp32 accumulate — one v_mfma_f32_32x32x16_bf16
+// per 32x32x16 block instead of six.  Process-global host switch (FC_BF16=1 / fc_set_bf16_fast); default off.
+static int g_bf16_fast = 0;
+extern "C" int fc_set_bf16_fast(int on) {
+  g_bf16_fast = on ? 1 : 0;
+  return FC_OK;
+}
+
 #include "conv_x6.h"
 #include "wgrad_x6.h"
 
@@ -1284,7 +1294,9 @@ static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in
 #define FC_ARGS6 <<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout, stats)
 #define FC_LAUNCH_X6(BM_, BN_, WM_)                                              \
   do {                                                                           \
-    if (pipe == 4 && nbr) k_conv_x6<BM_, BN_, true, WM_, 2> FC_ARGS6;       \
+    if (pipe == 4 && g_bf16_fast && BM_ == 128 && nbr) k_conv_x6<128, BN_, true, 2, 2, true> FC_ARGS6;   \
+    else if (pipe == 4 && g_bf16_fast && BM_ == 128) k_conv_x6<128, BN_, false, 2, 2, true> FC_ARGS6;  \
+    else if (pipe == 4 && nbr) k_conv_x6<BM_, BN_, true, WM_, 2> FC_ARGS6;       \
     else if (pipe == 4) k_conv_x6<BM_, BN_, false, WM_, 2> FC_ARGS6;        \
     else if (wt) k_conv_x6<BM_, BN_, true, WM_, 1> FC_ARGS6;                \
     else if (nbr) k_conv_x6<BM_, BN_, true, WM_, 0> FC_ARGS6;               \
@@ -2125,7 +2137,9 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     const int bn = (Cout % 128 == 0) ? 128 : 64;
     dim3 grid((unsigned)S, (unsigned)((K / WGRAD_KO) * (Cin / 64) * (Cout / bn)));
     if (flags & (1 << 24)) {                     // split-bf16 (wgrad_x6.h)
-      if (wgrad_tr() && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+      if (wgrad_tr() && g_bf16_fast && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false, true><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+      else if (wgrad_tr() && g_bf16_fast) k_wgrad_x6t<64, 64, WGRAD_KO, false, true><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+      else if (wgrad_tr() && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
       else if (wgrad_tr()) k_wgrad_x6t<64, 64, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
       else if (bn == 128) k_wgrad_x6<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
       else k_wgrad_x6<64, 64, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
@@ -2143,12 +2157,14 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
 #define FC_WX6(BM_, BN_)                                                                                                             \
   do {                                                                                                                               \
-    if (wgrad_tr()) k_wgrad_x6t<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); \
+    if (wgrad_tr() && g_bf16_fast) k_wgrad_x6t<BM_, BN_, 1, true, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); \
+    else if (wgrad_tr()) k_wgrad_x6t<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); \
     else k_wgrad_x6<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);    \
   } while (0)
     if (bm == 128 && bn == 128) FC_WX6(128, 128);
     else if (bm == 128) FC_WX6(128, 64);
     else if (bn == 128) FC_WX6(64, 128);
+    else if (g_bf16_fast) k_wgrad_x6t<64, 64, 1, true, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
     else k_wgrad_x6t<64, 64, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
 #undef FC_WX6
   } else if (mfma_ok && !nbr && !cnt && (flags & (1 << 24)) && wgrad_tr64()) {
@@ -2157,7 +2173,11 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     int bm = (Cin % 128 == 0) ? 128 : 64;
     if (bm == 128 && bn == 128 && (int64_t)S * (Cin / 128) * (Cout / 128) < 512) bm = 64;
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
-#define FC_WX6D(BM_, BN_) k_wgrad_x6t<BM_, BN_, 1, false><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps)
+#define FC_WX6D(BM_, BN_)                                                                                                              \
+  do {                                                                                                                                \
+    if (g_bf16_fast) k_wgrad_x6t<BM_, BN_, 1, false, true><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps); \
+    else k_wgrad_x6t<BM_, BN_, 1, false><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);   \
+  } while (0)
     if (bm == 128 && bn == 128) FC_WX6D(128, 128);
     else if (bm == 128) FC_WX6D(128, 64);
     else if (bn == 128) FC_WX6D(64, 128);

@@ -129,7 +129,11 @@ __global__ void k_x6_weight_images(const long long* __restrict__ desc, int n) {
 
 // BSRC: where the weight slab comes from — 0: fp32 (Cin, Cout) kernel, split in the staging; 1: the same kernel read
 // transposed (backward data on the layer's own weights); 2: a pre-split image of k_x6_weight_image (straight copy).
-template <int BM, int BN, bool HAS_NBR, int WM, int BSRC>
+// FAST (r5, SURVEY.md 8(f) rank 4 "bf16 fast mode" — a flagged NON-PARITY extra, never the benchmark's `value`): only plane 0 of
+// either operand — the operand rounded to nearest bf16 — is staged and multiplied: one MFMA per 32x32x16 block instead of six,
+// a third of the staged bytes.  Weight-image launches only; a compile-time variant (as a run-time branch it cost the product
+// kernel 92 spilled registers).
+template <int BM, int BN, bool HAS_NBR, int WM, int BSRC, bool FAST = false>
 __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_conv_x6(
     const float* __restrict__ in, const float* __restrict__ W, const int* __restrict__ nbr,
     const int* __restrict__ out_index, const int* __restrict__ cnt, float* __restrict__ out, int64_t n_out, int K, int Cin,
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
     if (rem) rem &= rem - 1;
     int lc0 = 0;
     bool sw = false;
+    constexpr bool fast = FAST && BSRC == 2;
     f32x4 av[AR];
     f32x4 bw[2 * CPT];                                    // BSRC 1: 2 float4 (8 reduction-consecutive floats) per column
     float bf[8][CPT];                                     // BSRC 0: 8 reduction rows x CPT adjacent columns
@@ -253,7 +258,8 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
       if (BSRC == 2) {
         const u32x4* src = img + (((int64_t)(kbase + lk) * nslab + lc0 / 32) * ngrp + n0 / 64) * X6_GROUP_U16 + tid;
 #pragma unroll
-        for (int i = 0; i < BU; ++i) bi[i] = src[256 * i];
+        for (int i = 0; i < BU; ++i)
+          if (!fast || i % 3 == 0) bi[i] = src[256 * i];          // (unit tid + 256 i lies in plane i % 3 of its 64-column group)
       } else if (WT) {
         const float* Wk = W + (int64_t)lk * Cin * Cout;
 #pragma unroll
@@ -310,6 +316,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
         const int slot = row * 4 + ((a_c4 >> 1) ^ ((row >> 2) & 3));
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
+          if (fast && pl) break;
           u32x2 v = {p[pl][0], p[pl][1]};
           reinterpret_cast<u32x2*>(As + pl * BM * 4 + slot)[a_c4 & 1] = v;
         }
@@ -317,7 +324,8 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
       // ---- the weight slab: image units as they are, or split 8 reduction indices of one column -> 16 B per plane
       if (BSRC == 2) {
 #pragma unroll
-        for (int i = 0; i < BU; ++i) Bs[tid + 256 * i] = bi[i];
+        for (int i = 0; i < BU; ++i)
+          if (!fast || i % 3 == 0) Bs[tid + 256 * i] = bi[i];
       } else {
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
@@ -348,6 +356,20 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
       // per 16-channel block: the three planes of the rows, then the weight planes one at a time, smallest products first
       // (a1b3 | a2b2 a1b2 | a3b1 a2b1 a1b1): 32 fragment registers live instead of 48
       if (pmode == 1) __builtin_amdgcn_s_setprio(1);
+      if (fast) {                                  // one product per block: a1 b1
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          u32x4 fa1[TM], fb1[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa1[i] = As[a_slot[b] + i * 32 * 4];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb1[j] = Bs[b_slot[b] + j * 32 * 4];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = X6_MFMA(fa1[i], fb1[j], acc[i][j]);
+        }
+      } else
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         u32x4 fa[3][TM];

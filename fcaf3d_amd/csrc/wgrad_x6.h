@@ -234,7 +234,7 @@ __device__ __forceinline__ u32x4 x6_tr_frag(const u32x2* base, int unit) {
   return v;
 }
 
-template <int BMc, int BNc, int KO, bool PAIRS>
+template <int BMc, int BNc, int KO, bool PAIRS, bool FAST = false>
 __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) void k_wgrad_x6t(
     const float* __restrict__ in, const float* __restrict__ gout, const int* __restrict__ nbr,
     const int* __restrict__ row_index, const int* __restrict__ cnt, float* __restrict__ part, int64_t n_out, int K, int Cin,
@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
     // 16-row block; lane i of the group ADDRESSES row i / 4, channels 4 (i % 4) .. + 3 and RECEIVES channel i
     const int fi = lane & 15, fg = lane >> 4;
     const int f_unit = (8 * (fg >> 1) + (fi >> 2)) * 8 + (fg & 1) * 4 + (fi & 3);
+    constexpr bool fast = FAST;                  // bf16 fast mode (flagged non-parity extra, conv_x6.h): plane 0 only
     for (int64_t rb = r_begin; rb < r_end; rb += 32) {
       fetch_idx(rb + 32 < r_end ? rb + 32 : rb);                 // (past the end the last stage is re-read and never used)
       __syncthreads();
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
         WG_SPLIT2(gv[p][2], gv[p][3], q[0][1], q[1][1], q[2][1]);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
+          if (fast && pl) break;
           u32x2 v = {q[pl][0], q[pl][1]};
           Gs[(pl * SG + p) * 256 + s_unit] = v;
         }
@@ -341,12 +343,31 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
           WG_SPLIT2(av[o][p][2], av[o][p][3], q[0][1], q[1][1], q[2][1]);
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
+            if (fast && pl) break;
             u32x2 v = {q[pl][0], q[pl][1]};
             As[((o * 3 + pl) * SA + p) * 256 + s_unit] = v;
           }
         }
       __syncthreads();
       load_rows();
+      if (fast) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          u32x4 fb1[TN], fa1[KO][TM];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb1[j] = x6_tr_frag(Gs, (wc * TN + j) * 256 + b * 128 + f_unit);
+#pragma unroll
+          for (int o = 0; o < KO; ++o)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa1[o][i] = x6_tr_frag(As, ((o * 3) * SA + wr * TM + i) * 256 + b * 128 + f_unit);
+#pragma unroll
+          for (int o = 0; o < KO; ++o)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[o][i][j] = X6_MFMA(fa1[o][i], fb1[j], acc[o][i][j]);
+        }
+      } else
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         u32x4 fb[3][TN];

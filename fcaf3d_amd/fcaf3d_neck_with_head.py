@@ -207,11 +207,16 @@ class Fcaf3DNeckWithHead(nn.Module):
         with torch.no_grad():
             interpolated = scores.features_at_coordinates(x.C).squeeze(1)
             mask = torch.zeros(len(interpolated), dtype=torch.bool, device=interpolated.device)
+            kept = 0
             for perm in perms:
                 k = min(len(perm), self.pts_threshold)
                 ids = torch.topk(interpolated[perm], k, sorted=False).indices
                 mask[perm[ids]] = True
-        return self.pruning(x, mask)
+                kept += k
+        # the number of kept rows is known on the host (top-k indices of a scene are distinct): MinkowskiPruning does not read the
+        # count back, so the host does not wait for the network body that produced the scores (r4: the one synchronisation that
+        # kept BASELINE config 5 and the 1 cm configuration host-bound, 18 ms of enqueue per step)
+        return self.pruning(x, mask, expect_n=kept)
 
     def _packed_head_kernel(self):
         """[centerness | reg | cls] kernels side by side, zero-padded to a multiple of 64 columns (the MFMA tile)."""

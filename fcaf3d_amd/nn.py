@@ -158,9 +158,9 @@ class MinkowskiMaxPooling(nn.Module):
 
 
 class MinkowskiPruning(nn.Module):
-    def forward(self, x, mask):
+    def forward(self, x, mask, expect_n=None):
         from .sparse import compact_mask
-        kept = compact_mask(mask)
+        kept = compact_mask(mask, expect_n)
         if kept.numel() == x.F.shape[0]:
             return x
         return SparseTensor(Fn.gather_rows(x.F, kept), coordinate_map_key=x.cmap.pruned(kept))

@@ -495,8 +495,9 @@ class CoordMap:
         return self._counts
 
 
-def compact_mask(mask):
-    """bool/uint8 mask (n,) -> int32 indices of set rows, ascending (ballot + prefix-sum kernel)."""
+def compact_mask(mask, expect_n=None):
+    """bool/uint8 mask (n,) -> int32 indices of set rows, ascending (ballot + prefix-sum kernel).  expect_n: the caller knows how
+    many rows are set (a per-scene top-k keeps exactly k): no read-back of the count — the host does not wait for the mask"""
     flags = mask.to(torch.uint8).contiguous()
     n = flags.numel()
     dev = flags.device
@@ -504,7 +505,7 @@ def compact_mask(mask):
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     ws = L.workspace(4 * (n // 1024 + 1), dev)
     L.call('fc_scan_flags', L.ptr(flags), n, L.ptr(pos), L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
-    m = int(cnt.item())
+    m = int(cnt.item()) if expect_n is None else int(expect_n)
     kept = torch.empty(m, dtype=torch.int32, device=dev)
     L.call('fc_compact_rows', L.ptr(flags), L.ptr(pos), n, L.ptr(kept), L.stream())
     return kept

@@ -405,6 +405,13 @@ int fc_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float
                   float weight_decay, float bias_correction1, float bias_correction2, const float* norm_and_clip,
                   hipStream_t stream);
 
+/* SURVEY.md 8(f) rank 4 "bf16 fast mode" (No reference counterpart: the reference trains in fp32 throughout, configs/fcaf3d/fcaf3d.py:30-33
+ * sets no fp16 hook).  A process-global, flagged NON-PARITY switch: while on, the split-bf16 convolution launches that read a
+ * weight image (flags bits 24 | 26, 128-row tiles) and the split-bf16 weight-gradient launches multiply ONLY the leading bf16
+ * piece of either operand (the operand rounded to nearest bf16; fp32 accumulate) — one MFMA product instead of six.  Default
+ * off; `bench.py` reports it as `config.bf16_fast_mode` with "parity": false, never as `value`. */
+int fc_set_bf16_fast(int on);
+
 /* ---- launch-list executor (the network body in one call per direction) ------------------------------------ */
 
 /* SingleStageSparse3DDetector.extract_feat (mmdet3d/models/detectors/single_stage_sparse.py:43-50: backbone me_resnet.py:43-50 +

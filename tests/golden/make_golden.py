@@ -217,6 +217,21 @@ def gen_iou(aiou, riou, out):
     np.savez_compressed(out, **d)
 
 
+def gen_iou64(riou, src, out):
+    """r5: the rotated-IoU gradients of iou3d.npz's inputs once more with the reference's own code (oriented_iou_loss.py:86-109)
+    run in FLOAT64 — the yardstick for the 1e-4 gradient bound of tests/test_gpu_model.py (the fp32 reference gradient itself
+    sits up to 1e-3 away from it: clipped-polygon vertices differenced at fp32)"""
+    d = np.load(src)
+    pa = torch.from_numpy(d['ro_pred']).double().requires_grad_(True)
+    pb = torch.from_numpy(d['ro_target']).double()
+    iou = riou.cal_iou_3d(pa[None], pb[None])[0]
+    ((1 - iou) * torch.from_numpy(d['ro_w']).double()).sum().backward()
+    g32 = d['ro_grad'].astype(np.float64)
+    print('rotated IoU, fp32 reference vs its fp64 run: iou', float(np.abs(iou.detach().numpy() - d['ro_iou']).max()),
+          'grad', float(np.abs(pa.grad.numpy() - g32).max()), 'of scale', float(np.abs(pa.grad.numpy()).max()))
+    np.savez_compressed(out, ro_iou64=iou.detach().numpy(), ro_grad64=pa.grad.numpy())
+
+
 def gen_indoor_eval(out):
     """mmdet3d/core/evaluation/indoor_eval.py run as it is (mmcv.print_log / terminaltables stubbed) on random
     detections; its per-box `overlaps` is served by the oracle's 3D IoU, so the golden pins the matching / AP logic."""
@@ -378,6 +393,10 @@ def gen_bev(out):
 if __name__ == '__main__':
     if sys.argv[1:] == ['indoor_eval']:            # only this fixture (the others are unchanged)
         gen_indoor_eval(os.path.join(HERE, 'indoor_eval.npz'))
+        sys.exit(0)
+    if sys.argv[1:] == ['iou64']:
+        head, utils, aiou, riou = load_reference()
+        gen_iou64(riou, os.path.join(HERE, 'iou3d.npz'), os.path.join(HERE, 'iou3d_f64.npz'))
         sys.exit(0)
     if sys.argv[1:] == ['pipeline']:
         gen_pipeline(os.path.join(HERE, 'pipeline.npz'))

@@ -89,7 +89,10 @@ def test_two_rank_training_keeps_parameters_identical_and_matches_global_batch()
     model = model.to(dev).train()
     glob = float(parse_losses(model(return_loss=True, **_batch(fa, [100, 101, 102, 103], dev))))
     dp = 0.5 * (l0[0] + l1[0])
-    assert abs(dp - glob) <= 0.05 * abs(glob), (dp, glob)
+    # two 2-scene ranks against one 4-scene process: the designed difference is the per-rank BatchNorm statistics (2 small scenes
+    # instead of 4 in every BatchNorm); r5: bound tightened from 5 % to 2 % (measured value printed)
+    print(f'two ranks x 2 scenes vs one process x 4 scenes: loss {dp:.6f} vs {glob:.6f}, relative difference {abs(dp - glob) / abs(glob):.2e}')
+    assert abs(dp - glob) <= 0.02 * abs(glob), (dp, glob)
 
 
 def _worker_cfg4(rank, world, port, q):
@@ -160,3 +163,30 @@ def test_config4_per_gpu_shape_two_ranks():
     print(f'config-4 per-GPU shape: data-parallel loss {dp:.6f} (ranks {l0[0]:.6f} / {l1[0]:.6f}), single process over the 4 scenes '
           f'{glob:.6f}: relative difference {abs(dp - glob) / abs(glob):.2e}')
     assert abs(dp - glob) <= 1e-3 * abs(glob), (dp, glob)
+
+
+def test_bench_two_ranks_on_one_gpu_prints_the_contract_line():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU) — here with both ranks on cuda:0 and
+    gloo instead of RCCL (FC_DIST_BACKEND=gloo; RCCL needs one GPU per rank): the ONE JSON line on rank 0 carries n_gpus = 2, weak
+    scaling, BASELINE config 4 (global batch 16 split over the ranks) and a non-empty bucket log.  RCCL itself with N > 1 is the
+    driver's N = 2 / 4 / 8 pass (tools/dist_train.sh:7-9, configs/fcaf3d/fcaf3d.py:43)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FC_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
+           '--no-cpu-baseline', '--infer-steps', '0', '--no-extras', '--no-fp32-route']
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['steps'] == 3 and out['value'] > 0
+    assert out['config']['global_batch'] == 16 and out['config']['parallelism'] == 'dp2'
+    c4 = out['config']['config4_global_batch_16']
+    assert c4 is not None and c4['global_batch'] == 16 and c4['scenes_per_gpu_per_step'] == 8 and c4['value'] > 0
+    dp = out['config']['data_parallel']
+    assert dp['buckets'] >= 2 and len(dp['last_step_launch_ms_after_first_grad']) == dp['buckets'] and dp['backend'] == 'gloo'
+    print('bench.py --gpus 2 (gloo, one GPU):', out['value'], 'scenes/s;', dp)

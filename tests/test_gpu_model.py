@@ -392,7 +392,12 @@ def test_iou_losses_vs_reference_goldens():
         iou = fn(pred, tgt)
         ((1 - iou) * w).sum().backward()
         assert np.allclose(iou.detach().cpu().numpy(), d[f'{key}_iou'], atol=1e-5), key
-        assert np.allclose(pred.grad.cpu().numpy(), d[f'{key}_grad'], atol=2e-4, rtol=1e-3), key
+        # gradients: within 1e-4 of the gradient's scale (the north_star bar) — the rotated IoU against the reference's own code run
+        # in float64 on the same boxes (tests/golden/iou3d_f64.npz, make_golden.py iou64; r4 allowed atol 2e-4 + rtol 1e-3)
+        ref_g = np.load(os.path.join(G, 'iou3d_f64.npz'))['ro_grad64'] if key == 'ro' else d[f'{key}_grad'].astype(np.float64)
+        err = float(np.abs(pred.grad.cpu().numpy().astype(np.float64) - ref_g).max())
+        print(f'{key}: IoU gradient, max difference {err:.2e} at gradient scale {float(np.abs(ref_g).max()):.3f}')
+        assert err <= 1e-4 * float(np.abs(ref_g).max()), (key, err)
     # module API incl. the zero-weight early-out (iou3d_loss.py:53-54)
     loss = IoU3DLoss(with_yaw=True)
     p = torch.from_numpy(d['ro_pred']).to(dev).requires_grad_(True)

@@ -795,3 +795,185 @@ def test_wgrad_transposing_read_is_bit_identical():
             assert float((gw[0].double() - ref).abs().max() / ref.abs().max()) < 2e-5, (n, Cin, Cout)
     finally:
         L.lib().fc_debug_set_wgrad_tr(1)
+
+
+# ---- r5: BatchNorm statistics out of the convolution's epilogue, two-consumer gradient add inside the BatchNorm backward ----------
+def _stats_case(dev, n_points, Cin, Cout, level_q, seed, B=2):
+    """-> (x, weight, kernel map, coordinate map) of a k3 s1 convolution on a synthetic level"""
+    from fcaf3d_amd.sparse import CoordMap
+    _, c_ref, _ = _scene_coords(seed, n_points=n_points, B=B)
+    if level_q > 1:
+        c_ref = c_ref.copy(); c_ref[:, 1:] = np.floor_divide(c_ref[:, 1:], level_q) * level_q
+    uc, _, _ = mo.unique_first(c_ref)
+    cm, _, _ = CoordMap.from_coords(torch.from_numpy(uc).to(dev), level_q, B)
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(len(uc), Cin, generator=g) + 0.5).to(dev)
+    w = (torch.randn(27, Cin, Cout, generator=g) / np.sqrt(Cin * 27)).to(dev)
+    return x, w, cm.kernel_map(cm, 3), cm
+
+
+@pytest.mark.parametrize('n_points,Cin,Cout,q,route', [
+    (100000, 64, 64, 4, 'tile epilogue'),           # ~64k rows: unsplit launch on the (mask-sorted) neighbour table
+    (100000, 128, 128, 8, 'pair lists'),            # ~16k rows, sparse: per offset over the pair lists, k_sum_pairs_stats
+    (100000, 256, 256, 16, 'pair lists, 64-row blocks'),   # ~3.7k rows
+    (100000, 256, 256, 32, 'pair lists, few rows'),  # ~900 rows: <= 64 row blocks of 16 rows
+])
+def test_conv_statistics_epilogue(n_points, Cin, Cout, q, route):
+    """fc_conv_fwd_stats / fc_conv_fwd_pairs_tiles_stats: the result is bit for bit the plain launch's, and the table holds the
+    column sums of the result and of its square (fp32 sums per row block; checked against fp64 over the result to 2e-6)"""
+    import fcaf3d_amd.functional as Fn
+    dev = _dev()
+    x, w, km, cm = _stats_case(dev, n_points, Cin, Cout, q, seed=17)
+    with torch.no_grad():
+        ref = Fn.sparse_conv(x, w, km, cm.n)
+        out, tab = Fn.sparse_conv(x, w, km, cm.n, True, want_stats=True)
+    assert tab is not None, 'this launch must have a statistics epilogue'
+    assert torch.equal(out, ref), route
+    o = out.double()
+    s1, s2 = tab[:, 0].double().sum(0), tab[:, 1].double().sum(0)
+    print(f'{route}: n = {cm.n}, row blocks = {tab.shape[0]}')
+    assert float((s1 - o.sum(0)).abs().max()) <= 2e-6 * float(o.abs().sum(0).max())
+    assert float((s2 - (o * o).sum(0)).abs().max()) <= 2e-6 * float((o * o).sum(0).max())
+
+
+def test_offset_split_statistics_epilogue_and_dense_gemm_groups():
+    """the two remaining producers: an offset-split launch (few rows on a DENSE map: k_sum_parts_stats) and the table-free dense
+    GEMM of a generative transposed convolution, whose (n, 8 C) result is normalised as (8 n, C): 8 column groups per channel"""
+    import fcaf3d_amd.functional as Fn
+    from fcaf3d_amd.sparse import CoordMap
+    dev = _dev()
+    x, w, km, cm = _stats_case(dev, 12000, 256, 256, 32, seed=19)
+    g = cm.generate()                                             # children set: 94 % dense, ~8k rows -> offset split
+    kg = g.kernel_map(g, 3)
+    assert not kg.use_pairs
+    xg = torch.randn(g.n, 128, device=dev)
+    wg = torch.randn(27, 128, 128, device=dev) / 60.0
+    with torch.no_grad():
+        ref = Fn.sparse_conv(xg, wg, kg, g.n)
+        out, tab = Fn.sparse_conv(xg, wg, kg, g.n, True, want_stats=True)
+    assert tab is not None and torch.equal(out, ref)
+    o = out.double()
+    assert float((tab[:, 0].double().sum(0) - o.sum(0)).abs().max()) <= 2e-6 * float(o.abs().sum(0).max())
+    assert float((tab[:, 1].double().sum(0) - (o * o).sum(0)).abs().max()) <= 2e-6 * float((o * o).sum(0).max())
+    # dense GEMM (n, 256) x (256, 8 * 64) + BatchNorm over (8 n, 64) from the table, against BatchNorm from the matrix itself
+    import fcaf3d_amd.nn as MEnn
+    torch.manual_seed(3)
+    gen = MEnn.MinkowskiGenerativeConvolutionTranspose(256, 64).to(dev).train()
+    bn_a, bn_b = MEnn.MinkowskiBatchNorm(64).to(dev).train(), MEnn.MinkowskiBatchNorm(64).to(dev).train()
+    from fcaf3d_amd.sparse import SparseTensor
+    xin = SparseTensor(x, coordinate_map_key=cm)
+    t = gen(xin, want_stats=True)
+    assert getattr(t, 'stats', None) is not None and t.stats[1] == 8
+    ya = bn_a(t, act='elu').F
+    t.stats = None
+    yb = bn_b(t, act='elu').F
+    _close(ya, yb, tol=2e-6, what='BatchNorm from the GEMM epilogue table vs from the matrix')
+    _close(bn_a.bn.running_var, bn_b.bn.running_var, tol=2e-6, what='running_var')
+
+
+@pytest.mark.parametrize('n,C,res', [(3000, 256, True), (60000, 64, True), (9000, 128, False)])
+def test_batchnorm_backward_adds_a_second_gradient_on_the_fly(n, C, res):
+    """fc_bn_train_bwd(gy, gy2) == fc_bn_train_bwd(gy + gy2): bit for bit (the executor's OP_ADD folded into the kernels)"""
+    from fcaf3d_amd import _lib as L
+    import fcaf3d_amd.functional as Fn
+    dev = _dev()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, C, generator=g).to(dev)
+    r = torch.randn(n, C, generator=g).to(dev) if res else None
+    gam, bet = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    g1, g2 = torch.randn(n, C, generator=g).to(dev), torch.randn(n, C, generator=g).to(dev)
+    y = torch.empty_like(x)
+    st = torch.empty((2, C), device=dev); cnt = torch.empty(1, device=dev)
+    ws = L.workspace(L.query('fc_bn_train_ws_bytes', n, C), dev)
+    L.call('fc_bn_train_fwd', L.ptr(x), n, C, 1e-5, L.ptr(gam), L.ptr(bet), L.ptr(r), 1, 0.1, L.ptr(y), L.ptr(st[0]), L.ptr(st[1]),
+           L.ptr(cnt), None, None, None, None, 0, 1, Fn.BN_SMALL_ELEMS, L.ptr(ws), ws.numel(), L.stream())
+    outs = []
+    for a, b in ((g1 + g2, None), (g1, g2)):
+        gx, gr, sums = torch.empty_like(x), torch.empty_like(x), torch.empty((2, C), device=dev)
+        L.call('fc_bn_train_bwd', L.ptr(x), L.ptr(y) if res else None, L.ptr(a), L.ptr(b), n, C, L.ptr(st[0]), L.ptr(st[1]), L.ptr(cnt),
+               1e-5, L.ptr(gam), L.ptr(bet), 1, L.ptr(gx), L.ptr(gr) if res else None, L.ptr(sums), None, 0, Fn.BN_SMALL_ELEMS,
+               L.ptr(ws), ws.numel(), L.stream())
+        outs.append((gx, gr if res else gx, sums))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+
+
+def test_head_backward_with_bias_and_scale_sums():
+    """fc_head_split_bwd_sums == fc_head_split_bwd + the two reductions autograd runs over its outputs"""
+    from fcaf3d_amd import _lib as L
+    dev = _dev()
+    n, n_reg, n_cls, ld = 70001, 6, 18, 64
+    g = torch.Generator().manual_seed(1)
+    y = torch.randn(n, ld, generator=g).to(dev)
+    bbox = torch.rand(n, n_reg, generator=g).to(dev) + 0.1
+    gc, gb, gk = (torch.randn(n, c, generator=g).to(dev) for c in (1, n_reg, n_cls))
+    sc = torch.tensor([1.3], device=dev)
+    gy0, gs_row = torch.empty_like(y), torch.empty(n, device=dev)
+    L.call('fc_head_split_bwd', L.ptr(y), ld, L.ptr(sc), L.ptr(bbox), L.ptr(gc), L.ptr(gb), L.ptr(gk), n, n_reg, n_cls, L.ptr(gy0),
+           L.ptr(gs_row), L.stream())
+    gy1, gbias, gscale = torch.empty_like(y), torch.empty(n_cls, device=dev), torch.empty(1, device=dev)
+    ws = L.workspace(L.query('fc_head_split_bwd_sums_ws_bytes', n), dev)
+    L.call('fc_head_split_bwd_sums', L.ptr(y), ld, L.ptr(sc), L.ptr(bbox), L.ptr(gc), L.ptr(gb), L.ptr(gk), n, n_reg, n_cls,
+           L.ptr(gy1), L.ptr(gbias), L.ptr(gscale), L.ptr(ws), ws.numel(), L.stream())
+    assert torch.equal(gy0, gy1)
+    _close(gbias, gk.double().sum(0).float(), tol=2e-6, what='class-bias gradient')
+    ref = float(gs_row.double().sum())
+    assert abs(float(gscale) - ref) <= 2e-6 * float(gs_row.double().abs().sum()), (float(gscale), ref)
+
+
+def test_bf16_fast_mode_is_a_flagged_non_parity_route():
+    """with fc_set_bf16_fast(1) the split-bf16 launches multiply bf16-rounded operands only (one MFMA
+    product instead of six).  NOT a parity route: bounded here at 2e-2 of the output scale (bf16 has 8 significand bits; a 27 x
+    64...256-term sum of products of rounded operands sits at ~3e-3), and clearly different from the exact route."""
+    from fcaf3d_amd import _lib as L
+    import fcaf3d_amd.functional as Fn
+    dev = _dev()
+    x, w, km, cm = _stats_case(dev, 100000, 128, 128, 8, seed=23)
+    go = torch.randn(cm.n, 128, device=dev)
+    res = {}
+    for mode in (0, 1):
+        L.lib().fc_set_bf16_fast(mode)
+        try:
+            xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            out = Fn.sparse_conv(xr, wr, km, cm.n)
+            gx, gw = torch.autograd.grad(out, [xr, wr], go)
+            torch.cuda.synchronize()
+            res[mode] = (out.detach(), gx, gw)
+        finally:
+            L.lib().fc_set_bf16_fast(0)
+    for a, b, what in zip(res[1], res[0], ('forward', 'backward data', 'backward weights')):
+        err = float((a - b).abs().max()) / float(b.abs().max())
+        print(f'bf16 fast mode, {what}: max difference to the exact route {err:.2e} of the tensor scale')
+        assert 1e-5 < err < 2e-2, (what, err)
+
+
+def test_non_finite_activations_on_the_split_route():
+    """csrc/conv_x6.h:14-15, documented behaviour: an overflowed activation (+-inf) splits into (inf, nan, nan), so the split-bf16
+    route yields NaN in every output row that gathers it where the fp32 MFMA route yields +-inf (or NaN where inf meets -inf / 0);
+    a NaN activation yields NaN on both.  Rows that gather no non-finite input are untouched on both routes."""
+    import fcaf3d_amd.functional as Fn
+    dev = _dev()
+    x, w, km, cm = _stats_case(dev, 100000, 64, 64, 8, seed=29)
+    w = w.abs()                                        # no inf - inf on the fp32 route: it must produce +inf exactly
+    x = x.clone()
+    x[5, 3] = float('inf')
+    x[9, 7] = float('nan')
+    nbr = km.nbr.cpu().numpy()
+    hit_inf, hit_nan = np.unique(np.nonzero(nbr == 5)[1]), np.unique(np.nonzero(nbr == 9)[1])
+    clean = np.setdiff1d(np.arange(cm.n), np.union1d(hit_inf, hit_nan))
+    only_inf = np.setdiff1d(hit_inf, hit_nan)
+    outs = {}
+    for x6 in (True, False):
+        x6_0, Fn.X6 = Fn.X6, x6
+        try:
+            with torch.no_grad():
+                outs[x6] = Fn.sparse_conv(x, w, km, cm.n).cpu().numpy()
+        finally:
+            Fn.X6 = x6_0
+    assert len(only_inf) > 0 and len(clean) > 0
+    for x6 in (True, False):
+        assert np.isfinite(outs[x6][clean]).all(), 'rows without a non-finite neighbour must be finite'
+        assert np.isnan(outs[x6][hit_nan]).any(axis=1).all(), 'a NaN input reaches every row that gathers it'
+    assert np.isposinf(outs[False][only_inf]).any(axis=1).all(), 'fp32 MFMA route: +inf'
+    assert np.isnan(outs[True][only_inf]).any(axis=1).all(), 'split-bf16 route: NaN (documented difference)'
+    np.testing.assert_allclose(outs[True][clean], outs[False][clean], rtol=0, atol=1e-4 * np.abs(outs[False][clean]).max())

@@ -4,6 +4,7 @@ pure-torch code (tests/golden/make_golden.py)."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 import fcaf3d_amd as fa
@@ -259,3 +260,29 @@ def test_committed_profile_tables_follow_from_the_committed_traces():
     assert abs(traffic['hbm_bytes_per_launch'] - traffic['fetch_bytes_per_launch'] - traffic['write_bytes_per_launch']) <= 1
     r = bench_line['roofline']
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+
+
+def test_r5_profiles_were_taken_on_the_committed_kernels():
+    """profiles/r5_meta.json records the hash of csrc/ (fcaf3d_amd.build.source_hash) and the commit every r5 profile was taken on;
+    a kernel change after the profiles makes this fail (the r4 weight-gradient rows predated the final routing), and
+    profiles/r5_kernel_stats.md must be tools/kernel_stats.py over the committed CSVs."""
+    import importlib.util
+    import json
+    from fcaf3d_amd.build import source_hash
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meta_path = os.path.join(root, 'profiles', 'r5_meta.json')
+    if not os.path.exists(meta_path):
+        pytest.skip('no r5 profiles committed yet')
+    meta = json.load(open(meta_path))
+    assert meta['kernel_source_sha16'] == source_hash(), 'csrc/ changed after the r5 profiles were taken: take them again'
+    spec = importlib.util.spec_from_file_location('kernel_stats', os.path.join(root, 'tools', 'kernel_stats.py'))
+    ks = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ks)
+    md = open(os.path.join(root, 'profiles', 'r5_kernel_stats.md')).read()
+    for name in ('r5_kernel_stats.csv', 'r5_kernel_stats_no_overlap.csv'):
+        assert ks.table(os.path.join(root, 'profiles', name), float(meta['steps_profiled'])) in md, name
+    bench_line = json.load(open(os.path.join(root, 'profiles', 'r5_bench_n1.json')))
+    assert bench_line['config']['kernel_source_sha16'] == meta['kernel_source_sha16']
+    tj = os.path.join(root, 'profiles', 'r5_traffic.json')
+    if os.path.exists(tj):
+        assert json.load(open(tj)).get('kernel_source_sha16') == meta['kernel_source_sha16']
