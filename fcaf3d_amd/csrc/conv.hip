@@ -842,29 +842,64 @@ __device__ __forceinline__ void stat_block_reduce(f32x4 a1, f32x4 a2, float* __r
   }
 }
 
+// per-thread channel parameters of the backward form of the statistics (X6Epi, conv_x6.h): 4 channels from c on
+struct StatCh { f32x4 mu, is, ga, be; bool bwd, from_y, has_add; int act; };
+__device__ __forceinline__ StatCh stat_channels(const X6Epi& epi, int c) {
+  StatCh p;
+  p.bwd = epi.bn_x != nullptr;
+  p.act = epi.act;
+  p.from_y = p.bwd && epi.bn_y != nullptr && epi.act != 0;
+  p.has_add = p.bwd && epi.add != nullptr;
+  p.mu = f32x4{0.f, 0.f, 0.f, 0.f}; p.is = f32x4{1.f, 1.f, 1.f, 1.f}; p.ga = p.is; p.be = p.mu;
+  if (p.bwd) {
+    p.mu = *reinterpret_cast<const f32x4*>(epi.mean + c);
+    const f32x4 va = *reinterpret_cast<const f32x4*>(epi.var + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p.is[j] = 1.f / sqrtf(va[j] + epi.eps);
+    if (epi.gamma) p.ga = *reinterpret_cast<const f32x4*>(epi.gamma + c);
+    if (epi.beta) p.be = *reinterpret_cast<const f32x4*>(epi.beta + c);
+  }
+  return p;
+}
+// `at`: element offset of (row, first channel) in the (n, C) matrices bn_x / add / bn_y
+__device__ __forceinline__ void stat_accumulate(const StatCh& p, const X6Epi& epi, const f32x4& a, int64_t at, f32x4& a1, f32x4& a2) {
+  f32x4 xv = {0.f, 0.f, 0.f, 0.f}, av = xv, yv = xv;
+  if (p.bwd) xv = *reinterpret_cast<const f32x4*>(epi.bn_x + at);
+  if (p.has_add) av = *reinterpret_cast<const f32x4*>(epi.add + at);
+  if (p.from_y) yv = *reinterpret_cast<const f32x4*>(epi.bn_y + at);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float t1, t2;
+    x6_epi_terms(p.bwd, p.bwd ? av[j] + a[j] : a[j], xv[j], p.mu[j], p.is[j], p.ga[j], p.be[j], p.act, p.from_y, yv[j], t1, t2);
+    a1[j] += t1;
+    a2[j] += t2;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_sum_parts_stats(const float* __restrict__ part, float* __restrict__ out, int64_t n, int C, int S,
-                                                         int RB, float* __restrict__ stats) {
+                                                         int RB, X6Epi epi) {
   __shared__ f32x4 sm[16 * 2 * 16];
   const int lane = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int64_t r0 = (int64_t)blockIdx.x * RB;
   const int c = blockIdx.y * 64 + lane * 4;
+  const StatCh p = stat_channels(epi, c);
   f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
   for (int64_t r = r0 + rl; r < r0 + RB && r < n; r += 16) {
     f32x4 a = *reinterpret_cast<const f32x4*>(part + r * C + c);
     for (int z = 1; z < S; ++z) a += *reinterpret_cast<const f32x4*>(part + ((int64_t)z * n + r) * C + c);
     *reinterpret_cast<f32x4*>(out + r * C + c) = a;
-    a1 += a;
-    a2 += a * a;
+    stat_accumulate(p, epi, a, r * C + c, a1, a2);
   }
-  stat_block_reduce(a1, a2, stats, C, sm);
+  stat_block_reduce(a1, a2, epi.stats, C, sm);
 }
 
 __global__ __launch_bounds__(256) void k_sum_pairs_stats(const float* __restrict__ part, const int* __restrict__ pos, float* __restrict__ out,
-                                                         int64_t n_out, int K, int Cout, int RB, float* __restrict__ stats) {
+                                                         int64_t n_out, int K, int Cout, int RB, X6Epi epi) {
   __shared__ f32x4 sm[16 * 2 * 16];
   const int lane = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int64_t r0 = (int64_t)blockIdx.x * RB;
   const int c = blockIdx.y * 64 + lane * 4;
+  const StatCh p = stat_channels(epi, c);
   f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
   for (int64_t o = r0 + rl; o < r0 + RB && o < n_out; o += 16) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};                           // as k_sum_pairs: offsets in order, nine in flight
@@ -883,10 +918,9 @@ __global__ __launch_bounds__(256) void k_sum_pairs_stats(const float* __restrict
         if (j[u] >= 0) a += v[u];
     }
     *reinterpret_cast<f32x4*>(out + o * Cout + c) = a;
-    a1 += a;
-    a2 += a * a;
+    stat_accumulate(p, epi, a, o * Cout + c, a1, a2);
   }
-  stat_block_reduce(a1, a2, stats, Cout, sm);
+  stat_block_reduce(a1, a2, epi.stats, Cout, sm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1258,8 +1292,10 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
 // and LDS-padding occupancy caps all lose or are neutral — profiles/r1_conv_pmc.md — and were removed in r2)
 static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr,
                             const int* out_index, const int* cnt, float* dst, int64_t n_rows, int K, int Cin, int Cout,
-                            hipStream_t stream, bool wt = false, bool apl = false, float* stats = nullptr) {
-  if (stats && (apl || pipe < 3 || bm < 128 || cnt || grid.z != 1)) return FC_EINVAL;      // the statistics epilogue lives in k_conv_x6
+                            hipStream_t stream, bool wt = false, bool apl = false, const X6Epi* epi = nullptr) {
+  if (epi && (apl || pipe < 3 || bm < 128 || cnt || grid.z != 1)) return FC_EINVAL;      // the statistics epilogue lives in k_conv_x6
+  X6Epi e6 = {};
+  if (epi) e6 = *epi;
   if (apl) {                                     // the input is pre-split planes (k_x6_planes): split-bf16 kernel with weight images only
     if (pipe != 4 || bm < 128) return FC_EINVAL;
     const u32x4* pl = reinterpret_cast<const u32x4*>(in);
@@ -1291,7 +1327,7 @@ static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in
   if (wt && !nbr) return FC_EINVAL;              // transposed weights: neighbour-table / pair-list launches only
   if (wt && pipe == 2) pipe = 0;                 // the LDS-DMA image cannot be transposed in flight
   if (pipe >= 3 && bm >= 128) {                  // split-bf16 kernel; pipe 4: the weights are a pre-split image
-#define FC_ARGS6 <<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout, stats)
+#define FC_ARGS6 <<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout, e6)
 #define FC_LAUNCH_X6(BM_, BN_, WM_)                                              \
   do {                                                                           \
     if (pipe == 4 && g_bf16_fast && BM_ == 128 && nbr) k_conv_x6<128, BN_, true, 2, 2, true> FC_ARGS6;   \
@@ -1347,16 +1383,17 @@ static int sum_parts(const float* part, float* out, int64_t n_out, int Cout, int
   return FC_OK;
 }
 
-static int sum_parts_stats(const float* part, float* out, int64_t n_out, int Cout, int S, float* stats, hipStream_t stream) {
+static int sum_parts_stats(const float* part, float* out, int64_t n_out, int Cout, int S, const X6Epi& epi, hipStream_t stream) {
   const int rb = fc_stat_rb(n_out);
-  k_sum_parts_stats<<<dim3((unsigned)fc_cdiv(n_out, rb), Cout / 64), 256, 0, stream>>>(part, out, n_out, Cout, S, rb, stats);
+  k_sum_parts_stats<<<dim3((unsigned)fc_cdiv(n_out, rb), Cout / 64), 256, 0, stream>>>(part, out, n_out, Cout, S, rb, epi);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
 
 static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const int* out_index,
                          float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
-                         int64_t ws_bytes, hipStream_t stream, float* stats = nullptr) {
+                         int64_t ws_bytes, hipStream_t stream, const X6Epi* epi = nullptr) {
+  const bool stats = epi != nullptr;
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (n_out == 0) return FC_OK;                 // nothing to write (an empty table may well be a NULL pointer)
   if (!nbr && (K != 1 || n_in != n_out)) return FC_EINVAL;
@@ -1382,9 +1419,9 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
   int rc = launch_conv_mfma(conv_pipe(flags, grid), bm, bn, grid, in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream, wt,
-                            (flags & FC_CONV_APL) != 0, S > 1 ? nullptr : stats);
+                            (flags & FC_CONV_APL) != 0, S > 1 ? nullptr : epi);
   if (rc != FC_OK) return rc;
-  if (S > 1) return stats ? sum_parts_stats(dst, out, n_out, Cout, S, stats, stream) : sum_parts(dst, out, n_out, Cout, S, stream);
+  if (S > 1) return stats ? sum_parts_stats(dst, out, n_out, Cout, S, *epi, stream) : sum_parts(dst, out, n_out, Cout, S, stream);
   return FC_OK;
 }
 
@@ -1404,7 +1441,24 @@ int fc_conv_fwd_stats(const float* in, const float* W, const int* nbr, const int
                       int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, float* stats,
                       hipStream_t stream) {
   if (stats && fc_conv_stats_blocks(n_out, K, Cin, Cout, flags, 0) == 0) return FC_EINVAL;
-  return conv_fwd_impl(in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream, stats);
+  X6Epi e = {};
+  e.stats = stats;
+  return conv_fwd_impl(in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream, stats ? &e : nullptr);
+}
+
+// The backward-data pass of a convolution whose INPUT came out of a BatchNorm (+ ReLU / ELU) layer: besides the gradient g it
+// writes, the launch leaves that layer's two backward reductions per row block — stats[blocks][2][Cout] = column sums of
+// g' = g act'(.) and of g' xhat, xhat from the layer's input bn_x (n_out, Cout) and its batch statistics — for
+// fc_bn_train_bwd(part = stats).  act: 0 none, 1 ReLU, 2 ELU; add (nullable): a second contribution to the gradient, g = result + add;
+// bn_y (nullable): the layer's output, which act'(.) is taken from (a layer WITH a residual; NULL: recomputed from bn_x).
+int fc_conv_fwd_bn_bwd_stats(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
+                             int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, float* stats,
+                             const float* bn_x, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                             int act, const float* add, const float* bn_y, hipStream_t stream) {
+  if (!stats || !bn_x || !mean || !var || act < 0 || act > 2) return FC_EINVAL;
+  if (fc_conv_stats_blocks(n_out, K, Cin, Cout, flags, 0) == 0) return FC_EINVAL;
+  X6Epi e = {stats, bn_x, mean, var, gamma, beta, eps, act, add, bn_y};
+  return conv_fwd_impl(in, W, nbr, out_index, out, n_in, n_out, K, Cin, Cout, flags, ws, ws_bytes, stream, &e);
 }
 
 // flags: bit0 = force the generic FMA kernel.
@@ -1464,7 +1518,7 @@ int64_t fc_conv_fwd_pairs_ws_bytes(int64_t n_out, int K, int Cout) {
 // Convolution over the exact pair lists: per offset a compacted gather-GEMM into the workspace, then a gather-sum.
 static int conv_fwd_pairs_impl(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
                             float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
-                            void* ws, int64_t ws_bytes, hipStream_t stream, float* stats) {
+                            void* ws, int64_t ws_bytes, hipStream_t stream, const X6Epi* epi) {
   if (n_in < 0 || n_out < 0 || K < 1 || K > 65535 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (!pair_in || !pair_cnt || !pair_pos) return FC_EINVAL;
   if (Cin % 32 != 0 || Cout % 64 != 0) return FC_EINVAL;       // MFMA shapes only; callers use fc_conv_fwd otherwise
@@ -1480,9 +1534,9 @@ static int conv_fwd_pairs_impl(const float* in, const float* W, const int* pair_
     int rc = launch_conv_mfma((live_tiles > 0 || (flags & (1 << 24))) ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt, (flags & FC_CONV_APL) != 0);
     if (rc != FC_OK) return rc;
   }
-  if (stats) {
+  if (epi) {
     const int rb = fc_stat_rb(n_out);
-    k_sum_pairs_stats<<<dim3((unsigned)fc_cdiv(n_out, rb), Cout / 64), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout, rb, stats);
+    k_sum_pairs_stats<<<dim3((unsigned)fc_cdiv(n_out, rb), Cout / 64), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout, rb, *epi);
   } else {
     k_sum_pairs<<<(unsigned)fc_cdiv(n_out * (Cout / 4), 256), 256, 0, stream>>>(part, pair_pos, out, n_out, K, Cout);
   }
@@ -1501,8 +1555,21 @@ int fc_conv_fwd_pairs_tiles_stats(const float* in, const float* W, const int* pa
                                   float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
                                   void* ws, int64_t ws_bytes, float* stats, hipStream_t stream) {
   if (stats && !(flags & (1 << 24))) return FC_EINVAL;
+  X6Epi e = {};
+  e.stats = stats;
   return conv_fwd_pairs_impl(in, W, pair_in, pair_cnt, pair_pos, out, n_in, n_out, K, Cin, Cout, live_tiles, flags, ws, ws_bytes, stream,
-                             stats);
+                             stats ? &e : nullptr);
+}
+
+int fc_conv_fwd_pairs_tiles_bn_bwd_stats(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
+                                         float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
+                                         void* ws, int64_t ws_bytes, float* stats, const float* bn_x, const float* mean,
+                                         const float* var, const float* gamma, const float* beta, float eps, int act,
+                                         const float* add, const float* bn_y, hipStream_t stream) {
+  if (!stats || !bn_x || !mean || !var || act < 0 || act > 2 || !(flags & (1 << 24))) return FC_EINVAL;
+  X6Epi e = {stats, bn_x, mean, var, gamma, beta, eps, act, add, bn_y};
+  return conv_fwd_pairs_impl(in, W, pair_in, pair_cnt, pair_pos, out, n_in, n_out, K, Cin, Cout, live_tiles, flags, ws, ws_bytes, stream,
+                             &e);
 }
 
 int fc_conv_fwd_pairs(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,

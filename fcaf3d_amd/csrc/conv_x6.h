@@ -129,6 +129,51 @@ __global__ void k_x6_weight_images(const long long* __restrict__ desc, int n) {
 
 // BSRC: where the weight slab comes from — 0: fp32 (Cin, Cout) kernel, split in the staging; 1: the same kernel read
 // transposed (backward data on the layer's own weights); 2: a pre-split image of k_x6_weight_image (straight copy).
+// r5: what the epilogue of a launch leaves for the BatchNorm next to it, besides the result (conv.hip / norm.hip):
+//   stats != NULL, bn_x == NULL: column sums of the result and of its square per row block (forward: the batch statistics of the
+//                                BatchNorm that FOLLOWS the convolution);
+//   stats != NULL, bn_x != NULL: the launch is a backward-data pass whose result g is the gradient arriving at a BatchNorm (+ ReLU /
+//                                ELU) layer with input bn_x: column sums of g' = g act'(pre) and of g' xhat per row block — the two
+//                                reductions of that layer's backward pass (norm.hip k_norm_bwd_partial), without its read pass.
+//                                add (nullable): a second contribution to that gradient, g = result + add (the layer's output had two
+//                                consumers); bn_y (nullable): the layer's OUTPUT, for act'(.) where a residual was added before the
+//                                activation (BasicBlock norm2: act' cannot be recomputed from bn_x alone).
+struct X6Epi {
+  float* stats;
+  const float* bn_x;
+  const float* mean;
+  const float* var;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int act;
+  const float* add;
+  const float* bn_y;
+};
+
+// the two terms an element contributes to the statistics table (see X6Epi); mu / is / ga / be: the channel's parameters
+// (yv: the layer's output where from_y, else unused; v already includes `add`)
+__device__ __forceinline__ void x6_epi_terms(bool bwd, float v, float xv, float mu, float is, float ga, float be, int act, bool from_y,
+                                             float yv, float& t1, float& t2) {
+  if (!bwd) {
+    t1 = v;
+    t2 = v * v;
+  } else {
+    float d = 1.f;
+    if (from_y) {                                              // norm.hip act_bwd_from_y
+      if (act == 1) d = yv > 0.f ? 1.f : 0.f;
+      else if (act == 2) d = yv > 0.f ? 1.f : yv + 1.f;
+    } else {
+      const float pre = fmaf((xv - mu) * is, ga, be);          // norm.hip bn_pre: the same instruction sequence
+      if (act == 1) d = pre > 0.f ? 1.f : 0.f;
+      else if (act == 2) d = pre > 0.f ? 1.f : expf(pre);
+    }
+    const float g = v * d;
+    t1 = g;
+    t2 = g * ((xv - mu) * is);
+  }
+}
+
 // FAST (r5, SURVEY.md 8(f) rank 4 "bf16 fast mode" — a flagged NON-PARITY extra, never the benchmark's `value`): only plane 0 of
 // either operand — the operand rounded to nearest bf16 — is staged and multiplied: one MFMA per 32x32x16 block instead of six,
 // a third of the staged bytes.  Weight-image launches only; a compile-time variant (as a run-time branch it cost the product
@@ -137,7 +182,8 @@ template <int BM, int BN, bool HAS_NBR, int WM, int BSRC, bool FAST = false>
 __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_conv_x6(
     const float* __restrict__ in, const float* __restrict__ W, const int* __restrict__ nbr,
     const int* __restrict__ out_index, const int* __restrict__ cnt, float* __restrict__ out, int64_t n_out, int K, int Cin,
-    int Cout, float* __restrict__ stats) {
+    int Cout, X6Epi epi) {
+  float* __restrict__ stats = epi.stats;
   constexpr int WN = 4 / WM;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);      // 32x32 MFMA tiles per wave
   constexpr int RW = BM / WM;                                  // rows of a wave's part of the tile
@@ -395,21 +441,81 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); lane r of sub-tile j holds
   // column 2 r + j of the wave's 64-column group (TN == 1: j = wc)
+  float* dst = out + (int64_t)z * n_out * Cout + n0 + bgrp * 64 + 2 * r + (TN == 2 ? 0 : wc);
+  int orow[TM][16];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = m0 + wr * RW + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      int o = -1;
+      if (row < n_out) o = out_index ? out_index[row] : (int)row;
+      orow[i][e] = o;
+    }
   if (stats) {
     // r5: BatchNorm statistics out of the epilogue (unsplit neighbour-table / dense launches only: the accumulators ARE the
-    // results): column sums of x and x^2 over this tile's rows -> stats[tile][2][Cout] (rows past the end and absent
-    // neighbours hold exact zeros).  Lane: 16 TM values per column; the other half-wave holds the same columns' other rows;
-    // the WM waves along the rows meet in LDS (the stage buffers are free now).  Fixed order: deterministic.
-    float s1[TN], s2[TN];
+    // results): per column the two sums of X6Epi over this tile's rows -> stats[tile][2][Cout] (forward: rows past the end and
+    // absent neighbours hold exact zeros; backward: they are skipped).  Lane: 16 TM values per column; the other half-wave holds
+    // the same columns' other rows; the WM waves along the rows meet in LDS (the stage buffers are free now).  Fixed order:
+    // deterministic.
+    const bool bwd = epi.bn_x != nullptr;
+    const bool from_y = bwd && epi.bn_y != nullptr && epi.act != 0;
+    const int col0 = n0 + bgrp * 64 + 2 * r + (TN == 2 ? 0 : wc);          // this lane's first column (TN == 2: and col0 + 1)
+    float mu[TN], is[TN], ga[TN], be[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      float a = 0.f, b = 0.f;
+      mu[j] = 0.f; is[j] = 1.f; ga[j] = 1.f; be[j] = 0.f;
+      if (bwd) {
+        mu[j] = epi.mean[col0 + j];
+        is[j] = 1.f / sqrtf(epi.var[col0 + j] + epi.eps);
+        ga[j] = epi.gamma ? epi.gamma[col0 + j] : 1.f;
+        be[j] = epi.beta ? epi.beta[col0 + j] : 0.f;
+      }
+    }
+    float s1[TN], s2[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; a += v; b += v * v; }
-      s1[j] = a + __shfl_xor(a, 32, 64);
-      s2[j] = b + __shfl_xor(b, 32, 64);
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e0 = 0; e0 < 16; e0 += 4) {
+        float xv[4][TN], av[4][TN], yv[4][TN];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                       // four rows of the layer's input (second gradient, output) in flight
+          const int o = orow[i][e0 + u];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) { xv[u][j] = 0.f; av[u][j] = 0.f; yv[u][j] = 0.f; }
+          if (bwd && o >= 0) {
+            const int64_t at = (int64_t)o * Cout + col0;
+            if (TN == 2) {
+              const f32x2 t = *reinterpret_cast<const f32x2*>(epi.bn_x + at);
+              xv[u][0] = t[0]; xv[u][TN - 1] = t[1];
+              if (epi.add) { const f32x2 a2 = *reinterpret_cast<const f32x2*>(epi.add + at); av[u][0] = a2[0]; av[u][TN - 1] = a2[1]; }
+              if (from_y) { const f32x2 y2 = *reinterpret_cast<const f32x2*>(epi.bn_y + at); yv[u][0] = y2[0]; yv[u][TN - 1] = y2[1]; }
+            } else {
+              xv[u][0] = epi.bn_x[at];
+              if (epi.add) av[u][0] = epi.add[at];
+              if (from_y) yv[u][0] = epi.bn_y[at];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (bwd && orow[i][e0 + u] < 0) continue;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float t1, t2;
+            x6_epi_terms(bwd, bwd ? av[u][j] + acc[i][j][e0 + u] : acc[i][j][e0 + u], xv[u][j], mu[j], is[j], ga[j], be[j], epi.act, from_y,
+                         yv[u][j], t1, t2);
+            s1[j] += t1;
+            s2[j] += t2;
+          }
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32, 64);
+      s2[j] += __shfl_xor(s2[j], 32, 64);
     }
     __syncthreads();
     float* red = reinterpret_cast<float*>(As);                 // [WM][BN][2]
@@ -430,17 +536,6 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
       stats[((int64_t)blockIdx.x * 2 + 1) * Cout + n0 + tid] = b;
     }
   }
-  float* dst = out + (int64_t)z * n_out * Cout + n0 + bgrp * 64 + 2 * r + (TN == 2 ? 0 : wc);
-  int orow[TM][16];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int64_t row = m0 + wr * RW + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      int o = -1;
-      if (row < n_out) o = out_index ? out_index[row] : (int)row;
-      orow[i][e] = o;
-    }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll

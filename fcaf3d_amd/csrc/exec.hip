@@ -242,15 +242,28 @@ int run_op_impl(Ctx& c, const int64_t* op) {
       return fc_maxpool_fwd(P<const float>(c, op[2]), reinterpret_cast<const int*>(m[3]), m[1], (int)m[2], (int)op[4], P<float>(c, op[5]),
                             P<int>(c, op[6]), st);
     }
-    case OP_CONV: {  // in, img, map (-1: dense GEMM over n rows), dir, out, n(dim, dense only), Cin, Cout, statistics table + 1 | 0
+    case OP_CONV: {  // in, img, map (-1: dense GEMM over n rows), dir, out, n(dim, dense only), Cin, Cout, statistics table + 1 | 0,
+                     // [BatchNorm-backward form of the table:] bn_x + 1 | 0, mean, var, gamma, beta, eps, act, add + 1 | 0, bn_y + 1 | 0
       const int Cin = (int)op[8], Cout = (int)op[9];
       const int fl = c.flags | CONV_X6;
       float* stats = (op[10] > 0 && stats_blocks_of(c, op) > 0) ? P<float>(c, op[10] - 1) : nullptr;
+      const float* bnx = (stats && op[11] > 0) ? P<const float>(c, op[11] - 1) : nullptr;
+      const float *bmean = P<const float>(c, op[12]), *bvar = P<const float>(c, op[13]), *bga = P<const float>(c, op[14]),
+                  *bbe = P<const float>(c, op[15]);
+      const float beps = (float)as_double(op[16]);
+      const int bact = (int)op[17];
+      const float* badd = op[18] > 0 ? P<const float>(c, op[18] - 1) : nullptr;     // second gradient contribution / the layer's output
+      const float* bny = op[19] > 0 ? P<const float>(c, op[19] - 1) : nullptr;
+      const float* in = P<const float>(c, op[2]);
+      const float* img = P<const float>(c, op[3]);
+      float* out = P<float>(c, op[6]);
       if (op[4] < 0) {
         const int64_t n = c.dims[op[7]];
         if (!want_ws(c, s, fc_conv_fwd_ws_bytes(n, 1, Cin, Cout, fl))) return 0;
-        return fc_conv_fwd_stats(P<const float>(c, op[2]), P<const float>(c, op[3]), nullptr, nullptr, P<float>(c, op[6]), n, n, 1, Cin, Cout,
-                                 fl, c.ws[s], c.ws_bytes[s], stats, st);
+        if (bnx)
+          return fc_conv_fwd_bn_bwd_stats(in, img, nullptr, nullptr, out, n, n, 1, Cin, Cout, fl, c.ws[s], c.ws_bytes[s], stats, bnx, bmean, bvar,
+                                          bga, bbe, beps, bact, badd, bny, st);
+        return fc_conv_fwd_stats(in, img, nullptr, nullptr, out, n, n, 1, Cin, Cout, fl, c.ws[s], c.ws_bytes[s], stats, st);
       }
       const int64_t* m = c.maps + op[4] * MAPW;
       const bool bwd = op[5] != 0;
@@ -258,15 +271,21 @@ int run_op_impl(Ctx& c, const int64_t* op) {
       const int K = (int)m[2];
       if (m[19] & (bwd ? 2 : 1)) {                       // per offset over the exact pair lists
         const int b = bwd ? 14 : 9;
+        const int *pi = reinterpret_cast<const int*>(m[b]), *pc = reinterpret_cast<const int*>(m[b + 3]),
+                  *pp = reinterpret_cast<const int*>(m[b + 2]);
         if (!want_ws(c, s, fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout))) return 0;
-        return fc_conv_fwd_pairs_tiles_stats(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[b]),
-                                             reinterpret_cast<const int*>(m[b + 3]), reinterpret_cast<const int*>(m[b + 2]),
-                                             P<float>(c, op[6]), n_in, n_out, K, Cin, Cout, m[b + 4], fl, c.ws[s], c.ws_bytes[s], stats, st);
+        if (bnx)
+          return fc_conv_fwd_pairs_tiles_bn_bwd_stats(in, img, pi, pc, pp, out, n_in, n_out, K, Cin, Cout, m[b + 4], fl, c.ws[s], c.ws_bytes[s],
+                                                      stats, bnx, bmean, bvar, bga, bbe, beps, bact, badd, bny, st);
+        return fc_conv_fwd_pairs_tiles_stats(in, img, pi, pc, pp, out, n_in, n_out, K, Cin, Cout, m[b + 4], fl, c.ws[s], c.ws_bytes[s], stats,
+                                             st);
       }
+      const int *tab = reinterpret_cast<const int*>(m[bwd ? 7 : 5]), *oidx = reinterpret_cast<const int*>(m[bwd ? 8 : 6]);
       if (!want_ws(c, s, fc_conv_fwd_ws_bytes(n_out, K, Cin, Cout, fl))) return 0;
-      return fc_conv_fwd_stats(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[bwd ? 7 : 5]),
-                               reinterpret_cast<const int*>(m[bwd ? 8 : 6]), P<float>(c, op[6]), n_in, n_out, K, Cin, Cout, fl, c.ws[s],
-                               c.ws_bytes[s], stats, st);
+      if (bnx)
+        return fc_conv_fwd_bn_bwd_stats(in, img, tab, oidx, out, n_in, n_out, K, Cin, Cout, fl, c.ws[s], c.ws_bytes[s], stats, bnx, bmean, bvar,
+                                        bga, bbe, beps, bact, badd, bny, st);
+      return fc_conv_fwd_stats(in, img, tab, oidx, out, n_in, n_out, K, Cin, Cout, fl, c.ws[s], c.ws_bytes[s], stats, st);
     }
     case OP_BN_FWD: {  // x, n(dim), C, eps, gamma, beta, res, act, momentum, y, mean, var, cnt, rmean, rvar, nbt, train
       const int64_t n = c.dims[op[3]];
@@ -348,15 +367,24 @@ int run_op_impl(Ctx& c, const int64_t* op) {
       return fc_conv_wgrad(P<const float>(c, op[2]), P<const float>(c, op[3]), reinterpret_cast<const int*>(m[3]), nullptr,
                            P<float>(c, op[5]), m[0], m[1], K, Cin, Cout, fl, c.ws[s], c.ws_bytes[s], st);
     }
-    case OP_BN_BWD: {  // x, y, gy, n(dim), C, mean, var, cnt, eps, gamma, beta, act, gx, gres, sums, gy2 + 1 | 0
+    case OP_BN_BWD: {  // x, y, gy, n(dim), C, mean, var, cnt, eps, gamma, beta, act, gx, gres, sums, gy2 + 1 | 0, producer of gy + 1 | 0
       const int64_t n = c.dims[op[5]];
       const int C = (int)op[6];
       const float eps = (float)as_double(op[10]);
+      // the backward-data convolution that wrote gy may have left this layer's two reductions in its epilogue (word 18: its index
+      // + 1 in this list; fc_conv_fwd_bn_bwd_stats)
+      const float* part = nullptr;
+      int64_t nbp = 0;
+      if (op[18] > 0) {
+        const int64_t* pop = c.ops + (op[18] - 1) * OPW;
+        nbp = (pop[10] > 0 && pop[11] > 0) ? stats_blocks_of(c, pop) : 0;
+        if (nbp > 0) part = P<const float>(c, pop[10] - 1);
+      }
       if (!want_ws(c, s, fc_bn_train_ws_bytes(n, C))) return 0;
       return fc_bn_train_bwd(P<const float>(c, op[2]), P<const float>(c, op[3]), P<const float>(c, op[4]),
                              op[17] > 0 ? P<const float>(c, op[17] - 1) : nullptr, n, C, P<const float>(c, op[7]), P<const float>(c, op[8]),
                              P<const float>(c, op[9]), eps, P<const float>(c, op[11]), P<const float>(c, op[12]), (int)op[13],
-                             P<float>(c, op[14]), P<float>(c, op[15]), P<float>(c, op[16]), nullptr, 0, c.bn_small_elems, c.ws[s],
+                             P<float>(c, op[14]), P<float>(c, op[15]), P<float>(c, op[16]), part, nbp, c.bn_small_elems, c.ws[s],
                              c.ws_bytes[s], st);
     }
     case OP_NORM_BWD: {  // x, y, gy, seg, n(dim), C, nseg(dim), mean, var, cnt, eps, gamma, beta, act, gx, gres, sums

@@ -110,43 +110,48 @@ __global__ void k_stats_partial(const float* __restrict__ x, const int* __restri
   }
 }
 
-// ---- pass 2: sum partials over blocks (fixed order); block = 64 channels x 16 slices -----------------
+// ---- pass 2: sum partials over blocks (fixed order); block = 16 channels x 64 slices -----------------
 // mode 0: out = sum / cnt (mean), also writes cnt[seg];  mode 1: out = sum / cnt (biased variance); mode 2: out = sum
+// r5: 16 channels x 64 slices per block (r1-r4: 64 x 16): these launches are pure latency — one block per 64 channels walked up to
+// 1 024 partial rows in 16 slices, 23 us per launch on the large levels; four times the blocks, a quarter of the chain per thread
+#define FIN_CB 16
+#define FIN_SL 64
 __global__ __launch_bounds__(1024) void k_stats_final(const float* __restrict__ part, const float* __restrict__ part_cnt,
                                                       int64_t nblocks, int nseg, int C, int mode, float* __restrict__ out,
                                                       float* __restrict__ cnt_io) {
-  __shared__ float red[16][65];
-  __shared__ float redc[16];
-  const int cgroups = (C + 63) / 64;
+  __shared__ float red[FIN_SL][FIN_CB + 1];
+  __shared__ float redc[FIN_SL];
+  const int cgroups = (C + FIN_CB - 1) / FIN_CB;
   const int s = blockIdx.x / cgroups, cg = blockIdx.x % cgroups;
-  const int c = cg * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;
+  const int cl = threadIdx.x & (FIN_CB - 1), j = threadIdx.x / FIN_CB;
+  const int c = cg * FIN_CB + cl;
   // four partials in flight per thread (r3: one dependent load per iteration made these tiny launches 13 us each); the
   // summation order is fixed by the code, hence still deterministic
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (c < C) {
     int64_t b = j;
-    for (; b + 48 < nblocks; b += 64) {
-      const float v0 = fc_ld(&part[(b * nseg + s) * C + c]), v1 = fc_ld(&part[((b + 16) * nseg + s) * C + c]);      // (one block reads the
-      const float v2 = fc_ld(&part[((b + 32) * nseg + s) * C + c]), v3 = fc_ld(&part[((b + 48) * nseg + s) * C + c]);   //  table once: past the L1)
+    for (; b + 3 * FIN_SL < nblocks; b += 4 * FIN_SL) {
+      const float v0 = fc_ld(&part[(b * nseg + s) * C + c]), v1 = fc_ld(&part[((b + FIN_SL) * nseg + s) * C + c]);      // (one block reads the
+      const float v2 = fc_ld(&part[((b + 2 * FIN_SL) * nseg + s) * C + c]), v3 = fc_ld(&part[((b + 3 * FIN_SL) * nseg + s) * C + c]);   //  table once: past the L1)
       a0 += v0; a1 += v1; a2 += v2; a3 += v3;
     }
-    for (; b < nblocks; b += 16) a0 += fc_ld(&part[(b * nseg + s) * C + c]);
+    for (; b < nblocks; b += FIN_SL) a0 += fc_ld(&part[(b * nseg + s) * C + c]);
   }
   float acc = (a0 + a1) + (a2 + a3);
-  red[j][threadIdx.x & 63] = acc;
-  if (mode == 0 && (threadIdx.x & 63) == 0) {
+  red[j][cl] = acc;
+  if (mode == 0 && cl == 0) {
     float cc = 0.f;
-    for (int64_t b = j; b < nblocks; b += 16) cc += fc_ld(&part_cnt[b * nseg + s]);
+    for (int64_t b = j; b < nblocks; b += FIN_SL) cc += fc_ld(&part_cnt[b * nseg + s]);
     redc[j] = cc;
   }
   __syncthreads();
   if (j == 0 && c < C) {
     float t = 0.f;
-    for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x & 63];
+    for (int q = 0; q < FIN_SL; ++q) t += red[q][cl];
     float cnt = 1.f;
     if (mode == 0) {
       float cc = 0.f;
-      for (int q = 0; q < 16; ++q) cc += redc[q];
+      for (int q = 0; q < FIN_SL; ++q) cc += redc[q];
       if (c == 0) cnt_io[s] = cc;
       cnt = cc;
     } else if (mode == 1) {
@@ -779,32 +784,33 @@ __global__ void k_bn2_apply(const float* __restrict__ x, int64_t n, int C, int64
   }
 }
 
-// many partial blocks: one 1024-thread block per 64 channels adds them (fp64, fixed order) and writes mean / biased var / count +
-// the nn.BatchNorm1d running-buffer update; follow with k_norm_act_fwd
+// many partial blocks: one 1024-thread block per 16 channels (64 slices of the table each) adds them (fp64, fixed order) and writes
+// mean / biased var / count + the nn.BatchNorm1d running-buffer update; follow with k_norm_act_fwd
 __global__ __launch_bounds__(1024) void k_bn2_finalize(const float* __restrict__ part, int nb, int C, int G, int64_t n, float momentum,
                                                        float* __restrict__ mean, float* __restrict__ var, float* __restrict__ cnt,
                                                        float* __restrict__ rmean, float* __restrict__ rvar,
                                                        long long* __restrict__ nbt) {
-  __shared__ double r1[16][65], r2[16][65];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;
+  __shared__ double r1[FIN_SL][FIN_CB + 1], r2[FIN_SL][FIN_CB + 1];
+  const int cl = threadIdx.x & (FIN_CB - 1), j = threadIdx.x / FIN_CB;
+  const int c = blockIdx.x * FIN_CB + cl;
   const int GC = G * C;
   double a1 = 0., a2 = 0.;
   if (c < C) {
     double p1[4] = {0., 0., 0., 0.}, p2[4] = {0., 0., 0., 0.};      // four partial blocks in flight
     const int total = nb * G;
     int t = j;
-    for (; t + 48 < total; t += 64) {
+    for (; t + 3 * FIN_SL < total; t += 4 * FIN_SL) {
       float u[4], w[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int tt = t + 16 * q, b = tt / G, g = tt % G;
+        const int tt = t + FIN_SL * q, b = tt / G, g = tt % G;
         u[q] = fc_ld(&part[((int64_t)b * 2) * GC + g * C + c]);
         w[q] = fc_ld(&part[((int64_t)b * 2 + 1) * GC + g * C + c]);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) { p1[q] += u[q]; p2[q] += w[q]; }
     }
-    for (; t < total; t += 16) {
+    for (; t < total; t += FIN_SL) {
       const int b = t / G, g = t % G;
       p1[0] += fc_ld(&part[((int64_t)b * 2) * GC + g * C + c]);
       p2[0] += fc_ld(&part[((int64_t)b * 2 + 1) * GC + g * C + c]);
@@ -812,12 +818,12 @@ __global__ __launch_bounds__(1024) void k_bn2_finalize(const float* __restrict__
     a1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
     a2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
   }
-  r1[j][threadIdx.x & 63] = a1;
-  r2[j][threadIdx.x & 63] = a2;
+  r1[j][cl] = a1;
+  r2[j][cl] = a2;
   __syncthreads();
   if (j == 0 && c < C) {
     double s1 = 0., s2 = 0.;
-    for (int q = 0; q < 16; ++q) { s1 += r1[q][threadIdx.x & 63]; s2 += r2[q][threadIdx.x & 63]; }
+    for (int q = 0; q < FIN_SL; ++q) { s1 += r1[q][cl]; s2 += r2[q][cl]; }
     float mu, va;
     bn2_stats(s1, s2, n, &mu, &va);
     mean[c] = mu;
@@ -876,7 +882,7 @@ int fc_col_stats(const float* x, const int* seg, int seg_stride, int64_t n, int 
     FC_HIP(hipMemsetAsync(cnt, 0, sizeof(float) * nseg, stream));
     return FC_OK;
   }
-  unsigned gfin = (unsigned)(nseg * ((C + 63) / 64));
+  unsigned gfin = (unsigned)(nseg * ((C + FIN_CB - 1) / FIN_CB));
   k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, nullptr, 0, rpb, part, part_cnt);
   FC_CHECK_LAUNCH();
   k_stats_final<<<gfin, 1024, 0, stream>>>(part, part_cnt, nb, nseg, C, 0, mean, cnt);
@@ -904,7 +910,7 @@ int fc_seg_col_sums(const float* x, const int* seg, int seg_stride, int64_t n, i
   float* part = (float*)ws;
   k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, nullptr, 0, rpb, part, nullptr);
   FC_CHECK_LAUNCH();
-  k_stats_final<<<(unsigned)(nseg * ((C + 63) / 64)), 1024, 0, stream>>>(part, nullptr, nb, nseg, C, 2, out, nullptr);
+  k_stats_final<<<(unsigned)(nseg * ((C + FIN_CB - 1) / FIN_CB)), 1024, 0, stream>>>(part, nullptr, nb, nseg, C, 2, out, nullptr);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
@@ -1044,7 +1050,7 @@ int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* 
   k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, seg, seg_stride, n, C, nseg, mean, var, eps, act, gamma,
                                                           beta, rpb, part);
   FC_CHECK_LAUNCH();
-  k_stats_final<<<(unsigned)(nseg * ((2 * C + 63) / 64)), 1024, 0, stream>>>(part, nullptr, nb, nseg, 2 * C, 2, sums, nullptr);
+  k_stats_final<<<(unsigned)(nseg * ((2 * C + FIN_CB - 1) / FIN_CB)), 1024, 0, stream>>>(part, nullptr, nb, nseg, 2 * C, 2, sums, nullptr);
   FC_CHECK_LAUNCH();
   k_norm_bwd_apply<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, y, gy, nullptr, seg, seg_stride, n, C, mean, var, eps,
                                                                            gamma, beta, sums, cnt, act, gx, gres);
@@ -1094,7 +1100,7 @@ int fc_bn_train_fwd(const float* x, int64_t n, int C, float eps, const float* ga
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
-  k_bn2_finalize<<<(unsigned)((C + 63) / 64), 1024, 0, stream>>>(part, (int)nb_part, C, groups, n, momentum, mean, var, cnt,
+  k_bn2_finalize<<<(unsigned)((C + FIN_CB - 1) / FIN_CB), 1024, 0, stream>>>(part, (int)nb_part, C, groups, n, momentum, mean, var, cnt,
                                                                  running_mean, running_var, num_batches_tracked);
   FC_CHECK_LAUNCH();
   return fc_norm_act_fwd(x, nullptr, 0, n, C, mean, var, eps, gamma, beta, residual, act, y, stream);
@@ -1131,7 +1137,7 @@ int fc_bn_train_bwd(const float* x, const float* y, const float* gy, const float
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
-  k_stats_final<<<(unsigned)((2 * C + 63) / 64), 1024, 0, stream>>>(p, nullptr, np, 1, 2 * C, 2, sums, nullptr);
+  k_stats_final<<<(unsigned)((2 * C + FIN_CB - 1) / FIN_CB), 1024, 0, stream>>>(p, nullptr, np, 1, 2 * C, 2, sums, nullptr);
   FC_CHECK_LAUNCH();
   k_norm_bwd_apply<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, y, gy, gy2, nullptr, 0, n, C, mean, var, eps, gamma, beta,
                                                                            sums, cnt, act, gx, gres);

@@ -294,6 +294,7 @@ class NetProgram:
             self.emit(Bk, OP_WGRAD, wstream(cur), *words)
 
         producer = {}                    # forward tensor -> (index of the OP_CONV that wrote it, rows, columns)
+        grad_src = {}                    # backward tensor -> (index in Bk of the backward-data OP_CONV that wrote it, rows, columns, stream)
 
         def conv(x, mod, mname, rows_in, rows_out, stream=S_MAIN):
             """MinkowskiConvolution on a kernel map (functional._SparseConv)"""
@@ -307,6 +308,7 @@ class NetProgram:
                     gy = take(y, rows_out, Cout) if stream == S_MAIN else got(y)
                     gx = self.T(rows_in, Cin, 'b')
                     self.emit(Bk, OP_CONV, stream, gy, self.IMG(mod.kernel, True), m, 1, gx, -1, Cout, Cin)
+                    grad_src[gx] = (len(Bk) - 1, rows_in, Cin, stream)
                     emit_wgrad(stream, x, gy, m, self.G(mod.kernel), -1, Cin, Cout)
                     wrote(mod.kernel)
                     accumulate(x, gx, rows_in, Cin, stream)
@@ -324,6 +326,7 @@ class NetProgram:
                     gy = take(y, rows, Cout) if stream == S_MAIN else got(y)
                     gx = self.T(rows, Cin, 'b')
                     self.emit(Bk, OP_CONV, stream, gy, self.IMG(w_tensor, True), -1, 1, gx, self.D(rows), Cout, Cin)
+                    grad_src[gx] = (len(Bk) - 1, rows, Cin, stream)
                     emit_wgrad(stream, x, gy, -1, gw_dst, self.D(rows), Cin, Cout)
                     if w_tensor is self.packed:
                         head_wgrads[0] += 1
@@ -365,8 +368,21 @@ class NetProgram:
                     gy, gy2 = take(y, rows, C, pair=True) if stream == S_MAIN else (got(y), None)
                     gx = self.T(rows, C, 'b')
                     gres = self.T(rows, C, 'b') if res is not None else -1
+                    prod = 0
+                    # the LAST contribution to gy is the result of a backward-data convolution (and at most one other contribution
+                    # arrived before it): that launch leaves this layer's two reductions (sum g', sum g' xhat) in its epilogue
+                    # (fc_conv_fwd_bn_bwd_stats; `add` = the earlier contribution, bn_y = this layer's output where act' needs it)
+                    # — no reduction pass over x, gy (, y)
+                    last, first = (gy, None) if gy2 is None else (gy2, gy)
+                    src = grad_src.get(last)
+                    if Fn.BN_FUSE and src is not None and src[3] == stream and src[1:3] == (rows, C):
+                        pi = src[0]
+                        Bk[pi][10] = self.T(rows, C // 8, 'b', extra=8 * C + 256) + 1
+                        Bk[pi][11:20] = [x + 1, mean, var, self.S(b.weight), self.S(b.bias), _f(b.eps), act,
+                                         0 if first is None else first + 1, 0 if res is None else y + 1]
+                        prod = pi + 1
                     self.emit(Bk, OP_BN_BWD, stream, x, y if res is not None else -1, gy, self.D(rows), C, mean, var, cnt, _f(b.eps),
-                              self.S(b.weight), self.S(b.bias), act, gx, gres, si, 0 if gy2 is None else gy2 + 1)
+                              self.S(b.weight), self.S(b.bias), act, gx, gres, si, 0 if gy2 is None else gy2 + 1, prod)
                     accumulate(x, gx, rows, C, stream)
                     if res is not None:
                         accumulate(res, gres, rows, C, stream)

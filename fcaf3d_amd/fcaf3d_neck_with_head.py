@@ -211,7 +211,11 @@ class Fcaf3DNeckWithHead(nn.Module):
             for perm in perms:
                 k = min(len(perm), self.pts_threshold)
                 ids = torch.topk(interpolated[perm], k, sorted=False).indices
-                mask[perm[ids]] = True
+                # (NOT `mask[perm[ids]] = True`: indexing-assignment of a Python scalar makes a CPU tensor of it and copies it to
+                # the device — a pageable host -> device copy, which blocks the host until everything enqueued before it on the
+                # stream has run: r5 host profile, 6.3 ms per call, the whole network body.  index_fill_ takes the scalar as a
+                # kernel argument)
+                mask.index_fill_(0, perm[ids], True)
                 kept += k
         # the number of kept rows is known on the host (top-k indices of a scene are distinct): MinkowskiPruning does not read the
         # count back, so the host does not wait for the network body that produced the scores (r4: the one synchronisation that

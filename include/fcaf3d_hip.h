@@ -195,6 +195,23 @@ int fc_conv_fwd_stats(const float* in, const float* W, const int* nbr, const int
 int fc_conv_fwd_pairs_tiles_stats(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
                                   float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
                                   void* ws, int64_t ws_bytes, float* stats, hipStream_t stream);
+/* ... and the backward half of the same pairing (r5): the backward-data pass of a convolution whose INPUT came out of a BatchNorm
+ * (+ ReLU / ELU, no residual: BasicBlock norm1 -> conv2, me_resnet.py:3; the neck's norm -> conv chains and out_block -> head,
+ * fcaf3d_neck_with_head.py:52-71, :257-263) also leaves that layer's two backward reductions per row block —
+ * stats[blocks][2][Cout] = column sums of g' = g act'(pre) and of g' xhat (pre, xhat from the layer's input bn_x (n_out, Cout) and
+ * its batch mean / var / gamma / beta / eps; act 0 none, 1 ReLU, 2 ELU) — which fc_bn_train_bwd(part = stats) consumes instead of
+ * reading bn_x and g once more.  add (nullable): a second contribution to that gradient, g = result + add (the layer's output had
+ * two consumers: BasicBlock's `out += residual`); bn_y (nullable): the layer's output, from which act'(.) is taken when a residual
+ * was added before the activation (norm2 of a BasicBlock; NULL: act' is recomputed from bn_x). */
+int fc_conv_fwd_bn_bwd_stats(const float* in, const float* W, const int* nbr, const int* out_index, float* out, int64_t n_in,
+                             int64_t n_out, int K, int Cin, int Cout, int flags, void* ws, int64_t ws_bytes, float* stats,
+                             const float* bn_x, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                             int act, const float* add, const float* bn_y, hipStream_t stream);
+int fc_conv_fwd_pairs_tiles_bn_bwd_stats(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
+                                         float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
+                                         void* ws, int64_t ws_bytes, float* stats, const float* bn_x, const float* mean,
+                                         const float* var, const float* gamma, const float* beta, float eps, int act,
+                                         const float* add, const float* bn_y, hipStream_t stream);
 
 /* backward-weights of ME.MinkowskiConvolution (autograd of me_resnet.py:19-21, :56-62 and fcaf3d_neck_with_head.py:52,
  * :60-69; `gW[k] += in[i]^T (x) gout[o]`): gW[k] = sum_o in[nbr[k][o]]^T (x) gout[o];

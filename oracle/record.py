@@ -24,10 +24,10 @@ class RecordDecisions:
         na0, bs0, mp0 = self.saved
         rec = self
 
-        def pr(mod, x, mask):
+        def pr(mod, x, mask, **kw):
             if not bool(mask.all()):
                 rec.prune.append(x.C[mask].cpu().numpy())
-            return rec.prune0(mod, x, mask)
+            return rec.prune0(mod, x, mask, **kw)
         MEnn.MinkowskiPruning.forward = pr
 
         def na(ctx, x, gamma, beta, residual, seg, nseg, eps, act, *rest):

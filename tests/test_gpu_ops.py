@@ -977,3 +977,76 @@ def test_non_finite_activations_on_the_split_route():
     assert np.isposinf(outs[False][only_inf]).any(axis=1).all(), 'fp32 MFMA route: +inf'
     assert np.isnan(outs[True][only_inf]).any(axis=1).all(), 'split-bf16 route: NaN (documented difference)'
     np.testing.assert_allclose(outs[True][clean], outs[False][clean], rtol=0, atol=1e-4 * np.abs(outs[False][clean]).max())
+
+
+@pytest.mark.parametrize('q,C,route', [(4, 64, 'tile epilogue'), (8, 128, 'pair lists'), (32, 256, 'pair lists, few rows')])
+@pytest.mark.parametrize('act,with_add,from_y', [(1, False, False), (2, False, False), (1, True, True)])
+def test_batchnorm_backward_sums_out_of_the_convolution_epilogue(q, C, route, act, with_add, from_y):
+    """fc_conv_fwd_bn_bwd_stats / fc_conv_fwd_pairs_tiles_bn_bwd_stats: a launch whose result g is the gradient arriving at a
+    BatchNorm (+ ReLU / ELU) layer also leaves, per row block, the column sums of g' = (g + add) act'(.) and of g' xhat — that
+    layer's two backward reductions.  Checked against the same sums in float64 (2e-5 of the column scale), the result itself bit
+    for bit against the plain launch, and fc_bn_train_bwd fed with the table against fc_bn_train_bwd reducing on its own."""
+    from fcaf3d_amd import _lib as L
+    import fcaf3d_amd.functional as Fn
+    dev = _dev()
+    x, w, km, cm = _stats_case(dev, 100000, C, C, q, seed=31)
+    n = cm.n
+    g = torch.Generator().manual_seed(q)
+    bn_x = torch.randn(n, C, generator=g).to(dev)
+    mean, var = bn_x.mean(0).contiguous(), bn_x.var(0, unbiased=False).contiguous()
+    gam, bet = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+    add = torch.randn(n, C, generator=g).to(dev) if with_add else None
+    res = torch.randn(n, C, generator=g).to(dev) if from_y else None
+    eps = 1e-5
+    pre = (bn_x - mean) / torch.sqrt(var + eps) * gam + bet + (res if res is not None else 0)
+    bn_y = (torch.relu(pre) if act == 1 else torch.nn.functional.elu(pre)).contiguous()
+    fl = Fn.FLAGS | Fn.CONV_X6
+    img = Fn._x6_image(w, False)
+    pairs = Fn._pair_conv(km, n, C, C)
+    nb = L.query('fc_conv_stats_blocks', n, 27, C, C, fl, 1 if pairs else 0)
+    assert nb > 0
+    stats = torch.zeros((nb, 2, C), device=dev)
+    out = torch.empty((n, C), device=dev)
+    with torch.no_grad():
+        ref = Fn.sparse_conv(x, w, km, n)
+    if pairs:
+        pi, _, pos, cnt = km.pairs()
+        ws = L.workspace(L.query('fc_conv_fwd_pairs_ws_bytes', n, 27, C), dev)
+        L.call('fc_conv_fwd_pairs_tiles_bn_bwd_stats', L.ptr(x), L.ptr(img), L.ptr(pi), L.ptr(cnt), L.ptr(pos), L.ptr(out), n, n, 27, C, C,
+               km.pair_tiles(), fl, L.ptr(ws), ws.numel(), L.ptr(stats), L.ptr(bn_x), L.ptr(mean), L.ptr(var), L.ptr(gam), L.ptr(bet), eps,
+               act, L.ptr(add), L.ptr(bn_y) if from_y else None, L.stream())
+    else:
+        nbr, oidx = km.sorted_fwd()
+        wsb = L.query('fc_conv_fwd_ws_bytes', n, 27, C, C, fl)
+        ws = L.workspace(max(wsb, 1), dev)
+        L.call('fc_conv_fwd_bn_bwd_stats', L.ptr(x), L.ptr(img), L.ptr(nbr), L.ptr(oidx), L.ptr(out), n, n, 27, C, C, fl, L.ptr(ws),
+               ws.numel(), L.ptr(stats), L.ptr(bn_x), L.ptr(mean), L.ptr(var), L.ptr(gam), L.ptr(bet), eps, act, L.ptr(add),
+               L.ptr(bn_y) if from_y else None, L.stream())
+    assert torch.equal(out, ref), route
+    gsum = out.double() + (add.double() if add is not None else 0)
+    xh = ((bn_x - mean) / torch.sqrt(var + eps)).double()
+    if from_y:
+        d = (bn_y > 0).double() if act == 1 else torch.where(bn_y > 0, torch.ones_like(bn_y), bn_y + 1).double()
+    else:
+        p0 = ((bn_x - mean) / torch.sqrt(var + eps) * gam + bet)
+        d = (p0 > 0).double() if act == 1 else torch.where(p0 > 0, torch.ones_like(p0), torch.exp(p0)).double()
+    gp = gsum * d
+    s1, s2 = stats[:, 0].double().sum(0), stats[:, 1].double().sum(0)
+    sc1, sc2 = float(gp.abs().sum(0).max()), float((gp * xh).abs().sum(0).max())
+    # (a ReLU decision on a pre-activation at rounding level may differ between torch's expression and the kernel's fused
+    # multiply-add: a handful of elements of ~4e6, each worth one |g| — allowed for on top of the 2e-5)
+    slack = 4.0 * float(gsum.abs().max()) if (act == 1 and not from_y) else 0.0
+    assert float((s1 - gp.sum(0)).abs().max()) <= 2e-5 * sc1 + slack, (route, float((s1 - gp.sum(0)).abs().max()), sc1)
+    assert float((s2 - (gp * xh).sum(0)).abs().max()) <= 2e-5 * sc2 + slack * float(xh.abs().max()), route
+    # the BatchNorm backward fed with the table == the one that reduces on its own (to summation order)
+    cntt = torch.full((1,), float(n), device=dev)
+    res_out = []
+    for part in (None, stats):
+        gx, gr, sums = torch.empty_like(bn_x), torch.empty_like(bn_x), torch.empty((2, C), device=dev)
+        wsb = L.workspace(L.query('fc_bn_train_ws_bytes', n, C), dev)
+        L.call('fc_bn_train_bwd', L.ptr(bn_x), L.ptr(bn_y) if from_y else None, L.ptr(out), L.ptr(add), n, C, L.ptr(mean), L.ptr(var),
+               L.ptr(cntt), eps, L.ptr(gam), L.ptr(bet), act, L.ptr(gx), L.ptr(gr) if from_y else None, L.ptr(sums),
+               L.ptr(part), nb if part is not None else 0, Fn.BN_SMALL_ELEMS, L.ptr(wsb), wsb.numel(), L.stream())
+        res_out.append((gx, sums))
+    _close(res_out[1][0], res_out[0][0], tol=2e-5, what='gx: table from the epilogue vs own reduction')
+    _close(res_out[1][1], res_out[0][1], tol=2e-5, what='d beta / d gamma')
