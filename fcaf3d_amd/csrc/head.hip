@@ -111,19 +111,20 @@ __global__ __launch_bounds__(256) void k_head_split_bwd_sums(const float* __rest
 
 // block b < n_cls: gbias[b] = sum over the partial blocks of column 1 + n_reg + b; block n_cls: gscale[0] = sum of entry 64
 // (fixed tree order: deterministic)
-__global__ __launch_bounds__(1024) void k_head_sums_final(const float* __restrict__ part, int64_t nb, int n_reg, int n_cls,
-                                                          float* __restrict__ gbias, float* __restrict__ gscale) {
-  __shared__ float red[1024];
+// (256 threads: a 1 024-thread workgroup waits for a whole compute unit to drain beside the weight-gradient stream, see norm.hip)
+__global__ __launch_bounds__(256) void k_head_sums_final(const float* __restrict__ part, int64_t nb, int n_reg, int n_cls,
+                                                         float* __restrict__ gbias, float* __restrict__ gscale) {
+  __shared__ float red[256];
   const int col = (int)blockIdx.x < n_cls ? 1 + n_reg + (int)blockIdx.x : 64;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int64_t b = threadIdx.x;
-  for (; b + 3 * 1024 < nb; b += 4 * 1024) {
-    a0 += part[b * 65 + col]; a1 += part[(b + 1024) * 65 + col]; a2 += part[(b + 2048) * 65 + col]; a3 += part[(b + 3072) * 65 + col];
+  for (; b + 3 * 256 < nb; b += 4 * 256) {
+    a0 += part[b * 65 + col]; a1 += part[(b + 256) * 65 + col]; a2 += part[(b + 512) * 65 + col]; a3 += part[(b + 768) * 65 + col];
   }
-  for (; b < nb; b += 1024) a0 += part[b * 65 + col];
+  for (; b < nb; b += 256) a0 += part[b * 65 + col];
   red[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  for (int w = 512; w > 0; w >>= 1) {
+  for (int w = 128; w > 0; w >>= 1) {
     if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
@@ -152,7 +153,7 @@ int fc_head_split_bwd_sums(const float* y, int ld, const float* scale_dev, const
   k_head_split_bwd_sums<<<(unsigned)nb, 256, 0, stream>>>(y, ld, scale_dev, bbox_pred, g_centerness, g_bbox, g_cls, n, n_reg, n_cls,
                                                          gy, part);
   FC_CHECK_LAUNCH();
-  k_head_sums_final<<<(unsigned)(n_cls + 1), 1024, 0, stream>>>(part, nb, n_reg, n_cls, gbias, gscale);
+  k_head_sums_final<<<(unsigned)(n_cls + 1), 256, 0, stream>>>(part, nb, n_reg, n_cls, gbias, gscale);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }

@@ -112,11 +112,13 @@ __global__ void k_stats_partial(const float* __restrict__ x, const int* __restri
 
 // ---- pass 2: sum partials over blocks (fixed order); block = 16 channels x 64 slices -----------------
 // mode 0: out = sum / cnt (mean), also writes cnt[seg];  mode 1: out = sum / cnt (biased variance); mode 2: out = sum
-// r5: 16 channels x 64 slices per block (r1-r4: 64 x 16): these launches are pure latency — one block per 64 channels walked up to
-// 1 024 partial rows in 16 slices, 23 us per launch on the large levels; four times the blocks, a quarter of the chain per thread
-#define FIN_CB 16
+// r5: 4 channels x 64 slices = 256 threads per block (r1-r4: 64 channels x 16 slices = 1 024 threads).  These launches are pure
+// latency, and a 1 024-thread workgroup needs four free wave slots on every SIMD of ONE compute unit: beside the weight-gradient
+// stream (two resident 250-register workgroups per CU) it waited for a whole CU to drain — up to 1.8 ms for a 10 us kernel
+// (rocprofv3, r5).  256-thread workgroups fit next to anything; 64 slices keep the chain per thread at nb / 256 loads.
+#define FIN_CB 4
 #define FIN_SL 64
-__global__ __launch_bounds__(1024) void k_stats_final(const float* __restrict__ part, const float* __restrict__ part_cnt,
+__global__ __launch_bounds__(256) void k_stats_final(const float* __restrict__ part, const float* __restrict__ part_cnt,
                                                       int64_t nblocks, int nseg, int C, int mode, float* __restrict__ out,
                                                       float* __restrict__ cnt_io) {
   __shared__ float red[FIN_SL][FIN_CB + 1];
@@ -784,9 +786,9 @@ __global__ void k_bn2_apply(const float* __restrict__ x, int64_t n, int C, int64
   }
 }
 
-// many partial blocks: one 1024-thread block per 16 channels (64 slices of the table each) adds them (fp64, fixed order) and writes
+// many partial blocks: one 256-thread block per 4 channels (64 slices of the table each) adds them (fp64, fixed order) and writes
 // mean / biased var / count + the nn.BatchNorm1d running-buffer update; follow with k_norm_act_fwd
-__global__ __launch_bounds__(1024) void k_bn2_finalize(const float* __restrict__ part, int nb, int C, int G, int64_t n, float momentum,
+__global__ __launch_bounds__(256) void k_bn2_finalize(const float* __restrict__ part, int nb, int C, int G, int64_t n, float momentum,
                                                        float* __restrict__ mean, float* __restrict__ var, float* __restrict__ cnt,
                                                        float* __restrict__ rmean, float* __restrict__ rvar,
                                                        long long* __restrict__ nbt) {
@@ -885,11 +887,11 @@ int fc_col_stats(const float* x, const int* seg, int seg_stride, int64_t n, int 
   unsigned gfin = (unsigned)(nseg * ((C + FIN_CB - 1) / FIN_CB));
   k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, nullptr, 0, rpb, part, part_cnt);
   FC_CHECK_LAUNCH();
-  k_stats_final<<<gfin, 1024, 0, stream>>>(part, part_cnt, nb, nseg, C, 0, mean, cnt);
+  k_stats_final<<<gfin, FIN_CB * FIN_SL, 0, stream>>>(part, part_cnt, nb, nseg, C, 0, mean, cnt);
   FC_CHECK_LAUNCH();
   k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, mean, 1, rpb, part, nullptr);
   FC_CHECK_LAUNCH();
-  k_stats_final<<<gfin, 1024, 0, stream>>>(part, nullptr, nb, nseg, C, 1, var, cnt);
+  k_stats_final<<<gfin, FIN_CB * FIN_SL, 0, stream>>>(part, nullptr, nb, nseg, C, 1, var, cnt);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
@@ -910,7 +912,7 @@ int fc_seg_col_sums(const float* x, const int* seg, int seg_stride, int64_t n, i
   float* part = (float*)ws;
   k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, nullptr, 0, rpb, part, nullptr);
   FC_CHECK_LAUNCH();
-  k_stats_final<<<(unsigned)(nseg * ((C + FIN_CB - 1) / FIN_CB)), 1024, 0, stream>>>(part, nullptr, nb, nseg, C, 2, out, nullptr);
+  k_stats_final<<<(unsigned)(nseg * ((C + FIN_CB - 1) / FIN_CB)), FIN_CB * FIN_SL, 0, stream>>>(part, nullptr, nb, nseg, C, 2, out, nullptr);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
@@ -1050,7 +1052,7 @@ int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* 
   k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, seg, seg_stride, n, C, nseg, mean, var, eps, act, gamma,
                                                           beta, rpb, part);
   FC_CHECK_LAUNCH();
-  k_stats_final<<<(unsigned)(nseg * ((2 * C + FIN_CB - 1) / FIN_CB)), 1024, 0, stream>>>(part, nullptr, nb, nseg, 2 * C, 2, sums, nullptr);
+  k_stats_final<<<(unsigned)(nseg * ((2 * C + FIN_CB - 1) / FIN_CB)), FIN_CB * FIN_SL, 0, stream>>>(part, nullptr, nb, nseg, 2 * C, 2, sums, nullptr);
   FC_CHECK_LAUNCH();
   k_norm_bwd_apply<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, y, gy, nullptr, seg, seg_stride, n, C, mean, var, eps,
                                                                            gamma, beta, sums, cnt, act, gx, gres);
@@ -1100,7 +1102,7 @@ int fc_bn_train_fwd(const float* x, int64_t n, int C, float eps, const float* ga
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
-  k_bn2_finalize<<<(unsigned)((C + FIN_CB - 1) / FIN_CB), 1024, 0, stream>>>(part, (int)nb_part, C, groups, n, momentum, mean, var, cnt,
+  k_bn2_finalize<<<(unsigned)((C + FIN_CB - 1) / FIN_CB), FIN_CB * FIN_SL, 0, stream>>>(part, (int)nb_part, C, groups, n, momentum, mean, var, cnt,
                                                                  running_mean, running_var, num_batches_tracked);
   FC_CHECK_LAUNCH();
   return fc_norm_act_fwd(x, nullptr, 0, n, C, mean, var, eps, gamma, beta, residual, act, y, stream);
@@ -1137,7 +1139,7 @@ int fc_bn_train_bwd(const float* x, const float* y, const float* gy, const float
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
-  k_stats_final<<<(unsigned)((2 * C + FIN_CB - 1) / FIN_CB), 1024, 0, stream>>>(p, nullptr, np, 1, 2 * C, 2, sums, nullptr);
+  k_stats_final<<<(unsigned)((2 * C + FIN_CB - 1) / FIN_CB), FIN_CB * FIN_SL, 0, stream>>>(p, nullptr, np, 1, 2 * C, 2, sums, nullptr);
   FC_CHECK_LAUNCH();
   k_norm_bwd_apply<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, y, gy, gy2, nullptr, 0, n, C, mean, var, eps, gamma, beta,
                                                                            sums, cnt, act, gx, gres);

@@ -251,6 +251,7 @@ class NetProgram:
         def flush2(t):
             g2, rows, cols, stream = grad2.pop(t)
             self.emit(Bk, OP_ADD, stream, grad[t], g2, self.D(rows), cols)
+            grad_src.pop(grad[t], None)          # added to in place: no longer the plain result of the convolution that wrote it
 
         def accumulate(t, g, rows, cols, stream):
             """gradient `g` (a backward tensor) arrives for forward tensor t.  The SECOND contribution is kept aside: if the
@@ -264,6 +265,7 @@ class NetProgram:
                 if t in grad2:
                     flush2(t)
                 self.emit(Bk, OP_ADD, stream, grad[t], g, self.D(rows), cols)
+                grad_src.pop(grad[t], None)
 
         def take(t, rows, cols, pair=False):
             """the complete gradient of forward tensor t, for the emitter of the operator that produced t (main stream); pair:

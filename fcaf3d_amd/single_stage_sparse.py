@@ -88,16 +88,6 @@ class SingleStageSparse3DDetector(nn.Module):
             self.neck_with_head.prepare_targets(head_maps, *gt)
         return x
 
-    # r5: the counts of the step that do NOT size a coordinate set — live pair-list tiles of every map, union membership of every
-    # neck level, per-scene rows — are read back in ONE device -> host copy after all their kernels are enqueued (r4: one read-back
-    # each, ~25 per step with the set sizes; now 7 + 1).  The strided sets themselves stay a chain, each sized by the previous one's
-    # count: making all of them from the finest set at once (plan_batch = 2; same rows in the same order — the first occurrence of
-    # a coarse cell in the finer level's row order is its first occurrence in the finest level's) saves six more read-backs but
-    # hashes the finest set six times into tables sized for it, and measured SLOWER wherever the coordinate kernels share the GPU
-    # with a busy main stream (8 scenes: 364.7 -> 356.6 scenes/s, enqueue 13.5 -> 17.2 ms; S3DIS 111.1 -> 107.5), so it is not the
-    # default.  FC_PLAN_BATCH=0: the r4 sequence.
-    plan_batch = int(os.environ.get('FC_PLAN_BATCH', '1'))
-
     def plan_maps(self, cm0):
         """Build, up front, every coordinate set and kernel map the step will use: they depend on the input
         coordinates only (unless pts_threshold pruning bites, where planning stops and the rest is built
@@ -108,8 +98,6 @@ class SingleStageSparse3DDetector(nn.Module):
         bottleneck = getattr(bb.BLOCK, 'expansion', 1) == 4
         bwd = self.training and torch.is_grad_enabled()
         nl = min(bb.n_outs, 4)
-        if self.plan_batch and not bottleneck and nl >= 1 and cm0.coords.is_cuda and cm0.n > 0:
-            return self._plan_maps_batched(cm0, nl, bwd)
         m1 = cm0.strided(2); cm0.kernel_map(m1, 3)                 # stem conv k3 s2
         m2 = m1.strided(2); m1.kernel_map(m2, 2)                   # max-pool k2 s2
         prev, levels = m2, []
@@ -122,10 +110,10 @@ class SingleStageSparse3DDetector(nn.Module):
             prev = mi
         if bottleneck or not levels:
             return None
-        return self._plan_neck(levels, bwd)
-
-    def _plan_neck(self, levels, bwd):
-        nh = self.neck_with_head
+        # (r5, measured and removed: reading the step's counts back in ONE copy — live pair-list tiles, union membership, per-scene
+        # rows; or even every strided set made from the finest one with a single size read-back — is SLOWER than this chain of ~25
+        # small read-backs: each of them lets the host go on enqueueing while the coordinate stream works, one late read-back makes
+        # it wait for the whole phase.  8 scenes 362.1 vs 361.7 / 358.4 scenes/s, S3DIS 111.7 vs 108.6 / 106.0: profiles/r5_notes.md)
         x = levels[-1]
         x.scene_counts
         head_maps = [x]                                            # coordinate sets of the head's levels, coarse -> fine
@@ -139,62 +127,6 @@ class SingleStageSparse3DDetector(nn.Module):
             x = u
             head_maps.append(x)
         return head_maps[::-1]                                     # finest first, the order of the head's outputs
-
-    def _plan_maps_batched(self, cm0, nl, bwd):
-        from .sparse import CoordMap
-        nh = self.neck_with_head
-        B = cm0.batch_size
-        # (1) the strided sets: a chain (a read-back each), or — plan_batch = 2 — all from the finest one with one read-back
-        if self.plan_batch >= 2:
-            chain = [2, 4] + [8 << i for i in range(nl)]
-            pend = [CoordMap.unique_deferred(cm0.coords, cm0.stride * s, B, cm0.stride * s) for s in chain]
-            sets, _ = CoordMap.finish_deferred(pend)
-            prev = cm0
-            for m in sets:
-                prev._strided[2] = m                               # what prev.strided(2) returns from now on
-                prev = m
-        else:
-            sets, prev = [], cm0
-            for _ in range(nl + 2):
-                prev = prev.strided(2)
-                sets.append(prev)
-        m1, m2, levels = sets[0], sets[1], sets[2:]
-        # (2) kernel maps and their derived tables; generated sets, their maps, the backbone levels' rows inside them
-        cm0.kernel_map(m1, 3)
-        m1.kernel_map(m2, 2)
-        tiles = []
-        prev = m2
-        for mi in levels:
-            prev.kernel_map(mi, 3).prefetch(bwd, defer=tiles); prev.kernel_map(mi, 1); mi.kernel_map(mi, 3).prefetch(bwd, defer=tiles)
-            prev = mi
-        x = levels[-1]
-        x._decompose()
-        gens, probes = [], []
-        for i in range(nl - 2, -1, -1):
-            g = x.generate(); g.kernel_map(g, 3).prefetch(bwd, defer=tiles)
-            probes.append((levels[i], g) + levels[i].union_probe(g))
-            gens.append(g)
-            x = g
-        extra = [t[2] for t in tiles] + [p[3] for p in probes] + [levels[-1]._counts_dev]
-        _, vals = CoordMap.finish_deferred([], extra)              # the second (and last) read-back of the phase
-        for (km, transposed, _), v in zip(tiles, vals):
-            km.set_tiles(transposed, v)
-        founds = vals[len(tiles):len(tiles) + len(probes)]
-        levels[-1]._counts = [int(c) for c in vals[-1]]
-        x = levels[-1]
-        head_maps = [x]
-        for k, ((lvl, g, rows, _), f) in enumerate(zip(probes, founds)):
-            g._counts = [8 * c for c in x._counts]                 # every voxel has its 8 children in its own scene
-            if not lvl.union_adopt(g, rows, f[0]):
-                # a backbone voxel outside the generated set (cannot happen while nothing is pruned: every level is the strided
-                # set of the finer one): the union adds rows, the finer generated sets hang off IT — the general, sequential route
-                return self._plan_neck(levels, bwd)
-            if nh.pts_threshold >= 0 and any(c > nh.pts_threshold for c in g._counts):
-                self._prune_level = nl - 2 - k
-                return None
-            x = g
-            head_maps.append(x)
-        return head_maps[::-1]
 
     def extract_feat(self, points, img_metas, gt=None):
         """gt (training only, optional): (gt_bboxes_3d, gt_labels_3d) — lets the target assignment start with the maps"""

@@ -214,22 +214,14 @@ class KernelMap:
             self._pairs_t = self._pair_lists(self.nbr_t, self.n_in, self.K)
         return self._pairs_t
 
-    def prefetch(self, backward=True, defer=None):
+    def prefetch(self, backward=True):
         """Build now (i.e. on the coordinate side stream, SingleStageSparse3DDetector.plan_maps) every derived table
         the MFMA convolutions on this map will ask for, instead of lazily on the main stream in the middle of the
-        convolution sequence: mask-sorted tables (an argsort each), pair lists, the transposed table.
-        defer (a list): the live-tile counts of the pair lists are not read back here — (map, transposed, cnt tensor) is appended
-        and the caller sets them from ONE read-back (set_tiles)"""
+        convolution sequence: mask-sorted tables (an argsort each), pair lists, the transposed table."""
         if self.K != 27:
             return
-
-        def tiles(transposed):
-            if defer is None or getattr(self, '_tiles_t' if transposed else '_tiles', None) is not None:
-                self.pair_tiles(transposed)
-            else:
-                defer.append((self, transposed, (self.pairs_t() if transposed else self.pairs())[3]))
         if self.use_pairs and self.n_out <= PAIR_CONV_ROWS:
-            tiles(False)
+            self.pair_tiles()
         else:
             self.sorted_fwd()
         if backward:
@@ -237,13 +229,9 @@ class KernelMap:
             if self.use_pairs:
                 self.pairs()
             if self.use_pairs and self.n_in <= PAIR_CONV_ROWS:
-                tiles(True)
+                self.pair_tiles(transposed=True)
             else:
                 self.sorted_bwd()
-
-    def set_tiles(self, transposed, cnt_list):
-        v = int(sum((c + 127) // 128 for c in cnt_list))
-        setattr(self, '_tiles_t' if transposed else '_tiles', v)
 
     def desc(self, conv=True, backward=True):
         """int64 descriptor of this map for the native executor (csrc/exec.hip, MAPW words): sizes, the tables the
@@ -376,40 +364,6 @@ class CoordMap:
         _rec(first, inv)
         return cm, (first[:m] if want_first else None), inv
 
-    @staticmethod
-    def unique_deferred(coords, stride, batch_size, q):
-        """from_coords without its read-back: -> pending tuple; CoordMap.finish_deferred turns a LIST of them into maps with one
-        read-back of all their counts (r5: SingleStageSparse3DDetector.plan_maps — every strided set of the step from the
-        finest one, ~25 count read-backs per step became 3)"""
-        coords = coords.contiguous()
-        dev = coords.device
-        n = coords.shape[0]
-        cap = _next_pow2(max(2 * n, 2))
-        keys = torch.empty(cap, dtype=torch.int64, device=dev)
-        vals = torch.empty(cap, dtype=torch.int32, device=dev)
-        out = torch.empty((n, 4), dtype=torch.int32, device=dev)
-        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-        ws = L.workspace(L.query('fc_hash_unique_ws_bytes', n), dev)
-        L.call('fc_hash_unique', L.ptr(coords), n, q, L.ptr(keys), L.ptr(vals), cap, L.ptr(out), None, None, L.ptr(cnt), L.ptr(ws),
-               ws.numel(), L.stream())
-        return (out, keys, vals, cnt, stride, batch_size, n)
-
-    @staticmethod
-    def finish_deferred(pending, extra=()):
-        """-> (maps, values of the `extra` int32 device tensors as lists) with ONE device -> host copy"""
-        flat = torch.cat([p[3] for p in pending] + [e.reshape(-1).to(torch.int32) for e in extra]).cpu().tolist()
-        maps = []
-        for p, m in zip(pending, flat):
-            out, keys, vals, _, stride, bs, n = p
-            if m < 0:
-                raise ValueError('voxel coordinate outside [-32639, 32639] (or batch index outside [0, 32767])')
-            maps.append(CoordMap(out[:m] if m != n else out, stride, keys, vals, bs))
-        vals_extra, o = [], len(pending)
-        for e in extra:
-            vals_extra.append(flat[o:o + e.numel()])
-            o += e.numel()
-        return maps, vals_extra
-
     def strided(self, s):
         """Output map of a stride-s conv / pooling (cached: k3s2 conv and k1s2 downsample share it)."""
         if s == 1:
@@ -512,26 +466,6 @@ class CoordMap:
         _rec(rows)
         self._unions[id(other)] = (cm, rows, swapped, other)       # keep `other` alive so id() stays unique
         return cm, rows, swapped
-
-    def union_probe(self, other):
-        """first half of union() for `other` = a generated children set: where each of my voxels sits in it (fc_child_rows) and how
-        many were found, WITHOUT the read-back -> (rows, found) device tensors; union_adopt() finishes once the count is known"""
-        assert other._gen_parent is not None and self.stride == other.stride
-        par = other._gen_parent
-        dev = self.coords.device
-        rows = torch.empty(self.n, dtype=torch.int32, device=dev)
-        found = torch.zeros(1, dtype=torch.int32, device=dev)
-        L.call('fc_child_rows', L.ptr(self.coords), self.n, L.ptr(par.keys), L.ptr(par.vals), par.cap, self.stride,
-               L.ptr(rows), L.ptr(found), L.stream())
-        return rows, found
-
-    def union_adopt(self, other, rows, found):
-        """every voxel found (the usual case): the union IS `other`; otherwise nothing is recorded and union() takes the general route"""
-        if found == self.n:
-            _rec(rows)
-            self._unions[id(other)] = (other, rows, True, other)
-            return True
-        return False
 
     def pruned(self, kept):
         """Map of the kept rows (int32 ascending row indices), order preserved."""

@@ -1099,46 +1099,3 @@ def test_indoor_eval_reference_test_vectors_hip():
     from tests.test_oracle_golden import _check_ref_indoor_eval
     _dev()
     _check_ref_indoor_eval(None)
-
-
-def test_batched_map_planning_equals_the_sequential_one():
-    """r5 `_plan_maps_batched` (every strided set from the finest one, two count read-backs) against the r4 sequence (each set from
-    the previous one, a read-back per set / pair list / union): the same coordinate sets in the same row order, the same kernel
-    maps, the same union rows, the same live-tile counts — and the same losses."""
-    dev = _dev()
-    from fcaf3d_amd.synthetic import make_scene
-    torch.manual_seed(0)
-    cfg = fa.get_config('fcaf3d_scannet-3d-18class', voxel_size=0.02)
-    model = fa.build_detector(cfg.model, train_cfg=cfg.model.get('train_cfg'), test_cfg=cfg.model.get('test_cfg')).to(dev).train()
-    sc = [make_scene(300 + i, n_points=40000) for i in range(3)]
-    pts = [torch.from_numpy(s[0]).to(dev) for s in sc]
-    got = {}
-    for batched in (0, 1, 2):
-        type(model).plan_batch = batched
-        try:
-            coords, feats = model.voxelize(pts)
-            from fcaf3d_amd.sparse import SparseTensor
-            x = SparseTensor(feats, coordinates=coords, batch_size=len(pts))
-            head_maps = model.plan_maps(x.cmap)
-            cm, chain = x.cmap, []
-            for _ in range(6):
-                nxt = cm.strided(2)
-                chain.append((nxt.coords.cpu(), cm.kernel_map(nxt, 3 if len(chain) != 1 else 2).nbr.cpu()))
-                cm = nxt
-            lv = []
-            m = x.cmap.strided(2).strided(2)
-            for _ in range(4):
-                m = m.strided(2)
-                km = m.kernel_map(m, 3)
-                lv.append((km.nbr.cpu(), getattr(km, '_tiles', None), getattr(km, '_tiles_t', None)))
-            got[batched] = (chain, lv, [h.coords.cpu() for h in head_maps], [h.scene_counts for h in head_maps])
-        finally:
-            type(model).plan_batch = 1
-    for mode in (1, 2):
-        for (ca, na), (cb, nb) in zip(got[0][0], got[mode][0]):
-            assert torch.equal(ca, cb) and torch.equal(na, nb)
-        for (na, ta, tta), (nb, tb, ttb) in zip(got[0][1], got[mode][1]):
-            assert torch.equal(na, nb) and ta == tb and tta == ttb, (ta, tb, tta, ttb)
-        for a, b in zip(got[0][2], got[mode][2]):
-            assert torch.equal(a, b)
-        assert got[0][3] == got[mode][3]
