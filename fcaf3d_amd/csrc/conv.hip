@@ -1209,28 +1209,8 @@ __global__ void k_conv_fma(const float* __restrict__ in, const float* __restrict
   out[t] = acc;
 }
 
-// Split-bf16 convolution with BOTH operands by LDS-DMA (k_conv_x6d): `planes` = fc_x6_planes of the input, `img` = the weight
-// image of the direction; neighbour-table launches (out_index: mask-sorted rows, may be NULL), no offset split.  bm = 128 / 256.
-template <int BM, int BN, int TM>
-static int launch_x6d(const u32x4* planes, const u32x4* img, const int* nbr, const int* out_index, const int* cnt, float* out,
-                      int64_t n_rows, int K, int Cin, int Cout, dim3 grid, hipStream_t stream) {
-  constexpr int NW = (BM / (32 * TM)) * (BN / 64);
-  constexpr size_t smem = 2 * (size_t)(3 * BM * 4 + (BN / 64) * X6_GROUP_U16) * 16;
-  static bool set_t = false, set_f = false;
-  if (nbr) {
-    if (!set_t) { FC_HIP(hipFuncSetAttribute((const void*)k_conv_x6d<BM, BN, TM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); set_t = true; }
-    k_conv_x6d<BM, BN, TM, true><<<grid, 64 * NW, smem, stream>>>(planes, img, nbr, out_index, cnt, out, n_rows, K, Cin, Cout);
-  } else {
-    if (!set_f) { FC_HIP(hipFuncSetAttribute((const void*)k_conv_x6d<BM, BN, TM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); set_f = true; }
-    k_conv_x6d<BM, BN, TM, false><<<grid, 64 * NW, smem, stream>>>(planes, img, nbr, out_index, cnt, out, n_rows, K, Cin, Cout);
-  }
-  FC_CHECK_LAUNCH();
-  return FC_OK;
-}
-
 extern "C" {
 
-#define FC_CONV_APL (1 << 27)  // fc_conv_fwd / fc_conv_fwd_pairs(_tiles), with bits 24 and 26: `in` is the pre-split planes of fc_x6_planes
 #define FC_CONV_WT (1 << 23)   // fc_conv_fwd / fc_conv_fwd_pairs(_tiles): W[k] is stored transposed, (Cout, Cin) row-major
 // The deeper-pipelined LDS kernel (k_conv_mfma_p) holds 3 workgroups per CU (768 slots) where k_conv_mfma holds 4 (1024): it
 // wins on launches of many rounds and on launches that fit 768 slots anyway, and loses a round in between (r2: +5.5 / +7 %
@@ -1249,6 +1229,12 @@ static inline int conv_pipe(int flags, dim3 grid) {
   return (grid.z > 1 && !(flags & (1 << 22))) ? 2 : 0;
 }
 
+// tuning knob (environment, read once): launches with fewer 128-row tiles than this are split over kernel offsets
+static int split_tiles() {
+  static const int v = getenv("FC_SPLIT_TILES") ? atoi(getenv("FC_SPLIT_TILES")) : 384;
+  return v;
+}
+
 static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* mfma, int* bm, int* bn, int* S) {
   *mfma = !(flags & 1) && (Cin % BK == 0) && (Cout % 64 == 0) && K <= 32;
   *bn = (Cout % 128 == 0) ? 128 : 64;
@@ -1264,7 +1250,7 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   // over (r1 rounded up) starts a second, nearly empty round (r2 sweep: 256->256 on 6.9k rows 275 us at S = 10 -> 238 at
   // S = 9); from ~400 tiles on the unsplit launch wins (64->64 on 64k rows: 159 us at S = 2 -> 144 at S = 1, and no
   // partial tiles to write and sum)
-  if (*mfma && K > 1 && tiles < 384) {
+  if (*mfma && K > 1 && tiles < split_tiles()) {
     s = (int)(1024 / tiles);
     if (s > K) s = K;
     if (s < 1) s = 1;
@@ -1283,7 +1269,7 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   if ((flags & (1 << 24)) && *mfma && *bm == 64) {     // the split-bf16 kernel has 128- and 256-row tiles only
     *bm = 128;
     const int64_t t3 = fc_cdiv(n_out, 128) * (Cout / *bn);
-    if (!fs) { s = 1; if (K > 1 && t3 < 384) { s = (int)(1024 / t3); if (s > K) s = K; } }
+    if (!fs) { s = 1; if (K > 1 && t3 < split_tiles()) { s = (int)(1024 / t3); if (s > K) s = K; } }
   }
   *S = s;
 }
@@ -1292,25 +1278,10 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
 // and LDS-padding occupancy caps all lose or are neutral — profiles/r1_conv_pmc.md — and were removed in r2)
 static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr,
                             const int* out_index, const int* cnt, float* dst, int64_t n_rows, int K, int Cin, int Cout,
-                            hipStream_t stream, bool wt = false, bool apl = false, const X6Epi* epi = nullptr) {
-  if (epi && (apl || pipe < 3 || bm < 128 || cnt || grid.z != 1)) return FC_EINVAL;      // the statistics epilogue lives in k_conv_x6
+                            hipStream_t stream, bool wt = false, const X6Epi* epi = nullptr) {
+  if (epi && (pipe < 3 || bm < 128 || cnt || grid.z != 1)) return FC_EINVAL;      // the statistics epilogue lives in k_conv_x6
   X6Epi e6 = {};
   if (epi) e6 = *epi;
-  if (apl) {                                     // the input is pre-split planes (k_x6_planes): split-bf16 kernel with weight images only
-    if (pipe != 4 || bm < 128) return FC_EINVAL;
-    const u32x4* pl = reinterpret_cast<const u32x4*>(in);
-#define FC_LAUNCH_X6P(BM_, BN_, WM_)                                                                                   \
-  do {                                                                                                                 \
-    if (nbr) k_conv_x6p<BM_, BN_, true, WM_><<<grid, 256, 0, stream>>>(pl, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout);  \
-    else k_conv_x6p<BM_, BN_, false, WM_><<<grid, 256, 0, stream>>>(pl, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout);     \
-  } while (0)
-    if (bm == 256) FC_LAUNCH_X6P(256, 64, 4);
-    else if (bn == 128) FC_LAUNCH_X6P(128, 128, 2);
-    else FC_LAUNCH_X6P(128, 64, 2);
-#undef FC_LAUNCH_X6P
-    FC_CHECK_LAUNCH();
-    return FC_OK;
-  }
 #define FC_ARGS <<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout)
 #define FC_LAUNCH_MFMA(KERNEL, BM_, BN_, WM_)                                    \
   do {                                                                           \
@@ -1408,9 +1379,9 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
   if (wt && !nbr) return FC_EINVAL;
   bool mfma_ok; int bm, bn, S;
   conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S);
-  if (stats && (!mfma_ok || !(flags & (1 << 24)) || (flags & FC_CONV_APL))) return FC_EINVAL;      // see fc_conv_stats_blocks
+  if (stats && (!mfma_ok || !(flags & (1 << 24)))) return FC_EINVAL;      // see fc_conv_stats_blocks
   if (!mfma_ok) {
-    if (out_index || (flags & ((1 << 26) | FC_CONV_APL))) return FC_EINVAL;      // sorted-row tables, weight images and planes are MFMA-path features
+    if (out_index || (flags & (1 << 26))) return FC_EINVAL;      // sorted-row tables and weight images are MFMA-path features
     k_conv_fma<<<(unsigned)fc_cdiv(n_out * Cout, 256), 256, 0, stream>>>(in, W, nbr, out, n_out, K, Cin, Cout, wt ? 1 : 0);
     FC_CHECK_LAUNCH();
     return FC_OK;
@@ -1419,7 +1390,7 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
   int rc = launch_conv_mfma(conv_pipe(flags, grid), bm, bn, grid, in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream, wt,
-                            (flags & FC_CONV_APL) != 0, S > 1 ? nullptr : epi);
+                            S > 1 ? nullptr : epi);
   if (rc != FC_OK) return rc;
   if (S > 1) return stats ? sum_parts_stats(dst, out, n_out, Cout, S, *epi, stream) : sum_parts(dst, out, n_out, Cout, S, stream);
   return FC_OK;
@@ -1429,7 +1400,7 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
 // fc_conv_fwd_pairs_tiles_stats: stats[blocks][2][Cout], column sums of the result and of its square per row block); 0: this launch
 // has no statistics epilogue (not the split-bf16 MFMA route).  pairs != 0: the per-offset pair-list route.
 int64_t fc_conv_stats_blocks(int64_t n_out, int K, int Cin, int Cout, int flags, int pairs) {
-  if (n_out < 1 || !(flags & (1 << 24)) || (flags & FC_CONV_APL)) return 0;
+  if (n_out < 1 || !(flags & (1 << 24))) return 0;
   if (pairs) return (Cin % 32 == 0 && Cout % 64 == 0) ? fc_cdiv(n_out, fc_stat_rb(n_out)) : 0;
   bool mfma_ok; int bm, bn, S;
   conv_plan(n_out, K, Cin, Cout, flags, &mfma_ok, &bm, &bn, &S);
@@ -1479,31 +1450,6 @@ int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int trans
   return FC_OK;
 }
 
-int64_t fc_x6_planes_bytes(int64_t n, int C) { return n * (int64_t)C * 6; }
-
-int fc_x6_planes(const float* x, void* planes, int64_t n, int C, hipStream_t stream) {
-  if (n < 0 || C < 32 || C % 32) return FC_EINVAL;
-  if (n == 0) return FC_OK;
-  const int64_t t = n * (C / 32) * 4;
-  k_x6_planes<<<(unsigned)fc_cdiv(t, 256), 256, 0, stream>>>(x, reinterpret_cast<u32x4*>(planes), n, C);
-  FC_CHECK_LAUNCH();
-  return FC_OK;
-}
-
-int fc_conv_x6d(const void* planes, const void* img, const int* nbr, const int* out_index, float* out, int64_t n_out, int K, int Cin,
-                int Cout, int bm, hipStream_t stream) {
-  if (n_out < 0 || K < 1 || K > 32 || Cin % 32 || Cout % 64 || (bm != 128 && bm != 256)) return FC_EINVAL;
-  if (n_out == 0) return FC_OK;
-  const u32x4* pl = reinterpret_cast<const u32x4*>(planes);
-  const u32x4* im = reinterpret_cast<const u32x4*>(img);
-  const int bn = Cout % 128 == 0 ? 128 : 64;
-  dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, 1);
-  if (bm == 256 && bn == 128) return launch_x6d<256, 128, 2>(pl, im, nbr, out_index, nullptr, out, n_out, K, Cin, Cout, grid, stream);
-  if (bm == 128 && bn == 128) return launch_x6d<128, 128, 2>(pl, im, nbr, out_index, nullptr, out, n_out, K, Cin, Cout, grid, stream);
-  if (bm == 256) return launch_x6d<256, 64, 1>(pl, im, nbr, out_index, nullptr, out, n_out, K, Cin, Cout, grid, stream);
-  return launch_x6d<128, 64, 1>(pl, im, nbr, out_index, nullptr, out, n_out, K, Cin, Cout, grid, stream);
-}
-
 int fc_x6_weight_images(const int64_t* desc, int n, int64_t total_blocks, hipStream_t stream) {
   if (!desc || n < 1 || total_blocks < 1 || total_blocks > 0x7fffffffll) return FC_EINVAL;
   k_x6_weight_images<<<(unsigned)total_blocks, 256, 0, stream>>>(reinterpret_cast<const long long*>(desc), n);
@@ -1531,7 +1477,7 @@ static int conv_fwd_pairs_impl(const float* in, const float* W, const int* pair_
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
   if (live_tiles > 0) grid = dim3((unsigned)live_tiles, Cout / bn, 1);       // linear list of the live (offset, tile) pairs
   {
-    int rc = launch_conv_mfma((live_tiles > 0 || (flags & (1 << 24))) ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt, (flags & FC_CONV_APL) != 0);
+    int rc = launch_conv_mfma((live_tiles > 0 || (flags & (1 << 24))) ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt);
     if (rc != FC_OK) return rc;
   }
   if (epi) {
@@ -2054,21 +2000,11 @@ static void wgrad_tiles(int Cin, int Cout, int flags, int* bm, int* bn) {
 #define WGRAD_KO 3
 // split-bf16 weight gradients: rows loaded 16 B per lane and transposed by ds_read_b64_tr_b16 (k_wgrad_x6t, r4) or the register
 // transposition of r3 (k_wgrad_x6; FC_WGRAD_TR=0) — bit-identical results
-static int g_wgrad_tr = -1;                    // -1: not decided yet (environment at first use)
-static inline bool wgrad_tr() {
-  if (g_wgrad_tr < 0) g_wgrad_tr = !(getenv("FC_WGRAD_TR") && atoi(getenv("FC_WGRAD_TR")) == 0);
-  return g_wgrad_tr != 0;
-}
-// 64 x 64-channel pair-list launches and the table-free dense GEMMs (generative transposed convolution, heads) on k_wgrad_x6t
-// as well (r4: one accumulator per wave lost to the fp32 kernel with the r3 kernel's loads, with 16-byte loads it is ahead:
-// 64.5k rows 64->64 pair lists 131 -> 90 us, stride-2 map 93.5 -> 69 us).  FC_WGRAD_TR64=0: those stay on the fp32 pipe.
+// (r5: the r3 register-transposing kernel k_wgrad_x6 and its FC_WGRAD_TR switch are gone; FC_WGRAD_TR64=0 keeps 64 x 64-channel
+// pair lists and the table-free dense GEMMs on the fp32 MFMA kernel)
 static inline bool wgrad_tr64() {
   static const bool on = !(getenv("FC_WGRAD_TR64") && atoi(getenv("FC_WGRAD_TR64")) == 0);
-  return on && wgrad_tr();
-}
-extern "C" int fc_debug_set_wgrad_tr(int on) {   // A/B and the bit-identity test (tests/test_gpu_ops.py); not a C-ABI entry point
-  g_wgrad_tr = on ? 1 : 0;
-  return FC_OK;
+  return on;
 }
 static inline bool wgrad_multi_ok(int64_t n_out, int K, int Cin, int Cout, int flags, bool dense_table) {
   return dense_table && !(flags & 1) && !(flags & (1 << 29)) && K % WGRAD_KO == 0 &&
@@ -2204,12 +2140,10 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     const int bn = (Cout % 128 == 0) ? 128 : 64;
     dim3 grid((unsigned)S, (unsigned)((K / WGRAD_KO) * (Cin / 64) * (Cout / bn)));
     if (flags & (1 << 24)) {                     // split-bf16 (wgrad_x6.h)
-      if (wgrad_tr() && g_bf16_fast && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false, true><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
-      else if (wgrad_tr() && g_bf16_fast) k_wgrad_x6t<64, 64, WGRAD_KO, false, true><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
-      else if (wgrad_tr() && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
-      else if (wgrad_tr()) k_wgrad_x6t<64, 64, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
-      else if (bn == 128) k_wgrad_x6<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
-      else k_wgrad_x6<64, 64, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+      if (g_bf16_fast && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false, true><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+      else if (g_bf16_fast) k_wgrad_x6t<64, 64, WGRAD_KO, false, true><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+      else if (bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+      else k_wgrad_x6t<64, 64, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
     } else
     if (bn == 128) k_wgrad_multi<128, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
     else k_wgrad_multi<64, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
@@ -2224,9 +2158,8 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
 #define FC_WX6(BM_, BN_)                                                                                                             \
   do {                                                                                                                               \
-    if (wgrad_tr() && g_bf16_fast) k_wgrad_x6t<BM_, BN_, 1, true, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); \
-    else if (wgrad_tr()) k_wgrad_x6t<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); \
-    else k_wgrad_x6<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);    \
+    if (g_bf16_fast) k_wgrad_x6t<BM_, BN_, 1, true, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); \
+    else k_wgrad_x6t<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); \
   } while (0)
     if (bm == 128 && bn == 128) FC_WX6(128, 128);
     else if (bm == 128) FC_WX6(128, 64);

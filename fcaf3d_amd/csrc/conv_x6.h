@@ -551,434 +551,6 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
     }
 }
 
-// ---- r4: activations as PRE-SPLIT PLANES ---------------------------------------------------------------------------------
-// A gathered row is split again by every tile that gathers it — ~25 times on the dense neck maps (once per kernel offset it
-// is a neighbour for), and the splitting VALU does not hide behind the matrix pipe: the stage loop of k_conv_x6 issues ~136 VALU
-// per 48 MFMAs per wave, of which ~96 are the split, ~0.8 of the SIMD's issue slots with three waves resident.  Here the
-// operand arrives split: `planes` = k_x6_planes(X): for every row and 32-channel slab three bf16 planes of 64 B, contiguous
-// (row-major [row][slab][plane][32 channels]: one gather = 192 contiguous bytes), so a stage is 6 x 16-byte loads and 6 x
-// ds_write_b128 per thread and NO arithmetic; ONE row index per thread and stage (two threads per tile row).  The pieces are
-// those of x6_split2, the LDS image and the MFMA block those of k_conv_x6: results are bit-identical to it.
-__global__ void k_x6_planes(const float* __restrict__ x, u32x4* __restrict__ planes, int64_t n, int C) {
-  // one thread per (row, slab, 8-channel chunk): 32 B in, one 16-byte unit per plane out
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int nslab = C / 32;
-  if (t >= n * nslab * 4) return;
-  const int chunk = (int)(t & 3);
-  const int64_t rs = t >> 2;                                     // row * nslab + slab
-  const float* src = x + (rs / nslab) * C + (rs % nslab) * 32 + chunk * 8;
-  const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
-  unsigned p[3][4];
-  x6_split2(a[0], a[1], p[0][0], p[1][0], p[2][0]);
-  x6_split2(a[2], a[3], p[0][1], p[1][1], p[2][1]);
-  x6_split2(b[0], b[1], p[0][2], p[1][2], p[2][2]);
-  x6_split2(b[2], b[3], p[0][3], p[1][3], p[2][3]);
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
-    u32x4 v = {p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
-    planes[rs * 12 + pl * 4 + chunk] = v;
-  }
-}
-
-__device__ __attribute__((aligned(16))) unsigned int g_zero_planes[48];          // what an absent neighbour gathers from (192 B)
-
-template <int BM, int BN, bool HAS_NBR, int WM>
-__global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_conv_x6p(
-    const u32x4* __restrict__ planes, const float* __restrict__ W, const int* __restrict__ nbr,
-    const int* __restrict__ out_index, const int* __restrict__ cnt, float* __restrict__ out, int64_t n_out, int K, int Cin,
-    int Cout) {
-  constexpr int WN = 4 / WM;
-  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);      // 32x32 MFMA tiles per wave
-  constexpr int RW = BM / WM;                                  // rows of a wave's part of the tile
-  constexpr int TPR = 256 / BM;                                // threads per tile row: 2 (BM = 128) or 1 (BM = 256)
-  constexpr int AU = 12 / TPR;                                 // 16-byte plane units per thread per stage
-  constexpr int BU = 3 * BN / 64;                              // 16-byte image units per thread per stage
-  __shared__ u32x4 As[3 * BM * 4];                             // [plane][row][4 chunks]
-  __shared__ u32x4 Bs[(BN / 64) * X6_GROUP_U16];               // [64-column group][plane][row][4 chunks]: x6_bslot
-  __shared__ unsigned int kmask_s;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = WM == 4 ? wave : wave >> 1, wc = WM == 4 ? 0 : wave & 1;
-  const int r = lane & 31, h = lane >> 5;
-  const int bgrp = TN == 2 ? wc : 0;
-  int64_t bx = blockIdx.x;
-  const int n0 = blockIdx.y * BN;
-  int S = gridDim.z, z = blockIdx.z;
-  int kbase = 0;
-  if (cnt) {                                     // pair mode: see k_conv_mfma
-    if (gridDim.z == 1 && K > 1) {
-      int k = 0;
-      for (; k < K - 1; ++k) {
-        const int64_t t = ((int64_t)cnt[k] + BM - 1) / BM;
-        if (bx < t) break;
-        bx -= t;
-      }
-      z = k;
-    }
-    const int64_t stride = n_out;
-    n_out = cnt[z];
-    if (bx * BM >= n_out) return;
-    nbr += (int64_t)z * stride;
-    kbase = z;
-    out += (int64_t)z * stride * Cout;
-    K = 1; S = 1; z = 0;
-  }
-  const int64_t m0 = bx * BM;
-  const int a_row = tid / TPR, a_half = tid % TPR;             // this thread's tile row and which part of its 12 units
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  unsigned int kmask;
-  {
-    if (tid == 0) kmask_s = 0u;
-    __syncthreads();
-    if (tid < BM) {
-      unsigned int mk = 0u;
-      int64_t row = m0 + tid;
-      if (row < n_out) {
-        if (HAS_NBR) {
-          for (int k = z; k < K; k += S)
-            if (nbr[(int64_t)k * n_out + row] >= 0) mk |= 1u << k;
-        } else {
-          mk = 1u;
-        }
-      }
-      for (int off = 32; off > 0; off >>= 1) mk |= __shfl_xor(mk, off, 64);
-      if (lane == 0 && mk) atomicOr(&kmask_s, mk);
-    }
-    __syncthreads();
-    kmask = kmask_s;
-  }
-
-  if (kmask) {
-    const int nslab = Cin / 32, ngrp = Cout / 64;
-    const int nst = __popc(kmask) * nslab;
-    unsigned int rem = kmask;
-    int lk = __ffs(rem) - 1;
-    rem &= rem - 1;
-    int lnk = rem ? __ffs(rem) - 1 : lk;
-    if (rem) rem &= rem - 1;
-    int ls = 0;                                                // channel slab of the stage requested next
-    bool sw = false;
-    u32x4 au[AU];
-    u32x4 bi[BU];
-    const int rows_here = (int)((n_out - m0) < BM ? (n_out - m0) : BM);
-    const bool row_ok = a_row < rows_here;
-    auto fetch_idx = [&](int kk) -> int {
-      const int64_t row = row_ok ? m0 + a_row : 0;
-      const int v = HAS_NBR ? nbr[(int64_t)kk * n_out + row] : (int)row;
-      return row_ok ? v : -1;
-    };
-    int vcur = fetch_idx(lk), vnxt = fetch_idx(lnk);
-    const u32x4* img = reinterpret_cast<const u32x4*>(W);
-    const u32x4* zero = reinterpret_cast<const u32x4*>(g_zero_planes);
-    auto load_stage = [&]() {
-      if (sw) {
-        sw = false;
-        lk = lnk;
-        vcur = vnxt;
-        if (rem) {
-          lnk = __ffs(rem) - 1;
-          rem &= rem - 1;
-        }
-        vnxt = fetch_idx(lnk);
-      }
-      const u32x4* bsrc = img + (((int64_t)(kbase + lk) * nslab + ls) * ngrp + n0 / 64) * X6_GROUP_U16 + tid;
-#pragma unroll
-      for (int i = 0; i < BU; ++i) bi[i] = bsrc[256 * i];
-      const u32x4* asrc = vcur >= 0 ? planes + ((int64_t)vcur * nslab + ls) * 12 + a_half * AU : zero;
-#pragma unroll
-      for (int i = 0; i < AU; ++i) au[i] = asrc[vcur >= 0 ? i : (i & 1)];
-    };
-    load_stage();
-    const int swz = (r >> 2) & 3;
-    int a_slot[2], b_slot[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      a_slot[b] = (wr * RW + r) * 4 + ((2 * b + h) ^ swz);
-      b_slot[b] = bgrp * X6_GROUP_U16 + ((TN == 2 ? 0 : wc * 32) + r) * 4 + ((2 * b + h) ^ swz);
-    }
-    const int a_swz = (a_row >> 2) & 3;
-    for (int st = 0; st < nst; ++st) {
-      __syncthreads();                           // previous stage fully consumed
-#pragma unroll
-      for (int i = 0; i < AU; ++i) {
-        const int u = a_half * AU + i;           // unit of the row: plane u / 4, chunk u % 4
-        As[(u >> 2) * BM * 4 + a_row * 4 + ((u & 3) ^ a_swz)] = au[i];
-      }
-#pragma unroll
-      for (int i = 0; i < BU; ++i) Bs[tid + 256 * i] = bi[i];
-      __syncthreads();
-      if (st + 1 < nst) {
-        if (++ls >= nslab) {
-          ls = 0;
-          sw = true;
-        }
-      }
-      load_stage();                              // (the last iteration re-reads its own stage: see k_conv_mfma_p)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        u32x4 fa[3][TM];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-          for (int i = 0; i < TM; ++i) fa[pl][i] = As[pl * BM * 4 + a_slot[b] + i * 32 * 4];
-#pragma unroll
-        for (int pb = 2; pb >= 0; --pb) {
-          u32x4 fb[TN];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) fb[j] = Bs[pb * 64 * 4 + b_slot[b] + j * 32 * 4];
-#pragma unroll
-          for (int pa = 2 - pb; pa >= 0; --pa)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j) acc[i][j] = X6_MFMA(fa[pa][i], fb[j], acc[i][j]);
-        }
-      }
-    }
-  }
-  float* dst = out + (int64_t)z * n_out * Cout + n0 + bgrp * 64 + 2 * r + (TN == 2 ? 0 : wc);
-  int orow[TM][16];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int64_t row = m0 + wr * RW + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      int o = -1;
-      if (row < n_out) o = out_index ? out_index[row] : (int)row;
-      orow[i][e] = o;
-    }
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      if (orow[i][e] >= 0) {
-        if (TN == 2) {
-          f32x2 v = {acc[i][0][e], acc[i][TN - 1][e]};
-          *reinterpret_cast<f32x2*>(dst + (int64_t)orow[i][e] * Cout) = v;
-        } else {
-          dst[(int64_t)orow[i][e] * Cout] = acc[i][0][e];
-        }
-      }
-    }
-}
-
-// ---- r4: planes AND weight image by LDS-DMA --------------------------------------------------------------------------------
-// k_conv_x6p showed that taking the split out of the stage loop is not enough: its stage still moves every byte through VGPRs
-// (12 loads + 12 ds_write_b128 per thread) and single-buffers the LDS, so the MFMA block waits for the write pass.  Here both
-// operands go from L2 STRAIGHT into LDS (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging registers, no
-// ds_write), into one of TWO stage buffers, ONE barrier per stage:
-//     wait for my DMAs of stage s -> barrier -> issue stage s+1's DMAs into the other buffer -> multiply stage s.
-// The LDS image of a DMA is lane-linear (wave-uniform base + lane x 16 B), the images of k_conv_x6 are kept by swizzling on the
-// SOURCE side: a plane row is 4 x 16 B, the lane that fills slot c' of tile row j fetches the row's chunk c' ^ ((j >> 2) & 3);
-// the weight image already is the LDS image (contiguous).  Wave tile 32 TM x 64, NW = (BM / 32 TM)(BN / 64) waves; a wave loads
-// two 16-row blocks of every plane (6 DMAs) and its share of the weight units per stage.
-template <int BM, int BN, int TM, bool HAS_NBR>
-__global__ __launch_bounds__(64 * (BM / (32 * TM)) * (BN / 64), 1) void k_conv_x6d(
-    const u32x4* __restrict__ planes, const u32x4* __restrict__ img, const int* __restrict__ nbr,
-    const int* __restrict__ out_index, const int* __restrict__ cnt, float* __restrict__ out, int64_t n_out, int K, int Cin,
-    int Cout) {
-  constexpr int NWC = BN / 64, NWR = BM / (32 * TM), NW = NWR * NWC;
-  constexpr int A_U = 3 * BM * 4, B_U = NWC * X6_GROUP_U16, STAGE_U = A_U + B_U;      // 16-byte units
-  constexpr int NBI = B_U / 64;                                                          // weight DMAs per stage
-  constexpr int BPW = (NBI + NW - 1) / NW;
-  static_assert(BM / 16 == 2 * NW, "a wave loads two 16-row blocks");
-  extern __shared__ __attribute__((aligned(1024))) u32x4 x6d_smem[];
-  __shared__ unsigned int kmask_s;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave / NWC, wc = wave % NWC;
-  const int r = lane & 31, h = lane >> 5;
-  int64_t bx = blockIdx.x;
-  const int n0 = blockIdx.y * BN;
-  int S = gridDim.z, z = blockIdx.z;
-  int kbase = 0;
-  if (cnt) {                                     // pair mode: see k_conv_mfma
-    if (gridDim.z == 1 && K > 1) {
-      int k = 0;
-      for (; k < K - 1; ++k) {
-        const int64_t t = ((int64_t)cnt[k] + BM - 1) / BM;
-        if (bx < t) break;
-        bx -= t;
-      }
-      z = k;
-    }
-    const int64_t stride = n_out;
-    n_out = cnt[z];
-    if (bx * BM >= n_out) return;
-    nbr += (int64_t)z * stride;
-    kbase = z;
-    out += (int64_t)z * stride * Cout;
-    K = 1; S = 1; z = 0;
-  }
-  const int64_t m0 = bx * BM;
-
-  f32x16 acc[TM][2];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  unsigned int kmask;
-  {
-    if (tid == 0) kmask_s = 0u;
-    __syncthreads();
-    for (int t = tid; t < BM; t += 64 * NW) {
-      unsigned int mk = 0u;
-      int64_t row = m0 + t;
-      if (row < n_out) {
-        if (HAS_NBR) {
-          for (int k = z; k < K; k += S)
-            if (nbr[(int64_t)k * n_out + row] >= 0) mk |= 1u << k;
-        } else {
-          mk = 1u;
-        }
-      }
-      for (int off = 32; off > 0; off >>= 1) mk |= __shfl_xor(mk, off, 64);
-      if (lane == 0 && mk) atomicOr(&kmask_s, mk);
-    }
-    __syncthreads();
-    kmask = kmask_s;
-  }
-
-  if (kmask) {
-    const int nslab = Cin / 32, ngrp = Cout / 64;
-    const int nst = __popc(kmask) * nslab;
-    unsigned int rem = kmask;
-    int lk = __ffs(rem) - 1;
-    rem &= rem - 1;
-    int lnk = rem ? __ffs(rem) - 1 : lk;
-    if (rem) rem &= rem - 1;
-    int ls = 0;
-    bool sw = false;
-    // this lane's part of the row DMAs: tile rows (2 wave + q) 16 + lane / 4, LDS slot lane % 4, source chunk swizzled
-    int64_t arow[2];
-    bool aok[2];
-    int a_chunk[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int lrow = (2 * wave + q) * 16 + (lane >> 2);
-      const int64_t row = m0 + lrow;
-      aok[q] = row < n_out;
-      arow[q] = aok[q] ? row : 0;
-      a_chunk[q] = (lane & 3) ^ ((lrow >> 2) & 3);
-    }
-    int vcur[2], vnxt[2];
-    auto fetch_idx = [&](int kk, int (&v)[2]) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) v[q] = HAS_NBR ? nbr[(int64_t)kk * n_out + arow[q]] : (int)arow[q];
-    };
-    fetch_idx(lk, vcur);
-    fetch_idx(lnk, vnxt);
-    const u32x4* zero = reinterpret_cast<const u32x4*>(g_zero_planes);
-    auto issue_stage = [&](int buf) {
-      if (sw) {
-        sw = false;
-        lk = lnk;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) vcur[q] = vnxt[q];
-        if (rem) {
-          lnk = __ffs(rem) - 1;
-          rem &= rem - 1;
-        }
-        fetch_idx(lnk, vnxt);
-      }
-      u32x4* As = x6d_smem + buf * STAGE_U;
-      u32x4* Bs = As + A_U;
-      // every source address first (consumes the index registers while nothing is in flight), then the DMAs back to back
-      const u32x4* asrc[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const bool ok = vcur[q] >= 0 && aok[q];
-        asrc[q] = ok ? planes + ((int64_t)vcur[q] * nslab + ls) * 12 + a_chunk[q] : zero + (lane & 1);
-      }
-      const u32x4* bsrc = img + (((int64_t)(kbase + lk) * nslab + ls) * ngrp + n0 / 64) * X6_GROUP_U16 + lane;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < BPW; ++i) {
-        const int j = wave + NW * i;
-        if (NBI % NW == 0 || j < NBI)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + 64 * j),
-                                           (__attribute__((address_space(3))) void*)(Bs + 64 * j), 16, 0, 0);
-      }
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const bool ok = vcur[q] >= 0 && aok[q];
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[q] + (ok ? pl * 4 : 0)),
-                                           (__attribute__((address_space(3))) void*)(As + pl * BM * 4 + (2 * wave + q) * 64), 16, 0, 0);
-        }
-    };
-    issue_stage(0);
-    const int swz = (r >> 2) & 3;
-    int a_slot[2], b_slot[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      a_slot[b] = (wr * 32 * TM + r) * 4 + ((2 * b + h) ^ swz);
-      b_slot[b] = A_U + wc * X6_GROUP_U16 + r * 4 + ((2 * b + h) ^ swz);
-    }
-    for (int st = 0; st < nst; ++st) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my DMAs of stage st have landed ...
-      __syncthreads();                                      // ... and everyone's; stage st-1 is fully consumed
-      if (st + 1 < nst) {
-        if (++ls >= nslab) {
-          ls = 0;
-          sw = true;
-        }
-        issue_stage((st + 1) & 1);
-      }
-      const u32x4* Sb = x6d_smem + (st & 1) * STAGE_U;
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        u32x4 fa[3][TM];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-          for (int i = 0; i < TM; ++i) fa[pl][i] = Sb[pl * BM * 4 + a_slot[b] + i * 32 * 4];
-#pragma unroll
-        for (int pb = 2; pb >= 0; --pb) {
-          u32x4 fb[2];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) fb[j] = Sb[pb * 64 * 4 + b_slot[b] + j * 32 * 4];
-#pragma unroll
-          for (int pa = 2 - pb; pa >= 0; --pa)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < 2; ++j) acc[i][j] = X6_MFMA(fa[pa][i], fb[j], acc[i][j]);
-        }
-      }
-    }
-  }
-  float* dst = out + (int64_t)z * n_out * Cout + n0 + wc * 64 + 2 * r;
-  int orow[TM][16];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int64_t row = m0 + wr * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      int o = -1;
-      if (row < n_out) o = out_index ? out_index[row] : (int)row;
-      orow[i][e] = o;
-    }
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      if (orow[i][e] >= 0) {
-        f32x2 v = {acc[i][0][e], acc[i][1][e]};
-        *reinterpret_cast<f32x2*>(dst + (int64_t)orow[i][e] * Cout) = v;
-      }
-    }
-}
+// (r4's two staging experiments — the gathered operand as pre-split bf16 planes, k_conv_x6p, and planes + weight image by LDS-DMA,
+// k_conv_x6d: bit-identical, +4...30 % per launch, about what writing the planes costs — were removed in r5; numbers and the
+// reasoning in profiles/r4_notes.md sections 5 and 10, profiles/r5_notes.md.)

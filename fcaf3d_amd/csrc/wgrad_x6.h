@@ -25,189 +25,8 @@
 #define WG_SPLIT2(x0, x1, p0, p1, p2) x6_split2(x0, x1, p0, p1, p2)
 #endif
 
-template <int BMc, int BNc, int KO, bool PAIRS>
-__global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) void k_wgrad_x6(
-    const float* __restrict__ in, const float* __restrict__ gout, const int* __restrict__ nbr,
-    const int* __restrict__ row_index, const int* __restrict__ cnt, float* __restrict__ part, int64_t n_out, int K, int Cin,
-    int Cout, int64_t rows_per_split) {
-  constexpr int TM = BMc / 64, TN = BNc / 64;    // 32x32 tiles per wave (waves 2 x 2 over the BMc x BNc tile)
-  constexpr int PA = BMc / 64, PG = BNc / 64;    // 64-channel staging passes per offset / for gout
-  __shared__ u32x4 As[KO * 3 * BMc * 4];         // [offset][plane][channel][4 chunks]
-  __shared__ u32x4 Gs[3 * BNc * 4];              // [plane][channel][4 chunks]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
-  const int tiles_n = Cout / BNc, tiles_m = Cin / BMc;
-  int y = blockIdx.y;
-  const int tn = y % tiles_n; y /= tiles_n;
-  const int tm = y % tiles_m; y /= tiles_m;
-  const int k0 = y * KO;
-  const int ci0 = tm * BMc, co0 = tn * BNc;
-  int64_t total = n_out;
-  if (PAIRS) {
-    total = cnt[k0];
-    rows_per_split = ((total + gridDim.x - 1) / gridDim.x + 31) / 32 * 32;
-  }
-  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_split;
-  int64_t r_end = r_begin + rows_per_split;
-  if (r_end > total) r_end = total;
-
-  f32x16 acc[KO][TM][TN];
-#pragma unroll
-  for (int o = 0; o < KO; ++o)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[o][i][j][e] = 0.f;
-
-  if (r_begin < r_end) {
-    // row indices of this wave's 8 rows of a stage: scalar (wave-uniform); requested at the top of a stage for the NEXT
-    // one, they arrive under the split + LDS-store phase and the row loads after the barrier find them ready (one set live:
-    // a second, deeper-prefetched set spills the scalar registers)
-    int ia[KO][8], ig[8];
-    auto fetch_idx = [&](int64_t rb, int (&va)[KO][8], int (&vg)[8]) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int64_t row = rb + 8 * wave + e;
-        const int64_t rc = row < r_end ? row : r_end - 1;
-#pragma unroll
-        for (int o = 0; o < KO; ++o) {
-          const int kk = k0 + o < K ? k0 + o : K - 1;
-#ifdef FC_KO_WG_NOIDX
-          const int t = (int)rc;
-#else
-          const int t = nbr[(int64_t)kk * n_out + rc];
-#endif
-          va[o][e] = (row < r_end && k0 + o < K) ? t : -1;
-        }
-        vg[e] = row < r_end ? (PAIRS ? row_index[(int64_t)k0 * n_out + rc] : (int)rc) : -1;
-      }
-    };
-    float av[KO][PA][8], gv[PG][8];
-    auto load_rows = [&]() {                     // rows of the stage whose indices sit in ia / ig
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-#pragma unroll
-        for (int p = 0; p < PG; ++p) {
-          const float* gp = ig[e] >= 0 ? gout + (int64_t)ig[e] * Cout + co0 + p * 64 : g_zero_row;
-#ifdef FC_KO_WG_NOLOAD
-          gv[p][e] = (float)(lane + e);
-#else
-          gv[p][e] = gp[lane];
-#endif
-        }
-#pragma unroll
-        for (int o = 0; o < KO; ++o)
-#pragma unroll
-          for (int p = 0; p < PA; ++p) {
-            const float* ap = ia[o][e] >= 0 ? in + (int64_t)ia[o][e] * Cin + ci0 + p * 64 : g_zero_row;
-#ifdef FC_KO_WG_NOLOAD
-            av[o][p][e] = (float)(lane + e + o);
-#else
-            av[o][p][e] = ap[lane];
-#endif
-          }
-      }
-    };
-    fetch_idx(r_begin, ia, ig);
-    load_rows();
-    const int pmode = g_fc_prio;                 // wave priorities, see k_conv_x6: default none; 1: MFMA block; 2: staging
-    const int swz = (r >> 2) & 3;
-    int a_slot[2], b_slot[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      a_slot[b] = (wr * (BMc / 2) + r) * 4 + ((2 * b + h) ^ swz);
-      b_slot[b] = (wc * (BNc / 2) + r) * 4 + ((2 * b + h) ^ swz);
-    }
-    // staging slot of this lane's channel (within a 64-channel pass) and this wave's row group
-    const int st_slot = lane * 4 + (wave ^ ((lane >> 2) & 3));
-    for (int64_t rb = r_begin; rb < r_end; rb += 32) {
-      fetch_idx(rb + 32 < r_end ? rb + 32 : rb, ia, ig);        // (past the end the last stage is re-read and never used)
-      __syncthreads();
-      if (pmode == 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int p = 0; p < PG; ++p) {
-        unsigned q[3][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) WG_SPLIT2(gv[p][2 * e], gv[p][2 * e + 1], q[0][e], q[1][e], q[2][e]);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          u32x4 v = {q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
-          Gs[(pl * BNc + p * 64) * 4 + st_slot] = v;
-        }
-      }
-#pragma unroll
-      for (int o = 0; o < KO; ++o)
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-          unsigned q[3][4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) WG_SPLIT2(av[o][p][2 * e], av[o][p][2 * e + 1], q[0][e], q[1][e], q[2][e]);
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            u32x4 v = {q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
-            As[((o * 3 + pl) * BMc + p * 64) * 4 + st_slot] = v;
-          }
-        }
-      if (pmode == 2) __builtin_amdgcn_s_setprio(0);
-      __syncthreads();
-      load_rows();
-      if (pmode == 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        u32x4 fb[3][TN];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) fb[pl][j] = Gs[pl * BNc * 4 + b_slot[b] + j * 32 * 4];
-        u32x4 fa[KO][3][TM];
-#pragma unroll
-        for (int o = 0; o < KO; ++o)
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[o][pl][i] = As[(o * 3 + pl) * BMc * 4 + a_slot[b] + i * 32 * 4];
-        // smallest products first (a1b3 | a2b2 a1b2 | a3b1 a2b1 a1b1); the offsets innermost: KO x TM x TN independent
-        // accumulators between two MFMAs on the same one
-#pragma unroll
-        for (int pb = 2; pb >= 0; --pb)
-#pragma unroll
-          for (int pa = 2 - pb; pa >= 0; --pa)
-#pragma unroll
-            for (int o = 0; o < KO; ++o)
-#pragma unroll
-              for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-#ifdef FC_KO_WG_NOMFMA
-                  acc[o][i][j][0] += __uint_as_float((fa[o][pa][i][0] ^ fb[pb][j][0]) & 0x3fffffu);
-#else
-                  acc[o][i][j] = X6_MFMA(fa[o][pa][i], fb[pb][j], acc[o][i][j]);
-#endif
-                }
-      }
-      if (pmode == 1) __builtin_amdgcn_s_setprio(0);
-    }
-  }
-#pragma unroll
-  for (int o = 0; o < KO; ++o) {
-    if (k0 + o >= K) break;
-    float* dst = part + ((int64_t)blockIdx.x * K + k0 + o) * Cin * Cout;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = ci0 + wr * (BMc / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const int col = co0 + wc * (BNc / 2) + j * 32 + r;
-          dst[(int64_t)row * Cout + col] = acc[o][i][j][e];
-        }
-  }
-}
+// (the r3 kernel k_wgrad_x6 — the transposition in the staging registers described above, 40 global_load_dword per thread and
+// stage — was removed in r5: k_wgrad_x6t below is bit-identical and 1.3-1.6x faster, profiles/r4_notes.md section 9.)
 
 // ---- r4: rows loaded 16 bytes per lane, transposed by the LDS read ------------------------------------------------------------
 // Knock-out builds of k_wgrad_x6 on the 441k-row maps (tools/knockout.sh, tools/nbench): without its MFMAs it runs 5 % faster,

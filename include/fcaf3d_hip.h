@@ -130,18 +130,6 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
  * fc_x6_weight_image: image of W (K, R, C) — or, transposed != 0, of the operator W[k]^T where W[k] is stored (C, R) —
  * for a launch with Cin = R, Cout = C; R % 32 == 0, C % 64 == 0; fc_x6_weight_image_bytes(K, R, C) = 6 K R C bytes. */
 int64_t fc_x6_weight_image_bytes(int K, int R, int C);
-/* flags bit27 (with bits 24 and 26; fc_conv_fwd, fc_conv_fwd_pairs_tiles): `in` is not the fp32 feature matrix but its PRE-SPLIT
- * PLANES built by fc_x6_planes — per row and 32-channel slab the three bf16 pieces, 192 contiguous bytes — so that the
- * convolution (me_resnet.py:56-62) stages its gathered rows by plain copies instead of splitting each row once per kernel
- * offset that gathers it; same pieces, same products, bit-identical results.  fc_x6_planes_bytes(n, C) = 6 n C; C % 32 == 0. */
-int64_t fc_x6_planes_bytes(int64_t n, int C);
-int fc_x6_planes(const float* x, void* planes, int64_t n, int C, hipStream_t stream);
-/* The same convolution (ME.MinkowskiConvolution, me_resnet.py:56-62) with BOTH operands copied from L2 straight into LDS
- * (global_load_lds_dwordx4, two stage buffers, one barrier per stage; csrc/conv_x6.h k_conv_x6d): `planes` of fc_x6_planes, `img` of fc_x6_weight_image(s); neighbour-table
- * launches (out_index: the mask-sorted row order or NULL); bm = 128 or 256 tile rows.  Bit-identical to fc_conv_fwd with
- * bits 24 | 26 on the same operands. */
-int fc_conv_x6d(const void* planes, const void* img, const int* nbr, const int* out_index, float* out, int64_t n_out, int K,
-                int Cin, int Cout, int bm, hipStream_t stream);
 int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int transposed, hipStream_t stream);
 /* The images of many kernels in ONE launch (all convolutions of a model — me_resnet.py:56-62, fcaf3d_neck_with_head.py:52,60-69 —
  * both directions, right after the optimizer step: the reference's optimizer hook, mmcv OptimizerHook.after_train_iter, is where

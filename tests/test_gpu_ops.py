@@ -659,144 +659,6 @@ def test_empty_and_degenerate_inputs():
     torch.cuda.synchronize()
 
 
-def test_conv_on_presplit_planes_is_bit_identical():
-    """fc_x6_planes + flags bit27 (k_conv_x6p): the gathered operand arrives as pre-split bf16 planes instead of being split
-    in the kernel — the same pieces and products, so the dense-table, sorted-table and pair-list routes must agree BIT FOR BIT
-    with the in-kernel split (r4 A/B: profiles/r4_notes.md; the route is not the default, it is not faster)."""
-    dev = _dev()
-    import fcaf3d_amd._lib as L
-    import fcaf3d_amd.functional as Fn
-    from fcaf3d_amd.sparse import SparseTensor
-    torch.manual_seed(3)
-    pts = (torch.rand((60000, 3), device=dev) * torch.tensor([6.0, 5.0, 2.5], device=dev) / 0.02).floor().int()
-    coords = torch.cat([torch.randint(0, 2, (60000, 1), device=dev, dtype=torch.int32), pts], 1)
-    x = SparseTensor(torch.randn((60000, 3), device=dev), coordinates=coords, batch_size=2)
-    cm = x.cmap.strided(4)
-    fine = cm.kernel_map(cm, 3)
-    coarse_map = cm.strided(4)
-    coarse = coarse_map.kernel_map(coarse_map, 3)
-    APL = 1 << 27
-    for km, Cin, Cout in ((fine, 64, 128), (fine, 128, 64), (coarse, 128, 128)):
-        f = torch.randn((km.n_in, Cin), device=dev)
-        w = torch.randn((27, Cin, Cout), device=dev) * 0.05
-        img = Fn._x6_image(w, False)
-        planes = torch.empty(L.query('fc_x6_planes_bytes', km.n_in, Cin), dtype=torch.uint8, device=dev)
-        L.call('fc_x6_planes', L.ptr(f), L.ptr(planes), km.n_in, Cin, L.stream())
-        fl = Fn.CONV_X6
-        a = torch.empty((km.n_out, Cout), device=dev)
-        b = torch.empty_like(a)
-        if Fn._pair_conv(km, km.n_out, Cin, Cout):
-            Fn._conv_pairs(f, img, km.pairs(), a, km.n_in, km.n_out, 27, Cin, Cout, km.pair_tiles(), flags=fl)
-            Fn._conv_pairs(planes, img, km.pairs(), b, km.n_in, km.n_out, 27, Cin, Cout, km.pair_tiles(), flags=fl | APL)
-        else:
-            nbr, oidx = km.sorted_fwd()
-            Fn._conv_fwd(f, img, nbr, a, km.n_in, km.n_out, 27, Cin, Cout, oidx, flags=fl)
-            Fn._conv_fwd(planes, img, nbr, b, km.n_in, km.n_out, 27, Cin, Cout, oidx, flags=fl | APL)
-        torch.cuda.synchronize()
-        assert torch.equal(a, b), (km.n_out, Cin, Cout)
-
-
-def test_conv_by_lds_dma_is_bit_identical():
-    """fc_conv_x6d (k_conv_x6d, r4): planes AND weight image copied from L2 straight into LDS (global_load_lds_dwordx4, two stage
-    buffers), 128- and 256-row tiles, 64- and 128-column tiles — the same pieces and products in the same order as k_conv_x6, so
-    a neighbour-table launch without offset split must agree BIT FOR BIT (r4 A/B: tools/planes_bench.py, profiles/r4_notes.md:
-    +4...30 % per launch, less than the planes cost; not the default route)."""
-    dev = _dev()
-    import fcaf3d_amd._lib as L
-    import fcaf3d_amd.functional as Fn
-    from fcaf3d_amd.sparse import SparseTensor
-    torch.manual_seed(4)
-    pts = (torch.rand((60000, 3), device=dev) * torch.tensor([6.0, 5.0, 2.5], device=dev) / 0.02).floor().int()
-    coords = torch.cat([torch.randint(0, 2, (60000, 1), device=dev, dtype=torch.int32), pts], 1)
-    x = SparseTensor(torch.randn((60000, 3), device=dev), coordinates=coords, batch_size=2)
-    cm = x.cmap.strided(4)
-    km = cm.kernel_map(cm, 3)
-    for Cin, Cout, sort in ((64, 128, True), (128, 64, True), (64, 64, False), (32, 256, False)):
-        f = torch.randn((km.n_in, Cin), device=dev)
-        f[::7] = 0
-        w = torch.randn((27, Cin, Cout), device=dev) * 0.05
-        img = Fn._x6_image(w, False)
-        planes = torch.empty(L.query('fc_x6_planes_bytes', km.n_in, Cin), dtype=torch.uint8, device=dev)
-        L.call('fc_x6_planes', L.ptr(f), L.ptr(planes), km.n_in, Cin, L.stream())
-        if sort:
-            nbr, oidx = km.sorted_fwd()
-        else:
-            nbr, oidx = km.nbr, None
-        a = torch.empty((km.n_out, Cout), device=dev)
-        Fn._conv_fwd(f, img, nbr, a, km.n_in, km.n_out, 27, Cin, Cout, oidx, flags=Fn.CONV_X6 | (1 << 8))      # S = 1: no offset split
-        for bm in (128, 256):
-            b = torch.full_like(a, float('nan'))
-            L.call('fc_conv_x6d', L.ptr(planes), L.ptr(img), L.ptr(nbr), L.ptr(oidx) if oidx is not None else None, L.ptr(b), km.n_out, 27,
-                   Cin, Cout, bm, L.stream())
-            torch.cuda.synchronize()
-            assert torch.equal(a, b), (Cin, Cout, bm, float((a - b).abs().max()))
-
-
-def test_wgrad_transposing_read_is_bit_identical():
-    """k_wgrad_x6t (r4: rows loaded 16 B per lane into row-major bf16 subtiles, MFMA operands by ds_read_b64_tr_b16) against
-    k_wgrad_x6 (r3: register transposition, one dword per lane and row): same pieces, same products, same k positions — the
-    weight gradients must agree BIT FOR BIT on dense tables (3 offsets per workgroup) and on pair lists, and both sit at fp32
-    rounding level against an fp64 evaluation."""
-    dev = _dev()
-    import fcaf3d_amd._lib as L
-    import fcaf3d_amd.functional as Fn
-    from fcaf3d_amd.sparse import SparseTensor
-    torch.manual_seed(5)
-    pts = (torch.rand((60000, 3), device=dev) * torch.tensor([6.0, 5.0, 2.5], device=dev) / 0.02).floor().int()
-    coords = torch.cat([torch.randint(0, 2, (60000, 1), device=dev, dtype=torch.int32), pts], 1)
-    x = SparseTensor(torch.randn((60000, 3), device=dev), coordinates=coords, batch_size=2)
-    cm = x.cmap.strided(4)
-    fine = cm.kernel_map(cm, 3)                     # dense-table route (>= 4096 rows)
-    c2 = cm.strided(4)
-    coarse = c2.kernel_map(c2, 3)                   # pair-list route
-    try:
-        for km, Cin, Cout in ((fine, 64, 128), (fine, 128, 64), (fine, 64, 64), (coarse, 128, 128), (coarse, 256, 128), (coarse, 64, 128), (coarse, 64, 64)):
-            f = torch.randn((km.n_in, Cin), device=dev)
-            g = torch.randn((km.n_out, Cout), device=dev) * 1e-3
-            fl = Fn.FLAGS | Fn.WGRAD_X6
-            ws = L.workspace(L.query('fc_conv_wgrad_ws_bytes', km.n_out, 27, Cin, Cout, fl), dev)
-            pi, po, _, cnt = km.pairs()
-            res = {'table': [], 'pairs': []}
-            for tr in (0, 1):
-                L.lib().fc_debug_set_wgrad_tr(tr)
-                for route in res:
-                    gw = torch.full((27, Cin, Cout), float('nan'), device=dev)
-                    if route == 'pairs':
-                        L.call('fc_conv_wgrad_pairs', L.ptr(f), L.ptr(g), L.ptr(pi), L.ptr(po), L.ptr(cnt), L.ptr(gw), km.n_in, km.n_out, 27,
-                               Cin, Cout, fl, L.ptr(ws), ws.numel(), L.stream())
-                    else:
-                        L.call('fc_conv_wgrad', L.ptr(f), L.ptr(g), L.ptr(km.nbr), None, L.ptr(gw), km.n_in, km.n_out, 27, Cin, Cout, fl,
-                               L.ptr(ws), ws.numel(), L.stream())
-                    res[route].append(gw)
-            torch.cuda.synchronize()
-            for route, (a, b) in res.items():
-                if route == 'pairs' and Cin == 64 and Cout == 64:
-                    continue      # the r3 side of the switch keeps 64 x 64 pair lists on the fp32 pipe: checked against fp64 below
-                assert torch.equal(a, b), (route, km.n_out, Cin, Cout, float((a - b).abs().max()))
-            res = [res['table'][1], res['pairs'][1]]
-            # fp64 evaluation of three offsets
-            for k in (0, 13, 26):
-                idx = km.nbr[k].long()
-                ok = idx >= 0
-                ref = f[idx[ok]].double().t() @ g[ok].double()
-                for gw in res:
-                    err = float((gw[k].double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
-                    assert err < 2e-5, (km.n_out, Cin, Cout, k, err)
-        # the table-free dense GEMM (generative transposed convolution, heads): fp32 pipe on the r3 side of the switch — against fp64
-        L.lib().fc_debug_set_wgrad_tr(1)
-        fl = Fn.FLAGS | Fn.WGRAD_X6
-        for n, Cin, Cout in ((5000, 128, 512), (777, 64, 64), (20000, 256, 64)):
-            f = torch.randn((n, Cin), device=dev)
-            g = torch.randn((n, Cout), device=dev) * 1e-3
-            ws = L.workspace(L.query('fc_conv_wgrad_ws_bytes', n, 1, Cin, Cout, fl), dev)
-            gw = torch.full((1, Cin, Cout), float('nan'), device=dev)
-            L.call('fc_conv_wgrad', L.ptr(f), L.ptr(g), None, None, L.ptr(gw), n, n, 1, Cin, Cout, fl, L.ptr(ws), ws.numel(), L.stream())
-            ref = f.double().t() @ g.double()
-            assert float((gw[0].double() - ref).abs().max() / ref.abs().max()) < 2e-5, (n, Cin, Cout)
-    finally:
-        L.lib().fc_debug_set_wgrad_tr(1)
-
-
 # ---- r5: BatchNorm statistics out of the convolution's epilogue, two-consumer gradient add inside the BatchNorm backward ----------
 def _stats_case(dev, n_points, Cin, Cout, level_q, seed, B=2):
     """-> (x, weight, kernel map, coordinate map) of a k3 s1 convolution on a synthetic level"""
