@@ -901,24 +901,40 @@ __global__ __launch_bounds__(256) void k_sum_pairs_stats(const float* __restrict
   const int c = blockIdx.y * 64 + lane * 4;
   const StatCh p = stat_channels(epi, c);
   f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
-  for (int64_t o = r0 + rl; o < r0 + RB && o < n_out; o += 16) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};                           // as k_sum_pairs: offsets in order, nine in flight
+  const int64_t rend = (r0 + RB < n_out) ? r0 + RB : n_out;
+  // TWO rows of this thread per pass (rows o and o + 16): their positions, then their partial rows, are requested together — with
+  // 64-row blocks (1k...4k result rows) a thread owns four rows, and one row per pass made them a chain of 4 x 3 x 2 dependent loads
+  for (int64_t o = r0 + rl; o < rend; o += 32) {
+    const int64_t o2 = o + 16;
+    const bool two = o2 < rend;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;              // as k_sum_pairs: offsets in order, nine in flight
     for (int k0 = 0; k0 < K; k0 += 9) {
-      int j[9];
+      int j[9], j2[9];
 #pragma unroll
-      for (int u = 0; u < 9; ++u) j[u] = k0 + u < K ? pos[(int64_t)(k0 + u) * n_out + o] : -1;
-      f32x4 v[9];
+      for (int u = 0; u < 9; ++u) {
+        j[u] = k0 + u < K ? pos[(int64_t)(k0 + u) * n_out + o] : -1;
+        j2[u] = (two && k0 + u < K) ? pos[(int64_t)(k0 + u) * n_out + o2] : -1;
+      }
+      f32x4 v[9], v2[9];
 #pragma unroll
       for (int u = 0; u < 9; ++u) {
         const float* src = j[u] >= 0 ? part + ((int64_t)(k0 + u) * n_out + j[u]) * Cout + c : g_zero_row + lane * 4;
+        const float* src2 = j2[u] >= 0 ? part + ((int64_t)(k0 + u) * n_out + j2[u]) * Cout + c : g_zero_row + lane * 4;
         v[u] = *reinterpret_cast<const f32x4*>(src);
+        v2[u] = *reinterpret_cast<const f32x4*>(src2);
       }
 #pragma unroll
-      for (int u = 0; u < 9; ++u)
+      for (int u = 0; u < 9; ++u) {
         if (j[u] >= 0) a += v[u];
+        if (j2[u] >= 0) b += v2[u];
+      }
     }
     *reinterpret_cast<f32x4*>(out + o * Cout + c) = a;
     stat_accumulate(p, epi, a, o * Cout + c, a1, a2);
+    if (two) {
+      *reinterpret_cast<f32x4*>(out + o2 * Cout + c) = b;
+      stat_accumulate(p, epi, b, o2 * Cout + c, a1, a2);
+    }
   }
   stat_block_reduce(a1, a2, epi.stats, Cout, sm);
 }

