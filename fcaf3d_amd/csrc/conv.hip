@@ -1245,12 +1245,6 @@ static inline int conv_pipe(int flags, dim3 grid) {
   return (grid.z > 1 && !(flags & (1 << 22))) ? 2 : 0;
 }
 
-// tuning knob (environment, read once): launches with fewer 128-row tiles than this are split over kernel offsets
-static int split_tiles() {
-  static const int v = getenv("FC_SPLIT_TILES") ? atoi(getenv("FC_SPLIT_TILES")) : 384;
-  return v;
-}
-
 static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* mfma, int* bm, int* bn, int* S) {
   *mfma = !(flags & 1) && (Cin % BK == 0) && (Cout % 64 == 0) && K <= 32;
   *bn = (Cout % 128 == 0) ? 128 : 64;
@@ -1266,7 +1260,7 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   // over (r1 rounded up) starts a second, nearly empty round (r2 sweep: 256->256 on 6.9k rows 275 us at S = 10 -> 238 at
   // S = 9); from ~400 tiles on the unsplit launch wins (64->64 on 64k rows: 159 us at S = 2 -> 144 at S = 1, and no
   // partial tiles to write and sum)
-  if (*mfma && K > 1 && tiles < split_tiles()) {
+  if (*mfma && K > 1 && tiles < 384) {          // (r5 sweep with the split-bf16 kernels: 256 / 512 / 768 change nothing, 368.1-368.5 scenes/s)
     s = (int)(1024 / tiles);
     if (s > K) s = K;
     if (s < 1) s = 1;
@@ -1285,7 +1279,7 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
   if ((flags & (1 << 24)) && *mfma && *bm == 64) {     // the split-bf16 kernel has 128- and 256-row tiles only
     *bm = 128;
     const int64_t t3 = fc_cdiv(n_out, 128) * (Cout / *bn);
-    if (!fs) { s = 1; if (K > 1 && t3 < split_tiles()) { s = (int)(1024 / t3); if (s > K) s = K; } }
+    if (!fs) { s = 1; if (K > 1 && t3 < 384) { s = (int)(1024 / t3); if (s > K) s = K; } }
   }
   *S = s;
 }
@@ -1488,6 +1482,8 @@ static int conv_fwd_pairs_impl(const float* in, const float* W, const int* pair_
   if (ws_bytes < fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout)) return FC_EWS;
   float* part = (float*)ws;
   const bool wt = (flags & FC_CONV_WT) != 0;
+  // (r5, measured null: 64-column tiles for the few-thousand-row pair-list launches — 4 workgroups per CU, finer rounds — 373.6 /
+  // 372.5 / 372.2 scenes/s at <= 1k / 4k / 16k rows against 375.4: profiles/r5_notes.md)
   const bool wide = (Cout % 128 == 0) && !(((flags >> 6) & 3) == 1);
   const int bn = wide ? 128 : 64;
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
