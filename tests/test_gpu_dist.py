@@ -95,7 +95,7 @@ def test_two_rank_training_keeps_parameters_identical_and_matches_global_batch()
     assert abs(dp - glob) <= 0.02 * abs(glob), (dp, glob)
 
 
-def _worker_cfg4(rank, world, port, q):
+def _worker_cfg4(rank, world, port, q, bucket_mb=8):
     """BASELINE config 4 as one of its GPUs sees it: fcaf3d_scannet-3d-18class (4 levels), 2 scenes of 100 000 points per rank."""
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
                       FC_DIST_BACKEND='gloo')
@@ -113,8 +113,11 @@ def _worker_cfg4(rank, world, port, q):
     Fn.WGRAD_ASYNC = True                                   # the bench's stream configuration
     for p in model.parameters():
         torch.distributed.broadcast(p.data, 0)
-    tr = TrainStep.from_config(model, cfg)
-    assert len(tr.averager.buckets) >= 2
+    # 8 MB buckets (r5): ~35 buckets, the first of them holding nothing but head-stream gradients (scales, out_block norms,
+    # the packed head kernels) — a bucket may only leave once the MAIN stream has joined the head branch that wrote it
+    # (executor._pready); with the default 64 MB the first bucket reached into layer4 and could not show the ordering
+    tr = TrainStep.from_config(model, cfg, bucket_mb=bucket_mb)
+    assert len(tr.averager.buckets) >= (20 if bucket_mb <= 8 else 1)
     sc = [make_scene(200 + 2 * rank + i, n_points=100000) for i in range(2)]
     batch = dict(points=[torch.from_numpy(s[0]).to(dev) for s in sc],
                  gt_bboxes_3d=[fa.DepthInstance3DBoxes(torch.from_numpy(s[1]), origin=(.5, .5, .5)) for s in sc],
@@ -135,16 +138,22 @@ def test_config4_per_gpu_shape_two_ranks():
     single process over the 4 scenes up to what the per-rank BatchNorm statistics cost (2 scenes instead of 4 in every
     BatchNorm of the step: measured 1.1e-4 relative at the first step; bound 1e-3)."""
     ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_cfg4, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=900) for _ in range(2))
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    (_, l0, d0), (_, l1, d1) = res
+    runs = {}
+    for bucket_mb in (8, 4096):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_cfg4, args=(r, 2, port, q, bucket_mb)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=900) for _ in range(2))
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        runs[bucket_mb] = res
+    # ONE bucket (launched when backward has ended) cannot leave early: the many-bucket run must end with the very same parameters —
+    # a bucket reduced before a gradient of it was final (r4 ADVICE: head-stream gradients) would show here
+    assert runs[8][0][2] == runs[4096][0][2], 'bucketed run differs from the single-bucket run: a bucket left before its gradients were final'
+    (_, l0, d0), (_, l1, d1) = runs[8]
     assert d0 == d1, 'parameters diverged between the ranks'
     import fcaf3d_amd as fa
     from fcaf3d_amd.runner import parse_losses

@@ -4,7 +4,10 @@ x2, calibrated here with tools/pmc_calib.py: 1 GiB copy -> FETCH 0.5 GiB, WRITE 
 usage: traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(path, counter, match):
@@ -38,7 +41,8 @@ def main():
     ft, wt = per_template(fetch_csv, 'FETCH_SIZE', match), per_template(write_csv, 'WRITE_SIZE', match)
     templates = {k: dict(launches=ft[k][1], fetch_MB_per_launch=round(2.0 * ft[k][0] * 1024 / ft[k][1] / 1e6, 2),
                          write_MB_per_launch=round(wt.get(k, [0.0, 1])[0] * 1024 / max(wt.get(k, [0.0, 1])[1], 1) / 1e6, 2)) for k in ft}
-    json.dump(dict(per_template=templates, kernel='k_conv_x6 + k_conv_mfma* + k_conv_glds', launches_fetch_pass=nf, launches_write_pass=nw,
+    from fcaf3d_amd.build import source_hash
+    json.dump(dict(kernel_source_sha16=source_hash(), per_template=templates, kernel='k_conv_x6 + k_conv_mfma* + k_conv_glds', launches_fetch_pass=nf, launches_write_pass=nw,
                    fetch_bytes_per_launch=round(fetch_b), write_bytes_per_launch=round(write_b),
                    hbm_bytes_per_launch=round(fetch_b + write_b),
                    method='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py; FETCH_SIZE x2 '
