@@ -610,6 +610,36 @@ def main():
     if bd:
         bd.report(args.steps, dt * 1e3)
     assert np.isfinite(final_loss), 'loss diverged'
+    # the roofline of the timed region's probed steps, read out now (the extra below probes once more)
+    rl = probe.summary() if probe else None
+    if rl:
+        probed_steps = len(range(0, args.steps, max(args.probe_every, 1)))
+        rl['probed_steps'] = probed_steps
+        rl['time_share_ms_per_step'] = round(rl['avg_launch_us'] * rl['launches'] / 1e3 / probed_steps, 3)
+        rl['hbm_kernels'] = probe.hbm_summary()
+    # r5: the convolution launches now ALSO compute the BatchNorm statistics / backward reductions of the layer next to them in their
+    # epilogues (csrc/conv_x6.h X6Epi) — work that used to be launches of its own sits inside the brackets of `roofline`.  One untimed
+    # probed step with the r4 arrangement (FC_BN_FUSE=0: the same convolution kernels without those epilogues) gives the per-launch
+    # figure that is comparable with r1-r4's
+    if rl and exec_on and Fn.BN_FUSE and world == 1 and not args.no_extras:
+        probe.timed, probe.exec_steps = {}, []
+        Fn.BN_FUSE = False
+        model.__dict__.pop('_programs', None)
+        try:
+            for i in range(2):
+                step(i)
+            step(0, 'time')
+            u = probe.summary()
+            rl['without_bn_epilogues'] = dict(achieved=u['achieved'], frac=u['frac'], avg_launch_us=u['avg_launch_us'], launches=u['launches'],
+                                              what='one untimed probed step with FC_BN_FUSE=0: the same convolution kernels with the BatchNorm '
+                                                   'statistics / backward reductions in passes of their own, as in r1-r4')
+        except Exception as e:
+            rl['without_bn_epilogues'] = dict(error=repr(e)[:200])
+        finally:
+            Fn.BN_FUSE = True
+            model.__dict__.pop('_programs', None)
+            probe.mode = None
+            probe.timed, probe.exec_steps = {}, []
 
     # ---- extras, all OUTSIDE the timed region above (every rank runs them: they hold collectives) ------------------
     # (a) SURVEY 8(d) protocol: forward_train + backward only, synchronised around every iteration, median
@@ -780,13 +810,6 @@ def main():
                        'executor': bool(exec_on) and 'network body through the native launch-list executor (fcaf3d_amd/executor.py, '
                                    'csrc/exec.hip), the probed step included (event brackets inside fc_exec)'},
         }
-        rl = probe.summary() if probe else None
-        if rl:
-            probed_steps = len(range(0, args.steps, max(args.probe_every, 1)))
-            conv_ms = rl['avg_launch_us'] * rl['launches'] / 1e3 / probed_steps
-            rl['probed_steps'] = probed_steps
-            rl['time_share_ms_per_step'] = round(conv_ms, 3)
-            rl['hbm_kernels'] = probe.hbm_summary()
         out['roofline'] = rl
         if world > 1 and dp_log:
             out['config']['data_parallel'] = D.summarize_bucket_log(trainer.averager, dp_log)
