@@ -618,28 +618,34 @@ def main():
         rl['time_share_ms_per_step'] = round(rl['avg_launch_us'] * rl['launches'] / 1e3 / probed_steps, 3)
         rl['hbm_kernels'] = probe.hbm_summary()
     # r5: the convolution launches now ALSO compute the BatchNorm statistics / backward reductions of the layer next to them in their
-    # epilogues (csrc/conv_x6.h X6Epi) — work that used to be launches of its own sits inside the brackets of `roofline`.  One untimed
-    # probed step with the r4 arrangement (FC_BN_FUSE=0: the same convolution kernels without those epilogues) gives the per-launch
-    # figure that is comparable with r1-r4's
+    # epilogues (csrc/conv_x6.h X6Epi) — work that used to be launches of its own sits inside the brackets of `roofline`.  Two untimed
+    # probed steps, back to back under identical conditions (nothing else enqueued: no next step's coordinate phase beside them, which
+    # is why both read higher than the timed region's figure): the default route, and the r4 arrangement (FC_BN_FUSE=0: the same
+    # convolution kernels without those epilogues) — the second is the per-launch figure comparable with r1-r4's
     if rl and exec_on and Fn.BN_FUSE and world == 1 and not args.no_extras:
-        probe.timed, probe.exec_steps = {}, []
-        Fn.BN_FUSE = False
-        model.__dict__.pop('_programs', None)
+        ab = {}
         try:
-            for i in range(2):
-                step(i)
-            step(0, 'time')
-            u = probe.summary()
-            rl['without_bn_epilogues'] = dict(achieved=u['achieved'], frac=u['frac'], avg_launch_us=u['avg_launch_us'], launches=u['launches'],
-                                              what='one untimed probed step with FC_BN_FUSE=0: the same convolution kernels with the BatchNorm '
-                                                   'statistics / backward reductions in passes of their own, as in r1-r4')
+            for fused in (True, False):
+                probe.timed, probe.exec_steps = {}, []
+                Fn.BN_FUSE = fused
+                model.__dict__.pop('_programs', None)
+                for i in range(2):
+                    step(i)
+                torch.cuda.synchronize()
+                step(0, 'time')
+                u = probe.summary()
+                ab['with_bn_epilogues' if fused else 'without_bn_epilogues'] = dict(achieved=u['achieved'], frac=u['frac'],
+                                                                                    avg_launch_us=u['avg_launch_us'], launches=u['launches'])
+            ab['what'] = ('two untimed probed steps on an otherwise idle GPU: the default route (BatchNorm statistics / backward reductions in '
+                          'the convolution epilogues, inside the brackets) and FC_BN_FUSE=0 (those reductions as passes of their own, as in r1-r4)')
         except Exception as e:
-            rl['without_bn_epilogues'] = dict(error=repr(e)[:200])
+            ab['error'] = repr(e)[:200]
         finally:
             Fn.BN_FUSE = True
             model.__dict__.pop('_programs', None)
             probe.mode = None
             probe.timed, probe.exec_steps = {}, []
+        rl['bn_epilogue_ab'] = ab
 
     # ---- extras, all OUTSIDE the timed region above (every rank runs them: they hold collectives) ------------------
     # (a) SURVEY 8(d) protocol: forward_train + backward only, synchronised around every iteration, median
