@@ -19,15 +19,8 @@ import os
 import sys
 import time
 
-# The step runs on four HIP streams (dependent chain at high priority; coordinates, head branch, weight gradients) beside RCCL's and
-# torch's own.  HIP multiplexes the streams of a priority level onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two of OUR
-# streams on one queue serialise what the step overlaps: r4 saw a 31 ms mode, r5 saw it again in 2 of ~45 bench processes (244.8
-# instead of 361 scenes/s; `profiles/r5_notes.md` section 11).  Eight queues leave room for every stream of the process; set before
-# the HIP runtime starts, and only if the caller has not chosen a value.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+import numpy as np
+import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -819,7 +812,6 @@ def main():
                        'config4_global_batch_16': cfg4, 'forced_dp_n1': forced, 'config4_per_gpu': cfg4_1,
                        'fp32_mfma_route': fp32_route, 'bf16_fast_mode': bf16_fast, 'inference': infer, 'inference_pipelined': infer_pipe,
                        **extras,
-                       'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                        'kernel_source_sha16': __import__('fcaf3d_amd.build', fromlist=['source_hash']).source_hash(),
                        'executor': bool(exec_on) and 'network body through the native launch-list executor (fcaf3d_amd/executor.py, '
                                    'csrc/exec.hip), the probed step included (event brackets inside fc_exec)'},
