@@ -16,7 +16,7 @@ def family(n):
         return 'weight gradient: k_wgrad_x6'
     if n.startswith(('k_wgrad', 'k_stem_wgrad')):
         return 'weight gradient: fp32 kernels + k_wgrad_reduce + stem'
-    if n.startswith(('k_bn', 'k_norm', 'k_stats')):
+    if n.startswith(('k_bn', 'k_norm', 'k_stats', 'k_seg_meanvar')):
         return 'normalisation (k_bn*, k_norm*, k_stats*)'
     if n.startswith(('k_sum_pairs', 'k_sum_parts')):
         return 'fixed-order sums of split launches (k_sum_pairs / k_sum_parts)'
