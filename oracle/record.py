@@ -16,6 +16,7 @@ class RecordDecisions:
         self.Fn, self.E, self.MEnn = Fn, E, MEnn
         self.relu, self.pool, self.prune = [], [], []
         self.saved = (Fn._NormAct.forward, Fn._BNTrainSmall.forward, Fn._MaxPool.forward)
+        self.fused0 = Fn._BNTrainFused.forward            # r5: BatchNorm with statistics from the convolution epilogue (module path)
         self.prune0 = MEnn.MinkowskiPruning.forward
         self.keep0 = E.KEEP_STATE
         E.KEEP_STATE = True
@@ -42,6 +43,15 @@ class RecordDecisions:
                 rec.relu.append((out[0] > 0).cpu())
             return out
 
+        fu0 = self.fused0
+
+        def fu(ctx, x, gamma, beta, residual, eps, act, *rest):
+            out = fu0(ctx, x, gamma, beta, residual, eps, act, *rest)
+            if act == Fn.ACT['relu']:
+                rec.relu.append((out[0] > 0).cpu())
+            return out
+        Fn._BNTrainFused.forward = staticmethod(fu)
+
         def mp(ctx, feats, kmap):
             out = mp0(ctx, feats, kmap)
             rec.pool.append(ctx.to_save[0].cpu())          # the arg-max rows (saved for backward)
@@ -52,6 +62,7 @@ class RecordDecisions:
     def __exit__(self, *a):
         Fn = self.Fn
         Fn._NormAct.forward, Fn._BNTrainSmall.forward, Fn._MaxPool.forward = (staticmethod(f) for f in self.saved)
+        Fn._BNTrainFused.forward = staticmethod(self.fused0)
         self.MEnn.MinkowskiPruning.forward = self.prune0
         self.E.KEEP_STATE = self.keep0
         last = getattr(self.model, '_last_exec', None) if self.model is not None else None

@@ -71,3 +71,47 @@ def test_bottleneck_and_wide_heads_fall_back():
     cfg = fa.get_config('fcaf3d_scannet-3d-18class', voxel_size=0.02)
     cfg.model.neck_with_head['n_classes'] = 80
     assert not E.supported(fa.build_detector(cfg.model, train_cfg=cfg.model.get('train_cfg'), test_cfg=cfg.model.get('test_cfg')))
+
+
+def test_batchnorm_fusions_are_wired_consistently():
+    """r5: the static links of the BatchNorm fusions — every forward BatchNorm names the convolution that wrote its input and that
+    convolution names a statistics table; a backward BatchNorm that names a producer names a backward-data convolution whose result
+    has the layer's shape and which carries the layer's input / statistics; a second gradient contribution is either handed to the
+    BatchNorm (gy2) or added by OP_ADD, never both; nothing is linked when FC_BN_FUSE is off."""
+    import fcaf3d_amd.functional as Fn
+    det = _model(4)
+    for wgrad_async, head_overlap in ((True, True), (False, False)):
+        p = E.NetProgram(det, True, wgrad_async, head_overlap)
+        f, b = p.ops_f, p.ops_b
+        bn_f = f[f[:, 0] == E.OP_BN_FWD]
+        assert (bn_f[:, 19] > 0).all(), 'every training-mode BatchNorm takes its statistics from a producer'
+        for row in bn_f:
+            prod = f[row[19] - 1]
+            assert prod[0] == E.OP_CONV and prod[5] == 0 and prod[10] > 0 and prod[6] == row[2], 'the producer wrote the BatchNorm input'
+            assert prod[9] == row[4] * row[20] and row[20] in (1, 8)       # columns = groups x channels
+        assert int(((f[:, 0] == E.OP_CONV) & (f[:, 10] > 0)).sum()) == len(bn_f)
+        bn_b = b[b[:, 0] == E.OP_BN_BWD]
+        linked = bn_b[bn_b[:, 18] > 0]
+        assert len(linked) >= 36 and len(bn_b) == len(bn_f)
+        for row in linked:
+            prod = b[row[18] - 1]
+            assert prod[0] == E.OP_CONV and prod[5] == 1 and prod[10] > 0
+            assert prod[11] - 1 == row[2] and prod[12] == row[7] and prod[13] == row[8] and prod[9] == row[6]     # layer input, mean, var, channels
+            last = row[17] - 1 if row[17] > 0 else row[4]                # the contribution that arrived last = the producer's result
+            assert prod[6] == last
+            if row[17] > 0:
+                assert prod[18] - 1 == row[4], 'the earlier contribution rides along as `add`'
+            assert (prod[19] > 0) == (row[3] >= 0), "act' from the output exactly where the layer had a residual"
+        # stream order: a linked producer precedes its BatchNorm and sits on the same stream
+        idx = {tuple(r): i for i, r in enumerate(map(tuple, b))}
+        for row in linked:
+            assert row[18] - 1 < idx[tuple(row)] and b[row[18] - 1][1] == row[1]
+    Fn.BN_FUSE = False
+    try:
+        p0 = E.NetProgram(det, True, True, True)
+        assert not (p0.ops_f[:, 10][p0.ops_f[:, 0] == E.OP_CONV] > 0).any() and not (p0.ops_f[:, 19][p0.ops_f[:, 0] == E.OP_BN_FWD] > 0).any()
+        bb = p0.ops_b[p0.ops_b[:, 0] == E.OP_BN_BWD]
+        assert not (bb[:, 17] > 0).any() and not (bb[:, 18] > 0).any()
+        assert int((p0.ops_b[:, 0] == E.OP_ADD).sum()) > int((p.ops_b[:, 0] == E.OP_ADD).sum())
+    finally:
+        Fn.BN_FUSE = True
