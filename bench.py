@@ -593,7 +593,12 @@ def main():
         bd.rec.clear()
     if world > 1:
         trainer.averager.log = []                # host-side launch times of the gradient buckets of the timed steps
-    dt, loss = timed_region(lambda i: step(args.warmup + i, 'time' if i % max(args.probe_every, 1) == 0 else None),
+    # probed steps: the LAST step of the timed region and every `probe_every`-th before it.  r1-r4 probed the first step of each window
+    # — with the next step's coordinate phase (its own stream) running beside the probed step's kernels and inside their brackets: 10 %
+    # above the kernels' own durations in the rocprofv3 trace.  Nothing is enqueued behind the last step before the region's closing
+    # synchronise, so its brackets are the kernels' own time (r5: 135 -> ~125 us per operator against 122 us in the trace)
+    pe = max(args.probe_every, 1)
+    dt, loss = timed_region(lambda i: step(args.warmup + i, 'time' if (args.steps - 1 - i) % pe == 0 else None),
                             args.steps, world, dev)
     final_loss = float(loss.item())
     dp_log = getattr(trainer.averager, 'log', None)
