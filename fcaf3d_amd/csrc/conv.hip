@@ -1288,8 +1288,11 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
 // and LDS-padding occupancy caps all lose or are neutral — profiles/r1_conv_pmc.md — and were removed in r2)
 static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr,
                             const int* out_index, const int* cnt, float* dst, int64_t n_rows, int K, int Cin, int Cout,
-                            hipStream_t stream, bool wt = false, const X6Epi* epi = nullptr) {
+                            hipStream_t stream, bool wt = false, const X6Epi* epi = nullptr, int64_t n_in = -1) {
   if (epi && (pipe < 3 || bm < 128 || cnt || grid.z != 1)) return FC_EINVAL;      // the statistics epilogue lives in k_conv_x6
+  // buffer addressing (k_conv_x6 BUF; gathering launches on a weight image): the gathered operand must end below the 2 GB its
+  // descriptor spans; n_in < 0: the caller asks for (flags bit27) or only knows flat addresses
+  const bool bufok = nbr && n_in >= 0 && (uint64_t)n_in * (uint64_t)Cin * 4u < (1ull << 31) - 4096u;
   X6Epi e6 = {};
   if (epi) e6 = *epi;
 #define FC_ARGS <<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout)
@@ -1313,6 +1316,7 @@ static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in
   do {                                                                           \
     if (pipe == 4 && g_bf16_fast && BM_ == 128 && nbr) k_conv_x6<128, BN_, true, 2, 2, true> FC_ARGS6;   \
     else if (pipe == 4 && g_bf16_fast && BM_ == 128) k_conv_x6<128, BN_, false, 2, 2, true> FC_ARGS6;  \
+    else if (pipe == 4 && bufok && BM_ == 128) k_conv_x6<128, BN_, true, 2, 2, false, true> FC_ARGS6;  \
     else if (pipe == 4 && nbr) k_conv_x6<BM_, BN_, true, WM_, 2> FC_ARGS6;       \
     else if (pipe == 4) k_conv_x6<BM_, BN_, false, WM_, 2> FC_ARGS6;        \
     else if (wt) k_conv_x6<BM_, BN_, true, WM_, 1> FC_ARGS6;                \
@@ -1400,7 +1404,7 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
   int rc = launch_conv_mfma(conv_pipe(flags, grid), bm, bn, grid, in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream, wt,
-                            S > 1 ? nullptr : epi);
+                            S > 1 ? nullptr : epi, (flags & (1 << 27)) ? -1 : n_in);
   if (rc != FC_OK) return rc;
   if (S > 1) return stats ? sum_parts_stats(dst, out, n_out, Cout, S, *epi, stream) : sum_parts(dst, out, n_out, Cout, S, stream);
   return FC_OK;
@@ -1489,7 +1493,7 @@ static int conv_fwd_pairs_impl(const float* in, const float* W, const int* pair_
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
   if (live_tiles > 0) grid = dim3((unsigned)live_tiles, Cout / bn, 1);       // linear list of the live (offset, tile) pairs
   {
-    int rc = launch_conv_mfma((live_tiles > 0 || (flags & (1 << 24))) ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt);
+    int rc = launch_conv_mfma((live_tiles > 0 || (flags & (1 << 24))) ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt, nullptr, (flags & (1 << 27)) ? -1 : n_in);
     if (rc != FC_OK) return rc;
   }
   if (epi) {

@@ -178,7 +178,12 @@ __device__ __forceinline__ void x6_epi_terms(bool bwd, float v, float xv, float 
 // either operand — the operand rounded to nearest bf16 — is staged and multiplied: one MFMA per 32x32x16 block instead of six,
 // a third of the staged bytes.  Weight-image launches only; a compile-time variant (as a run-time branch it cost the product
 // kernel 92 spilled registers).
-template <int BM, int BN, bool HAS_NBR, int WM, int BSRC, bool FAST = false>
+// BUF (r5; weight-image launches whose gathered operand is smaller than 2 GB): the gathered rows and the image units are read with
+// buffer loads — a lane's row is a 32-bit byte offset computed once per kernel offset (an absent neighbour: an offset past the
+// descriptor's range, the load returns zeros), the channel slab and the image's stage are SCALAR offsets — instead of 64-bit
+// per-lane addresses rebuilt every stage: the stage loop of the flat-address kernel issues ~3.4 VALU and 1.5 scalar instructions
+// per MFMA (profiles/r5_conv_pmc.md) of which the address arithmetic is a third.  Same loads, same values: bit-identical.
+template <int BM, int BN, bool HAS_NBR, int WM, int BSRC, bool FAST = false, bool BUF = false>
 __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_conv_x6(
     const float* __restrict__ in, const float* __restrict__ W, const int* __restrict__ nbr,
     const int* __restrict__ out_index, const int* __restrict__ cnt, float* __restrict__ out, int64_t n_out, int K, int Cin,
@@ -253,8 +258,10 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
       if (lane == 0 && mk) atomicOr(&kmask_s, mk);
     }
     __syncthreads();
-    kmask = kmask_s;
+    kmask = BUF ? (unsigned int)__builtin_amdgcn_readfirstlane((int)kmask_s) : kmask_s;
   }
+  constexpr bool buf = BUF && BSRC == 2;
+  constexpr unsigned X6_DEAD = 0x80000000u;      // BUF: the descriptor of the gathered operand ends here
 
   // ---- (2) software-pipelined stage loop -------------------------------------------------------------
   if (kmask) {
@@ -284,6 +291,16 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
     };
     fetch_idx(lk, vcur);
     fetch_idx(lnk, vnxt);
+    // BUF: byte offset of this lane's 16 bytes in the rows of the current kernel offset (channel slab 0)
+    unsigned ocur[AR];
+    auto row_offsets = [&]() {
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        ocur[i] = (vcur[i] >= 0 && a_r + 32 * i < rows_here) ? (unsigned)vcur[i] * (unsigned)(Cin * 4) + (unsigned)(a_c4 * 16) : X6_DEAD;
+    };
+    if (buf) row_offsets();
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)X6_DEAD, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, -1, 0x00020000);
     // weight staging roles.  BSRC 0: thread = (column group g = tid % 64 -> columns g * CPT .. + CPT - 1, chunk tid / 64);
     // BSRC 1: thread = (column tid / 4 + 64 u, chunk tid % 4); BSRC 2: units tid + 256 i of the stage's contiguous image
     const int b_g = WT ? (tid >> 2) : (tid & 63), b_c = WT ? (tid & 3) : (tid >> 6);
@@ -300,6 +317,17 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
           rem &= rem - 1;
         }
         fetch_idx(lnk, vnxt);
+        if (buf) row_offsets();
+      }
+      if (buf) {
+        const unsigned boff = (((unsigned)(kbase + lk) * (unsigned)nslab + (unsigned)(lc0 / 32)) * (unsigned)ngrp + (unsigned)(n0 / 64)) * (unsigned)(X6_GROUP_U16 * 16);
+#pragma unroll
+        for (int i = 0; i < BU; ++i)
+          if (!fast || i % 3 == 0) bi[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, tid * 16, (int)(boff + 4096u * i), 0);
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+          av[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)ocur[i], lc0 * 4, 0));
+        return;
       }
       if (BSRC == 2) {
         const u32x4* src = img + (((int64_t)(kbase + lk) * nslab + lc0 / 32) * ngrp + n0 / 64) * X6_GROUP_U16 + tid;
@@ -339,7 +367,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
     // wave priorities (tools/nbench --prio): unlike the fp32 kernels this one LOSES 15-20 % with s_setprio 1 around the MFMA
     // block (r3: 441k rows 64->128 1259 -> 1083 us without) — the waves that are splitting / storing the next stage need
     // the VALU slots between a multiplying wave's MFMAs.  Default: none; 1: MFMA block (the fp32 kernels' scheme); 2: staging.
-    const int pmode = g_fc_prio;
+    const int pmode = buf ? 0 : g_fc_prio;      // (BUF: no run-time priority switch — five branches per stage)
     // fragment slots of this lane (16-byte units): every row this lane reads is r + a multiple of 32, so the chunk
     // swizzle is (r >> 2) & 3 throughout
     const int swz = (r >> 2) & 3;
@@ -399,6 +427,9 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
         }
       }
       load_stage();                              // (the last iteration re-reads its own stage: see k_conv_mfma_p)
+      // BUF: the next stage's loads stay in front of this stage's MFMAs (with fewer address registers in the way hipcc sinks them
+      // behind the last MFMA, a step from their use: 378.6 -> 379.9 scenes/s, three interleaved pairs)
+      if (buf) __builtin_amdgcn_sched_barrier(0);
       // per 16-channel block: the three planes of the rows, then the weight planes one at a time, smallest products first
       // (a1b3 | a2b2 a1b2 | a3b1 a2b1 a1b1): 32 fragment registers live instead of 48
       if (pmode == 1) __builtin_amdgcn_s_setprio(1);

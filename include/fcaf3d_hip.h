@@ -128,7 +128,12 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
  * flags bit26 (with bit24): `W` is not the fp32 kernel but its pre-split image built by fc_x6_weight_image — for the
  * backward-data pass the image of the transposed operator (then bit23 is not needed).
  * fc_x6_weight_image: image of W (K, R, C) — or, transposed != 0, of the operator W[k]^T where W[k] is stored (C, R) —
- * for a launch with Cin = R, Cout = C; R % 32 == 0, C % 64 == 0; fc_x6_weight_image_bytes(K, R, C) = 6 K R C bytes. */
+ * for a launch with Cin = R, Cout = C; R % 32 == 0, C % 64 == 0; fc_x6_weight_image_bytes(K, R, C) = 6 K R C bytes.
+ * flags bit27 (with bit24 | bit26, r5): flat 64-bit addresses for the gathered rows and the image.  Without it a gathering launch
+ * whose `in` ends below 2 GB (n_in Cin 4 bytes) reads both through buffer descriptors — a lane's row is a 32-bit byte offset
+ * computed once per kernel offset, an absent neighbour an offset past the descriptor's end (the load returns zeros): the same
+ * loads, bit-identical results, a third fewer address instructions per stage (csrc/conv_x6.h BUF).  Larger operands and
+ * table-free launches (nbr == NULL) take the flat route by themselves. */
 int64_t fc_x6_weight_image_bytes(int K, int R, int C);
 int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int transposed, hipStream_t stream);
 /* The images of many kernels in ONE launch (all convolutions of a model — me_resnet.py:56-62, fcaf3d_neck_with_head.py:52,60-69 —

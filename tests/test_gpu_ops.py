@@ -841,6 +841,32 @@ def test_non_finite_activations_on_the_split_route():
     np.testing.assert_allclose(outs[True][clean], outs[False][clean], rtol=0, atol=1e-4 * np.abs(outs[False][clean]).max())
 
 
+@pytest.mark.parametrize('n_points,Cin,Cout,q', [(100000, 64, 64, 4), (100000, 64, 128, 4), (100000, 128, 128, 8), (100000, 256, 256, 32),
+                                                  (3000, 64, 64, 8), (777, 128, 64, 2)])
+def test_buffer_and_flat_addressing_are_bit_identical(n_points, Cin, Cout, q):
+    """csrc/conv_x6.h BUF (r5): gathering launches on a weight image read the rows and the image through buffer descriptors (32-bit
+    row offsets, absent neighbours = an offset past the descriptor: zeros); flags bit27 = the flat 64-bit addresses operands of
+    2 GB and more take.  Forward and backward-data, dense tables and pair lists, full and ragged tiles: the same bits."""
+    import fcaf3d_amd.functional as Fn
+    dev = _dev()
+    x, w, km, cm = _stats_case(dev, n_points, Cin, Cout, q, seed=31)
+    g = torch.randn(cm.n, Cout, generator=torch.Generator().manual_seed(5)).to(dev)
+    res = {}
+    f0 = Fn.FLAGS
+    try:
+        for flat in (False, True):
+            Fn.FLAGS = f0 | ((1 << 27) if flat else 0)
+            xx = x.clone().requires_grad_(True)
+            y = Fn.sparse_conv(xx, w, km, cm.n)
+            y.backward(g)
+            res[flat] = (y.detach().clone(), xx.grad.clone())
+    finally:
+        Fn.FLAGS = f0
+    assert torch.isfinite(res[False][0]).all() and float(res[False][0].abs().max()) > 0
+    assert torch.equal(res[False][0], res[True][0]), 'forward'
+    assert torch.equal(res[False][1], res[True][1]), 'backward data'
+
+
 @pytest.mark.parametrize('q,C,route', [(4, 64, 'tile epilogue'), (8, 128, 'pair lists'), (32, 256, 'pair lists, few rows')])
 @pytest.mark.parametrize('act,with_add,from_y', [(1, False, False), (2, False, False), (1, True, True)])
 def test_batchnorm_backward_sums_out_of_the_convolution_epilogue(q, C, route, act, with_add, from_y):

@@ -283,6 +283,7 @@ def test_r5_profiles_were_taken_on_the_committed_kernels():
         assert ks.table(os.path.join(root, 'profiles', name), float(meta['steps_profiled'])) in md, name
     bench_line = json.load(open(os.path.join(root, 'profiles', 'r5_bench_n1.json')))
     assert bench_line['config']['kernel_source_sha16'] == meta['kernel_source_sha16']
-    tj = os.path.join(root, 'profiles', 'r5_traffic.json')
-    if os.path.exists(tj):
-        assert json.load(open(tj)).get('kernel_source_sha16') == meta['kernel_source_sha16']
+    for name in ('r5_traffic.json', 'r5_conv_pmc.json'):
+        tj = os.path.join(root, 'profiles', name)
+        if os.path.exists(tj):
+            assert json.load(open(tj)).get('kernel_source_sha16') == meta['kernel_source_sha16'], name

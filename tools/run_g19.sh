@@ -1,0 +1,10 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out/r5g19
+mkdir -p $O
+timeout 600 python bench.py > $O/r5_bench_n1.json 2> $O/bench.err; echo "bench rc=$?"
+python -c "
+import json;d=json.load(open('$O/r5_bench_n1.json'));c=d['config'];r=d['roofline']
+print('value',d['value'],d['ms_per_step'],'roofline',r['achieved'],r['frac'],r['avg_launch_us'],'ab',{k:(v['frac'],v['avg_launch_us']) for k,v in r['bn_epilogue_ab'].items() if isinstance(v,dict)})
+for k in ('bf16_fast_mode','literal_1cm','two_scales','sunrgbd','s3dis','config4_per_gpu','forced_dp_n1','fp32_mfma_route','inference','inference_pipelined','fwd_bwd_only'): print(k, {kk:vv for kk,vv in (c.get(k) or {}).items() if kk in ('value','ms_per_step','ms','scenes_per_s','ms_per_batch','error')})
+print('cpu', d['cpu_baseline'].get('value'), c['kernel_source_sha16'])"
