@@ -88,7 +88,8 @@ def run_extra(args, key, dev, steps):
         tr(batches[i % 2])
     dt, loss = timed_region(lambda i: tr(batches[i % 2])[0], steps, 1, dev)
     out = dict(workload=f'{wl}, voxel {vs} m, {lv} levels', scenes_per_step=bs, steps=steps, ms_per_step=round(dt / steps * 1e3, 3),
-               value=round(bs * steps / dt, 3), unit='scenes/s', final_loss=round(float(loss), 4))
+               value=round(bs * steps / dt, 3), unit='scenes/s', final_loss=round(float(loss), 4),
+               host_enqueue_ms_per_step=round(LAST_HOST_S / steps * 1e3, 3))
     del tr, model, batches
     torch.cuda.empty_cache()
     return out
@@ -479,6 +480,19 @@ def hbm_steps(args, exec_on):
     return 1 if (exec_on and not (args.no_instrument or args.breakdown)) else 0
 
 
+LAST_HOST_S = 0.0
+
+
+def host_state():
+    """load average and usable CPUs of the host (diagnostic beside `host_enqueue_ms_per_step`: the slow mode of profiles/r5_notes.md
+    section 16 leaves the kernels at their speed — whether the HOST was slow or busy is what these fields record)"""
+    try:
+        la = [round(x, 2) for x in os.getloadavg()]
+    except OSError:
+        la = None
+    return dict(loadavg=la, cpus=len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count())
+
+
 def timed_region(fn, n, world, dev):
     """barrier + synchronize | n calls | synchronize + barrier; returns the MAX over ranks of the elapsed seconds"""
     if world > 1:
@@ -488,6 +502,8 @@ def timed_region(fn, n, world, dev):
     last = None
     for i in range(n):
         last = fn(i)
+    global LAST_HOST_S
+    LAST_HOST_S = time.perf_counter() - t0       # the host has ENQUEUED all n calls (diagnostic: close to the region's time = host-bound)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -501,6 +517,7 @@ def timed_region(fn, n, world, dev):
 
 def main():
     args = parse()
+    host0 = host_state()
     # stdout carries ONE line, the JSON result: everything else that writes to file descriptor 1 during the run (RCCL's
     # version banner, library warnings) goes to stderr
     sys.stdout.flush()
@@ -600,6 +617,7 @@ def main():
     pe = max(args.probe_every, 1)
     dt, loss = timed_region(lambda i: step(args.warmup + i, 'time' if (args.steps - 1 - i) % pe == 0 else None),
                             args.steps, world, dev)
+    host_main = dict(host_enqueue_ms_per_step=round(LAST_HOST_S / args.steps * 1e3, 3), after=host_state())
     final_loss = float(loss.item())
     dp_log = getattr(trainer.averager, 'log', None)
     trainer.averager.log = None
@@ -812,6 +830,9 @@ def main():
                        'scenes_per_gpu_per_step': args.batch, 'global_batch': args.batch * world,
                        'step': 'forward_train + backward + grad all-reduce + grad-clip + AdamW (fcaf3d_amd/runner.py TrainStep)',
                        'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
+                       'host': dict(host_main, at_start=host0,
+                                    what='host_enqueue_ms_per_step: host time until the timed steps were all ENQUEUED / steps (the last, '
+                                         'probed step synchronises inside); loadavg / usable CPUs when the process started and after the timed region'),
                        'fwd_bwd_only': {'protocol': 'SURVEY 8(d): forward_train + backward (+ all-reduce), synchronised per iteration, median of 5',
                                         'ms': round(fb_med * 1e3, 3), 'scenes_per_s': round(args.batch * world / fb_med, 3)},
                        'config4_global_batch_16': cfg4, 'forced_dp_n1': forced, 'config4_per_gpu': cfg4_1,

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (FC_X6_PIPE / FC_X6_BUF were switches of the experiment builds of this call; the product library has neither: buffer addressing is the default, flags bit27 = flat)
 # A/B of the in-wave pipelined stage loop of k_conv_x6 (FC_X6_PIPE bit 0: 128-column tiles, bit 1: 64-column tiles): bit-identity, then timing
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r5g14

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (FC_X6_PIPE / FC_X6_BUF were switches of the experiment builds of this call; the product library has neither: buffer addressing is the default, flags bit27 = flat)
 # kernel-alone durations (one stream) of the pipelined against the plain stage loop
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r5g15

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (FC_X6_PIPE / FC_X6_BUF were switches of the experiment builds of this call; the product library has neither: buffer addressing is the default, flags bit27 = flat)
 # A/B of buffer addressing in k_conv_x6 (FC_X6_BUF): bit-identity (gradient digest of a full forward + backward), then timing, then kernel-alone durations
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r5g16
