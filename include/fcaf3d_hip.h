@@ -133,7 +133,9 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
  * whose `in` ends below 2 GB (n_in Cin 4 bytes) reads both through buffer descriptors — a lane's row is a 32-bit byte offset
  * computed once per kernel offset, an absent neighbour an offset past the descriptor's end (the load returns zeros): the same
  * loads, bit-identical results, a third fewer address instructions per stage (csrc/conv_x6.h BUF).  Larger operands and
- * table-free launches (nbr == NULL) take the flat route by themselves. */
+ * table-free launches (nbr == NULL) take the flat route by themselves.  The descriptor route addresses the weight image with
+ * 32-bit offsets: a caller whose image reaches 4 GB (6 K Cin Cout bytes; 42 MB for the largest layer of the reference's networks)
+ * sets bit27. */
 int64_t fc_x6_weight_image_bytes(int K, int R, int C);
 int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int transposed, hipStream_t stream);
 /* The images of many kernels in ONE launch (all convolutions of a model — me_resnet.py:56-62, fcaf3d_neck_with_head.py:52,60-69 —
