@@ -1,0 +1,60 @@
+#!/bin/bash
+# The ONE lease script (r6; replaces the per-call run_g*.sh of r5): every gpurun call of the round goes through it.
+#   gpurun --timeout T -- 'bash tools/lease.sh <tag> <job> [<job> ...]'
+# Jobs run in the order given, output under gpurun_out/<tag>/.  A job is one of
+#   bench[:args]     python bench.py [args]            -> bench.json (+ one-line summary)         (FIRST job = driver conditions)
+#   quick[:args]     bench.py without the untimed extras -> quick<i>.json
+#   tests[:expr]     pytest -m gpu [-k expr]           -> tests.log
+#   file:<path>      pytest -m gpu <path>              -> tests_<name>.log
+#   smoke            __graft_entry__.smoke()
+#   trace            rocprofv3 --kernel-trace --stats over a short bench -> trace/ + kernel_stats
+#   trace1           the same with every kernel on ONE stream (--no-wgrad-overlap, FC_MAP_SYNC=1)
+#   pmc:<counters>   rocprofv3 --pmc <counters> over a short bench (own pass, no tracing)
+#   host[:B]         tools/hostprof.py for B scenes
+#   py:<script args> python <script args>
+cd "$GRAFT_REPO_ROOT" || exit 1
+TAG=$1; shift
+O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p "$O"
+export TMPDIR=/tmp
+uptime > "$O/uptime.txt"
+i=0
+for job in "$@"; do
+  i=$((i + 1))
+  kind=${job%%:*}; arg=""; [ "$kind" != "$job" ] && arg=${job#*:}
+  SECONDS=0
+  case $kind in
+    bench)
+      timeout 900 python bench.py $arg > "$O/bench$i.json" 2> "$O/bench$i.err"; rc=$?
+      python tools/lease_summary.py "$O/bench$i.json" ;;
+    quick)
+      timeout 600 python bench.py --no-cpu-baseline --infer-steps 0 --no-fp32-route --no-extras --no-force-dp $arg > "$O/quick$i.json" 2> "$O/quick$i.err"; rc=$?
+      python tools/lease_summary.py "$O/quick$i.json" ;;
+    tests)
+      if [ -n "$arg" ]; then timeout 2400 python -m pytest tests -x -q -m gpu -k "$arg" --durations=8 > "$O/tests$i.log" 2>&1; else
+        timeout 2400 python -m pytest tests -x -q -m gpu --durations=8 > "$O/tests$i.log" 2>&1; fi; rc=$?
+      tail -15 "$O/tests$i.log" | grep -v Warning ;;
+    file)
+      timeout 2400 python -m pytest $arg -x -q -m gpu --durations=8 > "$O/tests$i.log" 2>&1; rc=$?
+      tail -15 "$O/tests$i.log" | grep -v Warning ;;
+    smoke)
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; rc=$?; tail -2 "$O/smoke.log" ;;
+    trace|trace1)
+      extra=""; [ "$kind" = trace1 ] && extra="--no-wgrad-overlap"
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$kind" -o k -- python "$GRAFT_REPO_ROOT/bench.py" --steps 6 --warmup 3 --no-cpu-baseline \
+        --infer-steps 0 --no-fp32-route --no-extras --no-force-dp --no-instrument $extra $arg > "$O/$kind.json" 2> "$O/$kind.err"); rc=$?
+      cp "$(find "$O/$kind" -name '*kernel_stats.csv' | head -1)" "$O/${kind}_kernel_stats.csv" 2>> "$O/$kind.err"
+      python tools/lease_summary.py "$O/$kind.json"; head -25 "$O/${kind}_kernel_stats.csv" | cut -c1-160
+      find "$O/$kind" -name '*kernel_trace.csv' -size +40M -delete ;;
+    pmc)
+      (cd /tmp && timeout 900 rocprofv3 --pmc $arg -d "$O/pmc_${arg// /_}" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline \
+        --infer-steps 0 --no-fp32-route --no-extras --no-force-dp --no-instrument > "$O/pmc$i.json" 2> "$O/pmc$i.err"); rc=$? ;;
+    host)
+      timeout 600 python tools/hostprof.py ${arg:-8} > "$O/host$i.txt" 2>&1; rc=$?; tail -12 "$O/host$i.txt" ;;
+    py)
+      timeout 1800 python $arg > "$O/py$i.log" 2>&1; rc=$?; tail -25 "$O/py$i.log" ;;
+    *) echo "unknown job $job"; rc=64 ;;
+  esac
+  echo "[$TAG] job $i ($job): rc=$rc in ${SECONDS}s"
+done
+uptime >> "$O/uptime.txt"
