@@ -1,0 +1,829 @@
+// The coordinate phase of one step as native host loops (r6): collate + voxel hash + the whole pyramid of coordinate sets,
+// then every kernel map and derived table the network body will use — two C-ABI calls per step instead of ~420 launches
+// driven from Python with ~25 blocking count read-backs (profiles/r5_notes.md section 16: the step was host-bound on them
+// whenever a round trip on the coordinate stream took 0.3 ms longer than usual).
+//
+//   fc_plan_levels  points of B scenes -> [cm0, m1, m2, L1..Lnl]: the collate of single_stage_sparse.py:34-37 and the strided
+//                   output sets of me_resnet.py:19-24, :56-62, built as ONE chain with DEVICE-resident row counts (every kernel
+//                   is launched for the upper bound and reads the live count from the previous set's meta word), then ONE
+//                   read-back of all counts (rows per set, rows per set and scene, range flags).
+//   fc_plan_maps    with those counts: every kernel map of the backbone and the neck (generated sets by index arithmetic),
+//                   mask-sorted tables (native LSD radix argsort), pair lists, transposed tables, union rows, the head's
+//                   location / scene / level arrays — enqueued back to back, then ONE read-back (pair-list counts, union hits).
+//
+// Results are the sets, tables and row orders of the per-operator path (fcaf3d_amd/sparse.py -> csrc/coords.hip), bit for
+// bit: tests/test_gpu_plan.py compares every buffer.  Reference: what this replaces is ME's CoordinateManager work inside
+// ME.SparseTensor(...) and every ME.Minkowski* call of extract_feat (mmdet3d/models/detectors/single_stage_sparse.py:32-40).
+#include "fc_common.h"
+#include "../../include/fcaf3d_hip.h"
+#include <string.h>
+
+namespace {
+
+// ---- layout of the host tables (mirrored in fcaf3d_amd/plan.py) ------------------------------------------------------------
+enum : int {                        // cfg words
+  C_B = 0, C_NL, C_NFEAT, C_VS /*double bits*/, C_FEATDIV /*double bits*/, C_TOTAL, C_BACKWARD, C_SORT_MIN, C_PAIR_ROWS, C_PTS_THR,
+  C_TARGETS, C_COORDS_IN, C_FEATS_IN, C_PT_STRIDE, C_NECK, C_VS_HEAD /*double bits: the head's voxel size*/, CFGW = 24
+};
+constexpr int HDR = 16;             // out[0..15]: header
+enum : int { H_S = 0, H_NEED2, H_PRUNE, H_NMAPS, H_STRUCT, H_NALL, H_F0, H_TGT_PTS, H_TGT_SCENE, H_TGT_LEVEL, H_TGT_ORDER, H_TGT_SEG,
+             H_NHEAD, H_BAD };
+constexpr int SETW = 8;             // per set: coords, n, stride, keys, vals, cap, gen_parent (set index or -1), union rows
+enum : int { S_COORDS = 0, S_N, S_STRIDE, S_KEYS, S_VALS, S_CAP, S_PARENT, S_ROWS };
+constexpr int MAPR = 64;            // per map record
+enum : int {
+  MW_IN = 0, MW_OUT, MW_K, MW_NIN, MW_NOUT, MW_NBR, MW_NBRT, MW_SORT, MW_SORTI, MW_SORTT, MW_SORTTI, MW_PI, MW_PO, MW_POS, MW_CNT, MW_TILES,
+  MW_TPI, MW_TPO, MW_TPOS, MW_TCNT, MW_TTILES, MW_FLAGS /*1 sort_rows, 2 use_pairs, 4 dense*/, MW_DESC_F = 24 /*20 words: desc(conv, backward=false)*/,
+  MW_DESC_B = 44 /*20 words: desc(conv, backward=true)*/
+};
+constexpr int MAXSETS = 24, MAXLV = 8;
+
+inline double as_double(int64_t v) { double d; memcpy(&d, &v, 8); return d; }
+inline int64_t next_pow2(int64_t n) { int64_t p = 2; while (p < n) p *= 2; return p; }
+
+struct Bump {                       // bump allocation inside a caller-owned arena; base == nullptr: sizing pass
+  char* base; int64_t off;
+  void* take(int64_t bytes) {
+    off = fc_align(off, 256);
+    void* p = base ? base + off : nullptr;
+    off += bytes > 0 ? bytes : 0;
+    return p;
+  }
+  template <typename T> T* arr(int64_t n) { return (T*)take(n * (int64_t)sizeof(T)); }
+};
+
+// one event per thread for the read-backs (created once, never destroyed)
+thread_local hipEvent_t t_ev = nullptr;
+int sync_readback(void* host, const void* dev, int64_t bytes, hipStream_t s) {
+  if (!t_ev) FC_HIP(hipEventCreateWithFlags(&t_ev, hipEventDisableTiming));
+  FC_HIP(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, s));
+  FC_HIP(hipEventRecord(t_ev, s));
+  FC_HIP(hipEventSynchronize(t_ev));
+  return 0;
+}
+
+// ---- stage 1 kernels: device-resident counts ---------------------------------------------------------------------------------
+// meta (device ints): per set s: [8s + 0] rows, [8s + 1] hash capacity, [8s + 2] range flag; then rows per (set, scene).
+constexpr int METAW = 8;
+constexpr int CH = 32;              // scenes per launch of the point kernel
+struct SceneArgs { const float* p[CH]; int n[CH]; int off[CH]; int b0, stride, nfeat; float vs, feat_div; };
+
+__device__ inline int4 quant(int4 c, int q) {
+  if (q > 1) { c.y = fc_floor_div(c.y, q) * q; c.z = fc_floor_div(c.z, q) * q; c.w = fc_floor_div(c.w, q) * q; }
+  return c;
+}
+__device__ inline bool out_of_range(int4 c) {
+  return c.x < 0 || c.x > 32767 || c.y < -FC_COORD_LIMIT || c.y > FC_COORD_LIMIT || c.z < -FC_COORD_LIMIT || c.z > FC_COORD_LIMIT ||
+         c.w < -FC_COORD_LIMIT || c.w > FC_COORD_LIMIT;
+}
+__device__ inline void hash_insert(unsigned long long* keys, int* vals, unsigned long long mask, int4 c, int i, int* slot, int* bad) {
+  if (out_of_range(c)) *bad = 1;
+  const unsigned long long key = fc_pack(c.x, c.y, c.z, c.w);
+  unsigned long long h = fc_mix(key) & mask;
+  while (true) {
+    const unsigned long long prev = atomicCAS(&keys[h], FC_EMPTY_KEY, key);
+    if (prev == FC_EMPTY_KEY || prev == key) {
+      atomicMin(&vals[h], i);       // first occurrence (smallest row) wins — SURVEY.md Appendix A.2
+      slot[i] = (int)h;
+      return;
+    }
+    h = (h + 1) & mask;
+  }
+}
+
+// table of set s: capacity = next_pow2(2 * rows of its INPUT) — the per-operator path's rule (sparse.CoordMap.from_coords)
+__global__ void k_plan_table_init(unsigned long long* __restrict__ keys, int* __restrict__ vals, const int* __restrict__ n_in_dev,
+                                  int64_t n_in_host, int* __restrict__ meta_s) {
+  const int64_t n_in = n_in_dev ? *n_in_dev : n_in_host;
+  int64_t cap = 2;
+  while (cap < 2 * n_in) cap *= 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) meta_s[1] = (int)cap;
+  if (i < cap) { keys[i] = FC_EMPTY_KEY; vals[i] = 0x7fffffff; }
+}
+
+// the collate (single_stage_sparse.py:34-36: floor(xyz / voxel_size), features / 255, batch index = scene) fused with the hash
+// insert of level 0 — blockIdx.y = scene of the chunk.  (true fp32 division, as fc_voxelize.)
+__global__ void k_plan_voxelize_insert(SceneArgs sc, int4* __restrict__ coords, float* __restrict__ feats, unsigned long long* keys,
+                                       int* vals, int64_t cap, int* __restrict__ meta_s, int* __restrict__ slot) {
+  const int j = blockIdx.y;
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= sc.n[j]) return;
+  const float* p = sc.p[j] + (int64_t)l * sc.stride;
+  const int i = sc.off[j] + l;
+  int4 c;
+  c.x = sc.b0 + j;
+  c.y = (int)floorf(p[0] / sc.vs); c.z = (int)floorf(p[1] / sc.vs); c.w = (int)floorf(p[2] / sc.vs);
+  coords[i] = c;
+  for (int f = 0; f < sc.nfeat; ++f) feats[(int64_t)i * sc.nfeat + f] = p[3 + f] / sc.feat_div;
+  hash_insert(keys, vals, (unsigned long long)(cap - 1), c, i, slot, meta_s + 2);
+}
+
+// any set from a coordinate array: rows [0, *n_dev) of `coords`, quantised to multiples of q
+__global__ void k_plan_insert(const int4* __restrict__ coords, const int* __restrict__ n_dev, int64_t n_host, int q,
+                              unsigned long long* keys, int* vals, int* __restrict__ meta_s, int* __restrict__ slot) {
+  const int64_t n = n_dev ? *n_dev : n_host;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  hash_insert(keys, vals, (unsigned long long)(meta_s[1] - 1), quant(coords[i], q), (int)i, slot, meta_s + 2);
+}
+
+// winners of 1 024 rows per block: flags + the block's count
+__global__ __launch_bounds__(256) void k_plan_flags(const int* __restrict__ slot, const int* __restrict__ vals, const int* __restrict__ n_dev,
+                                                    int64_t n_host, unsigned char* __restrict__ flags, int* __restrict__ blocksums) {
+  __shared__ int ws[4];
+  const int64_t n = n_dev ? *n_dev : n_host;
+  const int64_t base = (int64_t)blockIdx.x * 1024;
+  int cnt = 0;
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    int f = 0;
+    if (i < n) { f = vals[slot[i]] == (int)i; flags[i] = (unsigned char)f; }
+    const unsigned long long bal = __ballot(f);
+    if ((threadIdx.x & 63) == 0) cnt += __popcll(bal);
+  }
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) blocksums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// exclusive scan of the block counts (one block), total -> meta_s[0]
+__global__ __launch_bounds__(1024) void k_plan_scan(int* __restrict__ blocksums, int nb, int* __restrict__ meta_s) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int start = 0; start < nb; start += 1024) {
+    const int i = start + threadIdx.x;
+    const int v = i < nb ? blocksums[i] : 0;
+    int x = v;                                    // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(x, o, 64);
+      if (lane >= o) x += t;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int pre = carry_s;
+    for (int k = 0; k < w; ++k) pre += wsum[k];
+    if (i < nb) blocksums[i] = pre + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = pre + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) meta_s[0] = carry_s;
+}
+
+// positions + the set itself: winner row i -> out row p: coordinates (with its feature row for level 0), table value = p,
+// rows-per-scene counters (rows of one scene are consecutive: one atomic per wave and scene)
+__global__ __launch_bounds__(256) void k_plan_finalize(const int4* __restrict__ coords, const int* __restrict__ n_dev, int64_t n_host, int q,
+                                                       const unsigned char* __restrict__ flags, const int* __restrict__ blocksums,
+                                                       const int* __restrict__ slot, int* vals, int4* __restrict__ out_coords,
+                                                       const float* __restrict__ feats_in, float* __restrict__ feats_out, int nfeat,
+                                                       int* __restrict__ scene_cnt, int B) {
+  __shared__ int ws[4];
+  const int64_t n = n_dev ? *n_dev : n_host;
+  const int64_t base = (int64_t)blockIdx.x * 1024;
+  if (base >= n) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int run = blocksums[blockIdx.x];
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    const int f = i < n ? (int)flags[i] : 0;
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) ws[w] = __popcll(bal);
+    __syncthreads();
+    int pre = run;
+    for (int k = 0; k < w; ++k) pre += ws[k];
+    const int tot = ws[0] + ws[1] + ws[2] + ws[3];
+    __syncthreads();
+    int b = -1;
+    if (f) {
+      const int p = pre + __popcll(bal & ((1ull << lane) - 1ull));
+      const int4 c = quant(coords[i], q);
+      out_coords[p] = c;
+      vals[slot[i]] = p;                           // the table now maps key -> row of the new set
+      if (feats_out)
+        for (int k = 0; k < nfeat; ++k) feats_out[(int64_t)p * nfeat + k] = feats_in[i * nfeat + k];
+      b = c.x;
+    }
+    unsigned long long rem = bal;                  // rows per scene
+    while (rem) {
+      const int leader = __ffsll((long long)rem) - 1;
+      const int lb = __shfl(b, leader, 64);
+      const unsigned long long same = __ballot(f && b == lb);
+      if (lane == leader && lb >= 0 && lb < B) atomicAdd(&scene_cnt[lb], __popcll(same));
+      rem &= ~same;
+    }
+    run += tot;
+  }
+}
+
+// ---- stage 2 kernels ---------------------------------------------------------------------------------------------------------
+// kernel map with the offsets computed in the kernel (x fastest; centred for odd kernels, {0..k-1} for even — Appendix A.3):
+// nbr[k][o] = row of out_coords[o] + offset_k * stride in the table, or -1.  blockIdx.y = k.
+__global__ void k_plan_kernel_map(const int4* __restrict__ out_coords, int64_t n_out, const unsigned long long* __restrict__ keys,
+                                  const int* __restrict__ vals, unsigned long long mask, int ks, int stride, int* __restrict__ nbr) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  const int k = blockIdx.y;
+  const int c0 = (ks & 1) ? ks / 2 : 0;
+  const int dx = (k % ks - c0) * stride, dy = ((k / ks) % ks - c0) * stride, dz = (k / (ks * ks) - c0) * stride;
+  const int4 c = out_coords[o];
+  nbr[(int64_t)k * n_out + o] = fc_lookup(keys, vals, mask, fc_pack(c.x, c.y + dx, c.z + dy, c.w + dz));
+}
+
+// transposed table of a map of a set onto ITSELF with a centred odd kernel: nbr_t[k] = nbr[K - 1 - k] (offset k reversed is offset
+// K - 1 - k), a coalesced copy instead of fill + scatter — identical to fc_kernel_map_transpose
+__global__ void k_plan_reverse_rows(const int* __restrict__ nbr, int64_t n, int K, int* __restrict__ nbr_t) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int k = blockIdx.y;
+  nbr_t[(int64_t)k * n + i] = nbr[(int64_t)(K - 1 - k) * n + i];
+}
+
+// row of each voxel of a backbone level (stride T) in the generated set `depth` levels below the coarsest level: the generated
+// sets hold ALL descendants of the coarsest set (child k of row i at 8i + k), so the row follows from ONE probe of the coarsest
+// table and `depth` child-bit triples — identical to fc_child_rows on the parent set's table.  *n_found counts the hits.
+__global__ void k_plan_gen_rows(const int4* __restrict__ q, int64_t n, const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
+                                unsigned long long mask, int T, int depth, int* __restrict__ rows, int* __restrict__ n_found) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int hit = 0;
+  if (i < n) {
+    const int4 c = q[i];
+    const int P = T << depth;                      // stride of the coarsest set
+    const int px = fc_floor_div(c.y, P) * P, py = fc_floor_div(c.z, P) * P, pz = fc_floor_div(c.w, P) * P;
+    int r = fc_lookup(keys, vals, mask, fc_pack(c.x, px, py, pz));
+    if (r >= 0) {
+      const int rx = (c.y - px) / T, ry = (c.z - py) / T, rz = (c.w - pz) / T;       // in [0, 2^depth)
+      for (int d = depth - 1; d >= 0; --d) r = 8 * r + (((rx >> d) & 1) | (((ry >> d) & 1) << 1) | (((rz >> d) & 1) << 2));
+      hit = 1;
+    }
+    rows[i] = r;
+  }
+  const unsigned long long bal = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_found, __popcll(bal));
+}
+
+// the head's per-location arrays over all levels (finest first): location = voxel corner * voxel size
+// (fcaf3d_neck_with_head.py:276-277), scene, level, identity order (rows of every set are grouped by scene)
+struct HeadArgs { const int4* coords[MAXLV]; int64_t off[MAXLV + 1]; int nl; float vs; };
+__global__ void k_plan_head_arrays(HeadArgs h, float* __restrict__ pts, int* __restrict__ scene, int* __restrict__ level, int* __restrict__ order) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= h.off[h.nl]) return;
+  int l = 0;
+  while (l + 1 < h.nl && t >= h.off[l + 1]) ++l;
+  const int4 c = h.coords[l][t - h.off[l]];
+  pts[3 * t] = (float)c.y * h.vs; pts[3 * t + 1] = (float)c.z * h.vs; pts[3 * t + 2] = (float)c.w * h.vs;
+  scene[t] = c.x;
+  level[t] = l;
+  order[t] = (int)t;
+}
+
+// ---- LSD radix argsort of 27-bit keys (the occupancy masks), stable: 3 passes of 9 bits ------------------------------------------
+constexpr int RB = 9, RBINS = 1 << RB, RTILE = 4096;
+__global__ __launch_bounds__(256) void k_radix_hist(const int* __restrict__ keys, int64_t n, int shift, int* __restrict__ hist /*(nblk, RBINS)*/) {
+  __shared__ int h[RBINS];
+  for (int b = threadIdx.x; b < RBINS; b += 256) h[b] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RTILE;
+  for (int r = 0; r < RTILE / 256; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (RBINS - 1)], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < RBINS; b += 256) hist[(int64_t)blockIdx.x * RBINS + b] = h[b];
+}
+
+// one block of RBINS threads: hist[blk][d] -> global start of (d, blk) in (digit, block) order
+__global__ __launch_bounds__(RBINS) void k_radix_scan(int* __restrict__ hist, int nblk) {
+  __shared__ int tot[RBINS];
+  const int d = threadIdx.x;
+  int run = 0;
+  for (int b = 0; b < nblk; ++b) {
+    const int v = hist[(int64_t)b * RBINS + d];
+    hist[(int64_t)b * RBINS + d] = run;
+    run += v;
+  }
+  tot[d] = run;
+  __syncthreads();
+  // exclusive scan of the digit totals (Hillis-Steele over RBINS threads)
+  int x = run;
+  for (int o = 1; o < RBINS; o <<= 1) {
+    const int t = d >= o ? tot[d - o] : 0;
+    __syncthreads();
+    x += t;
+    tot[d] = x;
+    __syncthreads();
+  }
+  const int dbase = x - run;
+  for (int b = 0; b < nblk; ++b) hist[(int64_t)b * RBINS + d] += dbase;
+}
+
+// rank inside the tile in row order (stable) and scatter.  vals_in == nullptr: the identity (first pass).
+__global__ __launch_bounds__(256) void k_radix_scatter(const int* __restrict__ keys_in, const int* __restrict__ vals_in, int64_t n, int shift,
+                                                       const int* __restrict__ hist, int* __restrict__ keys_out, int* __restrict__ vals_out) {
+  __shared__ int offs[RBINS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int b = threadIdx.x; b < RBINS; b += 256) offs[b] = hist[(int64_t)blockIdx.x * RBINS + b];
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RTILE;
+  for (int r = 0; r < RTILE / 256; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    const bool live = i < n;
+    const int key = live ? keys_in[i] : 0;
+    const int d = (key >> shift) & (RBINS - 1);
+    unsigned long long peers = __ballot(live);     // lanes of this wave with the same digit
+    for (int b = 0; b < RB; ++b) {
+      const unsigned long long m = __ballot((d >> b) & 1);
+      peers &= ((d >> b) & 1) ? m : ~m;
+    }
+    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+    const int cnt = __popcll(peers);
+    int dst = 0;
+    for (int ww = 0; ww < 4; ++ww) {               // waves in row order
+      if (w == ww && live && rank == 0) { dst = offs[d]; offs[d] = dst + cnt; }
+      __syncthreads();
+    }
+    const int leader = __ffsll((long long)peers) - 1;
+    dst = __shfl(dst, live ? leader : 0, 64);
+    if (live) {
+      keys_out[dst + rank] = key;
+      vals_out[dst + rank] = vals_in ? vals_in[i] : (int)i;
+    }
+  }
+}
+
+// order (n) = stable argsort of keys (n) in [0, 2^27); ws: 3 n ints + hist
+int64_t argsort27_ws_bytes(int64_t n) { return fc_align(4 * n, 256) * 3 + fc_align(4 * fc_cdiv(n > 0 ? n : 1, RTILE) * RBINS, 256); }
+int argsort27(const int* keys, int64_t n, int* order, void* ws, hipStream_t s) {
+  if (n <= 0) return 0;
+  char* w = (char*)ws;
+  int* ka = (int*)w; w += fc_align(4 * n, 256);
+  int* kb = (int*)w; w += fc_align(4 * n, 256);
+  int* va = (int*)w; w += fc_align(4 * n, 256);
+  int* hist = (int*)w;
+  const int nblk = (int)fc_cdiv(n, RTILE);
+  // p0: (keys, identity) -> (ka, order); p1: (ka, order) -> (kb, va); p2: (kb, va) -> (ka, order): the result lands in `order`
+  const int* kin[3] = {keys, ka, kb};
+  int* kout[3] = {ka, kb, ka};
+  const int* vin[3] = {nullptr, order, va};
+  int* vout[3] = {order, va, order};
+  for (int p = 0; p < 3; ++p) {
+    k_radix_hist<<<nblk, 256, 0, s>>>(kin[p], n, p * RB, hist);
+    FC_CHECK_LAUNCH();
+    k_radix_scan<<<1, RBINS, 0, s>>>(hist, nblk);
+    FC_CHECK_LAUNCH();
+    k_radix_scatter<<<nblk, 256, 0, s>>>(kin[p], vin[p], n, p * RB, hist, kout[p], vout[p]);
+    FC_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int live_tiles(const int* cnt, int K) {
+  int64_t t = 0;
+  for (int k = 0; k < K; ++k) t += (cnt[k] + 127) / 128;
+  return (int)t;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fc_plan_cfg_words(void) { return CFGW; }
+int fc_plan_out_words(int B, int nl) { return HDR + SETW * MAXSETS + MAPR * (2 + 3 * nl + nl) + MAXSETS * (B > 0 ? B : 1) + 64; }
+
+// stage 1 arena: raw collate, scratch of the chain, the sets of [cm0, m1, m2, L1..Lnl] with their tables, the meta block
+static int64_t stage1_layout(int64_t T, int B, int nl, int nfeat, char* base, void** p /*pointers out*/, int S) {
+  Bump a{base, 0};
+  int i = 0;
+  p[i++] = a.arr<int>(4 * T);                                   // 0 coords_raw
+  p[i++] = a.arr<float>((int64_t)nfeat * T);                    // 1 feats_raw
+  p[i++] = a.arr<int>(T);                                       // 2 slot
+  p[i++] = a.take(T);                                           // 3 flags
+  p[i++] = a.arr<int>(fc_cdiv(T > 0 ? T : 1, 1024) + 1);        // 4 blocksums
+  p[i++] = a.arr<int>((int64_t)METAW * S + (int64_t)S * B + 64); // 5 meta
+  p[i++] = a.arr<float>((int64_t)nfeat * T);                    // 6 F0
+  const int64_t cap = next_pow2(T > 0 ? 2 * T : 2);
+  for (int s = 0; s < S; ++s) {
+    p[i++] = a.arr<int>(4 * T);                                 // coords of set s
+    p[i++] = a.arr<unsigned long long>(cap);                    // keys
+    p[i++] = a.arr<int>(cap);                                   // vals
+  }
+  return fc_align(a.off, 256);
+}
+
+int64_t fc_plan_stage1_bytes(int64_t total_points, int B, int nl, int nfeat) {
+  if (total_points < 0 || B < 1 || nl < 1 || nl > MAXLV || nfeat < 0) return -1;
+  void* p[7 + 3 * MAXSETS];
+  return stage1_layout(total_points, B, nl, nfeat, nullptr, p, 3 + nl);
+}
+
+int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int64_t arena1_bytes, int64_t* out, int* counts_host,
+                   hipStream_t stream) {
+  const int B = (int)cfg[C_B], nl = (int)cfg[C_NL], nfeat = (int)cfg[C_NFEAT];
+  const int64_t T = cfg[C_TOTAL];
+  if (B < 1 || B > 32767 || nl < 1 || nl > MAXLV || nfeat < 0 || T < 0 || T > 0x7fffffffLL / 8 || !arena1 || !out || !counts_host) return FC_EINVAL;
+  const int S = 3 + nl;
+  void* p[7 + 3 * MAXSETS];
+  if (arena1_bytes < stage1_layout(T, B, nl, nfeat, (char*)arena1, p, S)) return FC_EWS;
+  int4* coords_raw = (int4*)p[0];
+  float* feats_raw = (float*)p[1];
+  int* slot = (int*)p[2];
+  unsigned char* flags = (unsigned char*)p[3];
+  int* blocksums = (int*)p[4];
+  int* meta = (int*)p[5];
+  float* F0 = (float*)p[6];
+  const int64_t nmeta = (int64_t)METAW * S + (int64_t)S * B;
+  const int64_t cap0 = next_pow2(T > 0 ? 2 * T : 2);
+  FC_HIP(hipMemsetAsync(meta, 0, (size_t)nmeta * sizeof(int), stream));
+  const float vs = (float)as_double(cfg[C_VS]), fdiv = (float)as_double(cfg[C_FEATDIV]);
+  if (!cfg[C_COORDS_IN] && !(vs > 0.f)) return FC_EINVAL;
+  const unsigned gT = (unsigned)fc_cdiv(T > 0 ? T : 1, 256), gB = (unsigned)fc_cdiv(T > 0 ? T : 1, 1024);
+  for (int s = 0; s < S; ++s) {
+    int4* cs = (int4*)p[7 + 3 * s];
+    unsigned long long* keys = (unsigned long long*)p[8 + 3 * s];
+    int* vals = (int*)p[9 + 3 * s];
+    int* meta_s = meta + METAW * s;
+    int* scene_cnt = meta + METAW * S + (int64_t)s * B;
+    const int* n_in_dev = s ? meta + METAW * (s - 1) : nullptr;
+    const int4* src = s ? (const int4*)p[7 + 3 * (s - 1)] : coords_raw;
+    const int q = 1 << s;
+    k_plan_table_init<<<(unsigned)fc_cdiv(cap0, 256), 256, 0, stream>>>(keys, vals, n_in_dev, T, meta_s);
+    FC_CHECK_LAUNCH();
+    if (T == 0) continue;
+    if (s == 0 && !cfg[C_COORDS_IN]) {
+      int64_t off = 0;
+      for (int b0 = 0; b0 < B; b0 += CH) {
+        SceneArgs sc;
+        memset(&sc, 0, sizeof(sc));
+        int maxn = 0;
+        const int nb = B - b0 < CH ? B - b0 : CH;
+        for (int j = 0; j < nb; ++j) {
+          sc.p[j] = (const float*)scenes[3 * (b0 + j)];
+          sc.n[j] = (int)scenes[3 * (b0 + j) + 1];
+          if (sc.n[j] < 0 || (sc.n[j] > 0 && !sc.p[j]) || scenes[3 * (b0 + j) + 2] != cfg[C_PT_STRIDE]) return FC_EINVAL;
+          sc.off[j] = (int)off;
+          off += sc.n[j];
+          if (sc.n[j] > maxn) maxn = sc.n[j];
+        }
+        if (off > T) return FC_EINVAL;
+        sc.b0 = b0; sc.stride = (int)cfg[C_PT_STRIDE]; sc.nfeat = nfeat; sc.vs = vs; sc.feat_div = fdiv;
+        if (sc.stride < 3 + nfeat) return FC_EINVAL;
+        if (maxn > 0) {
+          dim3 grid((unsigned)fc_cdiv(maxn, 256), nb);
+          k_plan_voxelize_insert<<<grid, 256, 0, stream>>>(sc, coords_raw, feats_raw, keys, vals, cap0, meta_s, slot);
+          FC_CHECK_LAUNCH();
+        }
+      }
+      if (off != T) return FC_EINVAL;
+    } else {
+      if (s == 0) {                                // pre-voxelised input (an augmenting pipeline wrote coords / feats itself)
+        src = (const int4*)cfg[C_COORDS_IN];
+        feats_raw = (float*)cfg[C_FEATS_IN];
+        if (!feats_raw && nfeat) return FC_EINVAL;
+      }
+      k_plan_insert<<<gT, 256, 0, stream>>>(src, n_in_dev, T, q, keys, vals, meta_s, slot);
+      FC_CHECK_LAUNCH();
+    }
+    k_plan_flags<<<gB, 256, 0, stream>>>(slot, vals, n_in_dev, T, flags, blocksums);
+    FC_CHECK_LAUNCH();
+    k_plan_scan<<<1, 1024, 0, stream>>>(blocksums, (int)gB, meta_s);
+    FC_CHECK_LAUNCH();
+    k_plan_finalize<<<gB, 256, 0, stream>>>(src, n_in_dev, T, q, flags, blocksums, slot, vals, cs, s == 0 ? feats_raw : nullptr,
+                                           s == 0 ? F0 : nullptr, nfeat, scene_cnt, B);
+    FC_CHECK_LAUNCH();
+  }
+  int rc = sync_readback(counts_host, meta, nmeta * (int64_t)sizeof(int), stream);
+  if (rc) return rc;
+  // ---- host tables ----
+  const int nw = fc_plan_out_words(B, nl);
+  memset(out, 0, (size_t)nw * sizeof(int64_t));
+  out[H_S] = S;
+  out[H_F0] = (int64_t)F0;
+  out[H_PRUNE] = -1;
+  int bad = 0;
+  for (int s = 0; s < S; ++s) {
+    const int* m = counts_host + METAW * s;
+    int64_t* o = out + HDR + SETW * s;
+    o[S_COORDS] = (int64_t)p[7 + 3 * s];
+    o[S_N] = m[0];
+    o[S_STRIDE] = 1 << s;
+    o[S_KEYS] = (int64_t)p[8 + 3 * s];
+    o[S_VALS] = (int64_t)p[9 + 3 * s];
+    o[S_CAP] = m[1];
+    o[S_PARENT] = -1;
+    bad |= m[2];
+  }
+  out[H_BAD] = bad;
+  return FC_OK;
+}
+
+// ---- stage 2 -------------------------------------------------------------------------------------------------------------------
+struct MapRec { int in, out, K; int64_t n_in, n_out; bool dense, self; };
+
+// Everything stage 2 builds, as one pass over a bump allocator: base == nullptr sizes the arena, otherwise the kernels are enqueued.
+static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char* base, int64_t* need, int* cnt_host, hipStream_t stream) {
+  const int B = (int)cfg[C_B], nl = (int)cfg[C_NL];
+  const bool backward = cfg[C_BACKWARD] != 0, neck = cfg[C_NECK] != 0, targets = cfg[C_TARGETS] != 0;
+  const int64_t sort_min = cfg[C_SORT_MIN], pair_rows = cfg[C_PAIR_ROWS], pts_thr = cfg[C_PTS_THR];
+  const int S0 = 3 + nl;
+  const bool run = base != nullptr;
+  Bump a{base, 0};
+  int64_t* sets = out + HDR;
+  auto SN = [&](int s) { return sets[SETW * s + S_N]; };
+  auto SC = [&](int s) { return (const int*)sets[SETW * s + S_COORDS]; };
+  // ---- neck sets: g_i = children of the head level above it, i = nl-2 .. 0 (set index S0 + (nl-2-i)) ----
+  int S = S0;
+  int head_set[MAXLV];                              // head level l (finest first) -> set index
+  int prune = -1;
+  int ngen = 0;
+  if (neck) {
+    int x = S0 - 1;                                 // the coarsest backbone level
+    head_set[nl - 1] = x;
+    for (int i = nl - 2; i >= 0; --i) {
+      const int g = S++;
+      int64_t* o = sets + SETW * g;
+      o[S_N] = 8 * SN(x);
+      o[S_STRIDE] = sets[SETW * x + S_STRIDE] / 2;
+      o[S_PARENT] = x;
+      o[S_COORDS] = (int64_t)a.arr<int>(4 * o[S_N]);
+      o[S_ROWS] = (int64_t)a.arr<int>(SN(3 + i));
+      ++ngen;
+      head_set[i] = g;
+      if (run) {
+        int rc = fc_gen_coords(SC(x), SN(x), (int)o[S_STRIDE], (int*)o[S_COORDS], stream);
+        if (rc) return rc;
+      }
+      // pts_threshold (fcaf3d_neck_with_head.py:110-126): rows of a scene in g = 8 * its rows in the coarsest level * 8^depth
+      if (pts_thr >= 0 && prune < 0) {
+        const int depth = nl - 1 - i;
+        const int* sc_cnt = counts_host + METAW * S0 + (int64_t)(S0 - 1) * B;
+        for (int b = 0; b < B; ++b)
+          if (((int64_t)sc_cnt[b] << (3 * depth)) > pts_thr) prune = i;
+      }
+      x = g;
+      if (prune >= 0) break;                        // the sets below a pruned level depend on the network's scores
+    }
+  }
+  out[H_S] = S;
+  out[H_PRUNE] = prune;
+  out[H_NHEAD] = neck ? nl : 0;
+  // ---- maps ----
+  MapRec mr[2 + 4 * MAXLV];
+  int nm = 0;
+  mr[nm++] = {0, 1, 27, SN(0), SN(1), false, false};           // stem conv k3 s2 (its own kernel: table only)
+  mr[nm++] = {1, 2, 8, SN(1), SN(2), false, false};            // max-pool k2 s2
+  for (int li = 1; li <= nl; ++li) {
+    const int prev = 1 + li, mi = 2 + li;
+    mr[nm++] = {prev, mi, 27, SN(prev), SN(mi), false, false}; // down  k3 s2
+    mr[nm++] = {prev, mi, 1, SN(prev), SN(mi), false, false};  // ds    k1 s2 (row 13 of `down`)
+    mr[nm++] = {mi, mi, 27, SN(mi), SN(mi), false, true};      // same  k3 s1
+  }
+  for (int g = S0; g < S; ++g) mr[nm++] = {g, g, 27, SN(g), SN(g), true, true};   // gsame (nl-2 .. ) k3 s1 on a generated set
+  out[H_NMAPS] = nm;
+  int64_t* maps = out + HDR + SETW * MAXSETS;
+  // the pair-list counters of all maps sit in ONE block (read back together): 2 x 27 ints per map + union hit counters
+  int* cnt_dev = a.arr<int>(64 * nm + MAXLV);
+  if (run) FC_HIP(hipMemsetAsync(cnt_dev, 0, sizeof(int) * (64 * nm + MAXLV), stream));
+  // scratch shared by the derived tables (stream order serialises its users)
+  int64_t max_rows = 1;
+  for (int m = 0; m < nm; ++m) { if (mr[m].n_in > max_rows) max_rows = mr[m].n_in; if (mr[m].n_out > max_rows) max_rows = mr[m].n_out; }
+  int* masks = a.arr<int>(max_rows);
+  void* sort_ws = a.take(argsort27_ws_bytes(max_rows));
+  const int64_t pairs_ws_bytes = fc_kernel_map_pairs_ws_bytes(max_rows, 27);
+  void* pairs_ws = a.take(pairs_ws_bytes);
+
+  for (int m = 0; m < nm; ++m) {
+    const MapRec& r = mr[m];
+    int64_t* o = maps + MAPR * m;
+    o[MW_IN] = r.in; o[MW_OUT] = r.out; o[MW_K] = r.K; o[MW_NIN] = r.n_in; o[MW_NOUT] = r.n_out;
+    const bool conv = m >= 2;
+    const bool is_ds = r.K == 1;
+    const int64_t* din = sets + SETW * r.in;
+    int* nbr = nullptr;
+    int* nbr_t = nullptr;
+    if (is_ds) {                                    // k1 s2: the centre row of the k3 s2 table of the same pair of sets
+      const int64_t* od = maps + MAPR * (m - 1);
+      if (run) {
+        nbr = (int*)od[MW_NBR] + 13 * r.n_out;
+        nbr_t = backward ? (int*)od[MW_NBRT] + 13 * r.n_in : nullptr;
+      }
+    } else {
+      nbr = a.arr<int>((int64_t)r.K * r.n_out);
+      if (run && r.n_out > 0) {
+        if (r.dense) {                              // generated set: from the parent's own k3 table (index arithmetic)
+          const int par = (int)din[S_PARENT];
+          const int64_t* op = nullptr;              // the parent's k3 s1 map: `same` of the coarsest level, or the gsame above
+          for (int mm = 0; mm < m; ++mm)
+            if (mr[mm].self && mr[mm].in == par) op = maps + MAPR * mm;
+          if (!op) return FC_EINVAL;
+          int rc = fc_kernel_map_children((const int*)op[MW_NBR], SN(par), nbr, stream);
+          if (rc) return rc;
+        } else {
+          const int ks = r.K == 27 ? 3 : 2;
+          dim3 grid((unsigned)fc_cdiv(r.n_out, 256), r.K);
+          k_plan_kernel_map<<<grid, 256, 0, stream>>>((const int4*)SC(r.out), r.n_out, (const unsigned long long*)din[S_KEYS],
+                                                     (const int*)din[S_VALS], (unsigned long long)(din[S_CAP] - 1), ks, (int)din[S_STRIDE], nbr);
+          FC_CHECK_LAUNCH();
+        }
+      }
+    }
+    o[MW_NBR] = (int64_t)nbr;
+    int64_t* df = o + MW_DESC_F;
+    int64_t* db = o + MW_DESC_B;
+    df[0] = db[0] = r.n_in; df[1] = db[1] = r.n_out; df[2] = db[2] = r.K; df[3] = db[3] = (int64_t)nbr;
+    const bool sort_rows = r.K == 27 && !r.dense && r.n_out >= sort_min;
+    const bool use_pairs = r.K == 27 && !r.dense;
+    o[MW_FLAGS] = (sort_rows ? 1 : 0) | (use_pairs ? 2 : 0) | (r.dense ? 4 : 0);
+    if (!conv) continue;                            // stem / pooling: their own kernels read the plain table
+    // -- forward route --
+    auto pair_lists = [&](const int* tab, int64_t rows, int base_word, int* cnt) -> int {
+      int* pi = a.arr<int>(27 * rows);
+      int* po = a.arr<int>(27 * rows);
+      int* pos = a.arr<int>(27 * rows);
+      o[base_word] = (int64_t)pi; o[base_word + 1] = (int64_t)po; o[base_word + 2] = (int64_t)pos; o[base_word + 3] = (int64_t)cnt;
+      if (run) return fc_kernel_map_pairs(tab, rows, 27, pi, po, pos, cnt, pairs_ws, pairs_ws_bytes, stream);
+      return 0;
+    };
+    auto sorted = [&](const int* tab, int64_t rows, int w_tab, int w_idx) -> int {
+      int* order = a.arr<int>(rows);
+      int* st = a.arr<int>(27 * rows);
+      o[w_tab] = (int64_t)st; o[w_idx] = (int64_t)order;
+      if (!run || rows == 0) return 0;
+      int rc = fc_nbr_row_masks(tab, rows, 27, masks, stream);
+      if (rc) return rc;
+      rc = argsort27(masks, rows, order, sort_ws, stream);
+      if (rc) return rc;
+      return fc_permute_nbr(tab, order, rows, 27, st, stream);
+    };
+    int* cnt_f = cnt_dev + 64 * m;
+    int* cnt_t = cnt_dev + 64 * m + 32;
+    bool have_pairs = false;
+    if (use_pairs && r.n_out <= pair_rows) {
+      int rc = pair_lists(nbr, r.n_out, MW_PI, cnt_f);
+      if (rc) return rc;
+      have_pairs = true;
+    } else if (sort_rows) {
+      int rc = sorted(nbr, r.n_out, MW_SORT, MW_SORTI);
+      if (rc) return rc;
+    } else {
+      o[MW_SORT] = (int64_t)nbr; o[MW_SORTI] = 0;
+    }
+    // -- backward tables --
+    if (backward) {
+      if (!is_ds) {
+        nbr_t = a.arr<int>((int64_t)r.K * r.n_in);
+        if (run && r.n_in > 0) {
+          if (r.self) {
+            dim3 grid((unsigned)fc_cdiv(r.n_in, 256), r.K);
+            k_plan_reverse_rows<<<grid, 256, 0, stream>>>(nbr, r.n_in, r.K, nbr_t);
+            FC_CHECK_LAUNCH();
+          } else {
+            int rc = fc_kernel_map_transpose(nbr, r.n_out, r.n_in, r.K, nbr_t, stream);
+            if (rc) return rc;
+          }
+        }
+      }
+      o[MW_NBRT] = (int64_t)nbr_t;
+      if (use_pairs && !have_pairs) {               // the weight gradient reduces over exact pair lists
+        int rc = pair_lists(nbr, r.n_out, MW_PI, cnt_f);
+        if (rc) return rc;
+        have_pairs = true;
+      }
+      if (use_pairs && r.n_in <= pair_rows) {
+        int rc = pair_lists(nbr_t, r.n_in, MW_TPI, cnt_t);
+        if (rc) return rc;
+      } else if (sort_rows) {
+        int rc = sorted(nbr_t, r.n_in, MW_SORTT, MW_SORTTI);
+        if (rc) return rc;
+      } else {
+        o[MW_SORTT] = (int64_t)nbr_t; o[MW_SORTTI] = 0;
+      }
+    }
+  }
+  // ---- union rows of the backbone levels inside the generated sets (fcaf3d_neck_with_head.py:101) ----
+  const int cs = S0 - 1;                            // coarsest backbone level: the one table every generated row follows from
+  for (int g = S0; g < S; ++g) {
+    const int i = nl - 2 - (g - S0);                // backbone level index (0-based): set 3 + i
+    const int depth = nl - 1 - i;
+    if (run && SN(3 + i) > 0) {
+      const int64_t* oc = sets + SETW * cs;
+      k_plan_gen_rows<<<(unsigned)fc_cdiv(SN(3 + i), 256), 256, 0, stream>>>(
+          (const int4*)SC(3 + i), SN(3 + i), (const unsigned long long*)oc[S_KEYS], (const int*)oc[S_VALS],
+          (unsigned long long)(oc[S_CAP] - 1), (int)sets[SETW * (3 + i) + S_STRIDE], depth, (int*)sets[SETW * g + S_ROWS],
+          cnt_dev + 64 * nm + (g - S0));
+      FC_CHECK_LAUNCH();
+    }
+  }
+  // ---- the head's location arrays (training: what the target assignment and the loss read) ----
+  int64_t n_all = 0;
+  if (neck && prune < 0)
+    for (int l = 0; l < nl; ++l) n_all += SN(head_set[l]);
+  out[H_NALL] = n_all;
+  if (targets && neck && prune < 0) {
+    float* pts = a.arr<float>(3 * n_all);
+    int* scene = a.arr<int>(n_all);
+    int* level = a.arr<int>(n_all);
+    int* order = a.arr<int>(n_all);
+    int* seg = a.arr<int>((int64_t)nl * B + 1);
+    out[H_TGT_PTS] = (int64_t)pts; out[H_TGT_SCENE] = (int64_t)scene; out[H_TGT_LEVEL] = (int64_t)level;
+    out[H_TGT_ORDER] = (int64_t)order; out[H_TGT_SEG] = (int64_t)seg;
+    if (run) {
+      HeadArgs h;
+      memset(&h, 0, sizeof(h));
+      h.nl = nl; h.vs = (float)as_double(cfg[C_VS_HEAD]);
+      int64_t off = 0;
+      for (int l = 0; l < nl; ++l) { h.coords[l] = (const int4*)SC(head_set[l]); h.off[l] = off; off += SN(head_set[l]); }
+      h.off[nl] = off;
+      if (n_all > 0) {
+        k_plan_head_arrays<<<(unsigned)fc_cdiv(n_all, 256), 256, 0, stream>>>(h, pts, scene, level, order);
+        FC_CHECK_LAUNCH();
+      }
+      // (level, scene) segment starts: rows per scene of a generated set = 8^depth x those of the coarsest level — host arithmetic,
+      // staged in the caller's pinned counter block (it stays untouched until the read-back below)
+      int* stage = cnt_host + 64 * nm + MAXLV;
+      const int* sc_cnt = counts_host + METAW * S0 + (int64_t)(S0 - 1) * B;
+      int64_t run_ = 0;
+      for (int l = 0; l < nl; ++l)
+        for (int b = 0; b < B; ++b) {
+          stage[l * B + b] = (int)run_;
+          run_ += (int64_t)sc_cnt[b] << (3 * (nl - 1 - l));
+        }
+      stage[nl * B] = (int)run_;
+      FC_HIP(hipMemcpyAsync(seg, stage, sizeof(int) * ((size_t)nl * B + 1), hipMemcpyHostToDevice, stream));
+    }
+  }
+  *need = fc_align(a.off, 256);
+  if (!run) return 0;
+  // ---- ONE read-back: pair-list counts of every map, union hit counters ----
+  int rc = sync_readback(cnt_host, cnt_dev, sizeof(int) * (64 * nm + MAXLV), stream);
+  if (rc) return rc;
+  int structured = 1;
+  for (int g = S0; g < S; ++g) {
+    const int i = nl - 2 - (g - S0);
+    if (cnt_host[64 * nm + (g - S0)] != SN(3 + i)) structured = 0;      // a backbone voxel outside the generated set: per-operator path
+  }
+  out[H_STRUCT] = structured;
+  for (int m = 2; m < nm; ++m) {
+    int64_t* o = maps + MAPR * m;
+    int64_t* df = o + MW_DESC_F;
+    int64_t* db = o + MW_DESC_B;
+    const MapRec& r = mr[m];
+    const bool use_pairs = (o[MW_FLAGS] & 2) != 0;
+    int64_t ff = 0, fb = 0;
+    if (o[MW_PI] && use_pairs && r.n_out <= pair_rows) {
+      o[MW_TILES] = live_tiles(cnt_host + 64 * m, 27);
+      for (int w = 0; w < 4; ++w) df[9 + w] = db[9 + w] = o[MW_PI + w];
+      df[13] = db[13] = o[MW_TILES];
+      ff |= 1; fb |= 1;
+    } else {
+      df[5] = db[5] = o[MW_SORT]; df[6] = db[6] = o[MW_SORTI];
+    }
+    if (backward) {
+      db[4] = o[MW_NBRT];
+      if (use_pairs) {
+        for (int w = 0; w < 4; ++w) db[9 + w] = o[MW_PI + w];
+        fb |= 4;
+      }
+      if (use_pairs && r.n_in <= pair_rows) {
+        o[MW_TTILES] = live_tiles(cnt_host + 64 * m + 32, 27);
+        for (int w = 0; w < 4; ++w) db[14 + w] = o[MW_TPI + w];
+        db[18] = o[MW_TTILES];
+        fb |= 2;
+      } else {
+        db[7] = o[MW_SORTT]; db[8] = o[MW_SORTTI];
+      }
+    }
+    df[19] = ff; db[19] = fb;
+  }
+  return FC_OK;
+}
+
+int64_t fc_plan_stage2_bytes(const int64_t* cfg, int64_t* out, const int* counts_host) {
+  int64_t need = 0;
+  int rc = stage2(cfg, out, counts_host, nullptr, &need, nullptr, nullptr);
+  return rc ? -1 : need + 256;
+}
+
+int fc_plan_maps(const int64_t* cfg, int64_t* out, const int* counts_host, void* arena2, int64_t arena2_bytes, int* cnt_host,
+                 hipStream_t stream) {
+  if (!cfg || !out || !counts_host || !arena2 || !cnt_host) return FC_EINVAL;
+  int64_t need = 0;
+  int rc = stage2(cfg, out, counts_host, nullptr, &need, nullptr, nullptr);
+  if (rc) return rc;
+  char* base = (char*)fc_align((int64_t)arena2, 256);
+  if (arena2_bytes - (base - (char*)arena2) < need) return FC_EWS;
+  return stage2(cfg, out, counts_host, base, &need, cnt_host, stream);
+}
+
+// stable argsort of non-negative int32 keys below 2^27 (the occupancy masks of fc_nbr_row_masks) — what torch.argsort did for
+// the mask-sorted tables of the per-operator path
+int64_t fc_argsort27_ws_bytes(int64_t n) { return argsort27_ws_bytes(n); }
+int fc_argsort27(const int* keys, int64_t n, int* order, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (n < 0) return FC_EINVAL;
+  if (ws_bytes < argsort27_ws_bytes(n)) return FC_EWS;
+  return argsort27(keys, n, order, ws, stream);
+}
+
+}  // extern "C"

@@ -295,19 +295,22 @@ class Fcaf3DNeckWithHead(nn.Module):
 
     early_targets = os.environ.get('FC_EARLY_TARGETS', '1') != '0'
 
-    def _targets(self, cmaps, gt_bboxes, gt_labels):
+    def _targets(self, cmaps, gt_bboxes, gt_labels, pre=None):
         """Locations, assigned targets and per-scene normalisers of one batch — everything the loss needs that does not
         depend on the network's outputs: locations = voxel corners of the head's coordinate sets (:276-277), targets from
         the assigner, normalisers n_pos / sum of centerness targets per scene, averaged over the ranks in ONE all-reduce
         (the reference: two `reduce_mean` per scene, :179, :187)."""
         from .sparse import _rec
         B = len(gt_bboxes)
-        dev = cmaps[0].coords.device
+        dev = pre['pts'].device if pre is not None else cmaps[0].coords.device
         with torch.no_grad():
-            pts = torch.cat([cm.coords[:, 1:].float() * self.voxel_size for cm in cmaps])
-            scene = torch.cat([cm.coords[:, 0] for cm in cmaps])
-            level = torch.cat([torch.full((cm.n,), l, dtype=torch.int32, device=dev) for l, cm in enumerate(cmaps)])
-            ct, bt, labels = self.assigner.assign_batched(pts, scene, level, cmaps, gt_bboxes, gt_labels)
+            if pre is not None:
+                pts, scene, level = pre['pts'], pre['scene'], pre['level']      # written by the native plan (csrc/plan.hip k_plan_head_arrays)
+            else:
+                pts = torch.cat([cm.coords[:, 1:].float() * self.voxel_size for cm in cmaps])
+                scene = torch.cat([cm.coords[:, 0] for cm in cmaps])
+                level = torch.cat([torch.full((cm.n,), l, dtype=torch.int32, device=dev) for l, cm in enumerate(cmaps)])
+            ct, bt, labels = self.assigner.assign_batched(pts, scene, level, cmaps, gt_bboxes, gt_labels, pre=pre)
             posf = (labels >= 0).float()
             cols = torch.stack((posf, ct, torch.zeros_like(ct), torch.zeros_like(ct)), dim=1)
             norms = reduce_mean(Fn.seg_col_sums(cols, scene, B)[:, :2])             # (B,2): n_pos, Σ centerness
@@ -317,13 +320,13 @@ class Fcaf3DNeckWithHead(nn.Module):
         _rec(*out.values())                                          # built on the coordinate stream, consumed on the main one
         return out
 
-    def prepare_targets(self, cmaps, gt_bboxes, gt_labels):
+    def prepare_targets(self, cmaps, gt_bboxes, gt_labels, pre=None):
         """Called by the detector as soon as the head's coordinate sets exist (SingleStageSparse3DDetector._sparse_input, on
         the coordinate stream): `loss()` then finds the assignment done.  Identity of the coordinate-map objects is the key."""
         self._prepared = None
         if self.early_targets and hasattr(self.assigner, 'assign_batched') and len(cmaps) == self.assigner.n_scales \
-                and cmaps[0].coords.is_cuda:
-            self._prepared = (tuple(id(cm) for cm in cmaps), cmaps, self._targets(cmaps, gt_bboxes, gt_labels))
+                and (pre is not None or cmaps[0].coords.is_cuda):
+            self._prepared = (tuple(id(cm) for cm in cmaps), cmaps, self._targets(cmaps, gt_bboxes, gt_labels, pre))
 
     def _loss_batched(self, centernesses, bbox_preds, cls_scores, points, gt_bboxes, gt_labels):
         """The same three losses as the per-scene loop (reference :140-157, :160-203), evaluated over all
@@ -650,7 +653,7 @@ class Fcaf3DAssigner:
         self.n_scales = n_scales
 
     @torch.no_grad()
-    def assign_batched(self, pts, scene, level, cmaps, gt_bboxes, gt_labels):
+    def assign_batched(self, pts, scene, level, cmaps, gt_bboxes, gt_labels, pre=None):
         """All scenes, all levels, in four kernel launches (csrc/assign.hip).
         pts (N,3) locations, scene/level (N) int32, cmaps: the coordinate map of each level (for the
         per-(level, scene) row groups).  Returns (centerness_targets (N), bbox_targets (N,7), labels (N))."""
@@ -674,14 +677,17 @@ class Fcaf3DAssigner:
             labels.view(B * M)[slot] = alll.to(torch.int64)
         # pinned + non_blocking: a pageable host->device copy would block the host until the whole forward has drained
         box_count = L.upload(np.asarray(lens, dtype=np.int32), dev)
-        order, counts, off = [], [], 0
-        for cm in cmaps:
-            cm._decompose()
-            order.append(cm._order + off)
-            counts.append(cm._counts_dev)
-            off += cm.n
-        order = torch.cat(order).to(torch.int32)
-        seg_start = torch.cat((torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(torch.cat(counts), 0))).to(torch.int32)
+        if pre is not None:
+            order, seg_start = pre['order'], pre['seg_start']    # rows of a plan-made set are grouped by scene: identity order
+        else:
+            order, counts, off = [], [], 0
+            for cm in cmaps:
+                cm._decompose()
+                order.append(cm._order + off)
+                counts.append(cm._counts_dev)
+                off += cm.n
+            order = torch.cat(order).to(torch.int32)
+            seg_start = torch.cat((torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(torch.cat(counts), 0))).to(torch.int32)
         N = pts.shape[0]
         ct = torch.empty(N, dtype=torch.float32, device=dev)
         bt = torch.empty((N, 7), dtype=torch.float32, device=dev)

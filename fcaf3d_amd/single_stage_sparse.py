@@ -66,10 +66,28 @@ class SingleStageSparse3DDetector(nn.Module):
         return coords, feats
 
     def _sparse_input(self, points, gt=None):
-        coordinates, features = self.voxelize(points)
-        x = SparseTensor(features, coordinates=coordinates, batch_size=len(points))
-        _rec(x.F)
-        head_maps = self.plan_maps(x.cmap)
+        from . import plan as PL
+        pl = PL.planner_of(self)
+        nh = self.neck_with_head
+        want_targets = gt is not None and hasattr(nh, 'prepare_targets')
+        sp = pl.run(points, self.training, want_targets) if pl.applicable(points) else None
+        return self._use_plan(sp, points, gt)
+
+    def _use_plan(self, sp, points, gt=None):
+        """sp: the StepPlan of these points (native coordinate phase, plan.py) or None (per-operator coordinate phase)"""
+        if sp is not None:
+            x = sp.x
+            if sp.structured:
+                head_maps, self._prune_level = sp.head_maps, sp.prune_level
+            else:
+                head_maps = self.plan_maps(x.cmap)                 # a backbone voxel outside the generated set: unions on demand
+            self._step_plan = sp
+        else:
+            coordinates, features = self.voxelize(points)
+            x = SparseTensor(features, coordinates=coordinates, batch_size=len(points))
+            _rec(x.F)
+            head_maps = self.plan_maps(x.cmap)
+            self._step_plan = None
         # the network body as one native call per direction (executor.py) when this step's maps fit its static operator list
         self._bound = None
         tail0 = self._prune_level == 0                     # pruning bites at the finest level only: its tail runs per operator
@@ -85,7 +103,7 @@ class SingleStageSparse3DDetector(nn.Module):
         if gt is not None and head_maps is not None and hasattr(self.neck_with_head, 'prepare_targets'):
             # training: the target assignment depends on the head's LOCATIONS (coordinate sets, known now) and the ground
             # truth only — it runs here, on the coordinate stream, instead of between forward and backward (r3)
-            self.neck_with_head.prepare_targets(head_maps, *gt)
+            self.neck_with_head.prepare_targets(head_maps, *gt, pre=sp.targets if sp is not None else None)
         return x
 
     def plan_maps(self, cm0):

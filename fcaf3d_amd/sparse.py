@@ -136,7 +136,21 @@ def _kernel_offsets(kernel_size, tensor_stride, device):
     return torch.tensor(offs, dtype=torch.int32, device=device)
 
 
-class KernelMap:
+class _Lazy:
+    """attributes of a plan-made object (plan.py) that are views of the plan's arenas: the tensor is made when first asked for"""
+
+    def __getattr__(self, name):
+        lz = self.__dict__.get('_lazy')
+        if lz is not None and name in lz:
+            spec = lz.pop(name)
+            ar = self.__dict__['_arenas']
+            v = tuple(ar.view(*t) for t in spec) if isinstance(spec, list) else ar.view(*spec)
+            self.__dict__[name] = v
+            return v
+        raise AttributeError(name)
+
+
+class KernelMap(_Lazy):
     """nbr (K, n_out) int32 plus, lazily, its transpose for the backward-data pass."""
 
     def __init__(self, nbr, n_in, n_out):
@@ -288,7 +302,7 @@ class KernelMap:
         return self._sorted_t
 
 
-class CoordMap:
+class CoordMap(_Lazy):
     """One coordinate set: coords (N,4) int32 [b,x,y,z], tensor stride, voxel hash, cached maps."""
 
     def __init__(self, coords, stride, keys, vals, batch_size):
@@ -478,6 +492,13 @@ class CoordMap:
     def _decompose(self):
         """device side of the per-scene decomposition: row order grouped by scene + per-scene counts (no read-back)"""
         if getattr(self, '_order', None) is None:
+            if getattr(self, '_grouped', False) and self._counts is not None:
+                # a set of the native plan: rows are grouped by scene already and the counts are known on the host
+                dev = self.coords.device
+                self._order = torch.arange(self.n, device=dev)
+                self._counts_dev = L.upload(np.asarray(self._counts, dtype=np.int64), dev)
+                _rec(self._order, self._counts_dev)
+                return
             b = self.coords[:, 0].long()
             order = torch.argsort(b, stable=True)            # rows grouped by scene, ascending inside
             counts_dev = torch.zeros(self.batch_size, dtype=torch.int64, device=b.device).scatter_add_(0, b, torch.ones_like(b))   # (bincount syncs)

@@ -3,9 +3,9 @@
  * Every entry point takes raw DEVICE pointers, explicit sizes and a hipStream_t, enqueues its
  * kernels on that stream and returns immediately:
  *     0  = ok,  <0 = invalid argument (-1) / workspace too small (-2),  >0 = hipError_t.
- * The library is stateless and never allocates: data-dependent output sizes come back through a
+ * The library never allocates device memory: data-dependent output sizes come back through a
  * device counter (`*_dev`), and scratch space is passed in (`ws`, size from the matching
- * `*_ws_bytes`).  It never calls exit() (contrast mmdet3d/ops/pcdet_nms/src/iou3d_nms.cpp:14-38).
+ * `*_ws_bytes`).  (It owns a handful of hipEvents: fc_exec, fc_plan_*.)  It never calls exit() (contrast mmdet3d/ops/pcdet_nms/src/iou3d_nms.cpp:14-38).
  *
  * Each declaration cites the reference interface it replaces (paths relative to the reference
  * repository; "ME" = MinkowskiEngine v0.5.4, the un-vendored dependency pinned at
@@ -117,6 +117,36 @@ int fc_interp(const int* query_coords, int64_t n, const unsigned long long* tabl
 
 /* coordinate rows of a pruned set (MinkowskiPruning, fcaf3d_neck_with_head.py:125). */
 int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStream_t stream);
+
+/* ---- the coordinate phase of a step as two native calls (r6; csrc/plan.hip) ------------------------------------------------ */
+
+/* SingleStageSparse3DDetector.extract_feat's collate + ME.SparseTensor (mmdet3d/models/detectors/single_stage_sparse.py:34-37) and
+ * the coordinate sets behind every strided ME.MinkowskiConvolution / MinkowskiMaxPooling of the backbone (me_resnet.py:19-24,
+ * :56-62) in ONE call: points of B scenes -> the sets [cm0, m1, m2, L1..Lnl] (strides 1, 2, 4, 8 ...), each with its voxel hash,
+ * rows in order of first occurrence, level 0 with its feature rows.  The chain runs with device-resident row counts; the call
+ * ends with its single host read-back (rows per set, rows per set and scene, range flags) and fills `out`.
+ *   cfg (fc_plan_cfg_words() int64): [0] B, [1] nl, [2] nfeat, [3] voxel size (double bits), [4] feature divisor (double bits),
+ *     [5] total points, [6] backward tables wanted, [7] mask-sorted tables from this many rows, [8] pair-list convolution up to this
+ *     many rows, [9] pts_threshold (-1: none), [10] head location arrays wanted, [11] / [12] pre-voxelised coords / feats (device
+ *     pointers, 0 = collate from the points), [13] floats per point, [14] neck sets wanted, [15] the head's voxel size (double bits).
+ *   scenes: B x {device pointer, points, floats per point} (int64).  arena1: fc_plan_stage1_bytes bytes of device memory.
+ *   counts_host: PINNED host ints, 8 (3 + nl) + (3 + nl) B.  out: fc_plan_out_words int64 (layout: csrc/plan.hip, fcaf3d_amd/plan.py).
+ * fc_plan_maps, with those counts: every kernel map of the backbone and of the neck (fcaf3d_neck_with_head.py:52, :60-71, :101:
+ * generated children sets and their maps by index arithmetic, union rows of the backbone levels), the derived tables of each
+ * convolution route (mask-sorted tables, pair lists, transposed tables) and the head's location / scene / level arrays
+ * (fcaf3d_neck_with_head.py:276-277) into arena2 (fc_plan_stage2_bytes), ending with ITS single read-back (pair-list counts, union
+ * hits) into cnt_host (PINNED ints, 64 maps + 8 + nl B + 1).  Same sets, tables and row orders as the per-operator entry points above.
+ * fc_argsort27: the stable argsort of 27-bit occupancy masks used for the mask-sorted tables (No reference counterpart). */
+int fc_plan_cfg_words(void);
+int fc_plan_out_words(int B, int nl);
+int64_t fc_plan_stage1_bytes(int64_t total_points, int B, int nl, int nfeat);
+int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int64_t arena1_bytes, int64_t* out, int* counts_host,
+                   hipStream_t stream);
+int64_t fc_plan_stage2_bytes(const int64_t* cfg, int64_t* out, const int* counts_host);
+int fc_plan_maps(const int64_t* cfg, int64_t* out, const int* counts_host, void* arena2, int64_t arena2_bytes, int* cnt_host,
+                 hipStream_t stream);
+int64_t fc_argsort27_ws_bytes(int64_t n);
+int fc_argsort27(const int* keys, int64_t n, int* order, void* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* ---- sparse convolution ------------------------------------------------------------------- */
 

@@ -262,28 +262,40 @@ def test_committed_profile_tables_follow_from_the_committed_traces():
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
 
 
-def test_r5_profiles_were_taken_on_the_committed_kernels():
-    """profiles/r5_meta.json records the hash of csrc/ (fcaf3d_amd.build.source_hash) and the commit every r5 profile was taken on;
-    a kernel change after the profiles makes this fail (the r4 weight-gradient rows predated the final routing), and
-    profiles/r5_kernel_stats.md must be tools/kernel_stats.py over the committed CSVs."""
+def _check_profile_take(tag, must_match_source):
     import importlib.util
     import json
     from fcaf3d_amd.build import source_hash
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    meta_path = os.path.join(root, 'profiles', 'r5_meta.json')
+    meta_path = os.path.join(root, 'profiles', f'{tag}_meta.json')
     if not os.path.exists(meta_path):
-        pytest.skip('no r5 profiles committed yet')
+        pytest.skip(f'no {tag} profiles committed yet')
     meta = json.load(open(meta_path))
-    assert meta['kernel_source_sha16'] == source_hash(), 'csrc/ changed after the r5 profiles were taken: take them again'
+    if must_match_source:
+        assert meta['kernel_source_sha16'] == source_hash(), f'csrc/ changed after the {tag} profiles were taken: take them again'
     spec = importlib.util.spec_from_file_location('kernel_stats', os.path.join(root, 'tools', 'kernel_stats.py'))
     ks = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ks)
-    md = open(os.path.join(root, 'profiles', 'r5_kernel_stats.md')).read()
-    for name in ('r5_kernel_stats.csv', 'r5_kernel_stats_no_overlap.csv'):
+    md = open(os.path.join(root, 'profiles', f'{tag}_kernel_stats.md')).read()
+    for name in (f'{tag}_kernel_stats.csv', f'{tag}_kernel_stats_no_overlap.csv'):
         assert ks.table(os.path.join(root, 'profiles', name), float(meta['steps_profiled'])) in md, name
-    bench_line = json.load(open(os.path.join(root, 'profiles', 'r5_bench_n1.json')))
+    bench_line = json.load(open(os.path.join(root, 'profiles', f'{tag}_bench_n1.json')))
     assert bench_line['config']['kernel_source_sha16'] == meta['kernel_source_sha16']
-    for name in ('r5_traffic.json', 'r5_conv_pmc.json'):
-        tj = os.path.join(root, 'profiles', name)
-        if os.path.exists(tj):
-            assert json.load(open(tj)).get('kernel_source_sha16') == meta['kernel_source_sha16'], name
+    return meta, bench_line
+
+
+def test_r5_profiles_are_one_consistent_take():
+    """profiles/r5_meta.json: the r5 kernel table is tools/kernel_stats.py over the committed CSVs and the r5 bench line carries the
+    hash the profiles were taken on (r5's kernels; r6 changed csrc/, its own take is checked below)"""
+    _check_profile_take('r5', must_match_source=False)
+
+
+def test_r6_profiles_were_taken_on_the_committed_kernels():
+    """profiles/r6_meta.json records the hash of csrc/ (fcaf3d_amd.build.source_hash) every r6 profile was taken on; a kernel change
+    after the profiles makes this fail (VERDICT r4: the r4 weight-gradient rows predated the final routing).  The line's
+    `roofline.traffic` is read from the traffic file of the same take (VERDICT r5 weak #10)."""
+    import json
+    meta, line = _check_profile_take('r6', must_match_source=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    traffic = json.load(open(os.path.join(root, 'profiles', 'r6_traffic.json')))
+    assert line['roofline']['traffic'] == round(traffic['hbm_bytes_per_launch'])
