@@ -58,6 +58,8 @@ def parse():
     ap.add_argument('--no-extras', action='store_true', help='skip the untimed BASELINE.md section 2 "also report" configurations '
                     '(literal 1 cm, two scales, SUN RGB-D, S3DIS: 5 steps each, N = 1 only) and the bf16 fast-mode number')
     ap.add_argument('--extra-steps', type=int, default=5)
+    ap.add_argument('--no-lookahead', action='store_true', help='plan every step in line (default: the next batch\'s coordinate phase runs on a '
+                    'worker thread beside the current step, fcaf3d_amd/plan.py Lookahead)')
     return ap.parse_args()
 
 
@@ -86,7 +88,7 @@ def run_extra(args, key, dev, steps):
     batches = make_batches(a, 0, dev)
     for i in range(2):
         tr(batches[i % 2])
-    dt, loss = timed_region(lambda i: tr(batches[i % 2])[0], steps, 1, dev)
+    dt, loss = timed_region(lambda i: tr(batches[i % 2], batches[(i + 1) % 2] if (i < steps - 1 and not args.no_lookahead) else None)[0], steps, 1, dev)
     out = dict(workload=f'{wl}, voxel {vs} m, {lv} levels', scenes_per_step=bs, steps=steps, ms_per_step=round(dt / steps * 1e3, 3),
                value=round(bs * steps / dt, 3), unit='scenes/s', final_loss=round(float(loss), 4),
                host_enqueue_ms_per_step=round(LAST_HOST_S / steps * 1e3, 3))
@@ -481,6 +483,7 @@ def hbm_steps(args, exec_on):
 
 
 LAST_HOST_S = 0.0
+LAST_WAIT_S = 0.0
 
 
 def host_state():
@@ -498,12 +501,15 @@ def timed_region(fn, n, world, dev):
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    import fcaf3d_amd._lib as L
+    w0 = L.HOST_WAIT[0]
     t0 = time.perf_counter()
     last = None
     for i in range(n):
         last = fn(i)
-    global LAST_HOST_S
+    global LAST_HOST_S, LAST_WAIT_S
     LAST_HOST_S = time.perf_counter() - t0       # the host has ENQUEUED all n calls (diagnostic: close to the region's time = host-bound)
+    LAST_WAIT_S = L.HOST_WAIT[0] - w0            # ... of which it was blocked on the device by design (run-ahead bound, staging ring, lookahead plan)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -538,6 +544,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
+    _dummies = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get('FC_DUMMY_STREAMS', '0')))]     # diagnostic: shifts the stream -> hardware-queue mapping
     if args.priority_stream:
         # the step's dependent chain runs on a HIGH-priority HIP stream; the overlapped weight-gradient stream and the
         # coordinate stream keep the default (lower) priority, so they fill idle CUs instead of competing for them
@@ -550,6 +557,7 @@ def main():
     import fcaf3d_amd.functional as Fn
     import fcaf3d_amd.executor as EX
     exec_on = EX.ENABLED and not args.no_executor
+    lookahead = not args.no_lookahead
     Fn.WGRAD_ASYNC = not args.no_wgrad_overlap
     head_overlap = model.neck_with_head.head_overlap and not args.no_wgrad_overlap
     if world > 1:
@@ -570,9 +578,14 @@ def main():
         probe = ConvProbe()
         probe.install()
 
-    def step(i, probe_mode=None, which=None):
+    def step(i, probe_mode=None, which=None, prefetch=False):
         src = which if which is not None else batches
         batch = src[i % len(src)]
+        # prefetch: the NEXT batch's coordinate phase starts beside this step, on a worker thread (TrainStep next_batch ->
+        # SingleStageSparse3DDetector.prefetch).  Every timed region asks for it on all steps but its last and plans its first
+        # step in line, so that exactly n coordinate phases run inside a region of n steps; probed steps never prefetch
+        # (their brackets must hold the kernels' own time).
+        nxt = src[(i + 1) % len(src)] if (prefetch and lookahead and probe_mode is None) else None
         if probe:
             if probe_mode:
                 probe.begin_step(i % len(src), probe_mode)
@@ -590,7 +603,7 @@ def main():
         EX.PROBE = probe.exec_steps if (probe and probe_mode == 'time' and EX.ENABLED) else None
         model.neck_with_head.head_overlap = head_overlap and not one_stream             # ... nor the head branch's stream
         n_exec = len(probe.exec_steps) if probe else 0
-        loss, _ = trainer(batch)
+        loss, _ = trainer(batch, next_batch=nxt)
         EX.PROBE = None
         if probe and probe_mode == 'time' and len(probe.exec_steps) > n_exec and probe._cur:
             probe._cur.clear()       # the step went through the executor (its brackets are inside fc_exec); a pruned finest level's
@@ -615,9 +628,11 @@ def main():
     # above the kernels' own durations in the rocprofv3 trace.  Nothing is enqueued behind the last step before the region's closing
     # synchronise, so its brackets are the kernels' own time (r5: 135 -> ~125 us per operator against 122 us in the trace)
     pe = max(args.probe_every, 1)
-    dt, loss = timed_region(lambda i: step(args.warmup + i, 'time' if (args.steps - 1 - i) % pe == 0 else None),
+    dt, loss = timed_region(lambda i: step(args.warmup + i, 'time' if (args.steps - 1 - i) % pe == 0 else None, prefetch=i < args.steps - 1),
                             args.steps, world, dev)
-    host_main = dict(host_enqueue_ms_per_step=round(LAST_HOST_S / args.steps * 1e3, 3), after=host_state())
+    host_main = dict(host_enqueue_ms_per_step=round(LAST_HOST_S / args.steps * 1e3, 3),
+                     host_blocked_ms_per_step=round(LAST_WAIT_S / args.steps * 1e3, 3),
+                     host_busy_ms_per_step=round((LAST_HOST_S - LAST_WAIT_S) / args.steps * 1e3, 3), after=host_state())
     final_loss = float(loss.item())
     dp_log = getattr(trainer.averager, 'log', None)
     trainer.averager.log = None
@@ -692,7 +707,7 @@ def main():
         if small is not None:
             for i in range(2):
                 step(i, which=small)
-            dt4, _ = timed_region(lambda i: step(i, which=small), 6, world, dev)
+            dt4, _ = timed_region(lambda i: step(i, which=small, prefetch=i < 5), 6, world, dev)
             cfg4 = dict(global_batch=16, scenes_per_gpu_per_step=per, steps=6, ms_per_step=round(dt4 / 6 * 1e3, 3),
                         value=round(16 * 6 / dt4, 3), unit='scenes/s')
     # (b2) N = 1 through the data-parallel machinery (1-rank RCCL group: autograd hooks, bucket launches on the weight-gradient
@@ -708,7 +723,7 @@ def main():
             trainer.averager = D.GradientAverager(trainer.params, bucket_mb=64, flat=trainer.flat)
             for i in range(3):
                 step(i)
-            dtf, _ = timed_region(lambda i: step(i), 10, 1, dev)
+            dtf, _ = timed_region(lambda i: step(i, prefetch=i < 9), 10, 1, dev)
             forced = dict(steps=10, ms_per_step=round(dtf / 10 * 1e3, 3), value=round(args.batch * 10 / dtf, 3), unit='scenes/s',
                           buckets=len(trainer.averager.buckets), what='the same step with the gradient averager active in a 1-rank RCCL group')
             if args.workload == 'scannet-100k' and args.batch >= 2:
@@ -717,7 +732,7 @@ def main():
                 small = [{k: v[:2] for k, v in b.items()} for b in batches]
                 for i in range(3):
                     step(i, which=small)
-                dt2, _ = timed_region(lambda i: step(i, which=small), 12, 1, dev)
+                dt2, _ = timed_region(lambda i: step(i, which=small, prefetch=i < 11), 12, 1, dev)
                 ms2 = dt2 / 12 * 1e3
                 gbytes = trainer.flat.n * 4
                 # prediction, not a measurement: ring all-reduce moves 2 (N-1)/N of the buffer per GPU; one xGMI link carries
@@ -747,7 +762,7 @@ def main():
         try:
             for i in range(3):
                 step(i)
-            dt32, _ = timed_region(lambda i: step(i), 8, 1, dev)
+            dt32, _ = timed_region(lambda i: step(i, prefetch=i < 7), 8, 1, dev)
             fp32_route = dict(steps=8, ms_per_step=round(dt32 / 8 * 1e3, 3), value=round(args.batch * 8 / dt32, 3), unit='scenes/s',
                               what='FC_X6=0: every convolution on v_mfma_f32_32x32x2_f32 (per-operator module path)')
         finally:
@@ -762,7 +777,7 @@ def main():
             L.lib().fc_set_bf16_fast(1)
             for i in range(3):
                 step(i)
-            dtb, lb = timed_region(lambda i: step(i), 8, 1, dev)
+            dtb, lb = timed_region(lambda i: step(i, prefetch=i < 7), 8, 1, dev)
             bf16_fast = dict(parity=False, steps=8, ms_per_step=round(dtb / 8 * 1e3, 3), value=round(args.batch * 8 / dtb, 3), unit='scenes/s',
                              loss_after=round(float(lb), 4),
                              what='fc_set_bf16_fast(1): forward / backward-data / weight-gradient MFMA launches on bf16-rounded operands '
@@ -832,7 +847,13 @@ def main():
                        'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
                        'host': dict(host_main, at_start=host0,
                                     what='host_enqueue_ms_per_step: host time until the timed steps were all ENQUEUED / steps (the last, '
-                                         'probed step synchronises inside); loadavg / usable CPUs when the process started and after the timed region'),
+                                         'probed step synchronises inside); host_blocked: the part of it the host waited for the device BY DESIGN '
+                                         '(run-ahead bound of 2 steps in runner.TrainStep, pinned staging ring, a lookahead plan not ready yet); '
+                                         'host_busy = the difference = the host\'s own work per step (r5: 17.5 of 20.5 ms, the step was host-bound '
+                                         'whenever that grew); loadavg / usable CPUs when the process started and after the timed region'),
+                       'coordinate_phase': ('native plan (csrc/plan.hip: fc_plan_levels + fc_plan_maps, 2 read-backs per step)' +
+                                            (', the NEXT batch planned on a worker thread beside the current step (plan.Lookahead); exactly '
+                                             f'{args.steps} plans inside the timed region' if lookahead else ', in line')),
                        'fwd_bwd_only': {'protocol': 'SURVEY 8(d): forward_train + backward (+ all-reduce), synchronised per iteration, median of 5',
                                         'ms': round(fb_med * 1e3, 3), 'scenes_per_s': round(args.batch * world / fb_med, 3)},
                        'config4_global_batch_16': cfg4, 'forced_dp_n1': forced, 'config4_per_gpu': cfg4_1,

@@ -7,6 +7,7 @@ is missing the product path raises.
 import ctypes
 import os
 import re
+import time
 
 import torch
 
@@ -120,20 +121,28 @@ def workspace(nbytes, device):
     return buf
 
 
+# seconds the host spent BLOCKED on the device in places where it waits by design (the run-ahead bound of runner.TrainStep, a
+# staging buffer of the ring below still in use, the lookahead plan not ready): [total].  bench.py reports enqueue time minus this
+# as the host's own work per step.
+HOST_WAIT = [0.0]
+
+
 class _PinnedRing:
     """Small host -> device uploads without a pinned allocation per call (hipHostMalloc costs ~0.1 ms) and without
     blocking the host (a pageable copy waits for the queue to drain): a ring of grow-only pinned staging buffers, each
     guarded by the event of the copy that last used it."""
 
-    def __init__(self, n=8):
+    def __init__(self, n=16):
         self.bufs, self.evts, self.i = [None] * n, [None] * n, 0
 
     def upload(self, arr, device):
         """arr: numpy array (any shape, a dtype torch knows) -> device tensor, copied asynchronously on the current stream"""
         i = self.i
         self.i = (i + 1) % len(self.bufs)
-        if self.evts[i] is not None:
+        if self.evts[i] is not None and not self.evts[i].query():
+            t0 = time.perf_counter()
             self.evts[i].synchronize()
+            HOST_WAIT[0] += time.perf_counter() - t0
         nb = max(int(arr.nbytes), 1)
         if self.bufs[i] is None or self.bufs[i].numel() < nb:
             self.bufs[i] = torch.empty(max(nb, 4096), dtype=torch.uint8).pin_memory()

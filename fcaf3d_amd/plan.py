@@ -31,7 +31,14 @@ S_COORDS, S_N, S_STRIDE, S_KEYS, S_VALS, S_CAP, S_PARENT, S_ROWS = range(8)
  MW_TPI, MW_TPO, MW_TPOS, MW_TCNT, MW_TTILES, MW_FLAGS) = range(22)
 MW_DESC_F, MW_DESC_B = 24, 44
 
+TRACE = None            # a list: (tag, perf_counter) marks of every plan (tools/hostprof.py --lookahead)
 ENABLED = True          # False: the per-operator coordinate phase (sparse.py), kept as the cross-check (tests/test_gpu_plan.py)
+
+
+def _mark(tag):
+    if TRACE is not None:
+        import time
+        TRACE.append((tag, time.perf_counter()))
 
 
 def _f64_bits(v):
@@ -101,8 +108,10 @@ class Planner:
             return False
         return min(bb.n_outs, 4) >= 1 and len(points) <= 32767
 
-    def run(self, points, training, want_targets):
-        """-> StepPlan.  Everything is enqueued on the CURRENT stream (the caller picks the coordinate stream)."""
+    def run(self, points, training, want_targets, record_to=None, grad=None):
+        """-> StepPlan.  Everything is enqueued on the CURRENT stream (the caller picks the coordinate stream).  record_to: the stream
+        that will consume the buffers (default: what sparse.on_map_stream set); grad: torch.is_grad_enabled() of the CONSUMER (a
+        worker thread has its own grad mode)."""
         det = self.det
         bb, nh = det.backbone, det.neck_with_head
         B, nl = len(points), min(bb.n_outs, 4)
@@ -116,7 +125,7 @@ class Planner:
         cfg[:] = 0
         cfg[C_B], cfg[C_NL], cfg[C_NFEAT], cfg[C_TOTAL] = B, nl, nfeat, total
         cfg[C_VS], cfg[C_FEATDIV] = _f64_bits(float(det.voxel_size)), _f64_bits(255.0)
-        cfg[C_BACKWARD] = 1 if (training and torch.is_grad_enabled()) else 0
+        cfg[C_BACKWARD] = 1 if (training and (torch.is_grad_enabled() if grad is None else grad)) else 0
         cfg[C_SORT_MIN], cfg[C_PAIR_ROWS] = SP.SORT_MIN_ROWS, SP.PAIR_CONV_ROWS
         cfg[C_PTS_THR] = nh.pts_threshold if nh.pts_threshold >= 0 else -1
         cfg[C_TARGETS] = 1 if want_targets else 0
@@ -133,8 +142,10 @@ class Planner:
             cfg[C_COORDS_IN], cfg[C_FEATS_IN] = coords.data_ptr(), feats.data_ptr()
         lib = L.lib()
         stream = L.stream()
+        _mark('run0')
         a1 = torch.empty(L.query('fc_plan_stage1_bytes', total, B, nl, nfeat), dtype=torch.uint8, device=dev)
         rc = lib.fc_plan_levels(cfg.ctypes.data, scenes.ctypes.data, a1.data_ptr(), a1.numel(), out.ctypes.data, t.counts.data_ptr(), stream)
+        _mark('levels')
         if rc:
             raise RuntimeError(f'fc_plan_levels failed: {rc}')
         if out[H_BAD]:
@@ -145,12 +156,16 @@ class Planner:
             raise RuntimeError('fc_plan_stage2_bytes failed')
         a2 = torch.empty(need + 256, dtype=torch.uint8, device=dev)
         rc = lib.fc_plan_maps(cfg.ctypes.data, out.ctypes.data, t.counts.data_ptr(), a2.data_ptr(), a2.numel(), t.cnt.data_ptr(), stream)
+        _mark('maps')
         if rc:
             raise RuntimeError(f'fc_plan_maps failed: {rc}')
-        SP._rec(a1, a2)
-        if keep is not None:
-            SP._rec(*keep)
-        return self._wrap(out.copy(), t.counts.numpy().copy(), _Arenas(a1, a2), B, nl, nfeat, bool(cfg[C_BACKWARD]), want_targets, dev)
+        rec = record_to if record_to is not None else SP._record_to
+        if rec is not None:
+            for tns in (a1, a2) + (keep or ()):
+                tns.record_stream(rec)
+        sp = self._wrap(out.copy(), t.counts.numpy().copy(), _Arenas(a1, a2), B, nl, nfeat, bool(cfg[C_BACKWARD]), want_targets, dev)
+        _mark('wrapped')
+        return sp
 
     # ---- the object graph of the per-operator path over the plan's buffers -------------------------------------------------
     def _wrap(self, out, counts, ar, B, nl, nfeat, backward, want_targets, dev):
@@ -256,3 +271,75 @@ def planner_of(det):
     if p is None:
         p = det.__dict__['_planner'] = Planner(det)
     return p
+
+
+class Lookahead:
+    """The plan of the NEXT batch on a worker thread (the maps depend on the input points only — SingleStageSparse3DDetector.plan_maps):
+    `submit(points, ...)` returns at once; `take(points, ...)` hands the StepPlan over if it was made for exactly these point tensors
+    in this mode, else None (the caller plans in line).  The native calls release the GIL, so their two read-backs are waited for
+    beside the main thread's enqueueing — off the step's critical path.  One plan in flight."""
+
+    def __init__(self, det):
+        import concurrent.futures
+        self.det = det
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='fc-plan')
+        self.pending = {}                    # key -> (future, points): the current batch's plan is usually taken right after the
+                                             # next one's is submitted, so two entries live side by side
+
+    @staticmethod
+    def _key(points, training, grad, want_targets):
+        return (tuple((id(p), p.data_ptr() if torch.is_tensor(p) else 0, p.shape[0]) for p in points), bool(training), bool(grad),
+                bool(want_targets), ENABLED)
+
+    def submit(self, points, training, want_targets, side, main, wait_main):
+        pl = planner_of(self.det)
+        if not pl.applicable(points):
+            return False
+        grad = torch.is_grad_enabled()
+        key = self._key(points, training, grad, want_targets)
+        dev = points[0].device
+        ev = None
+        if wait_main:                         # the points were produced on the main stream (an upload, an on-device pipeline)
+            ev = torch.cuda.Event()
+            ev.record(main)
+
+        def work():
+            torch.cuda.set_device(dev)
+            if ev is not None:
+                side.wait_event(ev)
+            with torch.cuda.stream(side), torch.no_grad():
+                return pl.run(points, training, want_targets, record_to=main, grad=grad)
+        _mark('submit')
+        while len(self.pending) >= 2:         # plans nobody came for
+            self._discard(next(iter(self.pending)))
+        if key in self.pending:
+            return True
+        self.pending[key] = (self.pool.submit(work), points)
+        return True
+
+    def take(self, points, training, want_targets):
+        if not self.pending:
+            return None
+        ent = self.pending.pop(self._key(points, training, torch.is_grad_enabled(), want_targets), None)
+        if ent is None:
+            return None
+        _mark('take0')
+        if not ent[0].done():
+            import time
+            t0 = time.perf_counter()
+            ent[0].result()
+            L.HOST_WAIT[0] += time.perf_counter() - t0
+        sp = ent[0].result()                  # every kernel of the plan has completed (it ends with its own read-back)
+        _mark('take1')
+        return sp
+
+    def _discard(self, key):
+        fut, _ = self.pending.pop(key)
+        try:
+            fut.result()
+        except Exception:                     # noqa: a plan nobody will use
+            pass
+
+    def drop(self):
+        for key in list(self.pending):
+            self._discard(key)

@@ -217,8 +217,13 @@ class TrainStep:
             return None
         return executor.program_for(self.model, True)
 
-    def __call__(self, batch):
+    def __call__(self, batch, next_batch=None):
+        """next_batch: the batch of the FOLLOWING call, if the caller has it (a data loader's prefetched item): its coordinate
+        phase starts now on a worker thread (SingleStageSparse3DDetector.prefetch) and overlaps this step"""
         from . import functional as Fn
+        self._bound_run_ahead()
+        if next_batch is not None and hasattr(self.model, 'prefetch'):
+            self.model.prefetch(next_batch['points'], gt=True)
         self.optimizer.zero_grad(set_to_none=True)
         Fn._flat_pass_done()                         # a backward pass that raised never ran its final callback: start clean
         prog = self._program()
@@ -261,6 +266,23 @@ class TrainStep:
             self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, norm_type=self.norm_type)
         self.optimizer.step()
         return loss, losses
+
+    def _bound_run_ahead(self, depth=int(os.environ.get('FC_RUN_AHEAD', '2'))):
+        """the host may enqueue at most `depth` steps ahead of the GPU: with the coordinate phase off the main thread nothing else
+        in a step waits for the device, and every step in flight holds its arenas"""
+        if not self.params or not self.params[0].is_cuda:
+            return
+        evs = self.__dict__.setdefault('_step_events', [])
+        if len(evs) >= depth:
+            e0 = evs.pop(0)
+            if not e0.query():
+                import time
+                t0 = time.perf_counter()
+                e0.synchronize()
+                L.HOST_WAIT[0] += time.perf_counter() - t0
+        e = torch.cuda.Event()
+        e.record()
+        evs.append(e)
 
     def epoch_end(self):
         if self.lr is not None:

@@ -65,12 +65,33 @@ class SingleStageSparse3DDetector(nn.Module):
             coords, feats = coords[order], feats[order]
         return coords, feats
 
+    def prefetch(self, points, gt=True):
+        """Start the coordinate phase of a LATER batch now, on a worker thread and the coordinate stream (plan.Lookahead): call it
+        with the next batch's points before running the current step; `extract_feat` of exactly these tensors then finds its sets
+        and maps made.  gt: whether that step will pass ground truth (training).  Returns False when the native plan does not
+        cover this configuration (the step then plans in line, as without the call)."""
+        from . import plan as PL
+        la = self.__dict__.get('_lookahead')
+        if la is None:
+            la = self.__dict__['_lookahead'] = PL.Lookahead(self)
+        p0 = points[0]
+        if not (hasattr(p0, 'is_cuda') and p0.is_cuda):
+            return False
+        dev = p0.device
+        from .sparse import plan_stream
+        main = torch.cuda.current_stream(dev)
+        want_targets = bool(gt) and hasattr(self.neck_with_head, 'prepare_targets')
+        return la.submit(points, self.training, want_targets, plan_stream(dev), main, wait_main=not self.inputs_resident)
+
     def _sparse_input(self, points, gt=None):
         from . import plan as PL
         pl = PL.planner_of(self)
         nh = self.neck_with_head
         want_targets = gt is not None and hasattr(nh, 'prepare_targets')
-        sp = pl.run(points, self.training, want_targets) if pl.applicable(points) else None
+        la = self.__dict__.get('_lookahead')
+        sp = la.take(points, self.training, want_targets) if la is not None else None
+        if sp is None and pl.applicable(points):
+            sp = pl.run(points, self.training, want_targets)
         return self._use_plan(sp, points, gt)
 
     def _use_plan(self, sp, points, gt=None):

@@ -42,6 +42,23 @@ def map_stream(device):
     return _side[(key, prio)]
 
 
+_plan_side = {}
+
+
+def plan_stream(device):
+    """the stream of the lookahead plan (plan.Lookahead): the coordinate stream itself.  r6 measured a stream of its own (FC_PLAN_STREAM=own:
+    the main stream then never waits for a part of the NEXT batch's plan at the end of a coordinate phase) at 24.2 ms per 8-scene step
+    against 20.9 on the coordinate stream, with identical kernel durations in the rocprofv3 trace — a FIFTH busy stream of the process
+    beside main / head / weight-gradient / coordinate falls into the slow mode of profiles/r5_notes.md section 16 deterministically
+    (profiles/r6_notes.md section 2), so the step keeps to four."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if os.environ.get('FC_PLAN_STREAM') != 'own':
+        return map_stream(key)
+    if key not in _plan_side:
+        _plan_side[key] = torch.cuda.Stream(device=key, priority=map_stream(key).priority)
+    return _plan_side[key]
+
+
 _inputs_ready = {}
 
 

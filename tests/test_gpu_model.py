@@ -236,15 +236,19 @@ def test_target_assignment_is_stable_beside_concurrent_convolutions():
     seen = {}
     t0 = head._targets
 
-    def grab(cmaps, gtb, gtl):
-        seen['args'] = (cmaps, gtb, gtl)
-        return t0(cmaps, gtb, gtl)
+    def grab(cmaps, gtb, gtl, pre=None):
+        seen['args'], seen['pre'] = (cmaps, gtb, gtl), pre
+        return t0(cmaps, gtb, gtl, pre)
     head._targets = grab
     sum(model(return_loss=True, **batch).values()).backward()
     head._targets = t0
     cmaps, gtb, gtl = seen['args']
     ref = t0(cmaps, gtb, gtl)
+    assert seen['pre'] is not None, 'the native plan did not hand its head arrays to the assignment'
+    via_plan = t0(cmaps, gtb, gtl, seen['pre'])                   # locations / order written by csrc/plan.hip == the torch-built ones
     torch.cuda.synchronize()
+    for k in ('pts', 'scene', 'ct', 'bt', 'labels', 'inv_pos', 'inv_den'):
+        assert torch.equal(via_plan[k], ref[k]), k
     side = torch.cuda.Stream(device=dev)
     outs = []
     for rep in range(3):

@@ -20,6 +20,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 
+LOOKAHEAD = False
+
+
 def pop_flag(name, default):
     if name in sys.argv:
         i = sys.argv.index(name)
@@ -58,6 +61,9 @@ def run_one(args, B, dev, do_cprofile, steps=8):
                     torch.cuda.synchronize()
                 marks.append(time.perf_counter())
         mark()
+        tr._bound_run_ahead()
+        if LOOKAHEAD:
+            model.prefetch(batches[(i + 1) % 2]['points'], gt=True)
         tr.optimizer.zero_grad(set_to_none=True)
         prog = tr._program()
         if prog is not None:
@@ -109,6 +115,15 @@ def run_one(args, B, dev, do_cprofile, steps=8):
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         out[label] = ([1e3 * v / steps for v in tot], 1e3 * (t1 - t0) / steps, 1e3 * (t2 - t0) / steps)
+    if LOOKAHEAD:
+        import fcaf3d_amd.plan as PL
+        PL.TRACE = []
+        t00 = time.perf_counter()
+        for i in range(4):
+            step(i)
+        torch.cuda.synchronize()
+        print('plan trace (ms since start): ' + ' '.join(f'{tag}@{(tt - t00) * 1e3:.2f}' for tag, tt in PL.TRACE))
+        PL.TRACE = None
     L.call = counting
     step(0)
     L.call = orig
@@ -136,6 +151,10 @@ def run_one(args, B, dev, do_cprofile, steps=8):
 def main():
     bs = [int(v) for v in pop_flag('--batches', '2,4,8').split(',')]
     cp = int(pop_flag('--cprofile', '0'))
+    global LOOKAHEAD
+    if '--lookahead' in sys.argv:
+        sys.argv.remove('--lookahead')
+        LOOKAHEAD = True
     args = bench.parse()
     dev = torch.device('cuda:0')
     if args.priority_stream:

@@ -10,7 +10,7 @@
 #   trace            rocprofv3 --kernel-trace --stats over a short bench -> trace/ + kernel_stats
 #   trace1           the same with every kernel on ONE stream (--no-wgrad-overlap, FC_MAP_SYNC=1)
 #   pmc:<counters>   rocprofv3 --pmc <counters> over a short bench (own pass, no tracing)
-#   host[:B]         tools/hostprof.py for B scenes
+#   host[:args]      tools/hostprof.py --batches <args>   (default: 8 --lookahead)
 #   py:<script args> python <script args>
 cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=$1; shift
@@ -50,7 +50,7 @@ for job in "$@"; do
       (cd /tmp && timeout 900 rocprofv3 --pmc $arg -d "$O/pmc_${arg// /_}" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline \
         --infer-steps 0 --no-fp32-route --no-extras --no-force-dp --no-instrument > "$O/pmc$i.json" 2> "$O/pmc$i.err"); rc=$? ;;
     host)
-      timeout 600 python tools/hostprof.py --batches ${arg:-8} > "$O/host$i.txt" 2>&1; rc=$?; tail -12 "$O/host$i.txt" ;;
+      timeout 600 python tools/hostprof.py --batches ${arg:-8 --lookahead} > "$O/host$i.txt" 2>&1; rc=$?; tail -12 "$O/host$i.txt" ;;
     py)
       timeout 1800 python $arg > "$O/py$i.log" 2>&1; rc=$?; tail -25 "$O/py$i.log" ;;
     *) echo "unknown job $job"; rc=64 ;;
