@@ -641,7 +641,15 @@ def main():
     for b in range(count_steps(args, len(batches))):
         step(b, 'count' if probe else None)
     for b in range(hbm_steps(args, exec_on)):      # untimed, per-operator path: the bandwidth-bound entry points for `hbm_kernels`
-        step(b, 'hbm' if probe else None)
+        # ... with NOTHING else on the GPU: the previous step's weight-image build (weight-gradient stream) has drained and this step's
+        # coordinate phase / target assignment stays on the main stream (r6: with the host no longer the bottleneck the image build of
+        # step i - 1 ran beside the stem convolution of the probed step and doubled its bracket)
+        torch.cuda.synchronize()
+        model.async_maps = False
+        try:
+            step(b, 'hbm' if probe else None)
+        finally:
+            model.async_maps = True
     if probe:
         probe.mode = None
     EX.ENABLED = exec_on

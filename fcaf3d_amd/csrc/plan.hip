@@ -62,8 +62,36 @@ int sync_readback(void* host, const void* dev, int64_t bytes, hipStream_t s) {
   return 0;
 }
 
+// ---- batched launches ------------------------------------------------------------------------------------------------------------
+// Most of the phase is many small independent jobs of one kind (ten kernel maps, thirteen pair lists, five argsorts ...): each kind
+// is ONE launch over the concatenated blocks of its jobs; a block finds its job by a scan of the (<= 24) first-block entries, which
+// sit in the kernel arguments (scalar loads).
+// (r6: a 2.1 KB argument block — 24 jobs of 80 bytes — made the launches misbehave on this stack, a 1.7 KB one did not: the
+// batches stay below 1.5 KB, static_assert below; four pyramid levels need at most 16 jobs of a kind)
+constexpr int MAXJ = 16;
+template <typename J> struct Batch {
+  J j[MAXJ];
+  int64_t blk0[MAXJ + 1];
+  int count;
+  bool overflow;
+  Batch() : count(0), overflow(false) { blk0[0] = 0; }
+  void add(const J& job, int64_t blocks) {
+    if (count >= MAXJ) { overflow = true; return; }
+    j[count] = job;
+    blk0[count + 1] = blk0[count] + (blocks > 0 ? blocks : 0);
+    ++count;
+  }
+  int64_t blocks() const { return blk0[count]; }
+};
+template <typename J> __device__ __forceinline__ int batch_find(const Batch<J>& b, int64_t blk, int64_t* local) {
+  int i = 0;
+  while (i + 1 < b.count && blk >= b.blk0[i + 1]) ++i;
+  *local = blk - b.blk0[i];
+  return i;
+}
+
 // ---- stage 1 kernels: device-resident counts ---------------------------------------------------------------------------------
-// meta (device ints): per set s: [8s + 0] rows, [8s + 1] hash capacity, [8s + 2] range flag; then rows per (set, scene).
+// meta (device ints): per set s: [8s + 0] rows, [8s + 2] range flag, [8s + 3] finished blocks of the flag pass; then rows per (set, scene).
 constexpr int METAW = 8;
 constexpr int CH = 32;              // scenes per launch of the point kernel
 struct SceneArgs { const float* p[CH]; int n[CH]; int off[CH]; int b0, stride, nfeat; float vs, feat_div; };
@@ -76,8 +104,13 @@ __device__ inline bool out_of_range(int4 c) {
   return c.x < 0 || c.x > 32767 || c.y < -FC_COORD_LIMIT || c.y > FC_COORD_LIMIT || c.z < -FC_COORD_LIMIT || c.z > FC_COORD_LIMIT ||
          c.w < -FC_COORD_LIMIT || c.w > FC_COORD_LIMIT;
 }
-__device__ inline void hash_insert(unsigned long long* keys, int* vals, unsigned long long mask, int4 c, int i, int* slot, int* bad) {
-  if (out_of_range(c)) *bad = 1;
+// capacity of the table of a set whose INPUT has n rows: next_pow2(2 n) — the per-operator path's rule (sparse.CoordMap.from_coords)
+__host__ __device__ inline unsigned long long table_mask(int64_t n_in) {
+  int64_t cap = 2;
+  while (cap < 2 * n_in) cap *= 2;
+  return (unsigned long long)(cap - 1);
+}
+__device__ inline void hash_insert(unsigned long long* keys, int* vals, unsigned long long mask, int4 c, int i, int* slot) {
   const unsigned long long key = fc_pack(c.x, c.y, c.z, c.w);
   unsigned long long h = fc_mix(key) & mask;
   while (true) {
@@ -91,21 +124,21 @@ __device__ inline void hash_insert(unsigned long long* keys, int* vals, unsigned
   }
 }
 
-// table of set s: capacity = next_pow2(2 * rows of its INPUT) — the per-operator path's rule (sparse.CoordMap.from_coords)
-__global__ void k_plan_table_init(unsigned long long* __restrict__ keys, int* __restrict__ vals, const int* __restrict__ n_in_dev,
-                                  int64_t n_in_host, int* __restrict__ meta_s) {
-  const int64_t n_in = n_in_dev ? *n_in_dev : n_in_host;
-  int64_t cap = 2;
-  while (cap < 2 * n_in) cap *= 2;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) meta_s[1] = (int)cap;
-  if (i < cap) { keys[i] = FC_EMPTY_KEY; vals[i] = 0x7fffffff; }
+// all tables of the chain in one launch: keys (S, cap) / vals (S, cap) contiguous, two key slots per thread
+__global__ void k_plan_tables_init(unsigned long long* __restrict__ keys, int* __restrict__ vals, int64_t total) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i + 1 < total) {
+    *reinterpret_cast<ulonglong2*>(keys + i) = make_ulonglong2(FC_EMPTY_KEY, FC_EMPTY_KEY);
+    *reinterpret_cast<int2*>(vals + i) = make_int2(0x7fffffff, 0x7fffffff);
+  } else if (i < total) {
+    keys[i] = FC_EMPTY_KEY; vals[i] = 0x7fffffff;
+  }
 }
 
 // the collate (single_stage_sparse.py:34-36: floor(xyz / voxel_size), features / 255, batch index = scene) fused with the hash
 // insert of level 0 — blockIdx.y = scene of the chunk.  (true fp32 division, as fc_voxelize.)
 __global__ void k_plan_voxelize_insert(SceneArgs sc, int4* __restrict__ coords, float* __restrict__ feats, unsigned long long* keys,
-                                       int* vals, int64_t cap, int* __restrict__ meta_s, int* __restrict__ slot) {
+                                       int* vals, unsigned long long mask, int* __restrict__ meta_s, int* __restrict__ slot) {
   const int j = blockIdx.y;
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= sc.n[j]) return;
@@ -116,76 +149,86 @@ __global__ void k_plan_voxelize_insert(SceneArgs sc, int4* __restrict__ coords, 
   c.y = (int)floorf(p[0] / sc.vs); c.z = (int)floorf(p[1] / sc.vs); c.w = (int)floorf(p[2] / sc.vs);
   coords[i] = c;
   for (int f = 0; f < sc.nfeat; ++f) feats[(int64_t)i * sc.nfeat + f] = p[3 + f] / sc.feat_div;
-  hash_insert(keys, vals, (unsigned long long)(cap - 1), c, i, slot, meta_s + 2);
+  if (out_of_range(c)) meta_s[2] = 1;
+  hash_insert(keys, vals, mask, c, i, slot);
 }
 
-// any set from a coordinate array: rows [0, *n_dev) of `coords`, quantised to multiples of q
-__global__ void k_plan_insert(const int4* __restrict__ coords, const int* __restrict__ n_dev, int64_t n_host, int q,
-                              unsigned long long* keys, int* vals, int* __restrict__ meta_s, int* __restrict__ slot) {
-  const int64_t n = n_dev ? *n_dev : n_host;
+// level 0 from a pre-voxelised coordinate array
+__global__ void k_plan_insert(const int4* __restrict__ coords, int64_t n, unsigned long long* keys, int* vals, unsigned long long mask,
+                              int* __restrict__ meta_s, int* __restrict__ slot) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  hash_insert(keys, vals, (unsigned long long)(meta_s[1] - 1), quant(coords[i], q), (int)i, slot, meta_s + 2);
+  const int4 c = coords[i];
+  if (out_of_range(c)) meta_s[2] = 1;
+  hash_insert(keys, vals, mask, c, (int)i, slot);
 }
 
-// winners of 1 024 rows per block: flags + the block's count
-__global__ __launch_bounds__(256) void k_plan_flags(const int* __restrict__ slot, const int* __restrict__ vals, const int* __restrict__ n_dev,
-                                                    int64_t n_host, unsigned char* __restrict__ flags, int* __restrict__ blocksums) {
+// winners of 1 024 rows per block: flags + the block's count; the LAST block to finish scans the block counts (exclusive, in place)
+// and writes the set's row count -> meta_s[0]
+__global__ __launch_bounds__(256) void k_plan_flags_scan(const int* __restrict__ slot, const int* __restrict__ vals, const int* __restrict__ n_dev,
+                                                         int64_t n_host, unsigned char* __restrict__ flags, int* __restrict__ blocksums,
+                                                         int* __restrict__ meta_s) {
   __shared__ int ws[4];
+  __shared__ int last_s, carry_s;
   const int64_t n = n_dev ? *n_dev : n_host;
   const int64_t base = (int64_t)blockIdx.x * 1024;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int cnt = 0;
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
     int f = 0;
     if (i < n) { f = vals[slot[i]] == (int)i; flags[i] = (unsigned char)f; }
     const unsigned long long bal = __ballot(f);
-    if ((threadIdx.x & 63) == 0) cnt += __popcll(bal);
+    if (lane == 0) cnt += __popcll(bal);
   }
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = cnt;
+  if (lane == 0) ws[w] = cnt;
   __syncthreads();
-  if (threadIdx.x == 0) blocksums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-}
-
-// exclusive scan of the block counts (one block), total -> meta_s[0]
-__global__ __launch_bounds__(1024) void k_plan_scan(int* __restrict__ blocksums, int nb, int* __restrict__ meta_s) {
-  __shared__ int wsum[16];
-  __shared__ int carry_s;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&blocksums[blockIdx.x], ws[0] + ws[1] + ws[2] + ws[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last_s = atomicAdd(&meta_s[3], 1) == (int)gridDim.x - 1;
+    carry_s = 0;
+  }
   __syncthreads();
-  for (int start = 0; start < nb; start += 1024) {
+  if (!last_s) return;
+  __threadfence();
+  const int nb = (int)gridDim.x;
+  for (int start = 0; start < nb; start += 256) {
     const int i = start + threadIdx.x;
-    const int v = i < nb ? blocksums[i] : 0;
+    const int v = i < nb ? fc_ld(&blocksums[i]) : 0;
     int x = v;                                    // inclusive scan inside the wave
     for (int o = 1; o < 64; o <<= 1) {
       const int t = __shfl_up(x, o, 64);
       if (lane >= o) x += t;
     }
-    if (lane == 63) wsum[w] = x;
+    if (lane == 63) ws[w] = x;
     __syncthreads();
     int pre = carry_s;
-    for (int k = 0; k < w; ++k) pre += wsum[k];
+    for (int k = 0; k < w; ++k) pre += ws[k];
     if (i < nb) blocksums[i] = pre + x - v;
     __syncthreads();
-    if (threadIdx.x == 1023) carry_s = pre + x;
+    if (threadIdx.x == 255) carry_s = pre + x;
     __syncthreads();
   }
   if (threadIdx.x == 0) meta_s[0] = carry_s;
 }
 
 // positions + the set itself: winner row i -> out row p: coordinates (with its feature row for level 0), table value = p,
-// rows-per-scene counters (rows of one scene are consecutive: one atomic per wave and scene)
+// rows-per-scene counters (rows of one scene are consecutive: one atomic per wave and scene) — and, fused, the hash insert of the
+// NEXT set of the chain: row p of this set, quantised to the next stride, goes into the next table with value p (first occurrence
+// = smallest p, as an insert pass over the finished set would give)
 __global__ __launch_bounds__(256) void k_plan_finalize(const int4* __restrict__ coords, const int* __restrict__ n_dev, int64_t n_host, int q,
                                                        const unsigned char* __restrict__ flags, const int* __restrict__ blocksums,
                                                        const int* __restrict__ slot, int* vals, int4* __restrict__ out_coords,
                                                        const float* __restrict__ feats_in, float* __restrict__ feats_out, int nfeat,
-                                                       int* __restrict__ scene_cnt, int B) {
+                                                       int* __restrict__ scene_cnt, int B, const int* __restrict__ meta_s,
+                                                       unsigned long long* next_keys, int* next_vals, int* __restrict__ next_slot) {
   __shared__ int ws[4];
   const int64_t n = n_dev ? *n_dev : n_host;
   const int64_t base = (int64_t)blockIdx.x * 1024;
   if (base >= n) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long nmask = next_keys ? table_mask(meta_s[0]) : 0ull;
   int run = blocksums[blockIdx.x];
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
@@ -206,6 +249,7 @@ __global__ __launch_bounds__(256) void k_plan_finalize(const int4* __restrict__ 
       if (feats_out)
         for (int k = 0; k < nfeat; ++k) feats_out[(int64_t)p * nfeat + k] = feats_in[i * nfeat + k];
       b = c.x;
+      if (next_keys) hash_insert(next_keys, next_vals, nmask, quant(c, 2 * q), p, next_slot);
     }
     unsigned long long rem = bal;                  // rows per scene
     while (rem) {
@@ -219,50 +263,81 @@ __global__ __launch_bounds__(256) void k_plan_finalize(const int4* __restrict__ 
   }
 }
 
-// ---- stage 2 kernels ---------------------------------------------------------------------------------------------------------
-// kernel map with the offsets computed in the kernel (x fastest; centred for odd kernels, {0..k-1} for even — Appendix A.3):
-// nbr[k][o] = row of out_coords[o] + offset_k * stride in the table, or -1.  blockIdx.y = k.
-__global__ void k_plan_kernel_map(const int4* __restrict__ out_coords, int64_t n_out, const unsigned long long* __restrict__ keys,
-                                  const int* __restrict__ vals, unsigned long long mask, int ks, int stride, int* __restrict__ nbr) {
-  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= n_out) return;
-  const int k = blockIdx.y;
-  const int c0 = (ks & 1) ? ks / 2 : 0;
-  const int dx = (k % ks - c0) * stride, dy = ((k / ks) % ks - c0) * stride, dz = (k / (ks * ks) - c0) * stride;
-  const int4 c = out_coords[o];
-  nbr[(int64_t)k * n_out + o] = fc_lookup(keys, vals, mask, fc_pack(c.x, c.y + dx, c.z + dy, c.w + dz));
+// ---- stage 2 kernels (batched) ---------------------------------------------------------------------------------------------------
+// kernel maps with the offsets computed in the kernel (x fastest; centred for odd kernels, {0..k-1} for even — Appendix A.3):
+// nbr[k][o] = row of out_coords[o] + offset_k * stride in the table, or -1.  job blocks = K * ceil(n_out / 256), k-major.
+struct KMapJob { const int4* oc; const unsigned long long* keys; const int* vals; unsigned long long mask; int* nbr; int64_t n_out; int K, ks, stride, nbx; };
+__global__ void k_plan_kernel_maps(Batch<KMapJob> bt) {
+  int64_t lb;
+  const KMapJob& j = bt.j[batch_find(bt, blockIdx.x, &lb)];
+  const int k = (int)(lb / j.nbx);
+  const int64_t o = (lb % j.nbx) * 256 + threadIdx.x;
+  if (o >= j.n_out) return;
+  const int ks = j.ks, c0 = (ks & 1) ? ks / 2 : 0;
+  const int dx = (k % ks - c0) * j.stride, dy = ((k / ks) % ks - c0) * j.stride, dz = (k / (ks * ks) - c0) * j.stride;
+  const int4 c = j.oc[o];
+  j.nbr[(int64_t)k * j.n_out + o] = fc_lookup(j.keys, j.vals, j.mask, fc_pack(c.x, c.y + dx, c.z + dy, c.w + dz));
 }
 
-// transposed table of a map of a set onto ITSELF with a centred odd kernel: nbr_t[k] = nbr[K - 1 - k] (offset k reversed is offset
-// K - 1 - k), a coalesced copy instead of fill + scatter — identical to fc_kernel_map_transpose
-__global__ void k_plan_reverse_rows(const int* __restrict__ nbr, int64_t n, int K, int* __restrict__ nbr_t) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int k = blockIdx.y;
-  nbr_t[(int64_t)k * n + i] = nbr[(int64_t)(K - 1 - k) * n + i];
+// row copies / fills of (K, n) tables.  mode 0: dst[k] = src[K - 1 - k] — the transposed table of a map of a set onto ITSELF with
+// a centred odd kernel (offset k reversed is offset K - 1 - k: identical to fc_kernel_map_transpose); mode 1: dst = -1;
+// mode 2: scatter dst[k][src[k][o]] = o (src (K, n), dst (K, n2)) — fc_kernel_map_transpose's second half
+struct RowJob { const int* src; int* dst; int64_t n, n2; int K, mode, nbx; };
+__global__ void k_plan_rows(Batch<RowJob> bt) {
+  int64_t lb;
+  const RowJob& j = bt.j[batch_find(bt, blockIdx.x, &lb)];
+  const int k = (int)(lb / j.nbx);
+  const int64_t i = (lb % j.nbx) * 256 + threadIdx.x;
+  if (i >= j.n) return;
+  if (j.mode == 0) j.dst[(int64_t)k * j.n + i] = j.src[(int64_t)(j.K - 1 - k) * j.n + i];
+  else if (j.mode == 1) j.dst[(int64_t)k * j.n + i] = -1;
+  else {
+    const int v = j.src[(int64_t)k * j.n + i];
+    if (v >= 0) j.dst[(int64_t)k * j.n2 + v] = (int)i;
+  }
+}
+
+// generated sets straight from the coarsest level (MinkowskiGenerativeConvolutionTranspose k2 s2 applied `depth` times, row 8i + k
+// each time — Appendix A.4): row t = ((i * 8 + k_depth-1) * 8 + ...) + k_0 sits at coarse[i] + sum_d bits(k_d) * (stride << d)
+struct GenJob { const int4* coarse; int4* out; int64_t n; int depth, stride, nbx; };
+__global__ void k_plan_gen_coords(Batch<GenJob> bt) {
+  int64_t lb;
+  const GenJob& j = bt.j[batch_find(bt, blockIdx.x, &lb)];
+  const int64_t t = lb * 256 + threadIdx.x;
+  if (t >= j.n) return;
+  int4 c = j.coarse[t >> (3 * j.depth)];
+  for (int d = 0; d < j.depth; ++d) {
+    const int k = (int)(t >> (3 * d)) & 7;
+    const int h = j.stride << d;
+    c.y += (k & 1) ? h : 0; c.z += (k & 2) ? h : 0; c.w += (k & 4) ? h : 0;
+  }
+  j.out[t] = c;
 }
 
 // row of each voxel of a backbone level (stride T) in the generated set `depth` levels below the coarsest level: the generated
 // sets hold ALL descendants of the coarsest set (child k of row i at 8i + k), so the row follows from ONE probe of the coarsest
 // table and `depth` child-bit triples — identical to fc_child_rows on the parent set's table.  *n_found counts the hits.
-__global__ void k_plan_gen_rows(const int4* __restrict__ q, int64_t n, const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
-                                unsigned long long mask, int T, int depth, int* __restrict__ rows, int* __restrict__ n_found) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+struct GenRowsJob { const int4* q; int* rows; int* n_found; int64_t n; int T, depth; };
+__global__ void k_plan_gen_rows(Batch<GenRowsJob> bt, const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
+                                unsigned long long mask) {
+  int64_t lb;
+  const GenRowsJob& j = bt.j[batch_find(bt, blockIdx.x, &lb)];
+  const int64_t i = lb * 256 + threadIdx.x;
   int hit = 0;
-  if (i < n) {
-    const int4 c = q[i];
-    const int P = T << depth;                      // stride of the coarsest set
+  if (i < j.n) {
+    const int4 c = j.q[i];
+    const int T = j.T, P = T << j.depth;           // stride of the coarsest set
     const int px = fc_floor_div(c.y, P) * P, py = fc_floor_div(c.z, P) * P, pz = fc_floor_div(c.w, P) * P;
     int r = fc_lookup(keys, vals, mask, fc_pack(c.x, px, py, pz));
     if (r >= 0) {
       const int rx = (c.y - px) / T, ry = (c.z - py) / T, rz = (c.w - pz) / T;       // in [0, 2^depth)
-      for (int d = depth - 1; d >= 0; --d) r = 8 * r + (((rx >> d) & 1) | (((ry >> d) & 1) << 1) | (((rz >> d) & 1) << 2));
+      for (int d = j.depth - 1; d >= 0; --d) r = 8 * r + (((rx >> d) & 1) | (((ry >> d) & 1) << 1) | (((rz >> d) & 1) << 2));
       hit = 1;
     }
-    rows[i] = r;
+    j.rows[i] = r;
   }
   const unsigned long long bal = __ballot(hit);
-  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_found, __popcll(bal));
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(j.n_found, __popcll(bal));
 }
 
 // the head's per-location arrays over all levels (finest first): location = voxel corner * voxel size
@@ -280,24 +355,63 @@ __global__ void k_plan_head_arrays(HeadArgs h, float* __restrict__ pts, int* __r
   order[t] = (int)t;
 }
 
-// ---- LSD radix argsort of 27-bit keys (the occupancy masks), stable: 3 passes of 9 bits ------------------------------------------
-constexpr int RB = 9, RBINS = 1 << RB, RTILE = 4096;
-__global__ __launch_bounds__(256) void k_radix_hist(const int* __restrict__ keys, int64_t n, int shift, int* __restrict__ hist /*(nblk, RBINS)*/) {
-  __shared__ int h[RBINS];
-  for (int b = threadIdx.x; b < RBINS; b += 256) h[b] = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * RTILE;
-  for (int r = 0; r < RTILE / 256; ++r) {
-    const int64_t i = base + r * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (RBINS - 1)], 1);
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < RBINS; b += 256) hist[(int64_t)blockIdx.x * RBINS + b] = h[b];
+// occupancy masks of the rows of (27, n) tables (fc_nbr_row_masks), all tables that get a mask-sorted copy in one launch
+struct SortJob { const int* tab; int* masks; int* order; int* sorted; int* ka; int* kb; int* va; int* hist; int64_t n; int nblk, nbx; };
+__global__ void k_plan_row_masks(Batch<SortJob> bt) {
+  int64_t lb;
+  const SortJob& j = bt.j[batch_find(bt, blockIdx.x, &lb)];
+  const int64_t o = lb * 256 + threadIdx.x;
+  if (o >= j.n) return;
+  unsigned int m = 0;
+  for (int k = 0; k < 27; ++k)
+    if (j.tab[(int64_t)k * j.n + o] >= 0) m |= 1u << k;
+  j.masks[o] = (int)m;
+}
+// sorted[k][t] = tab[k][order[t]] (fc_permute_nbr); job blocks = 27 * ceil(n / 256)
+__global__ void k_plan_permute(Batch<SortJob> bt) {
+  int64_t lb;
+  const SortJob& j = bt.j[batch_find(bt, blockIdx.x, &lb)];
+  const int k = (int)(lb / j.nbx);
+  const int64_t t = (lb % j.nbx) * 256 + threadIdx.x;
+  if (t >= j.n) return;
+  j.sorted[(int64_t)k * j.n + t] = j.tab[(int64_t)k * j.n + j.order[t]];
 }
 
-// one block of RBINS threads: hist[blk][d] -> global start of (d, blk) in (digit, block) order
-__global__ __launch_bounds__(RBINS) void k_radix_scan(int* __restrict__ hist, int nblk) {
+// ---- LSD radix argsort of 27-bit keys (the occupancy masks), stable: 3 passes of 9 bits; all sort jobs of a plan per launch -------
+constexpr int RB = 9, RBINS = 1 << RB, RTILE = 4096;
+struct RadixIO { const int* kin; const int* vin; int* kout; int* vout; };
+// p0: (masks, identity) -> (ka, order); p1: (ka, order) -> (kb, va); p2: (kb, va) -> (ka, order): the result lands in `order`.
+// PASS is a template parameter: with a run-time pass hipcc 7.2 left the key pointer of the third pass undefined in k_radix_scatter
+// (the switch lowering assigned it on one of two default paths only: it read job 0's `tab` — found with a null `tab`, r6_notes.md)
+template <int PASS> __device__ __forceinline__ RadixIO radix_io(const SortJob& j) {
+  if (PASS == 0) return {j.masks, nullptr, j.ka, j.order};
+  if (PASS == 1) return {j.ka, j.order, j.kb, j.va};
+  return {j.kb, j.va, j.ka, j.order};
+}
+template <int PASS> __global__ __launch_bounds__(256) void k_radix_hist(Batch<SortJob> bt) {
+  constexpr int pass = PASS;
+  __shared__ int h[RBINS];
+  int64_t lb;
+  const SortJob& j = bt.j[batch_find(bt, blockIdx.x, &lb)];
+  const int* keys = radix_io<PASS>(j).kin;
+  const int shift = pass * RB;
+  for (int b = threadIdx.x; b < RBINS; b += 256) h[b] = 0;
+  __syncthreads();
+  const int64_t base = lb * RTILE;
+  for (int r = 0; r < RTILE / 256; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < j.n) atomicAdd(&h[(keys[i] >> shift) & (RBINS - 1)], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < RBINS; b += 256) j.hist[lb * RBINS + b] = h[b];
+}
+
+// one block of RBINS threads per job: hist[blk][d] -> global start of (d, blk) in (digit, block) order
+__global__ __launch_bounds__(RBINS) void k_radix_scan(Batch<SortJob> bt) {
   __shared__ int tot[RBINS];
+  const SortJob& j = bt.j[blockIdx.x];
+  int* hist = j.hist;
+  const int nblk = j.nblk;
   const int d = threadIdx.x;
   int run = 0;
   for (int b = 0; b < nblk; ++b) {
@@ -307,8 +421,7 @@ __global__ __launch_bounds__(RBINS) void k_radix_scan(int* __restrict__ hist, in
   }
   tot[d] = run;
   __syncthreads();
-  // exclusive scan of the digit totals (Hillis-Steele over RBINS threads)
-  int x = run;
+  int x = run;                                     // inclusive scan of the digit totals (Hillis-Steele over RBINS threads)
   for (int o = 1; o < RBINS; o <<= 1) {
     const int t = d >= o ? tot[d - o] : 0;
     __syncthreads();
@@ -320,18 +433,23 @@ __global__ __launch_bounds__(RBINS) void k_radix_scan(int* __restrict__ hist, in
   for (int b = 0; b < nblk; ++b) hist[(int64_t)b * RBINS + d] += dbase;
 }
 
-// rank inside the tile in row order (stable) and scatter.  vals_in == nullptr: the identity (first pass).
-__global__ __launch_bounds__(256) void k_radix_scatter(const int* __restrict__ keys_in, const int* __restrict__ vals_in, int64_t n, int shift,
-                                                       const int* __restrict__ hist, int* __restrict__ keys_out, int* __restrict__ vals_out) {
+// rank inside the tile in row order (stable) and scatter.  vin == nullptr: the identity (first pass).
+template <int PASS> __global__ __launch_bounds__(256) void k_radix_scatter(Batch<SortJob> bt) {
+  constexpr int pass = PASS;
   __shared__ int offs[RBINS];
+  int64_t lb;
+  const SortJob& j = bt.j[batch_find(bt, blockIdx.x, &lb)];
+  const RadixIO io = radix_io<PASS>(j);
+  const int shift = pass * RB;
+  const int64_t n = j.n;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int b = threadIdx.x; b < RBINS; b += 256) offs[b] = hist[(int64_t)blockIdx.x * RBINS + b];
+  for (int b = threadIdx.x; b < RBINS; b += 256) offs[b] = j.hist[lb * RBINS + b];
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * RTILE;
+  const int64_t base = lb * RTILE;
   for (int r = 0; r < RTILE / 256; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
     const bool live = i < n;
-    const int key = live ? keys_in[i] : 0;
+    const int key = live ? io.kin[i] : 0;
     const int d = (key >> shift) & (RBINS - 1);
     unsigned long long peers = __ballot(live);     // lanes of this wave with the same digit
     for (int b = 0; b < RB; ++b) {
@@ -348,36 +466,85 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const int* __restrict__ k
     const int leader = __ffsll((long long)peers) - 1;
     dst = __shfl(dst, live ? leader : 0, 64);
     if (live) {
-      keys_out[dst + rank] = key;
-      vals_out[dst + rank] = vals_in ? vals_in[i] : (int)i;
+      io.kout[dst + rank] = key;
+      io.vout[dst + rank] = io.vin ? io.vin[i] : (int)i;
     }
   }
 }
 
-// order (n) = stable argsort of keys (n) in [0, 2^27); ws: 3 n ints + hist
 int64_t argsort27_ws_bytes(int64_t n) { return fc_align(4 * n, 256) * 3 + fc_align(4 * fc_cdiv(n > 0 ? n : 1, RTILE) * RBINS, 256); }
-int argsort27(const int* keys, int64_t n, int* order, void* ws, hipStream_t s) {
-  if (n <= 0) return 0;
-  char* w = (char*)ws;
-  int* ka = (int*)w; w += fc_align(4 * n, 256);
-  int* kb = (int*)w; w += fc_align(4 * n, 256);
-  int* va = (int*)w; w += fc_align(4 * n, 256);
-  int* hist = (int*)w;
-  const int nblk = (int)fc_cdiv(n, RTILE);
-  // p0: (keys, identity) -> (ka, order); p1: (ka, order) -> (kb, va); p2: (kb, va) -> (ka, order): the result lands in `order`
-  const int* kin[3] = {keys, ka, kb};
-  int* kout[3] = {ka, kb, ka};
-  const int* vin[3] = {nullptr, order, va};
-  int* vout[3] = {order, va, order};
-  for (int p = 0; p < 3; ++p) {
-    k_radix_hist<<<nblk, 256, 0, s>>>(kin[p], n, p * RB, hist);
-    FC_CHECK_LAUNCH();
-    k_radix_scan<<<1, RBINS, 0, s>>>(hist, nblk);
-    FC_CHECK_LAUNCH();
-    k_radix_scatter<<<nblk, 256, 0, s>>>(kin[p], vin[p], n, p * RB, hist, kout[p], vout[p]);
-    FC_CHECK_LAUNCH();
-  }
+// masks must be filled already (job.masks); ws of every job: ka, kb, va, hist
+int argsort27_batch(const Batch<SortJob>& bt, hipStream_t s) {
+  static_assert(sizeof(Batch<SortJob>) <= 1536, "batch descriptor too large for the kernel-argument block");
+  if (bt.overflow) return FC_EINVAL;
+  if (!bt.count || !bt.blocks()) return 0;
+  Batch<SortJob> tiles = bt;                       // blocks = RTILE tiles
+  tiles.count = 0; tiles.blk0[0] = 0;
+  for (int i = 0; i < bt.count; ++i) tiles.add(bt.j[i], bt.j[i].nblk);
+  const unsigned g = (unsigned)tiles.blocks(), nj = (unsigned)tiles.count;
+#define FC_RADIX_PASS(P)                                  \
+  k_radix_hist<P><<<g, 256, 0, s>>>(tiles);               \
+  FC_CHECK_LAUNCH();                                      \
+  k_radix_scan<<<nj, RBINS, 0, s>>>(tiles);               \
+  FC_CHECK_LAUNCH();                                      \
+  k_radix_scatter<P><<<g, 256, 0, s>>>(tiles);            \
+  FC_CHECK_LAUNCH();
+  FC_RADIX_PASS(0)
+  FC_RADIX_PASS(1)
+  FC_RADIX_PASS(2)
+#undef FC_RADIX_PASS
   return 0;
+}
+void sort_job_ws(SortJob& j, void* ws) {
+  char* w = (char*)ws;
+  j.ka = (int*)w; w += fc_align(4 * j.n, 256);
+  j.kb = (int*)w; w += fc_align(4 * j.n, 256);
+  j.va = (int*)w; w += fc_align(4 * j.n, 256);
+  j.hist = (int*)w;
+  j.nblk = (int)fc_cdiv(j.n > 0 ? j.n : 1, RTILE);
+  j.nbx = (int)fc_cdiv(j.n > 0 ? j.n : 1, 256);
+}
+
+// ---- exact pair lists (fc_kernel_map_pairs) of many (27, n) tables per launch: count pass + fill pass ------------------------------
+constexpr int PBLK = 1024;
+struct PairJob { const int* tab; int* pi; int* po; int* pos; int* cnt; int* blk_cnt; int64_t n; int nblk; };
+__global__ __launch_bounds__(PBLK) void k_plan_pairs_count(Batch<PairJob> bt) {
+  int64_t lb;
+  const PairJob& j = bt.j[batch_find(bt, blockIdx.x, &lb)];
+  const int k = (int)(lb / j.nblk), blk = (int)(lb % j.nblk);
+  const int64_t row = (int64_t)blk * PBLK + threadIdx.x;
+  const int present = row < j.n && j.tab[(int64_t)k * j.n + row] >= 0;
+  const int c = __syncthreads_count(present);
+  if (threadIdx.x == 0) j.blk_cnt[k * j.nblk + blk] = c;
+}
+__global__ __launch_bounds__(PBLK) void k_plan_pairs_fill(Batch<PairJob> bt) {
+  __shared__ int wave_cnt[PBLK / 64];
+  __shared__ int base_s;
+  int64_t lb;
+  const PairJob& j = bt.j[batch_find(bt, blockIdx.x, &lb)];
+  const int k = (int)(lb / j.nblk), blk = (int)(lb % j.nblk), nblk = j.nblk;
+  const int64_t n = j.n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {                                   // pairs of offset k in the blocks before this one
+    int a = 0;
+    for (int b = lane; b < blk; b += 64) a += j.blk_cnt[k * nblk + b];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) base_s = a;
+  }
+  const int64_t row = (int64_t)blk * PBLK + tid;
+  const int v = row < n ? j.tab[(int64_t)k * n + row] : -1;
+  const unsigned long long bal = __ballot(v >= 0);
+  if (lane == 0) wave_cnt[wave] = __popcll(bal);
+  __syncthreads();
+  int pre = base_s;
+  for (int w = 0; w < wave; ++w) pre += wave_cnt[w];
+  const int p = pre + __popcll(bal & ((1ull << lane) - 1ull));
+  if (v >= 0) {
+    j.pi[(int64_t)k * n + p] = v;
+    j.po[(int64_t)k * n + p] = (int)row;
+  }
+  if (row < n) j.pos[(int64_t)k * n + row] = v >= 0 ? p : -1;
+  if (blk == nblk - 1 && tid == PBLK - 1) j.cnt[k] = pre + __popcll(bal);
 }
 
 int live_tiles(const int* cnt, int K) {
@@ -386,12 +553,21 @@ int live_tiles(const int* cnt, int K) {
   return (int)t;
 }
 
+template <typename J, typename F> int launch_batch(const Batch<J>& bt, int threads, hipStream_t s, F kernel) {
+  static_assert(sizeof(Batch<J>) <= 1536, "batch descriptor too large for the kernel-argument block");
+  if (bt.overflow) return FC_EINVAL;
+  if (!bt.count || !bt.blocks()) return 0;
+  kernel<<<(unsigned)bt.blocks(), threads, 0, s>>>(bt);
+  FC_CHECK_LAUNCH();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
 
 int fc_plan_cfg_words(void) { return CFGW; }
-int fc_plan_out_words(int B, int nl) { return HDR + SETW * MAXSETS + MAPR * (2 + 3 * nl + nl) + MAXSETS * (B > 0 ? B : 1) + 64; }
+int fc_plan_out_words(int B, int nl) { return HDR + SETW * MAXSETS + MAPR * (2 + 4 * nl) + MAXSETS * (B > 0 ? B : 1) + 64; }
 
 // stage 1 arena: raw collate, scratch of the chain, the sets of [cm0, m1, m2, L1..Lnl] with their tables, the meta block
 static int64_t stage1_layout(int64_t T, int B, int nl, int nfeat, char* base, void** p /*pointers out*/, int S) {
@@ -399,23 +575,22 @@ static int64_t stage1_layout(int64_t T, int B, int nl, int nfeat, char* base, vo
   int i = 0;
   p[i++] = a.arr<int>(4 * T);                                   // 0 coords_raw
   p[i++] = a.arr<float>((int64_t)nfeat * T);                    // 1 feats_raw
-  p[i++] = a.arr<int>(T);                                       // 2 slot
+  p[i++] = a.arr<int>(T);                                       // 2 slot (even sets)
   p[i++] = a.take(T);                                           // 3 flags
   p[i++] = a.arr<int>(fc_cdiv(T > 0 ? T : 1, 1024) + 1);        // 4 blocksums
   p[i++] = a.arr<int>((int64_t)METAW * S + (int64_t)S * B + 64); // 5 meta
   p[i++] = a.arr<float>((int64_t)nfeat * T);                    // 6 F0
+  p[i++] = a.arr<int>(T);                                       // 7 slot (odd sets)
   const int64_t cap = next_pow2(T > 0 ? 2 * T : 2);
-  for (int s = 0; s < S; ++s) {
-    p[i++] = a.arr<int>(4 * T);                                 // coords of set s
-    p[i++] = a.arr<unsigned long long>(cap);                    // keys
-    p[i++] = a.arr<int>(cap);                                   // vals
-  }
+  p[i++] = a.arr<unsigned long long>(cap * S);                  // 8 keys of all sets (S, cap)
+  p[i++] = a.arr<int>(cap * S);                                 // 9 vals of all sets (S, cap)
+  for (int s = 0; s < S; ++s) p[i++] = a.arr<int>(4 * T);       // 10 + s: coords of set s
   return fc_align(a.off, 256);
 }
 
 int64_t fc_plan_stage1_bytes(int64_t total_points, int B, int nl, int nfeat) {
   if (total_points < 0 || B < 1 || nl < 1 || nl > MAXLV || nfeat < 0) return -1;
-  void* p[7 + 3 * MAXSETS];
+  void* p[10 + MAXSETS];
   return stage1_layout(total_points, B, nl, nfeat, nullptr, p, 3 + nl);
 }
 
@@ -425,34 +600,28 @@ int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int6
   const int64_t T = cfg[C_TOTAL];
   if (B < 1 || B > 32767 || nl < 1 || nl > MAXLV || nfeat < 0 || T < 0 || T > 0x7fffffffLL / 8 || !arena1 || !out || !counts_host) return FC_EINVAL;
   const int S = 3 + nl;
-  void* p[7 + 3 * MAXSETS];
+  void* p[10 + MAXSETS];
   if (arena1_bytes < stage1_layout(T, B, nl, nfeat, (char*)arena1, p, S)) return FC_EWS;
   int4* coords_raw = (int4*)p[0];
   float* feats_raw = (float*)p[1];
-  int* slot = (int*)p[2];
+  int* slots[2] = {(int*)p[2], (int*)p[7]};
   unsigned char* flags = (unsigned char*)p[3];
   int* blocksums = (int*)p[4];
   int* meta = (int*)p[5];
   float* F0 = (float*)p[6];
-  const int64_t nmeta = (int64_t)METAW * S + (int64_t)S * B;
   const int64_t cap0 = next_pow2(T > 0 ? 2 * T : 2);
+  unsigned long long* keys_all = (unsigned long long*)p[8];
+  int* vals_all = (int*)p[9];
+  const int64_t nmeta = (int64_t)METAW * S + (int64_t)S * B;
   FC_HIP(hipMemsetAsync(meta, 0, (size_t)nmeta * sizeof(int), stream));
   const float vs = (float)as_double(cfg[C_VS]), fdiv = (float)as_double(cfg[C_FEATDIV]);
   if (!cfg[C_COORDS_IN] && !(vs > 0.f)) return FC_EINVAL;
-  const unsigned gT = (unsigned)fc_cdiv(T > 0 ? T : 1, 256), gB = (unsigned)fc_cdiv(T > 0 ? T : 1, 1024);
-  for (int s = 0; s < S; ++s) {
-    int4* cs = (int4*)p[7 + 3 * s];
-    unsigned long long* keys = (unsigned long long*)p[8 + 3 * s];
-    int* vals = (int*)p[9 + 3 * s];
-    int* meta_s = meta + METAW * s;
-    int* scene_cnt = meta + METAW * S + (int64_t)s * B;
-    const int* n_in_dev = s ? meta + METAW * (s - 1) : nullptr;
-    const int4* src = s ? (const int4*)p[7 + 3 * (s - 1)] : coords_raw;
-    const int q = 1 << s;
-    k_plan_table_init<<<(unsigned)fc_cdiv(cap0, 256), 256, 0, stream>>>(keys, vals, n_in_dev, T, meta_s);
+  if (T > 0) {
+    k_plan_tables_init<<<(unsigned)fc_cdiv(cap0 * S, 512), 256, 0, stream>>>(keys_all, vals_all, cap0 * S);
     FC_CHECK_LAUNCH();
-    if (T == 0) continue;
-    if (s == 0 && !cfg[C_COORDS_IN]) {
+    // ---- level 0: the collate + insert ----
+    const int4* src0 = coords_raw;
+    if (!cfg[C_COORDS_IN]) {
       int64_t off = 0;
       for (int b0 = 0; b0 < B; b0 += CH) {
         SceneArgs sc;
@@ -472,27 +641,34 @@ int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int6
         if (sc.stride < 3 + nfeat) return FC_EINVAL;
         if (maxn > 0) {
           dim3 grid((unsigned)fc_cdiv(maxn, 256), nb);
-          k_plan_voxelize_insert<<<grid, 256, 0, stream>>>(sc, coords_raw, feats_raw, keys, vals, cap0, meta_s, slot);
+          k_plan_voxelize_insert<<<grid, 256, 0, stream>>>(sc, coords_raw, feats_raw, keys_all, vals_all, table_mask(T), meta, slots[0]);
           FC_CHECK_LAUNCH();
         }
       }
       if (off != T) return FC_EINVAL;
-    } else {
-      if (s == 0) {                                // pre-voxelised input (an augmenting pipeline wrote coords / feats itself)
-        src = (const int4*)cfg[C_COORDS_IN];
-        feats_raw = (float*)cfg[C_FEATS_IN];
-        if (!feats_raw && nfeat) return FC_EINVAL;
-      }
-      k_plan_insert<<<gT, 256, 0, stream>>>(src, n_in_dev, T, q, keys, vals, meta_s, slot);
+    } else {                                       // pre-voxelised input (an augmenting pipeline wrote coords / feats itself)
+      src0 = (const int4*)cfg[C_COORDS_IN];
+      feats_raw = (float*)cfg[C_FEATS_IN];
+      if (!feats_raw && nfeat) return FC_EINVAL;
+      k_plan_insert<<<(unsigned)fc_cdiv(T, 256), 256, 0, stream>>>(src0, T, keys_all, vals_all, table_mask(T), meta, slots[0]);
       FC_CHECK_LAUNCH();
     }
-    k_plan_flags<<<gB, 256, 0, stream>>>(slot, vals, n_in_dev, T, flags, blocksums);
-    FC_CHECK_LAUNCH();
-    k_plan_scan<<<1, 1024, 0, stream>>>(blocksums, (int)gB, meta_s);
-    FC_CHECK_LAUNCH();
-    k_plan_finalize<<<gB, 256, 0, stream>>>(src, n_in_dev, T, q, flags, blocksums, slot, vals, cs, s == 0 ? feats_raw : nullptr,
-                                           s == 0 ? F0 : nullptr, nfeat, scene_cnt, B);
-    FC_CHECK_LAUNCH();
+    // ---- the chain: two launches per set ----
+    const unsigned gB = (unsigned)fc_cdiv(T, 1024);
+    for (int s = 0; s < S; ++s) {
+      int* meta_s = meta + METAW * s;
+      const int* n_in_dev = s ? meta + METAW * (s - 1) : nullptr;
+      const int4* src = s ? (const int4*)p[10 + s - 1] : src0;
+      int* vals = vals_all + cap0 * s;
+      k_plan_flags_scan<<<gB, 256, 0, stream>>>(slots[s & 1], vals, n_in_dev, T, flags, blocksums, meta_s);
+      FC_CHECK_LAUNCH();
+      const bool more = s + 1 < S;
+      k_plan_finalize<<<gB, 256, 0, stream>>>(src, n_in_dev, T, 1 << s, flags, blocksums, slots[s & 1], vals, (int4*)p[10 + s],
+                                             s == 0 ? feats_raw : nullptr, s == 0 ? F0 : nullptr, nfeat,
+                                             meta + METAW * S + (int64_t)s * B, B, meta_s, more ? keys_all + cap0 * (s + 1) : nullptr,
+                                             more ? vals_all + cap0 * (s + 1) : nullptr, slots[(s + 1) & 1]);
+      FC_CHECK_LAUNCH();
+    }
   }
   int rc = sync_readback(counts_host, meta, nmeta * (int64_t)sizeof(int), stream);
   if (rc) return rc;
@@ -506,12 +682,12 @@ int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int6
   for (int s = 0; s < S; ++s) {
     const int* m = counts_host + METAW * s;
     int64_t* o = out + HDR + SETW * s;
-    o[S_COORDS] = (int64_t)p[7 + 3 * s];
+    o[S_COORDS] = (int64_t)p[10 + s];
     o[S_N] = m[0];
     o[S_STRIDE] = 1 << s;
-    o[S_KEYS] = (int64_t)p[8 + 3 * s];
-    o[S_VALS] = (int64_t)p[9 + 3 * s];
-    o[S_CAP] = m[1];
+    o[S_KEYS] = (int64_t)(keys_all + cap0 * s);
+    o[S_VALS] = (int64_t)(vals_all + cap0 * s);
+    o[S_CAP] = (int64_t)table_mask(s ? counts_host[METAW * (s - 1)] : T) + 1;
     o[S_PARENT] = -1;
     bad |= m[2];
   }
@@ -522,7 +698,8 @@ int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int6
 // ---- stage 2 -------------------------------------------------------------------------------------------------------------------
 struct MapRec { int in, out, K; int64_t n_in, n_out; bool dense, self; };
 
-// Everything stage 2 builds, as one pass over a bump allocator: base == nullptr sizes the arena, otherwise the kernels are enqueued.
+// Everything stage 2 builds, as one pass over a bump allocator: base == nullptr sizes the arena, otherwise the kernels are enqueued
+// — one (or a few) launches per KIND of job.
 static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char* base, int64_t* need, int* cnt_host, hipStream_t stream) {
   const int B = (int)cfg[C_B], nl = (int)cfg[C_NL];
   const bool backward = cfg[C_BACKWARD] != 0, neck = cfg[C_NECK] != 0, targets = cfg[C_TARGETS] != 0;
@@ -532,33 +709,31 @@ static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char
   Bump a{base, 0};
   int64_t* sets = out + HDR;
   auto SN = [&](int s) { return sets[SETW * s + S_N]; };
-  auto SC = [&](int s) { return (const int*)sets[SETW * s + S_COORDS]; };
+  auto SC = [&](int s) { return (const int4*)sets[SETW * s + S_COORDS]; };
+  const int cs = S0 - 1;                            // the coarsest backbone level: every generated row follows from it
   // ---- neck sets: g_i = children of the head level above it, i = nl-2 .. 0 (set index S0 + (nl-2-i)) ----
   int S = S0;
   int head_set[MAXLV];                              // head level l (finest first) -> set index
   int prune = -1;
-  int ngen = 0;
+  Batch<GenJob> gen;
   if (neck) {
-    int x = S0 - 1;                                 // the coarsest backbone level
+    int x = cs;
     head_set[nl - 1] = x;
     for (int i = nl - 2; i >= 0; --i) {
       const int g = S++;
+      const int depth = nl - 1 - i;
       int64_t* o = sets + SETW * g;
       o[S_N] = 8 * SN(x);
       o[S_STRIDE] = sets[SETW * x + S_STRIDE] / 2;
       o[S_PARENT] = x;
+      o[S_KEYS] = o[S_VALS] = o[S_CAP] = 0;
       o[S_COORDS] = (int64_t)a.arr<int>(4 * o[S_N]);
       o[S_ROWS] = (int64_t)a.arr<int>(SN(3 + i));
-      ++ngen;
       head_set[i] = g;
-      if (run) {
-        int rc = fc_gen_coords(SC(x), SN(x), (int)o[S_STRIDE], (int*)o[S_COORDS], stream);
-        if (rc) return rc;
-      }
-      // pts_threshold (fcaf3d_neck_with_head.py:110-126): rows of a scene in g = 8 * its rows in the coarsest level * 8^depth
+      gen.add({SC(cs), (int4*)o[S_COORDS], o[S_N], depth, (int)o[S_STRIDE], 0}, fc_cdiv(o[S_N], 256));
+      // pts_threshold (fcaf3d_neck_with_head.py:110-126): rows of a scene in g = its rows in the coarsest level * 8^depth
       if (pts_thr >= 0 && prune < 0) {
-        const int depth = nl - 1 - i;
-        const int* sc_cnt = counts_host + METAW * S0 + (int64_t)(S0 - 1) * B;
+        const int* sc_cnt = counts_host + METAW * S0 + (int64_t)cs * B;
         for (int b = 0; b < B; ++b)
           if (((int64_t)sc_cnt[b] << (3 * depth)) > pts_thr) prune = i;
       }
@@ -585,22 +760,22 @@ static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char
   int64_t* maps = out + HDR + SETW * MAXSETS;
   // the pair-list counters of all maps sit in ONE block (read back together): 2 x 27 ints per map + union hit counters
   int* cnt_dev = a.arr<int>(64 * nm + MAXLV);
-  if (run) FC_HIP(hipMemsetAsync(cnt_dev, 0, sizeof(int) * (64 * nm + MAXLV), stream));
-  // scratch shared by the derived tables (stream order serialises its users)
-  int64_t max_rows = 1;
-  for (int m = 0; m < nm; ++m) { if (mr[m].n_in > max_rows) max_rows = mr[m].n_in; if (mr[m].n_out > max_rows) max_rows = mr[m].n_out; }
-  int* masks = a.arr<int>(max_rows);
-  void* sort_ws = a.take(argsort27_ws_bytes(max_rows));
-  const int64_t pairs_ws_bytes = fc_kernel_map_pairs_ws_bytes(max_rows, 27);
-  void* pairs_ws = a.take(pairs_ws_bytes);
 
+  Batch<KMapJob> kmaps;
+  Batch<RowJob> fills, rows;                        // fills (-1) run before the scatters
+  Batch<SortJob> sorts;
+  Batch<PairJob> pairs;
+  struct Child { const int* pnbr; int64_t n_parent; int* nbr; } children[MAXLV];
+  int nchildren = 0;
+
+  // -- pass A: the tables themselves --
   for (int m = 0; m < nm; ++m) {
     const MapRec& r = mr[m];
     int64_t* o = maps + MAPR * m;
     o[MW_IN] = r.in; o[MW_OUT] = r.out; o[MW_K] = r.K; o[MW_NIN] = r.n_in; o[MW_NOUT] = r.n_out;
-    const bool conv = m >= 2;
-    const bool is_ds = r.K == 1;
     const int64_t* din = sets + SETW * r.in;
+    const bool is_ds = r.K == 1;
+    const bool conv = m >= 2;
     int* nbr = nullptr;
     int* nbr_t = nullptr;
     if (is_ds) {                                    // k1 s2: the centre row of the k3 s2 table of the same pair of sets
@@ -611,153 +786,162 @@ static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char
       }
     } else {
       nbr = a.arr<int>((int64_t)r.K * r.n_out);
-      if (run && r.n_out > 0) {
-        if (r.dense) {                              // generated set: from the parent's own k3 table (index arithmetic)
-          const int par = (int)din[S_PARENT];
-          const int64_t* op = nullptr;              // the parent's k3 s1 map: `same` of the coarsest level, or the gsame above
-          for (int mm = 0; mm < m; ++mm)
-            if (mr[mm].self && mr[mm].in == par) op = maps + MAPR * mm;
-          if (!op) return FC_EINVAL;
-          int rc = fc_kernel_map_children((const int*)op[MW_NBR], SN(par), nbr, stream);
-          if (rc) return rc;
+      if (r.dense) {                                // generated set: from the parent's own k3 table (index arithmetic)
+        const int par = (int)din[S_PARENT];
+        const int64_t* op = nullptr;                // the parent's k3 s1 map: `same` of the coarsest level, or the gsame above
+        for (int mm = 0; mm < m; ++mm)
+          if (mr[mm].self && mr[mm].in == par) op = maps + MAPR * mm;
+        if (!op) return FC_EINVAL;
+        children[nchildren++] = {(const int*)op[MW_NBR], SN(par), nbr};
+      } else {
+        const int ks = r.K == 27 ? 3 : 2;
+        const int nbx = (int)fc_cdiv(r.n_out, 256);
+        kmaps.add({SC(r.out), (const unsigned long long*)din[S_KEYS], (const int*)din[S_VALS], (unsigned long long)(din[S_CAP] - 1), nbr,
+                   r.n_out, r.K, ks, (int)din[S_STRIDE], nbx}, (int64_t)r.K * nbx);
+      }
+      if (conv && backward) {
+        nbr_t = a.arr<int>((int64_t)r.K * r.n_in);
+        const int nbx = (int)fc_cdiv(r.n_in, 256);
+        if (r.self) {
+          rows.add({nbr, nbr_t, r.n_in, r.n_in, r.K, 0, nbx}, (int64_t)r.K * nbx);
         } else {
-          const int ks = r.K == 27 ? 3 : 2;
-          dim3 grid((unsigned)fc_cdiv(r.n_out, 256), r.K);
-          k_plan_kernel_map<<<grid, 256, 0, stream>>>((const int4*)SC(r.out), r.n_out, (const unsigned long long*)din[S_KEYS],
-                                                     (const int*)din[S_VALS], (unsigned long long)(din[S_CAP] - 1), ks, (int)din[S_STRIDE], nbr);
-          FC_CHECK_LAUNCH();
+          fills.add({nullptr, nbr_t, r.n_in, r.n_in, r.K, 1, nbx}, (int64_t)r.K * nbx);
+          const int nbo = (int)fc_cdiv(r.n_out, 256);
+          rows.add({nbr, nbr_t, r.n_out, r.n_in, r.K, 2, nbo}, (int64_t)r.K * nbo);
         }
       }
     }
     o[MW_NBR] = (int64_t)nbr;
+    o[MW_NBRT] = (int64_t)nbr_t;
     int64_t* df = o + MW_DESC_F;
     int64_t* db = o + MW_DESC_B;
     df[0] = db[0] = r.n_in; df[1] = db[1] = r.n_out; df[2] = db[2] = r.K; df[3] = db[3] = (int64_t)nbr;
     const bool sort_rows = r.K == 27 && !r.dense && r.n_out >= sort_min;
     const bool use_pairs = r.K == 27 && !r.dense;
     o[MW_FLAGS] = (sort_rows ? 1 : 0) | (use_pairs ? 2 : 0) | (r.dense ? 4 : 0);
-    if (!conv) continue;                            // stem / pooling: their own kernels read the plain table
-    // -- forward route --
-    auto pair_lists = [&](const int* tab, int64_t rows, int base_word, int* cnt) -> int {
-      int* pi = a.arr<int>(27 * rows);
-      int* po = a.arr<int>(27 * rows);
-      int* pos = a.arr<int>(27 * rows);
-      o[base_word] = (int64_t)pi; o[base_word + 1] = (int64_t)po; o[base_word + 2] = (int64_t)pos; o[base_word + 3] = (int64_t)cnt;
-      if (run) return fc_kernel_map_pairs(tab, rows, 27, pi, po, pos, cnt, pairs_ws, pairs_ws_bytes, stream);
-      return 0;
+  }
+  // -- pass B: the derived tables of every convolution route --
+  for (int m = 2; m < nm; ++m) {
+    const MapRec& r = mr[m];
+    int64_t* o = maps + MAPR * m;
+    int* nbr = (int*)o[MW_NBR];
+    int* nbr_t = (int*)o[MW_NBRT];
+    const bool sort_rows = (o[MW_FLAGS] & 1) != 0, use_pairs = (o[MW_FLAGS] & 2) != 0;
+    auto pair_lists = [&](const int* tab, int64_t n, int base_word, int* cnt) {
+      PairJob j;
+      j.tab = tab; j.n = n; j.cnt = cnt;
+      j.pi = a.arr<int>(27 * n); j.po = a.arr<int>(27 * n); j.pos = a.arr<int>(27 * n);
+      j.nblk = (int)fc_cdiv(n > 0 ? n : 1, PBLK);
+      j.blk_cnt = a.arr<int>(27 * (int64_t)j.nblk);
+      o[base_word] = (int64_t)j.pi; o[base_word + 1] = (int64_t)j.po; o[base_word + 2] = (int64_t)j.pos; o[base_word + 3] = (int64_t)cnt;
+      pairs.add(j, n > 0 ? 27 * (int64_t)j.nblk : 0);
     };
-    auto sorted = [&](const int* tab, int64_t rows, int w_tab, int w_idx) -> int {
-      int* order = a.arr<int>(rows);
-      int* st = a.arr<int>(27 * rows);
-      o[w_tab] = (int64_t)st; o[w_idx] = (int64_t)order;
-      if (!run || rows == 0) return 0;
-      int rc = fc_nbr_row_masks(tab, rows, 27, masks, stream);
-      if (rc) return rc;
-      rc = argsort27(masks, rows, order, sort_ws, stream);
-      if (rc) return rc;
-      return fc_permute_nbr(tab, order, rows, 27, st, stream);
+    auto sorted = [&](const int* tab, int64_t n, int w_tab, int w_idx) {
+      SortJob j;
+      memset(&j, 0, sizeof(j));
+      j.tab = tab; j.n = n;
+      j.order = a.arr<int>(n);
+      j.sorted = a.arr<int>(27 * n);
+      j.masks = a.arr<int>(n);
+      sort_job_ws(j, a.take(argsort27_ws_bytes(n)));
+      o[w_tab] = (int64_t)j.sorted; o[w_idx] = (int64_t)j.order;
+      sorts.add(j, j.nbx);
     };
     int* cnt_f = cnt_dev + 64 * m;
     int* cnt_t = cnt_dev + 64 * m + 32;
     bool have_pairs = false;
     if (use_pairs && r.n_out <= pair_rows) {
-      int rc = pair_lists(nbr, r.n_out, MW_PI, cnt_f);
-      if (rc) return rc;
+      pair_lists(nbr, r.n_out, MW_PI, cnt_f);
       have_pairs = true;
     } else if (sort_rows) {
-      int rc = sorted(nbr, r.n_out, MW_SORT, MW_SORTI);
-      if (rc) return rc;
+      sorted(nbr, r.n_out, MW_SORT, MW_SORTI);
     } else {
       o[MW_SORT] = (int64_t)nbr; o[MW_SORTI] = 0;
     }
-    // -- backward tables --
     if (backward) {
-      if (!is_ds) {
-        nbr_t = a.arr<int>((int64_t)r.K * r.n_in);
-        if (run && r.n_in > 0) {
-          if (r.self) {
-            dim3 grid((unsigned)fc_cdiv(r.n_in, 256), r.K);
-            k_plan_reverse_rows<<<grid, 256, 0, stream>>>(nbr, r.n_in, r.K, nbr_t);
-            FC_CHECK_LAUNCH();
-          } else {
-            int rc = fc_kernel_map_transpose(nbr, r.n_out, r.n_in, r.K, nbr_t, stream);
-            if (rc) return rc;
-          }
-        }
-      }
-      o[MW_NBRT] = (int64_t)nbr_t;
-      if (use_pairs && !have_pairs) {               // the weight gradient reduces over exact pair lists
-        int rc = pair_lists(nbr, r.n_out, MW_PI, cnt_f);
-        if (rc) return rc;
-        have_pairs = true;
-      }
+      if (use_pairs && !have_pairs) pair_lists(nbr, r.n_out, MW_PI, cnt_f);      // the weight gradient reduces over exact pair lists
       if (use_pairs && r.n_in <= pair_rows) {
-        int rc = pair_lists(nbr_t, r.n_in, MW_TPI, cnt_t);
-        if (rc) return rc;
+        pair_lists(nbr_t, r.n_in, MW_TPI, cnt_t);
       } else if (sort_rows) {
-        int rc = sorted(nbr_t, r.n_in, MW_SORTT, MW_SORTTI);
-        if (rc) return rc;
+        sorted(nbr_t, r.n_in, MW_SORTT, MW_SORTTI);
       } else {
         o[MW_SORTT] = (int64_t)nbr_t; o[MW_SORTTI] = 0;
       }
     }
   }
   // ---- union rows of the backbone levels inside the generated sets (fcaf3d_neck_with_head.py:101) ----
-  const int cs = S0 - 1;                            // coarsest backbone level: the one table every generated row follows from
+  Batch<GenRowsJob> grows;
   for (int g = S0; g < S; ++g) {
     const int i = nl - 2 - (g - S0);                // backbone level index (0-based): set 3 + i
-    const int depth = nl - 1 - i;
-    if (run && SN(3 + i) > 0) {
-      const int64_t* oc = sets + SETW * cs;
-      k_plan_gen_rows<<<(unsigned)fc_cdiv(SN(3 + i), 256), 256, 0, stream>>>(
-          (const int4*)SC(3 + i), SN(3 + i), (const unsigned long long*)oc[S_KEYS], (const int*)oc[S_VALS],
-          (unsigned long long)(oc[S_CAP] - 1), (int)sets[SETW * (3 + i) + S_STRIDE], depth, (int*)sets[SETW * g + S_ROWS],
-          cnt_dev + 64 * nm + (g - S0));
-      FC_CHECK_LAUNCH();
-    }
+    grows.add({SC(3 + i), (int*)sets[SETW * g + S_ROWS], cnt_dev + 64 * nm + (g - S0), SN(3 + i), (int)sets[SETW * (3 + i) + S_STRIDE],
+               nl - 1 - i}, fc_cdiv(SN(3 + i), 256));
   }
   // ---- the head's location arrays (training: what the target assignment and the loss read) ----
   int64_t n_all = 0;
   if (neck && prune < 0)
     for (int l = 0; l < nl; ++l) n_all += SN(head_set[l]);
   out[H_NALL] = n_all;
-  if (targets && neck && prune < 0) {
-    float* pts = a.arr<float>(3 * n_all);
-    int* scene = a.arr<int>(n_all);
-    int* level = a.arr<int>(n_all);
-    int* order = a.arr<int>(n_all);
-    int* seg = a.arr<int>((int64_t)nl * B + 1);
+  float* pts = nullptr; int* scene = nullptr; int* level = nullptr; int* order = nullptr; int* seg = nullptr;
+  const bool want_head = targets && neck && prune < 0;
+  if (want_head) {
+    pts = a.arr<float>(3 * n_all); scene = a.arr<int>(n_all); level = a.arr<int>(n_all); order = a.arr<int>(n_all);
+    seg = a.arr<int>((int64_t)nl * B + 1);
     out[H_TGT_PTS] = (int64_t)pts; out[H_TGT_SCENE] = (int64_t)scene; out[H_TGT_LEVEL] = (int64_t)level;
     out[H_TGT_ORDER] = (int64_t)order; out[H_TGT_SEG] = (int64_t)seg;
-    if (run) {
-      HeadArgs h;
-      memset(&h, 0, sizeof(h));
-      h.nl = nl; h.vs = (float)as_double(cfg[C_VS_HEAD]);
-      int64_t off = 0;
-      for (int l = 0; l < nl; ++l) { h.coords[l] = (const int4*)SC(head_set[l]); h.off[l] = off; off += SN(head_set[l]); }
-      h.off[nl] = off;
-      if (n_all > 0) {
-        k_plan_head_arrays<<<(unsigned)fc_cdiv(n_all, 256), 256, 0, stream>>>(h, pts, scene, level, order);
-        FC_CHECK_LAUNCH();
-      }
-      // (level, scene) segment starts: rows per scene of a generated set = 8^depth x those of the coarsest level — host arithmetic,
-      // staged in the caller's pinned counter block (it stays untouched until the read-back below)
-      int* stage = cnt_host + 64 * nm + MAXLV;
-      const int* sc_cnt = counts_host + METAW * S0 + (int64_t)(S0 - 1) * B;
-      int64_t run_ = 0;
-      for (int l = 0; l < nl; ++l)
-        for (int b = 0; b < B; ++b) {
-          stage[l * B + b] = (int)run_;
-          run_ += (int64_t)sc_cnt[b] << (3 * (nl - 1 - l));
-        }
-      stage[nl * B] = (int)run_;
-      FC_HIP(hipMemcpyAsync(seg, stage, sizeof(int) * ((size_t)nl * B + 1), hipMemcpyHostToDevice, stream));
-    }
   }
   *need = fc_align(a.off, 256);
   if (!run) return 0;
+
+  // ---- launches, in dependency order ----
+  FC_HIP(hipMemsetAsync(cnt_dev, 0, sizeof(int) * (64 * nm + MAXLV), stream));
+  int rc;
+  if ((rc = launch_batch(gen, 256, stream, k_plan_gen_coords))) return rc;
+  if ((rc = launch_batch(kmaps, 256, stream, k_plan_kernel_maps))) return rc;
+  for (int c = 0; c < nchildren; ++c)              // a chain: each generated set's table from the one above it
+    if ((rc = fc_kernel_map_children(children[c].pnbr, children[c].n_parent, children[c].nbr, stream))) return rc;
+  if ((rc = launch_batch(fills, 256, stream, k_plan_rows))) return rc;
+  if ((rc = launch_batch(rows, 256, stream, k_plan_rows))) return rc;
+  if ((rc = launch_batch(sorts, 256, stream, k_plan_row_masks))) return rc;
+  if ((rc = argsort27_batch(sorts, stream))) return rc;
+  {
+    Batch<SortJob> perm;
+    for (int i = 0; i < sorts.count; ++i) perm.add(sorts.j[i], 27 * (int64_t)sorts.j[i].nbx);
+    if ((rc = launch_batch(perm, 256, stream, k_plan_permute))) return rc;
+  }
+  if ((rc = launch_batch(pairs, PBLK, stream, k_plan_pairs_count))) return rc;
+  if ((rc = launch_batch(pairs, PBLK, stream, k_plan_pairs_fill))) return rc;
+  if (grows.count && grows.blocks()) {
+    const int64_t* oc = sets + SETW * cs;
+    k_plan_gen_rows<<<(unsigned)grows.blocks(), 256, 0, stream>>>(grows, (const unsigned long long*)oc[S_KEYS], (const int*)oc[S_VALS],
+                                                                 (unsigned long long)(oc[S_CAP] - 1));
+    FC_CHECK_LAUNCH();
+  }
+  if (want_head) {
+    HeadArgs h;
+    memset(&h, 0, sizeof(h));
+    h.nl = nl; h.vs = (float)as_double(cfg[C_VS_HEAD]);
+    int64_t off = 0;
+    for (int l = 0; l < nl; ++l) { h.coords[l] = SC(head_set[l]); h.off[l] = off; off += SN(head_set[l]); }
+    h.off[nl] = off;
+    if (n_all > 0) {
+      k_plan_head_arrays<<<(unsigned)fc_cdiv(n_all, 256), 256, 0, stream>>>(h, pts, scene, level, order);
+      FC_CHECK_LAUNCH();
+    }
+    // (level, scene) segment starts: rows per scene of a generated set = 8^depth x those of the coarsest level — host arithmetic,
+    // staged in the caller's pinned counter block (it stays untouched until the read-back below)
+    int* stage = cnt_host + 64 * nm + MAXLV;
+    const int* sc_cnt = counts_host + METAW * S0 + (int64_t)cs * B;
+    int64_t run_ = 0;
+    for (int l = 0; l < nl; ++l)
+      for (int b = 0; b < B; ++b) {
+        stage[l * B + b] = (int)run_;
+        run_ += (int64_t)sc_cnt[b] << (3 * (nl - 1 - l));
+      }
+    stage[nl * B] = (int)run_;
+    FC_HIP(hipMemcpyAsync(seg, stage, sizeof(int) * ((size_t)nl * B + 1), hipMemcpyHostToDevice, stream));
+  }
   // ---- ONE read-back: pair-list counts of every map, union hit counters ----
-  int rc = sync_readback(cnt_host, cnt_dev, sizeof(int) * (64 * nm + MAXLV), stream);
+  rc = sync_readback(cnt_host, cnt_dev, sizeof(int) * (64 * nm + MAXLV), stream);
   if (rc) return rc;
   int structured = 1;
   for (int g = S0; g < S; ++g) {
@@ -823,7 +1007,14 @@ int64_t fc_argsort27_ws_bytes(int64_t n) { return argsort27_ws_bytes(n); }
 int fc_argsort27(const int* keys, int64_t n, int* order, void* ws, int64_t ws_bytes, hipStream_t stream) {
   if (n < 0) return FC_EINVAL;
   if (ws_bytes < argsort27_ws_bytes(n)) return FC_EWS;
-  return argsort27(keys, n, order, ws, stream);
+  if (n == 0) return FC_OK;
+  Batch<SortJob> bt;
+  SortJob j;
+  memset(&j, 0, sizeof(j));
+  j.n = n; j.masks = const_cast<int*>(keys); j.order = order;
+  sort_job_ws(j, ws);
+  bt.add(j, j.nbx);
+  return argsort27_batch(bt, stream);
 }
 
 }  // extern "C"
