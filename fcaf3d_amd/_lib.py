@@ -40,6 +40,7 @@ def parse_header(path=HEADER):
     return protos
 
 
+ABI_VERSION = 6          # include/fcaf3d_hip.h FC_ABI_VERSION
 _lib = None
 _protos = None
 
@@ -57,6 +58,9 @@ def lib():
             fn = getattr(l, name)            # AttributeError if the library lacks a declared symbol
             fn.restype = ret
             fn.argtypes = [t for _, t in args]
+        if l.fc_abi_version() != ABI_VERSION:
+            raise RuntimeError(f'{LIB_PATH} speaks ABI version {l.fc_abi_version()}, this host code was written for {ABI_VERSION}: rebuild '
+                               'with `python -m fcaf3d_amd.build`')
         _lib = l
         if os.environ.get('FC_PRIO_OFF') or os.environ.get('FC_PRIO_MODE'):     # A/B switches of the MFMA-block wave priority
             l.fc_debug_set_prio(-1 if os.environ.get('FC_PRIO_OFF') else int(os.environ['FC_PRIO_MODE']))      # (conv.hip: g_fc_prio)

@@ -232,16 +232,23 @@ int fc_scan_flags(const unsigned char* flags, int64_t n, int* pos, int* total_de
   return scan_flags(flags, n, pos, total_dev, (int*)ws, stream);
 }
 
-// kept[pos[i]] = i for flagged rows
+__global__ void k_fill_i32(int* __restrict__ p, int64_t n, int v);
+// kept[pos[i]] = i for flagged rows; entries at or past the output's capacity m are dropped (a caller that sizes `kept` from a
+// count it knows by construction — sparse.compact_mask(expect_n) — can never be written out of bounds: ADVICE r5)
 __global__ void k_scatter_kept(const unsigned char* __restrict__ flags, const int* __restrict__ pos, int64_t n,
-                               int* __restrict__ kept) {
+                               int* __restrict__ kept, int64_t m) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && flags[i]) kept[pos[i]] = (int)i;
+  if (i < n && flags[i] && pos[i] < m) kept[pos[i]] = (int)i;
 }
 
-int fc_compact_rows(const unsigned char* flags, const int* pos, int64_t n, int* kept, hipStream_t stream) {
-  if (n <= 0) return n < 0 ? FC_EINVAL : FC_OK;
-  k_scatter_kept<<<(unsigned)fc_cdiv(n, 256), 256, 0, stream>>>(flags, pos, n, kept);
+int fc_compact_rows(const unsigned char* flags, const int* pos, int64_t n, int* kept, int64_t m, hipStream_t stream) {
+  if (n < 0 || m < 0) return FC_EINVAL;
+  if (m > 0) {                                   // deterministic contents where fewer than m flags are set
+    k_fill_i32<<<(unsigned)fc_cdiv(m, 256), 256, 0, stream>>>(kept, m, 0);
+    FC_CHECK_LAUNCH();
+  }
+  if (n == 0 || m == 0) return FC_OK;
+  k_scatter_kept<<<(unsigned)fc_cdiv(n, 256), 256, 0, stream>>>(flags, pos, n, kept, m);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }

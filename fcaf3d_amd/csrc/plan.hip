@@ -566,6 +566,7 @@ template <typename J, typename F> int launch_batch(const Batch<J>& bt, int threa
 
 extern "C" {
 
+int fc_abi_version(void) { return FC_ABI_VERSION; }
 int fc_plan_cfg_words(void) { return CFGW; }
 int fc_plan_out_words(int B, int nl) { return HDR + SETW * MAXSETS + MAPR * (2 + 4 * nl) + MAXSETS * (B > 0 ? B : 1) + 64; }
 

@@ -935,9 +935,10 @@ def program_for(det, training, tail0=False):
     if tail0 and min(det.backbone.n_outs, 4) < 2:
         return None
     key = (bool(training), bool(Fn.WGRAD_ASYNC), bool(nh.head_overlap), bool(tail0))
+    fuse = bool(Fn.BN_FUSE)                    # changes the emitted program (statistics tables, producer words): part of the cache key
     cache = det.__dict__.setdefault('_programs', {})
     sig = NetProgram.signature(det)
-    prog = cache.get(key)
+    prog = cache.get(key + (fuse,))
     if prog is None or prog._sig != sig:
-        prog = cache[key] = NetProgram(det, *key)
+        prog = cache[key + (fuse,)] = NetProgram(det, *key)
     return prog

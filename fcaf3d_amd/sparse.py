@@ -548,7 +548,7 @@ def compact_mask(mask, expect_n=None):
     L.call('fc_scan_flags', L.ptr(flags), n, L.ptr(pos), L.ptr(cnt), L.ptr(ws), ws.numel(), L.stream())
     m = int(cnt.item()) if expect_n is None else int(expect_n)
     kept = torch.empty(m, dtype=torch.int32, device=dev)
-    L.call('fc_compact_rows', L.ptr(flags), L.ptr(pos), n, L.ptr(kept), L.stream())
+    L.call('fc_compact_rows', L.ptr(flags), L.ptr(pos), n, L.ptr(kept), m, L.stream())
     return kept
 
 

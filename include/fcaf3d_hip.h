@@ -28,6 +28,13 @@ typedef struct ihipStream_t* hipStream_t;
 extern "C" {
 #endif
 
+/* Version of this ABI (No reference counterpart): bumped whenever a prototype or the meaning of a flag bit changes — r5 -> 5
+ * (flags bit27 went from "input is pre-split planes" to "flat addressing", fc_x6_planes / fc_conv_x6d removed: ADVICE r5),
+ * r6 -> 6 (fc_compact_rows takes the output capacity; fc_plan_*, fc_argsort27, fc_set_split3 added).  A caller built against another
+ * version must not go on: tests/test_cabi.py pins the number the Python host was written for. */
+#define FC_ABI_VERSION 6
+int fc_abi_version(void);
+
 /* ---- coordinates -------------------------------------------------------------------------- */
 
 /* ME.utils.batch_sparse_collate quantisation of one scene — single_stage_sparse.py:34-36.
@@ -52,10 +59,11 @@ int fc_augment_voxelize(const float* points, int64_t n_src, int pt_stride, const
 int fc_morton_keys(const int* coords, int64_t n, long long* keys, hipStream_t stream);
 
 /* Order-preserving compaction primitive (wave ballot + prefix sum): pos[i] = #set flags before i — the row selection
- * of ME.MinkowskiPruning (fcaf3d_neck_with_head.py:76, called at :124-125) and of the per-scene decomposition. */
+ * of ME.MinkowskiPruning (fcaf3d_neck_with_head.py:76, called at :124-125) and of the per-scene decomposition.
+ * fc_compact_rows: kept has room for m entries (r6: set flags past that capacity are dropped, missing ones read 0). */
 int fc_scan_flags(const unsigned char* flags, int64_t n, int* pos, int* total_dev, void* ws, int64_t ws_bytes,
                   hipStream_t stream);
-int fc_compact_rows(const unsigned char* flags, const int* pos, int64_t n, int* kept, hipStream_t stream);
+int fc_compact_rows(const unsigned char* flags, const int* pos, int64_t n, int* kept, int64_t m, hipStream_t stream);
 
 /* ME.SparseTensor(coordinates, features) de-duplication (single_stage_sparse.py:37) and the strided
  * output coordinate set of MinkowskiConvolution/MaxPooling(stride=2) (me_resnet.py:19-24,56-62):

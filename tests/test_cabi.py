@@ -16,6 +16,13 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_abi_version_matches_the_header_and_the_host():
+    import re
+    from fcaf3d_amd._lib import HEADER
+    v = int(re.search(r'#define FC_ABI_VERSION (\d+)', open(HEADER).read()).group(1))
+    assert L.lib().fc_abi_version() == v == L.ABI_VERSION
+
+
 def test_size_queries_run_without_gpu():
     assert L.query('fc_hash_unique_ws_bytes', 1000) > 0
     assert L.query('fc_conv_wgrad_ws_bytes', 100000, 27, 64, 64, 0) >= 27 * 64 * 64 * 4

@@ -193,28 +193,33 @@ def test_config4_per_gpu_shape_two_ranks():
     assert abs(dp - glob) <= 1e-3 * abs(glob), (dp, glob)
 
 
-def test_bench_two_ranks_on_one_gpu_prints_the_contract_line():
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU) — here with both ranks on cuda:0 and
-    gloo instead of RCCL (FC_DIST_BACKEND=gloo; RCCL needs one GPU per rank): the ONE JSON line on rank 0 carries n_gpus = 2, weak
-    scaling, BASELINE config 4 (global batch 16 split over the ranks) and a non-empty bucket log.  RCCL itself with N > 1 is the
-    driver's N = 2 / 4 / 8 pass (tools/dist_train.sh:7-9, configs/fcaf3d/fcaf3d.py:43)."""
+@pytest.mark.parametrize('ranks,batch', [(2, 8), (4, 4), (8, 2)])
+def test_bench_n_ranks_on_one_gpu_prints_the_contract_line(ranks, batch):
+    """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one rank per GPU) — here with all N ranks on cuda:0 and
+    gloo instead of RCCL (FC_DIST_BACKEND=gloo; RCCL needs one GPU per rank): the ONE JSON line on rank 0 carries n_gpus = N, weak
+    scaling, BASELINE config 4 (global batch 16 split over the ranks: 8 / 4 / 2 scenes per rank) and a non-empty bucket log; every
+    rank runs the same number of steps (a rank that took one step more or fewer would hang the others in a collective: the run must
+    end within the timeout, with the lookahead plan threads of all ranks alive beside the collectives).  r6:
+    N = 4 and N = 8 — the shapes of the driver's first real SCALE pass — were never launched before.  RCCL itself with N > 1 is
+    the driver's N = 2 / 4 / 8 pass (tools/dist_train.sh:7-9, configs/fcaf3d/fcaf3d.py:43)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FC_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
-           '--no-cpu-baseline', '--infer-steps', '0', '--no-extras', '--no-fp32-route']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', str(ranks), '--steps', '3', '--warmup', '2',
+           '--batch', str(batch), '--no-cpu-baseline', '--infer-steps', '0', '--no-extras', '--no-fp32-route']
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['steps'] == 3 and out['value'] > 0
-    assert out['config']['global_batch'] == 16 and out['config']['parallelism'] == 'dp2'
+    assert out['n_gpus'] == ranks and out['scaling'] == 'weak' and out['steps'] == 3 and out['value'] > 0
+    assert out['config']['global_batch'] == batch * ranks and out['config']['parallelism'] == f'dp{ranks}'
     c4 = out['config']['config4_global_batch_16']
-    assert c4 is not None and c4['global_batch'] == 16 and c4['scenes_per_gpu_per_step'] == 8 and c4['value'] > 0
+    assert c4 is not None and c4['global_batch'] == 16 and c4['scenes_per_gpu_per_step'] == 16 // ranks and c4['value'] > 0
     dp = out['config']['data_parallel']
     assert dp['buckets'] >= 2 and len(dp['last_step_launch_ms_after_first_grad']) == dp['buckets'] and dp['backend'] == 'gloo'
-    print('bench.py --gpus 2 (gloo, one GPU):', out['value'], 'scenes/s;', dp)
+    assert 'worker thread' in out['config']['coordinate_phase']
+    print(f'bench.py --gpus {ranks} (gloo, one GPU):', out['value'], 'scenes/s;', dp)

@@ -66,7 +66,8 @@ from oracle.record import RecordDecisions as _RecordDecisions
 
 
 # rows of the deepest stage: a (scene, level-4) set of 109-862 voxels — BatchNorm statistics over so few rows amplify
-# rounding differences of the same arithmetic by the conditioning of 1 / sigma; the bound there is 1e-3
+# rounding differences of the same arithmetic by the conditioning of 1 / sigma (printed apart; r6: the same 1e-4 bound as everywhere,
+# arbitrated by the fp64 oracle where the fp32 oracle is further away than that)
 DEEP = ('backbone.layer4.', 'neck_with_head.up_block_3.', 'neck_with_head.out_block_3.')
 
 
@@ -86,8 +87,8 @@ def test_forward_train_parity(name, levels, B, n_points, kw, x6):
 
     Gradients are compared with EQUAL DISCRETE DECISIONS: the HIP forward's ReLU signs and max-pool
     arg-max rows are recorded and the fp32 oracle is run with those decisions (oracle.model_oracle.DecisionTape), so that both
-    sides differentiate the same piecewise-smooth function.  Then every gradient must agree to 1e-4 of the tensor's scale
-    (1e-3 in the deepest stage, DEEP) — no envelope.  r3 compared gradients across DIFFERENT decisions (a pre-activation of
+    sides differentiate the same piecewise-smooth function.  Then every gradient must agree to 1e-4 of the tensor's scale with the fp32 oracle, or — where the fp32
+    oracle itself is further than that from the fp64 gradient — be as close to the fp64 gradient as the fp32 oracle is: no envelope.  r3 compared gradients across DIFFERENT decisions (a pre-activation of
     +-1e-8 falls on either side of zero in any two fp32 implementations) and needed a 6e-2 envelope for it, which a 5 %
     defect in one weight-gradient variant would have passed; what was attributed to flips then is counted here: the number of
     elements where the oracle's own pre-activation has the other sign is printed and bounded, with the magnitude of those
@@ -143,12 +144,16 @@ def test_forward_train_parity(name, levels, B, n_points, kw, x6):
     ws, wd = max(shallow, key=shallow.get), (max(deep, key=deep.get) if deep else None)
     print(f'   gradients vs the fp32 oracle with equal decisions: worst {errs[worst]:.2e} ({worst}); outside the deepest stage '
           f'{shallow[ws]:.2e} ({ws}); deepest stage {deep[wd] if wd else 0:.2e} ({wd}); median {np.median(list(errs.values())):.2e}')
-    over = [k for k, v in shallow.items() if v >= 1e-4] + [k for k, v in deep.items() if v >= 1e-3]
+    # r6: north_star's bound is 1e-4 EVERYWHERE.  Every tensor beyond it against the fp32 oracle — the deepest
+    # stage included, which r3-r5 passed at 1e-3 without a second opinion — is arbitrated by the fp64 oracle with the same
+    # decisions: is it the HIP path, or is the fp32 ORACLE itself that far from the exact gradient there?  (BatchNorm over the
+    # 109-862 rows of a (scene, level-4) set amplifies the rounding of the same arithmetic by 1 / sigma; the head's 1x1 kernels sum
+    # mixed-sign products over every location of the batch: 1.6e-4 on cls_conv.kernel at 2 x 30k points on both convolution
+    # routes.)  The HIP gradient must be within 1e-4 of the fp64 gradient or as close to it as the fp32 oracle's own gradient
+    # is (within 2x).
+    over = [k for k, v in errs.items() if v >= 1e-4]
+    rows = []
     if over:
-        # A tensor beyond the bound with equal decisions: is it the HIP path, or is the fp32 ORACLE itself that far from the exact
-        # gradient there?  (The head's 1x1 kernels sum mixed-sign products over every location of the batch: 1.6e-4 on
-        # cls_conv.kernel at 2 x 30k points, the same on both convolution routes.)  The fp64 oracle with the same decisions
-        # settles it: the HIP gradient must be as close to it as the fp32 oracle's own gradient is (within 2x), or within the bound.
         P64 = {k: (v.detach().double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in P.items()}
         MO.TAPE = tape.replay()
         try:
@@ -157,10 +162,22 @@ def test_forward_train_parity(name, levels, B, n_points, kw, x6):
             MO.TAPE = None
         named = dict(model.named_parameters())
         for k in over:
-            bound = 1e-3 if k.startswith(DEEP) else 1e-4
             e_hip, e_o = _rel(named[k].grad, P64[k].grad), _rel(P[k].grad, P64[k].grad)
-            print(f'   {k}: vs the fp64 oracle (same decisions): HIP {e_hip:.2e}, fp32 oracle {e_o:.2e}')
-            assert e_hip < max(bound, 2.0 * e_o), (k, e_hip, e_o)
+            rows.append((k, errs[k], e_hip, e_o))
+            print(f'   {k}: vs the fp32 oracle {errs[k]:.2e}; vs the fp64 oracle (same decisions): HIP {e_hip:.2e}, fp32 oracle {e_o:.2e}')
+    _note_parity(f'{name} L={levels} B={B} n={n_points} x6={x6}', errs, worst, rows)
+    for k, e32, e_hip, e_o in rows:
+        assert e_hip < max(1e-4, 2.0 * e_o), (k, e_hip, e_o)
+
+
+def _note_parity(case, errs, worst, rows):
+    """the table profiles/r6_notes.md quotes: appended to gpurun_out/parity_table.md when the tests run through tools/lease.sh"""
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if not os.path.isdir(out):
+        return
+    with open(os.path.join(out, 'parity_table.md'), 'a') as fh:
+        fh.write(f'| {case} | {len(errs)} | {errs[worst]:.2e} ({worst}) | {float(np.median(list(errs.values()))):.2e} | '
+                 + ('; '.join(f'{k}: fp32-oracle {a:.1e}, HIP-vs-fp64 {b:.1e}, oracle-vs-fp64 {c:.1e}' for k, a, b, c in rows) or 'none') + ' |\n')
 
 
 def test_bottleneck_backbone_parity_depth50():
