@@ -222,6 +222,7 @@ class ConvProbe:
 
     def __init__(self):
         self.hbm = []          # (kernel, compulsory bytes, start, end) of the bandwidth-bound launches of the probed steps
+        self.hbm_native = []   # (kernel, compulsory bytes, ms): brackets taken inside the native plan calls
         self.pool_n_in = 0
         self.timed = {}        # batch index -> list of per-step lists of (start, end)
         self.counted = {}      # batch index -> list of (pairs_dev | None, flops_per_pair, n_out, bytes)
@@ -329,6 +330,11 @@ class ConvProbe:
             d[0] += 1
             d[1] += nbytes
             d[2] += s.elapsed_time(e)
+        for name, nbytes, ms in self.hbm_native:
+            d = agg.setdefault(name, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += nbytes
+            d[2] += ms
         rows = []
         for name, (n, b, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
             gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -486,6 +492,47 @@ LAST_HOST_S = 0.0
 LAST_WAIT_S = 0.0
 
 
+def gpu_local_cpus(dev_index):
+    """CPUs of the NUMA node the GPU hangs off (sysfs, by PCI address), or None"""
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        bdf = f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0'
+        txt = open(f'/sys/bus/pci/devices/{bdf}/local_cpulist').read().strip()
+        cpus = set()
+        for part in txt.split(','):
+            a, _, b = part.partition('-')
+            cpus.update(range(int(a), int(b or a) + 1))
+        return cpus or None
+    except Exception:
+        return None
+
+
+def host_micro(dev):
+    """three micro-measurements of the host, taken right after the timed region (diagnostic for the slow mode of profiles/r5_notes.md
+    section 16 / r6_notes.md section 3: is the CPU slow, is a launch slow, or is a device round trip slow?)"""
+    t0 = time.perf_counter()
+    acc = 0
+    for i in range(200000):
+        acc += i & 3
+    py_ms = (time.perf_counter() - t0) * 1e3
+    x = torch.zeros(64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        x.add_(1.0)
+    launch_us = (time.perf_counter() - t0) / 300 * 1e6
+    torch.cuda.synchronize()
+    ev = torch.cuda.Event()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        x.add_(1.0)
+        ev.record()
+        ev.synchronize()
+    sync_us = (time.perf_counter() - t0) / 50 * 1e6
+    return dict(python_200k_loop_ms=round(py_ms, 2), torch_launch_us=round(launch_us, 2), launch_plus_event_sync_us=round(sync_us, 2),
+                cpu=os.sched_getcpu() if hasattr(os, 'sched_getcpu') else None)
+
+
 def host_state():
     """load average and usable CPUs of the host (diagnostic beside `host_enqueue_ms_per_step`: the slow mode of profiles/r5_notes.md
     section 16 leaves the kernels at their speed — whether the HOST was slow or busy is what these fields record)"""
@@ -543,6 +590,17 @@ def main():
         local %= torch.cuda.device_count()       # smoke mode only: several ranks may share one GPU
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    # keep the process (main thread, the lookahead plan thread, the HIP runtime's threads created from here on) on the CPUs of the NUMA
+    # node the GPU hangs off: doorbells, signal polling and pinned staging buffers then stay on one socket (FC_NUMA_PIN=0: leave the
+    # scheduler alone)
+    pinned = None
+    if os.environ.get('FC_NUMA_PIN', '1') != '0' and hasattr(os, 'sched_setaffinity'):
+        loc = gpu_local_cpus(local)
+        if loc:
+            allowed = os.sched_getaffinity(0) & loc
+            if len(allowed) >= 4:
+                os.sched_setaffinity(0, allowed)
+                pinned = len(allowed)
 
     _dummies = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get('FC_DUMMY_STREAMS', '0')))]     # diagnostic: shifts the stream -> hardware-queue mapping
     if args.priority_stream:
@@ -628,11 +686,14 @@ def main():
     # above the kernels' own durations in the rocprofv3 trace.  Nothing is enqueued behind the last step before the region's closing
     # synchronise, so its brackets are the kernels' own time (r5: 135 -> ~125 us per operator against 122 us in the trace)
     pe = max(args.probe_every, 1)
+    ph0 = list(trainer.phase_s)
     dt, loss = timed_region(lambda i: step(args.warmup + i, 'time' if (args.steps - 1 - i) % pe == 0 else None, prefetch=i < args.steps - 1),
                             args.steps, world, dev)
     host_main = dict(host_enqueue_ms_per_step=round(LAST_HOST_S / args.steps * 1e3, 3),
                      host_blocked_ms_per_step=round(LAST_WAIT_S / args.steps * 1e3, 3),
-                     host_busy_ms_per_step=round((LAST_HOST_S - LAST_WAIT_S) / args.steps * 1e3, 3), after=host_state())
+                     host_busy_ms_per_step=round((LAST_HOST_S - LAST_WAIT_S) / args.steps * 1e3, 3),
+                     phases_ms_per_step=[round((b - a) / args.steps * 1e3, 3) for a, b in zip(ph0, trainer.phase_s)],
+                     micro=host_micro(dev), pinned_to_gpu_numa_node=pinned, after=host_state())
     final_loss = float(loss.item())
     dp_log = getattr(trainer.averager, 'log', None)
     trainer.averager.log = None
@@ -646,10 +707,17 @@ def main():
         # step i - 1 ran beside the stem convolution of the probed step and doubled its bracket)
         torch.cuda.synchronize()
         model.async_maps = False
+        import fcaf3d_amd.plan as PL
+        PL.PROBE = bool(probe)
         try:
             step(b, 'hbm' if probe else None)
         finally:
             model.async_maps = True
+            PL.PROBE = False
+        if probe:                                  # the coordinate phase's own launches (brackets inside fc_plan_levels / fc_plan_maps)
+            torch.cuda.synchronize()
+            for kind, nbytes, ms in PL.probe_read():
+                probe.hbm_native.append(('fc_plan:' + kind, nbytes, ms))
     if probe:
         probe.mode = None
     EX.ENABLED = exec_on
@@ -858,7 +926,9 @@ def main():
                                          'probed step synchronises inside); host_blocked: the part of it the host waited for the device BY DESIGN '
                                          '(run-ahead bound of 2 steps in runner.TrainStep, pinned staging ring, a lookahead plan not ready yet); '
                                          'host_busy = the difference = the host\'s own work per step (r5: 17.5 of 20.5 ms, the step was host-bound '
-                                         'whenever that grew); loadavg / usable CPUs when the process started and after the timed region'),
+                                         'whenever that grew); phases_ms_per_step: [run-ahead bound + prefetch, forward_train enqueue, backward enqueue, '
+                                         'all-reduce finish + clip + AdamW + weight images]; micro: a pure-Python loop, a torch launch, a launch + event '
+                                         'round trip, taken right after the region; loadavg / usable CPUs when the process started and after the timed region'),
                        'coordinate_phase': ('native plan (csrc/plan.hip: fc_plan_levels + fc_plan_maps, 2 read-backs per step)' +
                                             (', the NEXT batch planned on a worker thread beside the current step (plan.Lookahead); exactly '
                                              f'{args.steps} plans inside the timed region' if lookahead else ', in line')),

@@ -17,13 +17,14 @@
 #include "fc_common.h"
 #include "../../include/fcaf3d_hip.h"
 #include <string.h>
+#include <vector>
 
 namespace {
 
 // ---- layout of the host tables (mirrored in fcaf3d_amd/plan.py) ------------------------------------------------------------
 enum : int {                        // cfg words
   C_B = 0, C_NL, C_NFEAT, C_VS /*double bits*/, C_FEATDIV /*double bits*/, C_TOTAL, C_BACKWARD, C_SORT_MIN, C_PAIR_ROWS, C_PTS_THR,
-  C_TARGETS, C_COORDS_IN, C_FEATS_IN, C_PT_STRIDE, C_NECK, C_VS_HEAD /*double bits: the head's voxel size*/, CFGW = 24
+  C_TARGETS, C_COORDS_IN, C_FEATS_IN, C_PT_STRIDE, C_NECK, C_VS_HEAD /*double bits: the head's voxel size*/, C_PROBE, CFGW = 24
 };
 constexpr int HDR = 16;             // out[0..15]: header
 enum : int { H_S = 0, H_NEED2, H_PRUNE, H_NMAPS, H_STRUCT, H_NALL, H_F0, H_TGT_PTS, H_TGT_SCENE, H_TGT_LEVEL, H_TGT_ORDER, H_TGT_SEG,
@@ -61,6 +62,32 @@ int sync_readback(void* host, const void* dev, int64_t bytes, hipStream_t s) {
   FC_HIP(hipEventSynchronize(t_ev));
   return 0;
 }
+
+// ---- probe: HIP-event brackets around every launch (group) of a plan, with its compulsory bytes — bench.py's `roofline.hbm_kernels`
+// (cfg[C_PROBE] != 0; one thread at a time; read out by fc_plan_probe_read after the device has drained) ----------------------------
+enum : int { PK_TABLES = 0, PK_VOXELIZE, PK_FLAGS, PK_FINALIZE, PK_GEN, PK_KMAPS, PK_CHILDREN, PK_FILL, PK_TRANSPOSE, PK_MASKS, PK_RADIX,
+             PK_PERMUTE, PK_PAIRS, PK_GENROWS, PK_HEAD, PK_KINDS };
+struct PlanProbe { int kind; double bytes; hipEvent_t a, b; };
+std::vector<PlanProbe> g_pp;
+std::vector<hipEvent_t> g_pp_pool;
+hipEvent_t pp_event() {
+  if (!g_pp_pool.empty()) { hipEvent_t e = g_pp_pool.back(); g_pp_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+struct Bracket {                     // RAII: records the closing event when the launch (group) has been enqueued
+  hipStream_t s; bool on; size_t idx;
+  Bracket(bool probe, int kind, double bytes, hipStream_t st) : s(st), on(probe), idx(0) {
+    if (!on) return;
+    PlanProbe p{kind, bytes, pp_event(), pp_event()};
+    if (!p.a || !p.b) { on = false; return; }
+    (void)hipEventRecord(p.a, s);
+    idx = g_pp.size();
+    g_pp.push_back(p);
+  }
+  ~Bracket() { if (on) (void)hipEventRecord(g_pp[idx].b, s); }
+};
 
 // ---- batched launches ------------------------------------------------------------------------------------------------------------
 // Most of the phase is many small independent jobs of one kind (ten kernel maps, thirteen pair lists, five argsorts ...): each kind
@@ -163,7 +190,7 @@ __global__ void k_plan_insert(const int4* __restrict__ coords, int64_t n, unsign
   hash_insert(keys, vals, mask, c, (int)i, slot);
 }
 
-// winners of 1 024 rows per block: flags + the block's count; the LAST block to finish scans the block counts (exclusive, in place)
+// winners: flags + the count of every 256-row sub-block; the LAST block to finish scans the block counts (exclusive, in place)
 // and writes the set's row count -> meta_s[0]
 __global__ __launch_bounds__(256) void k_plan_flags_scan(const int* __restrict__ slot, const int* __restrict__ vals, const int* __restrict__ n_dev,
                                                          int64_t n_host, unsigned char* __restrict__ flags, int* __restrict__ blocksums,
@@ -171,20 +198,30 @@ __global__ __launch_bounds__(256) void k_plan_flags_scan(const int* __restrict__
   __shared__ int ws[4];
   __shared__ int last_s, carry_s;
   const int64_t n = n_dev ? *n_dev : n_host;
-  const int64_t base = (int64_t)blockIdx.x * 1024;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int cnt = 0;
+  __shared__ int wsr[4][4];
+  // 1 024 rows per block, as four sub-blocks of 256 (the unit k_plan_finalize works in: blocksums holds one entry per sub-block);
+  // the four dependent read pairs of a thread (slot, table value) are issued together
+  int f[4];
+#pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int64_t i = base + r * 256 + threadIdx.x;
-    int f = 0;
-    if (i < n) { f = vals[slot[i]] == (int)i; flags[i] = (unsigned char)f; }
-    const unsigned long long bal = __ballot(f);
-    if (lane == 0) cnt += __popcll(bal);
+    const int64_t i = (int64_t)blockIdx.x * 1024 + r * 256 + threadIdx.x;
+    f[r] = i < n ? (vals[slot[i]] == (int)i) : 0;
   }
-  if (lane == 0) ws[w] = cnt;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = (int64_t)blockIdx.x * 1024 + r * 256 + threadIdx.x;
+    if (i < n) flags[i] = (unsigned char)f[r];
+    const unsigned long long bal = __ballot(f[r]);
+    if (lane == 0) wsr[r][w] = __popcll(bal);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int r = threadIdx.x;
+    __hip_atomic_store(&blocksums[4 * blockIdx.x + r], wsr[r][0] + wsr[r][1] + wsr[r][2] + wsr[r][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_store(&blocksums[blockIdx.x], ws[0] + ws[1] + ws[2] + ws[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
     last_s = atomicAdd(&meta_s[3], 1) == (int)gridDim.x - 1;
     carry_s = 0;
@@ -192,7 +229,7 @@ __global__ __launch_bounds__(256) void k_plan_flags_scan(const int* __restrict__
   __syncthreads();
   if (!last_s) return;
   __threadfence();
-  const int nb = (int)gridDim.x;
+  const int nb = 4 * (int)gridDim.x;
   for (int start = 0; start < nb; start += 256) {
     const int i = start + threadIdx.x;
     const int v = i < nb ? fc_ld(&blocksums[i]) : 0;
@@ -225,41 +262,35 @@ __global__ __launch_bounds__(256) void k_plan_finalize(const int4* __restrict__ 
                                                        unsigned long long* next_keys, int* next_vals, int* __restrict__ next_slot) {
   __shared__ int ws[4];
   const int64_t n = n_dev ? *n_dev : n_host;
-  const int64_t base = (int64_t)blockIdx.x * 1024;
+  const int64_t base = (int64_t)blockIdx.x * 256;
   if (base >= n) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const unsigned long long nmask = next_keys ? table_mask(meta_s[0]) : 0ull;
-  int run = blocksums[blockIdx.x];
-  for (int r = 0; r < 4; ++r) {
-    const int64_t i = base + r * 256 + threadIdx.x;
-    const int f = i < n ? (int)flags[i] : 0;
-    const unsigned long long bal = __ballot(f);
-    if (lane == 0) ws[w] = __popcll(bal);
-    __syncthreads();
-    int pre = run;
-    for (int k = 0; k < w; ++k) pre += ws[k];
-    const int tot = ws[0] + ws[1] + ws[2] + ws[3];
-    __syncthreads();
-    int b = -1;
-    if (f) {
-      const int p = pre + __popcll(bal & ((1ull << lane) - 1ull));
-      const int4 c = quant(coords[i], q);
-      out_coords[p] = c;
-      vals[slot[i]] = p;                           // the table now maps key -> row of the new set
-      if (feats_out)
-        for (int k = 0; k < nfeat; ++k) feats_out[(int64_t)p * nfeat + k] = feats_in[i * nfeat + k];
-      b = c.x;
-      if (next_keys) hash_insert(next_keys, next_vals, nmask, quant(c, 2 * q), p, next_slot);
-    }
-    unsigned long long rem = bal;                  // rows per scene
-    while (rem) {
-      const int leader = __ffsll((long long)rem) - 1;
-      const int lb = __shfl(b, leader, 64);
-      const unsigned long long same = __ballot(f && b == lb);
-      if (lane == leader && lb >= 0 && lb < B) atomicAdd(&scene_cnt[lb], __popcll(same));
-      rem &= ~same;
-    }
-    run += tot;
+  const int64_t i = base + threadIdx.x;
+  const int f = i < n ? (int)flags[i] : 0;
+  const unsigned long long bal = __ballot(f);
+  if (lane == 0) ws[w] = __popcll(bal);
+  __syncthreads();
+  int pre = blocksums[blockIdx.x];
+  for (int k = 0; k < w; ++k) pre += ws[k];
+  int b = -1;
+  if (f) {
+    const int p = pre + __popcll(bal & ((1ull << lane) - 1ull));
+    const int4 c = quant(coords[i], q);
+    out_coords[p] = c;
+    vals[slot[i]] = p;                             // the table now maps key -> row of the new set
+    if (feats_out)
+      for (int k = 0; k < nfeat; ++k) feats_out[(int64_t)p * nfeat + k] = feats_in[i * nfeat + k];
+    b = c.x;
+    if (next_keys) hash_insert(next_keys, next_vals, nmask, quant(c, 2 * q), p, next_slot);
+  }
+  unsigned long long rem = bal;                    // rows per scene
+  while (rem) {
+    const int leader = __ffsll((long long)rem) - 1;
+    const int lb = __shfl(b, leader, 64);
+    const unsigned long long same = __ballot(f && b == lb);
+    if (lane == leader && lb >= 0 && lb < B) atomicAdd(&scene_cnt[lb], __popcll(same));
+    rem &= ~same;
   }
 }
 
@@ -578,7 +609,7 @@ static int64_t stage1_layout(int64_t T, int B, int nl, int nfeat, char* base, vo
   p[i++] = a.arr<float>((int64_t)nfeat * T);                    // 1 feats_raw
   p[i++] = a.arr<int>(T);                                       // 2 slot (even sets)
   p[i++] = a.take(T);                                           // 3 flags
-  p[i++] = a.arr<int>(fc_cdiv(T > 0 ? T : 1, 1024) + 1);        // 4 blocksums
+  p[i++] = a.arr<int>(4 * fc_cdiv(T > 0 ? T : 1, 1024) + 4);    // 4 blocksums (one per 256 rows)
   p[i++] = a.arr<int>((int64_t)METAW * S + (int64_t)S * B + 64); // 5 meta
   p[i++] = a.arr<float>((int64_t)nfeat * T);                    // 6 F0
   p[i++] = a.arr<int>(T);                                       // 7 slot (odd sets)
@@ -615,11 +646,16 @@ int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int6
   int* vals_all = (int*)p[9];
   const int64_t nmeta = (int64_t)METAW * S + (int64_t)S * B;
   FC_HIP(hipMemsetAsync(meta, 0, (size_t)nmeta * sizeof(int), stream));
+  const bool probe = cfg[C_PROBE] != 0;
+  size_t stage1_pp[MAXSETS] = {};
   const float vs = (float)as_double(cfg[C_VS]), fdiv = (float)as_double(cfg[C_FEATDIV]);
   if (!cfg[C_COORDS_IN] && !(vs > 0.f)) return FC_EINVAL;
   if (T > 0) {
-    k_plan_tables_init<<<(unsigned)fc_cdiv(cap0 * S, 512), 256, 0, stream>>>(keys_all, vals_all, cap0 * S);
-    FC_CHECK_LAUNCH();
+    {
+      Bracket br(probe, PK_TABLES, 12.0 * (double)(cap0 * S), stream);
+      k_plan_tables_init<<<(unsigned)fc_cdiv(cap0 * S, 512), 256, 0, stream>>>(keys_all, vals_all, cap0 * S);
+      FC_CHECK_LAUNCH();
+    }
     // ---- level 0: the collate + insert ----
     const int4* src0 = coords_raw;
     if (!cfg[C_COORDS_IN]) {
@@ -641,6 +677,8 @@ int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int6
         sc.b0 = b0; sc.stride = (int)cfg[C_PT_STRIDE]; sc.nfeat = nfeat; sc.vs = vs; sc.feat_div = fdiv;
         if (sc.stride < 3 + nfeat) return FC_EINVAL;
         if (maxn > 0) {
+          // points read, coords + features + slot written, one 12-byte table slot read and written per point
+          Bracket br(probe, PK_VOXELIZE, (double)(off - sc.off[0]) * (4.0 * sc.stride + 16.0 + 4.0 * nfeat + 4.0 + 24.0), stream);
           dim3 grid((unsigned)fc_cdiv(maxn, 256), nb);
           k_plan_voxelize_insert<<<grid, 256, 0, stream>>>(sc, coords_raw, feats_raw, keys_all, vals_all, table_mask(T), meta, slots[0]);
           FC_CHECK_LAUNCH();
@@ -651,20 +689,27 @@ int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int6
       src0 = (const int4*)cfg[C_COORDS_IN];
       feats_raw = (float*)cfg[C_FEATS_IN];
       if (!feats_raw && nfeat) return FC_EINVAL;
+      Bracket br(probe, PK_VOXELIZE, (double)T * (16.0 + 4.0 + 24.0), stream);
       k_plan_insert<<<(unsigned)fc_cdiv(T, 256), 256, 0, stream>>>(src0, T, keys_all, vals_all, table_mask(T), meta, slots[0]);
       FC_CHECK_LAUNCH();
     }
     // ---- the chain: two launches per set ----
-    const unsigned gB = (unsigned)fc_cdiv(T, 1024);
+    const unsigned gB = (unsigned)fc_cdiv(T, 1024), gF = (unsigned)fc_cdiv(T, 256);
     for (int s = 0; s < S; ++s) {
       int* meta_s = meta + METAW * s;
       const int* n_in_dev = s ? meta + METAW * (s - 1) : nullptr;
       const int4* src = s ? (const int4*)p[10 + s - 1] : src0;
       int* vals = vals_all + cap0 * s;
-      k_plan_flags_scan<<<gB, 256, 0, stream>>>(slots[s & 1], vals, n_in_dev, T, flags, blocksums, meta_s);
-      FC_CHECK_LAUNCH();
+      const size_t pp0 = g_pp.size();
+      {
+        Bracket br(probe, PK_FLAGS, 0.0, stream);        // bytes are filled in after the read-back (they depend on the live counts)
+        k_plan_flags_scan<<<gB, 256, 0, stream>>>(slots[s & 1], vals, n_in_dev, T, flags, blocksums, meta_s);
+        FC_CHECK_LAUNCH();
+      }
+      if (probe) stage1_pp[s] = pp0;
       const bool more = s + 1 < S;
-      k_plan_finalize<<<gB, 256, 0, stream>>>(src, n_in_dev, T, 1 << s, flags, blocksums, slots[s & 1], vals, (int4*)p[10 + s],
+      Bracket br(probe, PK_FINALIZE, 0.0, stream);
+      k_plan_finalize<<<gF, 256, 0, stream>>>(src, n_in_dev, T, 1 << s, flags, blocksums, slots[s & 1], vals, (int4*)p[10 + s],
                                              s == 0 ? feats_raw : nullptr, s == 0 ? F0 : nullptr, nfeat,
                                              meta + METAW * S + (int64_t)s * B, B, meta_s, more ? keys_all + cap0 * (s + 1) : nullptr,
                                              more ? vals_all + cap0 * (s + 1) : nullptr, slots[(s + 1) & 1]);
@@ -673,6 +718,13 @@ int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int6
   }
   int rc = sync_readback(counts_host, meta, nmeta * (int64_t)sizeof(int), stream);
   if (rc) return rc;
+  if (probe && T > 0)
+    for (int s = 0; s < S; ++s) {                   // compulsory bytes of the chain's launches, now that the counts are known
+      const double n_in = s ? counts_host[METAW * (s - 1)] : (double)T, n_out = counts_host[METAW * s];
+      g_pp[stage1_pp[s]].bytes = n_in * (4.0 + 4.0 + 1.0);                                     // slot, table value, flag
+      g_pp[stage1_pp[s] + 1].bytes = n_in * (1.0 + 4.0) + n_out * (16.0 + 16.0 + 4.0 + (s == 0 ? 8.0 * nfeat : 0.0)) +
+                                     (s + 1 < S ? n_out * (24.0 + 4.0) : 0.0);                 // ... + the next set's insert
+    }
   // ---- host tables ----
   const int nw = fc_plan_out_words(B, nl);
   memset(out, 0, (size_t)nw * sizeof(int64_t));
@@ -707,6 +759,7 @@ static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char
   const int64_t sort_min = cfg[C_SORT_MIN], pair_rows = cfg[C_PAIR_ROWS], pts_thr = cfg[C_PTS_THR];
   const int S0 = 3 + nl;
   const bool run = base != nullptr;
+  const bool probe = run && cfg[C_PROBE] != 0;
   Bump a{base, 0};
   int64_t* sets = out + HDR;
   auto SN = [&](int s) { return sets[SETW * s + S_N]; };
@@ -896,23 +949,44 @@ static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char
   // ---- launches, in dependency order ----
   FC_HIP(hipMemsetAsync(cnt_dev, 0, sizeof(int) * (64 * nm + MAXLV), stream));
   int rc;
-  if ((rc = launch_batch(gen, 256, stream, k_plan_gen_coords))) return rc;
-  if ((rc = launch_batch(kmaps, 256, stream, k_plan_kernel_maps))) return rc;
-  for (int c = 0; c < nchildren; ++c)              // a chain: each generated set's table from the one above it
-    if ((rc = fc_kernel_map_children(children[c].pnbr, children[c].n_parent, children[c].nbr, stream))) return rc;
-  if ((rc = launch_batch(fills, 256, stream, k_plan_rows))) return rc;
-  if ((rc = launch_batch(rows, 256, stream, k_plan_rows))) return rc;
-  if ((rc = launch_batch(sorts, 256, stream, k_plan_row_masks))) return rc;
-  if ((rc = argsort27_batch(sorts, stream))) return rc;
+  auto rows_bytes = [](const Batch<RowJob>& b) { double t = 0; for (int i = 0; i < b.count; ++i) t += (double)b.j[i].K * b.j[i].n * (b.j[i].mode == 1 ? 4.0 : 8.0); return t; };
+  double by = 0;
+  for (int i = 0; i < gen.count; ++i) by += 16.0 * gen.j[i].n;
+  { Bracket br(probe, PK_GEN, by, stream); if ((rc = launch_batch(gen, 256, stream, k_plan_gen_coords))) return rc; }
+  by = 0;
+  for (int i = 0; i < kmaps.count; ++i) by += (double)kmaps.j[i].n_out * (16.0 + kmaps.j[i].K * (4.0 + 12.0));      // coords, table entry written, slot probed
+  { Bracket br(probe, PK_KMAPS, by, stream); if ((rc = launch_batch(kmaps, 256, stream, k_plan_kernel_maps))) return rc; }
+  by = 0;
+  for (int c = 0; c < nchildren; ++c) by += 27.0 * 4.0 * (children[c].n_parent + 8.0 * children[c].n_parent);
+  {
+    Bracket br(probe, PK_CHILDREN, by, stream);
+    for (int c = 0; c < nchildren; ++c)            // a chain: each generated set's table from the one above it
+      if ((rc = fc_kernel_map_children(children[c].pnbr, children[c].n_parent, children[c].nbr, stream))) return rc;
+  }
+  { Bracket br(probe, PK_FILL, rows_bytes(fills), stream); if ((rc = launch_batch(fills, 256, stream, k_plan_rows))) return rc; }
+  { Bracket br(probe, PK_TRANSPOSE, rows_bytes(rows), stream); if ((rc = launch_batch(rows, 256, stream, k_plan_rows))) return rc; }
+  double nsort = 0;
+  for (int i = 0; i < sorts.count; ++i) nsort += (double)sorts.j[i].n;
+  { Bracket br(probe, PK_MASKS, nsort * (27.0 * 4.0 + 4.0), stream); if ((rc = launch_batch(sorts, 256, stream, k_plan_row_masks))) return rc; }
+  { Bracket br(probe, PK_RADIX, nsort * 3.0 * (8.0 + 4.0 + 8.0), stream); if ((rc = argsort27_batch(sorts, stream))) return rc; }      // per pass: keys + values read twice-ish, written once
   {
     Batch<SortJob> perm;
     for (int i = 0; i < sorts.count; ++i) perm.add(sorts.j[i], 27 * (int64_t)sorts.j[i].nbx);
+    Bracket br(probe, PK_PERMUTE, nsort * (27.0 * 8.0 + 4.0), stream);
     if ((rc = launch_batch(perm, 256, stream, k_plan_permute))) return rc;
   }
-  if ((rc = launch_batch(pairs, PBLK, stream, k_plan_pairs_count))) return rc;
-  if ((rc = launch_batch(pairs, PBLK, stream, k_plan_pairs_fill))) return rc;
+  by = 0;
+  for (int i = 0; i < pairs.count; ++i) by += 27.0 * (double)pairs.j[i].n * (4.0 + 4.0 + 12.0);      // table read twice, lists + positions written
+  {
+    Bracket br(probe, PK_PAIRS, by, stream);
+    if ((rc = launch_batch(pairs, PBLK, stream, k_plan_pairs_count))) return rc;
+    if ((rc = launch_batch(pairs, PBLK, stream, k_plan_pairs_fill))) return rc;
+  }
   if (grows.count && grows.blocks()) {
     const int64_t* oc = sets + SETW * cs;
+    by = 0;
+    for (int i = 0; i < grows.count; ++i) by += (double)grows.j[i].n * (16.0 + 4.0 + 12.0);
+    Bracket br(probe, PK_GENROWS, by, stream);
     k_plan_gen_rows<<<(unsigned)grows.blocks(), 256, 0, stream>>>(grows, (const unsigned long long*)oc[S_KEYS], (const int*)oc[S_VALS],
                                                                  (unsigned long long)(oc[S_CAP] - 1));
     FC_CHECK_LAUNCH();
@@ -925,6 +999,7 @@ static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char
     for (int l = 0; l < nl; ++l) { h.coords[l] = SC(head_set[l]); h.off[l] = off; off += SN(head_set[l]); }
     h.off[nl] = off;
     if (n_all > 0) {
+      Bracket br(probe, PK_HEAD, (double)n_all * (16.0 + 12.0 + 12.0), stream);
       k_plan_head_arrays<<<(unsigned)fc_cdiv(n_all, 256), 256, 0, stream>>>(h, pts, scene, level, order);
       FC_CHECK_LAUNCH();
     }
@@ -1000,6 +1075,20 @@ int fc_plan_maps(const int64_t* cfg, int64_t* out, const int* counts_host, void*
   char* base = (char*)fc_align((int64_t)arena2, 256);
   if (arena2_bytes - (base - (char*)arena2) < need) return FC_EWS;
   return stage2(cfg, out, counts_host, base, &need, cnt_host, stream);
+}
+
+// brackets of the plans run with cfg[C_PROBE] since the last read-out: ms (float), bytes (double), kind (int) per bracket; -> count
+int64_t fc_plan_probe_read(float* ms, double* bytes, int* kind, int64_t cap) {
+  int64_t n = 0;
+  for (PlanProbe& p : g_pp) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, p.a, p.b) != hipSuccess) t = 0.f;
+    if (n < cap) { ms[n] = t; bytes[n] = p.bytes; kind[n] = p.kind; ++n; }
+    g_pp_pool.push_back(p.a);
+    g_pp_pool.push_back(p.b);
+  }
+  g_pp.clear();
+  return n;
 }
 
 // stable argsort of non-negative int32 keys below 2^27 (the occupancy masks of fc_nbr_row_masks) — what torch.argsort did for

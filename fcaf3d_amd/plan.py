@@ -22,7 +22,7 @@ from . import sparse as SP
 
 # ---- layout of the native tables (csrc/plan.hip) --------------------------------------------------------------------------------
 C_B, C_NL, C_NFEAT, C_VS, C_FEATDIV, C_TOTAL, C_BACKWARD, C_SORT_MIN, C_PAIR_ROWS, C_PTS_THR, C_TARGETS, C_COORDS_IN, C_FEATS_IN, \
-    C_PT_STRIDE, C_NECK, C_VS_HEAD = range(16)
+    C_PT_STRIDE, C_NECK, C_VS_HEAD, C_PROBE = range(17)
 HDR = 16
 H_S, H_NEED2, H_PRUNE, H_NMAPS, H_STRUCT, H_NALL, H_F0, H_TGT_PTS, H_TGT_SCENE, H_TGT_LEVEL, H_TGT_ORDER, H_TGT_SEG, H_NHEAD, H_BAD = range(14)
 SETW, MAXSETS, MAPR, METAW, MAXLV = 8, 24, 64, 8, 8
@@ -31,6 +31,9 @@ S_COORDS, S_N, S_STRIDE, S_KEYS, S_VALS, S_CAP, S_PARENT, S_ROWS = range(8)
  MW_TPI, MW_TPO, MW_TPOS, MW_TCNT, MW_TTILES, MW_FLAGS) = range(22)
 MW_DESC_F, MW_DESC_B = 24, 44
 
+PROBE = False           # True: HIP-event brackets around every launch of the plans (fc_plan_probe_read; bench.py hbm_kernels)
+PROBE_KINDS = ('tables_init', 'collate_insert', 'flags_scan', 'finalize_insert', 'gen_coords', 'kernel_maps', 'children_maps', 'fill',
+               'transpose', 'row_masks', 'radix_argsort', 'permute', 'pair_lists', 'union_rows', 'head_arrays')
 TRACE = None            # a list: (tag, perf_counter) marks of every plan (tools/hostprof.py --lookahead)
 ENABLED = True          # False: the per-operator coordinate phase (sparse.py), kept as the cross-check (tests/test_gpu_plan.py)
 
@@ -131,6 +134,7 @@ class Planner:
         cfg[C_TARGETS] = 1 if want_targets else 0
         cfg[C_NECK] = 1
         cfg[C_VS_HEAD] = _f64_bits(float(nh.voxel_size))
+        cfg[C_PROBE] = 1 if PROBE else 0
         keep = None
         if raw:
             cfg[C_PT_STRIDE] = points[0].shape[1]
@@ -343,3 +347,12 @@ class Lookahead:
     def drop(self):
         for key in list(self.pending):
             self._discard(key)
+
+
+def probe_read():
+    """[(kind name, compulsory bytes, ms)] of the plans run with PROBE since the last call (the device must have drained)"""
+    import ctypes
+    cap = 4096
+    ms, by, kd = (ctypes.c_float * cap)(), (ctypes.c_double * cap)(), (ctypes.c_int * cap)()
+    n = L.lib().fc_plan_probe_read(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(by, ctypes.c_void_p), ctypes.cast(kd, ctypes.c_void_p), cap)
+    return [(PROBE_KINDS[kd[i]], float(by[i]), float(ms[i])) for i in range(n)]

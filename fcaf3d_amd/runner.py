@@ -173,6 +173,9 @@ class TrainStep:
         self.lr = build_lr_updater(self.optimizer, lr_config) if lr_config else None
         self.averager = D.GradientAverager(self.params, bucket_mb=bucket_mb, flat=self.flat)
         self.last_grad_norm = None
+        # host seconds per phase, accumulated over the calls: [run-ahead bound + prefetch submit, forward_train enqueue, backward enqueue,
+        # averager + clip + AdamW + weight images] (bench.py config.host.phases_ms: which phase grows when the host is slow)
+        self.phase_s = [0.0, 0.0, 0.0, 0.0]
         # split-bf16 convolutions read pre-split weight images: with the flat optimizer this loop is the only writer of the
         # weights, so it builds all of them in one launch right after its step (on the weight-gradient stream, under the
         # next step's voxelisation and stem) instead of ~100 per-layer launches on the critical path of the next step.
@@ -221,9 +224,14 @@ class TrainStep:
         """next_batch: the batch of the FOLLOWING call, if the caller has it (a data loader's prefetched item): its coordinate
         phase starts now on a worker thread (SingleStageSparse3DDetector.prefetch) and overlaps this step"""
         from . import functional as Fn
+        import time
+        ph = self.phase_s
+        t0 = time.perf_counter()
         self._bound_run_ahead()
         if next_batch is not None and hasattr(self.model, 'prefetch'):
             self.model.prefetch(next_batch['points'], gt=True)
+        t1 = time.perf_counter()
+        ph[0] += t1 - t0
         self.optimizer.zero_grad(set_to_none=True)
         Fn._flat_pass_done()                         # a backward pass that raised never ran its final callback: start clean
         prog = self._program()
@@ -243,7 +251,11 @@ class TrainStep:
         try:
             losses = self.model(return_loss=True, **batch)
             loss = parse_losses(losses)
+            t2 = time.perf_counter()
+            ph[1] += t2 - t1
             loss.backward()
+            t3 = time.perf_counter()
+            ph[2] += t3 - t2
         finally:
             Fn.PREBUILT, Fn.PREBUILT_EVENT = {}, None
             executor.TRUSTED = None
@@ -261,6 +273,7 @@ class TrainStep:
                 self.images_version = None               # the module path's images are stale now; rebuilt if a step takes that path
             elif self.images is not None and self.images.n:
                 self._build_images(side_stream=True)
+            ph[3] += time.perf_counter() - t3
             return loss, losses
         if self.max_norm is not None:
             self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, norm_type=self.norm_type)

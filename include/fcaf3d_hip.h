@@ -144,7 +144,12 @@ int fc_gather_coords(const int* src, const int* idx, int64_t n, int* dst, hipStr
  * convolution route (mask-sorted tables, pair lists, transposed tables) and the head's location / scene / level arrays
  * (fcaf3d_neck_with_head.py:276-277) into arena2 (fc_plan_stage2_bytes), ending with ITS single read-back (pair-list counts, union
  * hits) into cnt_host (PINNED ints, 64 maps + 8 + nl B + 1).  Same sets, tables and row orders as the per-operator entry points above.
- * fc_argsort27: the stable argsort of 27-bit occupancy masks used for the mask-sorted tables (No reference counterpart). */
+ * fc_argsort27: the stable argsort of 27-bit occupancy masks used for the mask-sorted tables (No reference counterpart).
+ * cfg[16] != 0: every launch (group) of the two calls is bracketed with a HIP-event pair; fc_plan_probe_read(ms, bytes, kind, cap),
+ * called after the device has drained, returns the brackets since the last read-out with their compulsory bytes and kind (0 tables,
+ * 1 collate + insert, 2 winner flags + scan, 3 finalize + next insert, 4 generated coordinates, 5 kernel maps, 6 children maps, 7 fills,
+ * 8 transposes, 9 row masks, 10 radix argsort, 11 permute, 12 pair lists, 13 union rows, 14 head arrays): bench.py's
+ * `roofline.hbm_kernels` (the reference times whole iterations only: tools/analysis_tools/benchmark.py:64-91). */
 int fc_plan_cfg_words(void);
 int fc_plan_out_words(int B, int nl);
 int64_t fc_plan_stage1_bytes(int64_t total_points, int B, int nl, int nfeat);
@@ -153,6 +158,7 @@ int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int6
 int64_t fc_plan_stage2_bytes(const int64_t* cfg, int64_t* out, const int* counts_host);
 int fc_plan_maps(const int64_t* cfg, int64_t* out, const int* counts_host, void* arena2, int64_t arena2_bytes, int* cnt_host,
                  hipStream_t stream);
+int64_t fc_plan_probe_read(float* ms, double* bytes, int* kind, int64_t cap);
 int64_t fc_argsort27_ws_bytes(int64_t n);
 int fc_argsort27(const int* keys, int64_t n, int* order, void* ws, int64_t ws_bytes, hipStream_t stream);
 
