@@ -541,26 +541,27 @@ __global__ void k_bn1_partial(const float* __restrict__ x, int64_t n, int C, int
 }
 
 // every block: reduce part[nb][2][C] -> (S1,S2) per channel (fixed order), then apply to its rows
+// (CG channels from c0 on: a block may own a channel window of the table, k_bn1_bwd_apply's grid.y; CG == C, c0 == 0: all of them)
 __device__ static inline void bn1_reduce_parts(const float* __restrict__ part, int nb, int C, int cl, int rl, int nrl,
-                                               float* sm /*[nrl][2][C]*/, float4* s1, float4* s2) {
+                                               float* sm /*[nrl][2][CG]*/, float4* s1, float4* s2, int CG, int c0) {
   float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
   // a SMALL table (the deep levels: a few KB at the same workspace address layer after layer) can survive in a CU's L1
   // from the previous layer: read it past the L1 (fc_common.h: fc_ld4); a big one streams through the L1 anyway
   const bool past_l1 = (int64_t)nb * C * 8 <= 32768;
   for (int b = rl; b < nb; b += nrl) {
-    const float* src = part + ((int64_t)b * 2) * C;
+    const float* src = part + ((int64_t)b * 2) * C + c0;
     float4 u = past_l1 ? fc_ld4(src + cl * 4) : *reinterpret_cast<const float4*>(src + cl * 4);
     float4 w = past_l1 ? fc_ld4(src + C + cl * 4) : *reinterpret_cast<const float4*>(src + C + cl * 4);
     a1.x += u.x; a1.y += u.y; a1.z += u.z; a1.w += u.w;
     a2.x += w.x; a2.y += w.y; a2.z += w.z; a2.w += w.w;
   }
-  *reinterpret_cast<float4*>(&sm[(rl * 2 + 0) * C + cl * 4]) = a1;
-  *reinterpret_cast<float4*>(&sm[(rl * 2 + 1) * C + cl * 4]) = a2;
+  *reinterpret_cast<float4*>(&sm[(rl * 2 + 0) * CG + cl * 4]) = a1;
+  *reinterpret_cast<float4*>(&sm[(rl * 2 + 1) * CG + cl * 4]) = a2;
   __syncthreads();
   float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
   for (int j = 0; j < nrl; ++j) {
-    float4 u = *reinterpret_cast<const float4*>(&sm[(j * 2 + 0) * C + cl * 4]);
-    float4 w = *reinterpret_cast<const float4*>(&sm[(j * 2 + 1) * C + cl * 4]);
+    float4 u = *reinterpret_cast<const float4*>(&sm[(j * 2 + 0) * CG + cl * 4]);
+    float4 w = *reinterpret_cast<const float4*>(&sm[(j * 2 + 1) * CG + cl * 4]);
     t1.x += u.x; t1.y += u.y; t1.z += u.z; t1.w += u.w;
     t2.x += w.x; t2.y += w.y; t2.z += w.z; t2.w += w.w;
   }
@@ -577,7 +578,7 @@ __global__ void k_bn1_apply(const float* __restrict__ x, int64_t n, int C, int64
   const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
   const int nrl = blockDim.x / c4n;
   float4 s1, s2;
-  bn1_reduce_parts(part, nb, C, cl, rl, nrl, sm, &s1, &s2);
+  bn1_reduce_parts(part, nb, C, cl, rl, nrl, sm, &s1, &s2, C, 0);
   const float4 sh = *reinterpret_cast<const float4*>(x + cl * 4);
   const float inv_n = 1.f / (float)n;
   float d[4] = {s1.x * inv_n, s1.y * inv_n, s1.z * inv_n, s1.w * inv_n};
@@ -690,16 +691,24 @@ __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __rest
                                 const float* __restrict__ gy2, int64_t n, int C, int64_t rpb, const float* __restrict__ part, int nb,
                                 const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                float* __restrict__ gx, float* __restrict__ gres, float* __restrict__ sums /*[2][C]*/) {
+                                float* __restrict__ gx, float* __restrict__ gres, float* __restrict__ sums /*[2][C]*/, int CG) {
+  // r6: grid.y channel windows of CG channels (few rows x many channels — 872 x 512 — used to be 14 blocks of 2 row lanes, 49 us)
   extern __shared__ float sm[];
-  const int c4n = C / 4;
+  const int c0 = blockIdx.y * CG;
+  x += c0; gy += c0; gx += c0; mean += c0; var += c0;
+  if (y) y += c0;
+  if (gy2) gy2 += c0;
+  if (gres) gres += c0;
+  if (gamma) gamma += c0;
+  if (beta) beta += c0;
+  const int c4n = CG / 4;
   const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
   const int nrl = blockDim.x / c4n;
   float4 t1, t2;
-  bn1_reduce_parts(part, nb, C, cl, rl, nrl, sm, &t1, &t2);
+  bn1_reduce_parts(part, nb, C, cl, rl, nrl, sm, &t1, &t2, CG, c0);
   if (blockIdx.x == 0 && rl == 0) {
-    *reinterpret_cast<float4*>(sums + cl * 4) = t1;
-    *reinterpret_cast<float4*>(sums + C + cl * 4) = t2;
+    *reinterpret_cast<float4*>(sums + c0 + cl * 4) = t1;
+    *reinterpret_cast<float4*>(sums + C + c0 + cl * 4) = t2;
   }
   const float inv_n = 1.f / (float)n;
   float s1[4] = {t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n};
@@ -770,9 +779,16 @@ __global__ void k_bn2_apply(const float* __restrict__ x, int64_t n, int C, int64
                             float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                             const float* __restrict__ residual, int act, float momentum, float* __restrict__ y,
                             float* __restrict__ mean_out, float* __restrict__ var_out, float* __restrict__ cnt_out,
-                            float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt) {
-  extern __shared__ double smd[];             // [nrl][2][C]
-  const int c4n = C / 4;
+                            float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt, int CG) {
+  // r6: grid.y channel windows of CG channels (see k_bn1_bwd_apply)
+  extern __shared__ double smd[];             // [nrl][2][CG]
+  const int c0 = blockIdx.y * CG;
+  x += c0; y += c0; part += c0; mean_out += c0; var_out += c0;
+  if (residual) residual += c0;
+  if (gamma) gamma += c0;
+  if (beta) beta += c0;
+  if (rmean) { rmean += c0; rvar += c0; }
+  const int c4n = CG / 4;
   const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
   const int nrl = blockDim.x / c4n;
   double a1[4] = {0., 0., 0., 0.}, a2[4] = {0., 0., 0., 0.};
@@ -786,15 +802,15 @@ __global__ void k_bn2_apply(const float* __restrict__ x, int64_t n, int C, int64
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    smd[(rl * 2 + 0) * C + cl * 4 + j] = a1[j];
-    smd[(rl * 2 + 1) * C + cl * 4 + j] = a2[j];
+    smd[(rl * 2 + 0) * CG + cl * 4 + j] = a1[j];
+    smd[(rl * 2 + 1) * CG + cl * 4 + j] = a2[j];
   }
   __syncthreads();
   float mu[4], va[4], is[4], g[4], bt[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     double t1 = 0., t2 = 0.;
-    for (int q = 0; q < nrl; ++q) { t1 += smd[(q * 2 + 0) * C + cl * 4 + j]; t2 += smd[(q * 2 + 1) * C + cl * 4 + j]; }
+    for (int q = 0; q < nrl; ++q) { t1 += smd[(q * 2 + 0) * CG + cl * 4 + j]; t2 += smd[(q * 2 + 1) * CG + cl * 4 + j]; }
     bn2_stats(t1, t2, n, &mu[j], &va[j]);
     is[j] = 1.f / sqrtf(va[j] + eps);
     g[j] = gamma ? gamma[cl * 4 + j] : 1.f;
@@ -803,7 +819,7 @@ __global__ void k_bn2_apply(const float* __restrict__ x, int64_t n, int C, int64
   if (blockIdx.x == 0 && rl == 0) {
     *reinterpret_cast<float4*>(mean_out + cl * 4) = make_float4(mu[0], mu[1], mu[2], mu[3]);
     *reinterpret_cast<float4*>(var_out + cl * 4) = make_float4(va[0], va[1], va[2], va[3]);
-    if (cl == 0) { cnt_out[0] = (float)n; if (nbt) nbt[0] += 1; }
+    if (cl == 0 && blockIdx.y == 0) { cnt_out[0] = (float)n; if (nbt) nbt[0] += 1; }
     if (rmean) {
       float unbias = (float)n / fmaxf((float)n - 1.f, 1.f);
 #pragma unroll
@@ -1063,7 +1079,7 @@ int fc_bn_act_train_bwd(const float* x, const float* y, const float* gy, int64_t
   k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, nullptr, 0, n, C, 1, mean, var, eps, act, gamma, beta, rpb, part);
   FC_CHECK_LAUNCH();
   k_bn1_bwd_apply<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, n, C, rpb, part, (int)nb, mean, var, eps, gamma, beta, act, gx,
-                                                        gres, sums);
+                                                        gres, sums, C);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
@@ -1113,6 +1129,9 @@ int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* 
 }
 
 // ---- r5: training-mode BatchNorm, one entry point per direction for every size ------------------------------------------------
+// channel window of the prologue-reducing apply kernels: with few row blocks (the deep levels: 872 x 512, 3.5k x 256) a block owns 64
+// channels and the grid's y dimension walks the windows — 8x the blocks, 16 row lanes each, the SAME total table traffic; else all of C
+static int ap_window(int64_t n, int C) { return (C >= 128 && C % 64 == 0 && fc_cdiv(n > 0 ? n : 1, 64) * (C / 64) <= 1024 && fc_cdiv(n > 0 ? n : 1, 64) < 128) ? 64 : C; }
 static void ap_plan(int64_t n, int64_t* nb, int64_t* rpb) {     // apply grid of the prologue-reducing kernels: up to 256 blocks
   int64_t m = n > 0 ? n : 1;
   int64_t g = fc_cdiv(m, 64);
@@ -1148,9 +1167,11 @@ int fc_bn_train_fwd(const float* x, int64_t n, int C, float eps, const float* ga
   if (nb_part <= BN1_MAXB) {
     int64_t nb, rpb;
     ap_plan(n, &nb, &rpb);
-    const size_t smem = (size_t)(threads / (C / 4)) * 2 * C * sizeof(double);
-    k_bn2_apply<<<(unsigned)nb, threads, smem, stream>>>(x, n, C, rpb, part, (int)nb_part, groups, eps, gamma, beta, residual, act,
-                                                        momentum, y, mean, var, cnt, running_mean, running_var, num_batches_tracked);
+    const int CG = ap_window(n, C);
+    if (CG != C && stats_geometry(CG, &threads, &sf, &sb)) return FC_EINVAL;
+    const size_t smem = (size_t)(threads / (CG / 4)) * 2 * CG * sizeof(double);
+    k_bn2_apply<<<dim3((unsigned)nb, C / CG), threads, smem, stream>>>(x, n, C, rpb, part, (int)nb_part, groups, eps, gamma, beta, residual, act,
+                                                        momentum, y, mean, var, cnt, running_mean, running_var, num_batches_tracked, CG);
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
@@ -1186,8 +1207,10 @@ int fc_bn_train_bwd(const float* x, const float* y, const float* gy, const float
   if (np <= BN1_MAXB) {
     int64_t nb, rpb;
     if (!part) bn1_plan(n, &nb, &rpb); else ap_plan(n, &nb, &rpb);
-    k_bn1_bwd_apply<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, gy2, n, C, rpb, p, (int)np, mean, var, eps, gamma, beta, act, gx,
-                                                          gres, sums);
+    const int CG = ap_window(n, C);
+    if (CG != C && stats_geometry(CG, &threads, &sf, &sb)) return FC_EINVAL;
+    k_bn1_bwd_apply<<<dim3((unsigned)nb, C / CG), threads, sb, stream>>>(x, y, gy, gy2, n, C, rpb, p, (int)np, mean, var, eps, gamma, beta, act, gx,
+                                                          gres, sums, CG);
     FC_CHECK_LAUNCH();
     return FC_OK;
   }

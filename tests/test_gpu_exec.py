@@ -280,8 +280,12 @@ def test_pruned_finest_level_runs_as_a_tail_of_the_executor():
             E.ENABLED = True
             Fn.WGRAD_ASYNC = False
     print('pruned tail, TrainStep losses', traj)
-    for a, b in zip(traj[True], traj[False]):
-        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), traj
+    # step 1 to rounding; later steps: the two paths add BatchNorm-backward partial sums in different orders, the weights
+    # then differ in their last bits, and this run is deliberately badly conditioned (initial loss 170, 514 after one AdamW step with
+    # the widened score kernel): ONE flipped near-tie of the per-scene top-k moves the loss by ~1e-3 (seen in r6 at step 3 when the
+    # deep levels' BatchNorm kernels changed their summation order).  5e-3 bounds that; a wrong gradient shows at step 2 as O(1).
+    for i, (a, b) in enumerate(zip(traj[True], traj[False])):
+        assert abs(a - b) <= (1e-5 if i == 0 else 5e-3) * max(1.0, abs(b)), traj
 
 
 def test_simple_test_async_equals_simple_test():
