@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_X6_TFLOPS = round(2500.0 / 6, 1)   # fp32 products as 6 bf16 MFMA products each (csrc/conv_x6.h): bf16 dense peak / 6
+PEAK_H3_TFLOPS = round(2500.0 / 3, 1)   # r6: as 3 fp16 MFMA products each (csrc/conv_x6.h "h3"): fp16 dense peak (= bf16's) / 3
 
 
 def parse():
@@ -348,7 +349,7 @@ class ConvProbe:
         import ctypes
         import fcaf3d_amd._lib as L
         torch.cuda.synchronize()
-        cap = sum(e['nf'] + e['nb'] for e in self.exec_steps) + 16
+        cap = sum(e['nf'] + e['nb'] + e.get('na', 0) for e in self.exec_steps) + 16
         ms = (ctypes.c_float * cap)()
         meta = (ctypes.c_int64 * (8 * cap))()
         n = L.lib().fc_exec_probe_read(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(meta, ctypes.c_void_p), cap)
@@ -356,11 +357,15 @@ class ConvProbe:
         out, i = [], 0
         for e in self.exec_steps:
             pairs = {k: float(v.item()) for k, v in e['pairs'].items()}
-            for _ in range(e['nf'] + e['nb']):
+            for _ in range(e['nf'] + e['nb'] + e.get('na', 0)):
                 mp, _dir, n_in, n_out, K, Cin, Cout, _pm = (int(meta[8 * i + j]) for j in range(8))
+                if mp == -2:         # the amax pass of a convolution operand (h3 split): time of the operator family, no FLOPs, no launch of its own
+                    out.append((0.0, 0.0, float(ms[i]), True))
+                    i += 1
+                    continue
                 P = pairs[mp] if mp >= 0 else float(n_out)
                 nbytes = 4.0 * (n_in * Cin + n_out * Cout + K * Cin * Cout) + (4.0 * K * n_out if mp >= 0 else 0.0)
-                out.append((2.0 * P * Cin * Cout, nbytes, float(ms[i])))
+                out.append((2.0 * P * Cin * Cout, nbytes, float(ms[i]), False))
                 i += 1
         return out
 
@@ -370,14 +375,15 @@ class ConvProbe:
         if self.exec_steps and not any(e['nf'] for e in self.exec_steps):
             self.exec_steps = []
         torch.cuda.synchronize()
-        flops = ms = alg_bytes = 0.0
+        flops = ms = alg_bytes = amax_ms = 0.0
         n = 0
         if self.exec_steps:
-            for f, nb, t in self.exec_records():
+            for f, nb, t, is_amax in self.exec_records():
                 flops += f
                 alg_bytes += nb
                 ms += t
-                n += 1
+                n += 0 if is_amax else 1
+                amax_ms += t if is_amax else 0.0
         for bi, steps in self.timed.items():
             steps = [ev for ev in steps if ev]             # (steps that went through the executor left no per-call brackets)
             if not steps or bi not in self.counted:
@@ -410,16 +416,25 @@ class ConvProbe:
                 break
         import fcaf3d_amd.functional as Fn
         x6 = bool(Fn.X6)
-        peak = PEAK_X6_TFLOPS if x6 else PEAK_F32_MFMA_TFLOPS
+        h3 = x6 and Fn.split_mode() == 2
+        peak = (PEAK_H3_TFLOPS if h3 else PEAK_X6_TFLOPS) if x6 else PEAK_F32_MFMA_TFLOPS
         return dict(bound='mfma',
-                    kernel=('k_conv_x6 (sparse conv fwd + dgrad, dense GEMMs of convT/heads: fp32 in / fp32 accumulate, every fp32 '
-                            'product as 6 exact bf16 x bf16 products on v_mfma_f32_32x32x16_bf16)') if x6 else
+                    kernel=('k_conv_x6 MODE 2 "h3" (sparse conv fwd + dgrad, dense GEMMs of convT/heads: fp32 in / fp32 accumulate, every fp32 '
+                            'product as 3 exact fp16 x fp16 products of two-piece operands on v_mfma_f32_32x32x16_f16; the operands\' amax '
+                            'passes are inside the measured time)') if h3 else
+                    ('k_conv_x6 (sparse conv fwd + dgrad, dense GEMMs of convT/heads: fp32 in / fp32 accumulate, every fp32 '
+                     'product as 6 exact bf16 x bf16 products on v_mfma_f32_32x32x16_bf16)') if x6 else
                     'k_conv_mfma (sparse conv fwd + dgrad, dense GEMMs of convT/heads)',
                     achieved=round(achieved, 3), peak=peak, unit='TFLOP/s',
-                    peak_source=('bf16 dense MFMA peak 2500 TFLOP/s / 6 matrix products per fp32 product (MI355X_MICROARCH.md); '
-                                 'achieved counts the ALGORITHMIC fp32 FLOPs 2 P Cin Cout') if x6 else
+                    peak_source=('fp16 dense MFMA peak 2500 TFLOP/s / 3 matrix products per fp32 product (MI355X_MICROARCH.md); '
+                                 'achieved counts the ALGORITHMIC fp32 FLOPs 2 P Cin Cout') if h3 else
+                    ('bf16 dense MFMA peak 2500 TFLOP/s / 6 matrix products per fp32 product (MI355X_MICROARCH.md); '
+                     'achieved counts the ALGORITHMIC fp32 FLOPs 2 P Cin Cout') if x6 else
                     'v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)',
                     frac=round(achieved / peak, 4), vs_f32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    vs_six_product_peak=round(achieved / PEAK_X6_TFLOPS, 4) if x6 else None,
+                    products_per_fp32_product=(3 if h3 else 6) if x6 else 1,
+                    amax_ms_in_measured_time=round(amax_ms, 4),
                     traffic=traffic, traffic_unit='B/launch',
                     traffic_source=traffic_src, algorithmic_bytes_per_launch=round(alg_bytes / n), launches=n,
                     avg_launch_us=round(ms * 1e3 / n, 2), flops_per_launch=round(flops / n / 1e9, 4),
@@ -851,6 +866,7 @@ def main():
         try:
             torch.cuda.synchronize()
             L.lib().fc_set_bf16_fast(1)
+            trainer.invalidate_images()          # the fast mode reads six-product (bf16) images
             for i in range(3):
                 step(i)
             dtb, lb = timed_region(lambda i: step(i, prefetch=i < 7), 8, 1, dev)
@@ -863,6 +879,7 @@ def main():
         finally:
             torch.cuda.synchronize()
             L.lib().fc_set_bf16_fast(0)
+            trainer.invalidate_images()
     # (b5) BASELINE.md section 2 "also report" configurations (their own models; 5 steps each)
     extras = {}
     if world == 1 and not args.no_extras and args.workload == 'scannet-100k' and args.levels == 4 and args.voxel_size == 0.02:

@@ -40,7 +40,7 @@ def parse_header(path=HEADER):
     return protos
 
 
-ABI_VERSION = 6          # include/fcaf3d_hip.h FC_ABI_VERSION
+ABI_VERSION = 7          # include/fcaf3d_hip.h FC_ABI_VERSION
 _lib = None
 _protos = None
 

@@ -55,8 +55,118 @@ extern "C" int fc_set_bf16_fast(int on) {
   return FC_OK;
 }
 
+// r6: how the split kernels cut an fp32 operand (conv_x6.h): 2 = two fp16 pieces, three products ("h3", the default), 0 = three
+// bf16 pieces, six products (r3-r5).  Process-global (FC_SPLIT_MODE / fc_set_split_mode): weight images are built in the mode
+// that is current when fc_x6_weight_image(s) runs and MUST be read in that mode — whoever switches rebuilds them (functional.py
+// set_split_mode does).  The bf16 fast mode reads plane 0 of a SIX-product image: fc_set_bf16_fast(1) implies mode 0 while it is on.
+static int g_split_mode = -1;
+static inline int split_mode() {
+  if (g_split_mode < 0) {
+    const char* e = getenv("FC_SPLIT_MODE");
+    g_split_mode = (e && atoi(e) == 0) ? 0 : 2;
+  }
+  return g_bf16_fast ? 0 : g_split_mode;
+}
+extern "C" int fc_set_split_mode(int mode) {
+  if (mode != 0 && mode != 2) return FC_EINVAL;
+  g_split_mode = mode;
+  return FC_OK;
+}
+extern "C" int fc_get_split_mode(void) { return split_mode(); }
+
 #include "conv_x6.h"
 #include "wgrad_x6.h"
+#include "conv_h3r.h"
+
+// ---- r6: max |x| of an operand tensor (the scale of the h3 split, conv_x6.h) -----------------------------------------------------
+// slot = FC_AMAX_SLOT_BYTES (fc_common.h: 32 sub-words, one per 64-byte line; the kernels read their maximum); this pass uses the
+// first line: [0] the result (sub-word 0: bit pattern of max |x|), [1] running maximum, [2] finished blocks.
+// Every block folds its elements into [1] with ONE integer atomicMax (order-independent: bit-reproducible); the last block to
+// finish publishes [1] to [0] and clears [1], [2] for the slot's next use.  Slots must start zeroed (fc_amax_slots / the ring).
+__global__ __launch_bounds__(256) void k_amax(const f32x4* __restrict__ x, int64_t n4, const float* __restrict__ tail, int ntail,
+                                              unsigned* __restrict__ slot) {
+  __shared__ unsigned wm[4];
+  __shared__ int last_s;
+  unsigned m = 0u;
+  // FINITE elements only: an overflowed activation must poison the rows that gather it (inf s = inf -> NaN, as on the six-product
+  // route), not flatten the scale of the whole tensor.  Four loads in flight per thread.
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = i + q * stride < n4 ? x[i + q * stride] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const unsigned u = __float_as_uint(v[q][j]) & 0x7fffffffu; m = (u > m && u < 0x7f800000u) ? u : m; }
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) { const unsigned u = __float_as_uint(tail[threadIdx.x]) & 0x7fffffffu; m = (u > m && u < 0x7f800000u) ? u : m; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned b = wm[0];
+    for (int w = 1; w < 4; ++w) b = wm[w] > b ? wm[w] : b;
+    if (b > __hip_atomic_load(&slot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&slot[1], b);
+    __threadfence();
+    last_s = atomicAdd(&slot[2], 1u) == gridDim.x - 1;
+    if (last_s) {
+      __threadfence();
+      slot[0] = atomicExch(&slot[1], 0u);
+      slot[2] = 0u;
+    }
+  }
+}
+
+// library-owned ring of slots per device, for the operands whose caller brings no amax word of its own
+constexpr int AMAX_RING = 2048;
+static unsigned* g_amax_ring[16] = {};
+static unsigned g_amax_next[16] = {};
+static int amax_ring_slot(unsigned** slot) {
+  int dev = 0;
+  FC_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return FC_EINVAL;
+  if (!g_amax_ring[dev]) {
+    FC_HIP(hipMalloc((void**)&g_amax_ring[dev], (size_t)AMAX_RING * FC_AMAX_SLOT_BYTES));
+    FC_HIP(hipMemset(g_amax_ring[dev], 0, (size_t)AMAX_RING * FC_AMAX_SLOT_BYTES));
+  }
+  const unsigned i = __atomic_fetch_add(&g_amax_next[dev], 1u, __ATOMIC_RELAXED) % AMAX_RING;
+  *slot = g_amax_ring[dev] + (size_t)i * (FC_AMAX_SLOT_BYTES / 4);
+  return FC_OK;
+}
+static int amax_launch(const float* x, int64_t n, unsigned* slot, hipStream_t stream) {
+  if (n <= 0) { FC_HIP(hipMemsetAsync(slot, 0, 4, stream)); return FC_OK; }
+  const int64_t n4 = n / 4;
+  int64_t blocks = fc_cdiv(n4 > 0 ? n4 : 1, 256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  k_amax<<<(unsigned)blocks, 256, 0, stream>>>(reinterpret_cast<const f32x4*>(x), n4, x + 4 * n4, (int)(n - 4 * n4), slot);
+  FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+// the caller's amax words for the NEXT convolution / weight-gradient call of this thread (fc_conv_amax_hint): a0 = the gathered
+// operand (`in`), a1 = `gout` (weight gradients); NULL: computed here, into a ring slot.  Consumed by that call.
+static thread_local const unsigned* t_amax_hint[2] = {nullptr, nullptr};
+struct AmaxHintScope { ~AmaxHintScope() { t_amax_hint[0] = t_amax_hint[1] = nullptr; } };      // every convolution entry point drops the hints when it returns
+static int operand_amax(const float* x, int64_t n, int which, hipStream_t stream, const unsigned** out) {
+  const unsigned* h = t_amax_hint[which];
+  if (h) { *out = h; return FC_OK; }
+  unsigned* slot;
+  int rc = amax_ring_slot(&slot);
+  if (rc) return rc;
+  rc = amax_launch(x, n, slot, stream);
+  *out = slot;
+  return rc;
+}
+extern "C" int fc_amax(const float* x, int64_t n, unsigned* slot, hipStream_t stream) {
+  if (!slot || n < 0 || (n > 0 && !x) || ((uintptr_t)x & 15)) return FC_EINVAL;
+  return amax_launch(x, n, slot, stream);
+}
+extern "C" int fc_conv_amax_hint(const unsigned* amax_in, const unsigned* amax_gout) {
+  t_amax_hint[0] = amax_in;
+  t_amax_hint[1] = amax_gout;
+  return FC_OK;
+}
 
 #define BK 32            // reduction slab (input channels per stage / rows per stage for wgrad)
 #define LDA (BK + 4)     // A row stride in floats: 16B-aligned rows, conflict-free ds_read_b128 (9r mod 16)
@@ -1288,13 +1398,20 @@ static void conv_plan(int64_t n_out, int K, int Cin, int Cout, int flags, bool* 
 // and LDS-padding occupancy caps all lose or are neutral — profiles/r1_conv_pmc.md — and were removed in r2)
 static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in, const float* W, const int* nbr,
                             const int* out_index, const int* cnt, float* dst, int64_t n_rows, int K, int Cin, int Cout,
-                            hipStream_t stream, bool wt = false, const X6Epi* epi = nullptr, int64_t n_in = -1) {
+                            hipStream_t stream, bool wt = false, const X6Epi* epi = nullptr, int64_t n_in = -1,
+                            int64_t n_in_rows = -1) {
   if (epi && (pipe < 3 || bm < 128 || cnt || grid.z != 1)) return FC_EINVAL;      // the statistics epilogue lives in k_conv_x6
   // buffer addressing (k_conv_x6 BUF; gathering launches on a weight image): the gathered operand must end below the 2 GB its
   // descriptor spans; n_in < 0: the caller asks for (flags bit27) or only knows flat addresses
   const bool bufok = nbr && n_in >= 0 && (uint64_t)n_in * (uint64_t)Cin * 4u < (1ull << 31) - 4096u;
   X6Epi e6 = {};
   if (epi) e6 = *epi;
+  const bool h3 = pipe == 4 && bm >= 128 && split_mode() == 2;
+  if (h3) {                                      // the gathered operand's amax word: the caller's hint or a pass of our own
+    if (n_in_rows < 0) return FC_EINVAL;
+    int rc = operand_amax(in, n_in_rows * (int64_t)Cin, 0, stream, &e6.amax_in);
+    if (rc != FC_OK) return rc;
+  }
 #define FC_ARGS <<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout)
 #define FC_LAUNCH_MFMA(KERNEL, BM_, BN_, WM_)                                    \
   do {                                                                           \
@@ -1310,13 +1427,30 @@ static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in
   if (pipe == 4) wt = false;                     // a weight image already is the operator of its direction
   if (wt && !nbr) return FC_EINVAL;              // transposed weights: neighbour-table / pair-list launches only
   if (wt && pipe == 2) pipe = 0;                 // the LDS-DMA image cannot be transposed in flight
+  // r6: h3 launches on 128-row tiles take the register-operand kernel (conv_h3r.h; FC_H3R=0: the LDS-staged k_conv_x6 MODE 2, A/B)
+  static const bool h3r = !(getenv("FC_H3R") && atoi(getenv("FC_H3R")) == 0);
+  if (h3 && h3r && bm == 128 && !g_bf16_fast) {
+#define FC_LAUNCH_H3R(BN_)                                                                                               \
+  do {                                                                                                                  \
+    if (nbr && bufok) k_conv_h3r<BN_, true, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout, e6);       \
+    else if (nbr) k_conv_h3r<BN_, true, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout, e6);          \
+    else k_conv_h3r<BN_, false, false><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout, e6);                  \
+  } while (0)
+    if (bn == 128) FC_LAUNCH_H3R(128); else FC_LAUNCH_H3R(64);
+#undef FC_LAUNCH_H3R
+    FC_CHECK_LAUNCH();
+    return FC_OK;
+  }
   if (pipe >= 3 && bm >= 128) {                  // split-bf16 kernel; pipe 4: the weights are a pre-split image
 #define FC_ARGS6 <<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout, e6)
 #define FC_LAUNCH_X6(BM_, BN_, WM_)                                              \
   do {                                                                           \
-    if (pipe == 4 && g_bf16_fast && BM_ == 128 && nbr) k_conv_x6<128, BN_, true, 2, 2, true> FC_ARGS6;   \
-    else if (pipe == 4 && g_bf16_fast && BM_ == 128) k_conv_x6<128, BN_, false, 2, 2, true> FC_ARGS6;  \
-    else if (pipe == 4 && bufok && BM_ == 128) k_conv_x6<128, BN_, true, 2, 2, false, true> FC_ARGS6;  \
+    if (pipe == 4 && g_bf16_fast && BM_ == 128 && nbr) k_conv_x6<128, BN_, true, 2, 2, 1> FC_ARGS6;   \
+    else if (pipe == 4 && g_bf16_fast && BM_ == 128) k_conv_x6<128, BN_, false, 2, 2, 1> FC_ARGS6;  \
+    else if (pipe == 4 && h3 && bufok && BM_ == 128) k_conv_x6<128, BN_, true, 2, 2, 2, true> FC_ARGS6;  \
+    else if (pipe == 4 && h3 && nbr) k_conv_x6<BM_, BN_, true, WM_, 2, 2> FC_ARGS6;  \
+    else if (pipe == 4 && h3) k_conv_x6<BM_, BN_, false, WM_, 2, 2> FC_ARGS6;  \
+    else if (pipe == 4 && bufok && BM_ == 128) k_conv_x6<128, BN_, true, 2, 2, 0, true> FC_ARGS6;  \
     else if (pipe == 4 && nbr) k_conv_x6<BM_, BN_, true, WM_, 2> FC_ARGS6;       \
     else if (pipe == 4) k_conv_x6<BM_, BN_, false, WM_, 2> FC_ARGS6;        \
     else if (wt) k_conv_x6<BM_, BN_, true, WM_, 1> FC_ARGS6;                \
@@ -1378,6 +1512,7 @@ static int sum_parts_stats(const float* part, float* out, int64_t n_out, int Cou
 static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const int* out_index,
                          float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
                          int64_t ws_bytes, hipStream_t stream, const X6Epi* epi = nullptr) {
+  AmaxHintScope hint_scope;
   const bool stats = epi != nullptr;
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (n_out == 0) return FC_OK;                 // nothing to write (an empty table may well be a NULL pointer)
@@ -1404,7 +1539,7 @@ static int conv_fwd_impl(const float* in, const float* W, const int* nbr, const 
   float* dst = S > 1 ? (float*)ws : out;
   dim3 grid((unsigned)fc_cdiv(n_out, bm), Cout / bn, S);
   int rc = launch_conv_mfma(conv_pipe(flags, grid), bm, bn, grid, in, W, nbr, out_index, nullptr, dst, n_out, K, Cin, Cout, stream, wt,
-                            S > 1 ? nullptr : epi, (flags & (1 << 27)) ? -1 : n_in);
+                            S > 1 ? nullptr : epi, (flags & (1 << 27)) ? -1 : n_in, n_in);
   if (rc != FC_OK) return rc;
   if (S > 1) return stats ? sum_parts_stats(dst, out, n_out, Cout, S, *epi, stream) : sum_parts(dst, out, n_out, Cout, S, stream);
   return FC_OK;
@@ -1459,14 +1594,28 @@ int64_t fc_x6_weight_image_bytes(int K, int R, int C) { return (int64_t)K * R * 
 int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int transposed, hipStream_t stream) {
   if (K < 1 || R < 32 || C < 64 || R % 32 != 0 || C % 64 != 0) return FC_EINVAL;
   const int64_t total = (int64_t)K * (R / 32) * (C / 64) * 256;
-  k_x6_weight_image<<<(unsigned)fc_cdiv(total, 256), 256, 0, stream>>>(W, (u32x4*)img, K, R, C, transposed);
+  const unsigned nb = (unsigned)fc_cdiv(total, 256);
+  if (split_mode() == 2) {                       // h3: max |W| into the image's amax word, then the fp16 pieces
+    FC_HIP(hipMemsetAsync((char*)img + 4 * X6_IMG_AMAX_WORD, 0, 4, stream));
+    k_x6_weight_image<3><<<nb, 256, 0, stream>>>(W, (u32x4*)img, K, R, C, transposed);
+    k_x6_weight_image<2><<<nb, 256, 0, stream>>>(W, (u32x4*)img, K, R, C, transposed);
+  } else {
+    k_x6_weight_image<0><<<nb, 256, 0, stream>>>(W, (u32x4*)img, K, R, C, transposed);
+  }
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
 
 int fc_x6_weight_images(const int64_t* desc, int n, int64_t total_blocks, hipStream_t stream) {
   if (!desc || n < 1 || total_blocks < 1 || total_blocks > 0x7fffffffll) return FC_EINVAL;
-  k_x6_weight_images<<<(unsigned)total_blocks, 256, 0, stream>>>(reinterpret_cast<const long long*>(desc), n);
+  const long long* d = reinterpret_cast<const long long*>(desc);
+  if (split_mode() == 2) {
+    k_x6_weight_images<4><<<(unsigned)fc_cdiv(n, 256), 256, 0, stream>>>(d, n);
+    k_x6_weight_images<3><<<(unsigned)total_blocks, 256, 0, stream>>>(d, n);
+    k_x6_weight_images<2><<<(unsigned)total_blocks, 256, 0, stream>>>(d, n);
+  } else {
+    k_x6_weight_images<0><<<(unsigned)total_blocks, 256, 0, stream>>>(d, n);
+  }
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
@@ -1479,6 +1628,7 @@ int64_t fc_conv_fwd_pairs_ws_bytes(int64_t n_out, int K, int Cout) {
 static int conv_fwd_pairs_impl(const float* in, const float* W, const int* pair_in, const int* pair_cnt, const int* pair_pos,
                             float* out, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int64_t live_tiles, int flags,
                             void* ws, int64_t ws_bytes, hipStream_t stream, const X6Epi* epi) {
+  AmaxHintScope hint_scope;
   if (n_in < 0 || n_out < 0 || K < 1 || K > 65535 || Cin < 1 || Cout < 1) return FC_EINVAL;
   if (!pair_in || !pair_cnt || !pair_pos) return FC_EINVAL;
   if (Cin % 32 != 0 || Cout % 64 != 0) return FC_EINVAL;       // MFMA shapes only; callers use fc_conv_fwd otherwise
@@ -1493,7 +1643,7 @@ static int conv_fwd_pairs_impl(const float* in, const float* W, const int* pair_
   dim3 grid((unsigned)fc_cdiv(n_out, 128), Cout / bn, K);
   if (live_tiles > 0) grid = dim3((unsigned)live_tiles, Cout / bn, 1);       // linear list of the live (offset, tile) pairs
   {
-    int rc = launch_conv_mfma((live_tiles > 0 || (flags & (1 << 24))) ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt, nullptr, (flags & (1 << 27)) ? -1 : n_in);
+    int rc = launch_conv_mfma((live_tiles > 0 || (flags & (1 << 24))) ? conv_pipe(flags, grid) : ((flags & (1 << 21)) ? 2 : ((flags & (1 << 18)) ? 1 : 0)), 128, bn, grid, in, W, pair_in, nullptr, pair_cnt, part, n_out, K, Cin, Cout, stream, wt, nullptr, (flags & (1 << 27)) ? -1 : n_in, n_in);
     if (rc != FC_OK) return rc;
   }
   if (epi) {
@@ -2135,6 +2285,7 @@ int64_t fc_conv_wgrad_ws_bytes(int64_t n_out, int K, int Cin, int Cout, int flag
 static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, const int* row_index, const int* cnt,
                            float* gW, int64_t n_in, int64_t n_out, int K, int Cin, int Cout, int flags, void* ws,
                            int64_t ws_bytes, hipStream_t stream) {
+  AmaxHintScope hint_scope;
   if (n_in < 0 || n_out < 0 || K < 1 || Cin < 1 || Cout < 1) return FC_EINVAL;
   const int64_t elems = (int64_t)K * Cin * Cout;
   if (n_out == 0) {
@@ -2149,6 +2300,17 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
   float* part = (S == 1) ? gW : (float*)ws;
   bool mfma_ok = !(flags & 1) && (Cin % 64 == 0) && (Cout % 64 == 0);
   if (cnt && !mfma_ok) return FC_EINVAL;       // pair lists are an MFMA-path feature
+  // h3 (conv_x6.h): the k_wgrad_x6t launches below split both operands into two fp16 pieces, scaled by their amax words
+  const bool x6t = mfma_ok && (flags & (1 << 24)) &&
+                   (wgrad_multi_ok(n_out, K, Cin, Cout, flags, dense_table) ||
+                    (cnt && (Cin % 128 == 0 || Cout % 128 == 0 || wgrad_tr64())) || (!nbr && !cnt && wgrad_tr64()));
+  const bool h3 = x6t && split_mode() == 2;
+  const unsigned *am_a = nullptr, *am_g = nullptr;
+  if (h3) {
+    int rc = operand_amax(in, n_in * (int64_t)Cin, 0, stream, &am_a);
+    if (rc == FC_OK) rc = operand_amax(gout, n_out * (int64_t)Cout, 1, stream, &am_g);
+    if (rc != FC_OK) return rc;
+  }
   if (!(flags & 1) && nbr && Cin == STEM_CIN && Cout == STEM_COUT && K <= 27) {
     size_t smem = (size_t)(STEM_ROWS * STEM_JP + STEM_ROWS * 64) * sizeof(float);
     k_stem_wgrad<<<(unsigned)S, 256, smem, stream>>>(in, gout, nbr, part, n_out, K, rps);
@@ -2156,10 +2318,12 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     const int bn = (Cout % 128 == 0) ? 128 : 64;
     dim3 grid((unsigned)S, (unsigned)((K / WGRAD_KO) * (Cin / 64) * (Cout / bn)));
     if (flags & (1 << 24)) {                     // split-bf16 (wgrad_x6.h)
-      if (g_bf16_fast && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false, true><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
-      else if (g_bf16_fast) k_wgrad_x6t<64, 64, WGRAD_KO, false, true><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
-      else if (bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
-      else k_wgrad_x6t<64, 64, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);
+      if (g_bf16_fast && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false, 1><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr);
+      else if (g_bf16_fast) k_wgrad_x6t<64, 64, WGRAD_KO, false, 1><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr);
+      else if (h3 && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false, 2><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, am_a, am_g);
+      else if (h3) k_wgrad_x6t<64, 64, WGRAD_KO, false, 2><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, am_a, am_g);
+      else if (bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr);
+      else k_wgrad_x6t<64, 64, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr);
     } else
     if (bn == 128) k_wgrad_multi<128, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
     else k_wgrad_multi<64, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
@@ -2174,14 +2338,14 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
 #define FC_WX6(BM_, BN_)                                                                                                             \
   do {                                                                                                                               \
-    if (g_bf16_fast) k_wgrad_x6t<BM_, BN_, 1, true, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); \
-    else k_wgrad_x6t<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps); \
+    if (g_bf16_fast) k_wgrad_x6t<BM_, BN_, 1, true, 1><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps, nullptr, nullptr); \
+    else if (h3) k_wgrad_x6t<BM_, BN_, 1, true, 2><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps, am_a, am_g); \
+    else k_wgrad_x6t<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps, nullptr, nullptr); \
   } while (0)
     if (bm == 128 && bn == 128) FC_WX6(128, 128);
     else if (bm == 128) FC_WX6(128, 64);
     else if (bn == 128) FC_WX6(64, 128);
-    else if (g_bf16_fast) k_wgrad_x6t<64, 64, 1, true, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
-    else k_wgrad_x6t<64, 64, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps);
+    else FC_WX6(64, 64);
 #undef FC_WX6
   } else if (mfma_ok && !nbr && !cnt && (flags & (1 << 24)) && wgrad_tr64()) {
     // table-free dense GEMM gW = in^T gout over the rows (K = 1): the same kernel with the row itself as the index
@@ -2191,8 +2355,9 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
 #define FC_WX6D(BM_, BN_)                                                                                                              \
   do {                                                                                                                                \
-    if (g_bf16_fast) k_wgrad_x6t<BM_, BN_, 1, false, true><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps); \
-    else k_wgrad_x6t<BM_, BN_, 1, false><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps);   \
+    if (g_bf16_fast) k_wgrad_x6t<BM_, BN_, 1, false, 1><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr); \
+    else if (h3) k_wgrad_x6t<BM_, BN_, 1, false, 2><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, am_a, am_g); \
+    else k_wgrad_x6t<BM_, BN_, 1, false><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr);   \
   } while (0)
     if (bm == 128 && bn == 128) FC_WX6D(128, 128);
     else if (bm == 128) FC_WX6D(128, 64);

@@ -69,6 +69,47 @@ __device__ __forceinline__ void x6_split2(float x0, float x1, unsigned& p0, unsi
 }
 #endif
 
+// ---- r6: TWO fp16 pieces per operand, THREE products ("h3") -------------------------------------------------------------------
+// An fp16 carries 11 significant bits.  With round-to-nearest pieces  h = RN11(s x),  l = RN11(s x - h)  the residual s x - h is
+// a multiple of x's last bit with at most 12 significant bits, so the pair (h, l) holds s x EXACTLY for three values in four and
+// to one fp32 ulp (2^-23 |s x|) otherwise — provided the pieces stay inside fp16's exponent range, which is what the power-of-two
+// scale s is for: s = 2^(14 - floor(log2 max|x|)) over the whole operand tensor puts its largest element in [2^14, 2^15) (fp16
+// overflows at 65 504), an element 2^-16 of the maximum still has both pieces normal, and below that the low piece goes subnormal
+// (kept by the MFMA: scratch/h3_probe.hip) with an ABSOLUTE error <= 2^-25 = 2^-39 of the tensor's maximum.  A product
+// a b = (ah + al)(bh + bl) keeps ah bh + ah bl + al bh, each EXACT in the fp32 accumulator (11 x 11 = 22 bits); dropped: al bl
+// <= 2^-22 |a b| and the two representation residuals <= 2^-23 |a b| each: worst case 2^-21, on average 2^-25 of a product, no
+// common sign (oracle/x6_oracle.py + its test pin these numbers).  Measured on a 1 728-term heavy-tailed reduction: 5.8e-7 of the
+// result scale against 1.3e-6 for an fp32 FMA chain (rms 1.0e-7; a fourth product changes nothing), and on every benchmark layer
+// closer to fp64 than the six-product route (tools/nbench).  3 x 32 = 96 matrix-pipe cycles per 32x32x16 block instead of 192,
+// two planes instead of three through LDS.
+// The scale travels with the data: every operand tensor has a word holding max |x| (bit pattern; fc_amax, conv.hip), weight
+// images carry theirs in the unused third plane (X6_IMG_AMAX_WORD), and the kernels derive s and 1 / (sa sb) from the exponent
+// fields — nothing but integer arithmetic on the host or the device decides a scale, so runs are bit-reproducible.
+typedef _Float16 x6_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define X6_IMG_AMAX_WORD 2048          // dword index in a weight image: plane 2, row 0, chunk 0 of the first (k, slab, group) block
+__device__ __forceinline__ float h3_scale(unsigned amax_bits) {       // 2^(14 - floor(log2 amax)), clamped to the normal range
+  int se = 268 - (int)((amax_bits >> 23) & 0xffu);
+  se = se > 254 ? 254 : (se < 1 ? 1 : se);
+  return __uint_as_float((unsigned)se << 23);
+}
+__device__ __forceinline__ float h3_unscale(float sa, float sb) {      // 1 / (sa sb) as a power of two (clamped)
+  int e = 381 - (int)(__float_as_uint(sa) >> 23) - (int)(__float_as_uint(sb) >> 23);
+  e = e > 254 ? 254 : (e < 1 ? 1 : e);
+  return __uint_as_float((unsigned)e << 23);
+}
+__device__ __forceinline__ unsigned h3_rn2(float x0, float x1) {
+  const x6_f32x2 v = {x0, x1};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, x6_f16x2));
+}
+// two fp32 (already scaled) -> two dwords, each the fp16 pair (piece of x0 low half, piece of x1 high half)
+__device__ __forceinline__ void h3_split2(float x0, float x1, unsigned& p0, unsigned& p1) {
+  p0 = h3_rn2(x0, x1);
+  const x6_f16x2 h = __builtin_bit_cast(x6_f16x2, p0);
+  const float r0 = __builtin_fmaf((float)h[0], -1.0f, x0), r1 = __builtin_fmaf((float)h[1], -1.0f, x1);      // exact
+  p1 = h3_rn2(r0, r1);
+}
+
 // Weight slab in LDS and in a pre-split weight image: per 64-column group three planes of 64 rows x 64 B.  Column c of the
 // group lives in row (c % 2) * 32 + c / 2: a wave's sub-tile j reads rows j * 32 + r = the INTERLEAVED columns 2 r + j
 // (8-byte output stores).  16-byte unit index of (group-local column c, plane, chunk):
@@ -103,15 +144,81 @@ __device__ __forceinline__ void x6_weight_image_unit(const float* __restrict__ W
   }
 }
 
+// h3 image: planes 0 / 1 hold the fp16 pieces of sw W, plane 2 is unused (its first word holds max |W|: X6_IMG_AMAX_WORD, written
+// by the amax pass that runs before this one)
+__device__ __forceinline__ void h3_weight_image_unit(const float* __restrict__ W, u32x4* __restrict__ img, int64_t t, int R, int C,
+                                                     int transposed) {
+  const float sw = h3_scale(reinterpret_cast<const unsigned*>(img)[X6_IMG_AMAX_WORD]);
+  const int chunk = (int)(t & 3), c = (int)((t >> 2) & 63);
+  const int64_t blk = t >> 8;
+  const int g = (int)(blk % (C / 64));
+  const int slab = (int)((blk / (C / 64)) % (R / 32));
+  const int k = (int)(blk / ((int64_t)(C / 64) * (R / 32)));
+  const int col = g * 64 + c, r0 = slab * 32 + chunk * 8;
+  const float* Wk = W + (int64_t)k * R * C;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = sw * (transposed ? Wk[(int64_t)col * R + r0 + e] : Wk[(int64_t)(r0 + e) * C + col]);
+  unsigned p[2][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) h3_split2(x[2 * e], x[2 * e + 1], p[0][e], p[1][e]);
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+    u32x4 v = {p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
+    img[blk * X6_GROUP_U16 + x6_bslot(c, pl, chunk)] = v;
+  }
+}
+// max |W| of the 8 weights of image unit t (the same elements the image pass reads)
+__device__ __forceinline__ unsigned h3_weight_unit_amax(const float* __restrict__ W, int64_t t, int R, int C, int transposed) {
+  const int chunk = (int)(t & 3), c = (int)((t >> 2) & 63);
+  const int64_t blk = t >> 8;
+  const int g = (int)(blk % (C / 64));
+  const int slab = (int)((blk / (C / 64)) % (R / 32));
+  const int k = (int)(blk / ((int64_t)(C / 64) * (R / 32)));
+  const int col = g * 64 + c, r0 = slab * 32 + chunk * 8;
+  const float* Wk = W + (int64_t)k * R * C;
+  unsigned m = 0u;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned u = __float_as_uint(transposed ? Wk[(int64_t)col * R + r0 + e] : Wk[(int64_t)(r0 + e) * C + col]) & 0x7fffffffu;
+    m = (u > m && u < 0x7f800000u) ? u : m;          // finite weights only (k_amax)
+  }
+  return m;
+}
+__device__ __forceinline__ void h3_block_amax(unsigned m, unsigned* __restrict__ dst) {      // 256 threads -> one atomicMax
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
+  // (skipped when the word already holds as much: 4 waves x 69k blocks on ~100 words cost the weight pass 0.7 ms per step without)
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, m);
+}
+
+// MODE: 0 six bf16 products, 2 three fp16 products (amax pass: MODE 3)
+template <int MODE>
+__global__ void k_x6_weight_image(const float* __restrict__ W, u32x4* __restrict__ img, int K, int R, int C, int transposed) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (k, slab, group, column, chunk)
+  const bool live = t < (int64_t)K * (R / 32) * (C / 64) * 256;
+  if (MODE == 3) { h3_block_amax(live ? h3_weight_unit_amax(W, t, R, C, transposed) : 0u, reinterpret_cast<unsigned*>(img) + X6_IMG_AMAX_WORD); return; }
+  if (!live) return;
+  if (MODE == 2) h3_weight_image_unit(W, img, t, R, C, transposed);
+  else x6_weight_image_unit(W, img, t, R, C, transposed);
+}
+#if 0
 __global__ void k_x6_weight_image(const float* __restrict__ W, u32x4* __restrict__ img, int K, int R, int C, int transposed) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (k, slab, group, column, chunk)
   if (t < (int64_t)K * (R / 32) * (C / 64) * 256) x6_weight_image_unit(W, img, t, R, C, transposed);
 }
+#endif
 
 // Images of MANY kernels in one launch (every convolution of a model, both directions, after an optimizer step):
 // desc[e] = {W, img, K, R, C, transposed, first block, -}; an entry owns the blocks [first block, first block of e + 1) and
 // K (R / 32) (C / 64) of them are live (256 threads = one (k, slab, group) unit each).
+template <int MODE>           // 0 / 2: the image pass of that mode; 3: the amax pass of h3; 4: zero the amax words (one thread per entry)
 __global__ void k_x6_weight_images(const long long* __restrict__ desc, int n) {
+  if (MODE == 4) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) reinterpret_cast<unsigned*>(desc[8 * e + 1])[X6_IMG_AMAX_WORD] = 0u;
+    return;
+  }
   int lo = 0, hi = n - 1;
   const long long b = blockIdx.x;
   while (lo < hi) {                                                         // last entry whose first block <= b
@@ -121,11 +228,17 @@ __global__ void k_x6_weight_images(const long long* __restrict__ desc, int n) {
   const long long* d = desc + 8 * lo;
   const int K = (int)d[2], R = (int)d[3], C = (int)d[4];
   const int64_t t = (b - d[6]) * 256 + threadIdx.x;
-  if (t < (int64_t)K * (R / 32) * (C / 64) * 256)
-    x6_weight_image_unit(reinterpret_cast<const float*>(d[0]), reinterpret_cast<u32x4*>(d[1]), t, R, C, (int)d[5]);
+  const bool live = t < (int64_t)K * (R / 32) * (C / 64) * 256;
+  const float* W = reinterpret_cast<const float*>(d[0]);
+  u32x4* img = reinterpret_cast<u32x4*>(d[1]);
+  if (MODE == 3) { h3_block_amax(live ? h3_weight_unit_amax(W, t, R, C, (int)d[5]) : 0u, reinterpret_cast<unsigned*>(img) + X6_IMG_AMAX_WORD); return; }
+  if (!live) return;
+  if (MODE == 2) h3_weight_image_unit(W, img, t, R, C, (int)d[5]);
+  else x6_weight_image_unit(W, img, t, R, C, (int)d[5]);
 }
 
 #define X6_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+#define H3_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
 
 // BSRC: where the weight slab comes from — 0: fp32 (Cin, Cout) kernel, split in the staging; 1: the same kernel read
 // transposed (backward data on the layer's own weights); 2: a pre-split image of k_x6_weight_image (straight copy).
@@ -149,6 +262,7 @@ struct X6Epi {
   int act;
   const float* add;
   const float* bn_y;
+  const unsigned* amax_in;       // h3 launches: the amax SLOT (fc_common.h fc_amax_read) of the gathered operand
 };
 
 // the two terms an element contributes to the statistics table (see X6Epi); mu / is / ga / be: the channel's parameters
@@ -183,7 +297,8 @@ __device__ __forceinline__ void x6_epi_terms(bool bwd, float v, float xv, float 
 // descriptor's range, the load returns zeros), the channel slab and the image's stage are SCALAR offsets — instead of 64-bit
 // per-lane addresses rebuilt every stage: the stage loop of the flat-address kernel issues ~3.4 VALU and 1.5 scalar instructions
 // per MFMA (profiles/r5_conv_pmc.md) of which the address arithmetic is a third.  Same loads, same values: bit-identical.
-template <int BM, int BN, bool HAS_NBR, int WM, int BSRC, bool FAST = false, bool BUF = false>
+// MODE (r6; was the bool FAST): 0 six bf16 products, 1 FAST, 2 h3 — three fp16 products on two planes (weight-image launches only)
+template <int BM, int BN, bool HAS_NBR, int WM, int BSRC, int MODE = 0, bool BUF = false>
 __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_conv_x6(
     const float* __restrict__ in, const float* __restrict__ W, const int* __restrict__ nbr,
     const int* __restrict__ out_index, const int* __restrict__ cnt, float* __restrict__ out, int64_t n_out, int K, int Cin,
@@ -196,8 +311,12 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
   constexpr int CPT = BN / 64;                                 // weight columns per thread per stage (BSRC 0 / 1)
   constexpr int BU = 3 * BN / 64;                              // 16-byte image units per thread per stage (BSRC 2)
   constexpr bool WT = BSRC == 1;
-  __shared__ u32x4 As[3 * BM * 4];                             // [plane][row][4 chunks]
-  __shared__ u32x4 Bs[(BN / 64) * X6_GROUP_U16];               // [64-column group][plane][row][4 chunks]: x6_bslot
+  constexpr bool FAST = MODE == 1;
+  constexpr bool H3 = MODE == 2 && BSRC == 2;
+  constexpr int NPL = H3 ? 2 : 3;                              // planes staged per operand
+  constexpr int GU = NPL * 64 * 4;                             // 16-byte units of a 64-column group in LDS (the IMAGE keeps 3 planes)
+  __shared__ u32x4 As[NPL * BM * 4];                           // [plane][row][4 chunks]
+  __shared__ u32x4 Bs[(BN / 64) * GU];                         // [64-column group][plane][row][4 chunks]: x6_bslot
   __shared__ unsigned int kmask_s;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -229,6 +348,11 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
   }
   const int64_t m0 = bx * BM;
   const int a_c4 = tid & 7, a_r = tid >> 3;      // A staging: 8 float4 per gathered 32-channel row slab, 32 rows per pass
+  float h3_sa = 1.f, h3_inv = 1.f;               // h3: scale of the gathered operand, 1 / (sa sw) for the epilogue
+  if (H3) {
+    h3_sa = h3_scale(fc_amax_read(epi.amax_in));
+    h3_inv = h3_unscale(h3_sa, h3_scale(reinterpret_cast<const unsigned*>(W)[X6_IMG_AMAX_WORD]));
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -323,7 +447,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
         const unsigned boff = (((unsigned)(kbase + lk) * (unsigned)nslab + (unsigned)(lc0 / 32)) * (unsigned)ngrp + (unsigned)(n0 / 64)) * (unsigned)(X6_GROUP_U16 * 16);
 #pragma unroll
         for (int i = 0; i < BU; ++i)
-          if (!fast || i % 3 == 0) bi[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, tid * 16, (int)(boff + 4096u * i), 0);
+          if ((!fast || i % 3 == 0) && !(H3 && i % 3 == 2)) bi[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, tid * 16, (int)(boff + 4096u * i), 0);
 #pragma unroll
         for (int i = 0; i < AR; ++i)
           av[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)ocur[i], lc0 * 4, 0));
@@ -333,7 +457,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
         const u32x4* src = img + (((int64_t)(kbase + lk) * nslab + lc0 / 32) * ngrp + n0 / 64) * X6_GROUP_U16 + tid;
 #pragma unroll
         for (int i = 0; i < BU; ++i)
-          if (!fast || i % 3 == 0) bi[i] = src[256 * i];          // (unit tid + 256 i lies in plane i % 3 of its 64-column group)
+          if ((!fast || i % 3 == 0) && !(H3 && i % 3 == 2)) bi[i] = src[256 * i];          // (unit tid + 256 i lies in plane i % 3 of its 64-column group)
       } else if (WT) {
         const float* Wk = W + (int64_t)lk * Cin * Cout;
 #pragma unroll
@@ -375,7 +499,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       a_slot[b] = (wr * RW + r) * 4 + ((2 * b + h) ^ swz);
-      b_slot[b] = bgrp * X6_GROUP_U16 + ((TN == 2 ? 0 : wc * 32) + r) * 4 + ((2 * b + h) ^ swz);
+      b_slot[b] = bgrp * GU + ((TN == 2 ? 0 : wc * 32) + r) * 4 + ((2 * b + h) ^ swz);
     }
     for (int st = 0; st < nst; ++st) {
       __syncthreads();                           // previous stage fully consumed
@@ -385,11 +509,16 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
       for (int i = 0; i < AR; ++i) {
         const int row = a_r + 32 * i;
         unsigned p[3][2];
-        x6_split2(av[i][0], av[i][1], p[0][0], p[1][0], p[2][0]);
-        x6_split2(av[i][2], av[i][3], p[0][1], p[1][1], p[2][1]);
+        if (H3) {
+          h3_split2(av[i][0] * h3_sa, av[i][1] * h3_sa, p[0][0], p[1][0]);
+          h3_split2(av[i][2] * h3_sa, av[i][3] * h3_sa, p[0][1], p[1][1]);
+        } else {
+          x6_split2(av[i][0], av[i][1], p[0][0], p[1][0], p[2][0]);
+          x6_split2(av[i][2], av[i][3], p[0][1], p[1][1], p[2][1]);
+        }
         const int slot = row * 4 + ((a_c4 >> 1) ^ ((row >> 2) & 3));
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
           if (fast && pl) break;
           u32x2 v = {p[pl][0], p[pl][1]};
           reinterpret_cast<u32x2*>(As + pl * BM * 4 + slot)[a_c4 & 1] = v;
@@ -399,7 +528,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
       if (BSRC == 2) {
 #pragma unroll
         for (int i = 0; i < BU; ++i)
-          if (!fast || i % 3 == 0) Bs[tid + 256 * i] = bi[i];
+          if ((!fast || i % 3 == 0) && !(H3 && i % 3 == 2)) Bs[H3 ? (i / 3) * GU + (i % 3) * 256 + tid : tid + 256 * i] = bi[i];
       } else {
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
@@ -446,6 +575,27 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = X6_MFMA(fa1[i], fb1[j], acc[i][j]);
         }
+      } else if (H3) {                             // three products per block, smallest first: ah bl | al bh, ah bh
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          u32x4 fa[2][TM];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[pl][i] = As[pl * BM * 4 + a_slot[b] + i * 32 * 4];
+#pragma unroll
+          for (int pb = 1; pb >= 0; --pb) {
+            u32x4 fb[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = Bs[pb * 64 * 4 + b_slot[b] + j * 32 * 4];
+#pragma unroll
+            for (int pa = 1 - pb; pa >= 0; --pa)
+#pragma unroll
+              for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = H3_MFMA(fa[pa][i], fb[j], acc[i][j]);
+          }
+        }
       } else
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
@@ -469,6 +619,14 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
       }
       if (pmode == 1) __builtin_amdgcn_s_setprio(0);
     }
+  }
+  if (H3) {                                      // back to the operands' own scale (a power of two: exact)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] *= h3_inv;
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); lane r of sub-tile j holds
   // column 2 r + j of the wave's 64-column group (TN == 1: j = wc)

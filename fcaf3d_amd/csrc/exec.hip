@@ -23,7 +23,7 @@ namespace {
 enum : int64_t {
   OP_STEM_FWD = 1, OP_COL_STATS, OP_NORM_FWD, OP_MAXPOOL_FWD, OP_CONV, OP_BN_FWD, OP_UNION_FWD, OP_HEAD_FWD, OP_RECORD, OP_WAIT,
   OP_HEAD_BWD, OP_WGRAD, OP_BN_BWD, OP_NORM_BWD, OP_MAXPOOL_BWD, OP_STEM_WGRAD, OP_GATHER, OP_ADD, OP_SMALL_GRADS,
-  OP_PERMUTE_GENT, OP_HEAD_WFIN, OP_COPY, OP_COL_SUM, OP_ROW_SUM
+  OP_PERMUTE_GENT, OP_HEAD_WFIN, OP_COPY, OP_COL_SUM, OP_ROW_SUM, OP_AMAX, OP_CLEAR
 };
 constexpr int OPW = 24;            // int64 words per operator
 constexpr int MAPW = 20;           // int64 words per kernel-map descriptor
@@ -159,13 +159,16 @@ struct Ctx {
 int run_op_impl(Ctx& c, const int64_t* op);
 
 int run_op(Ctx& c, const int64_t* op) {
-  if (c.dry || !c.probe || op[0] != 5 /* OP_CONV */) return run_op_impl(c, op);
+  if (c.dry || !c.probe || (op[0] != OP_CONV && op[0] != OP_AMAX)) return run_op_impl(c, op);
   ProbeRec r;
   r.a = probe_event(); r.b = probe_event();
   if (!r.a || !r.b) return run_op_impl(c, op);
   hipStream_t st = c.streams[op[1]];
   const int64_t Cin = op[8], Cout = op[9];
-  if (op[4] < 0) {
+  if (op[0] == OP_AMAX) {          // the amax pass of a convolution operand (h3): meta[0] = -2, n_in = rows, Cin = columns, no FLOPs
+    const int64_t m[8] = {-2, 0, c.dims[op[3]], 0, 0, op[4], 0, 0};
+    __builtin_memcpy(r.meta, m, sizeof m);
+  } else if (op[4] < 0) {
     const int64_t n = c.dims[op[7]];
     const int64_t m[8] = {-1, op[5], n, n, 1, Cin, Cout, 0};
     __builtin_memcpy(r.meta, m, sizeof m);
@@ -236,9 +239,10 @@ int run_op_impl(Ctx& c, const int64_t* op) {
                              P<const float>(c, op[6]), P<const float>(c, op[7]), (float)as_double(op[8]), P<const float>(c, op[9]),
                              P<const float>(c, op[10]), P<const float>(c, op[11]), (int)op[12], P<float>(c, op[13]), st);
     }
-    case OP_MAXPOOL_FWD: {  // in, map, C, out, arg
+    case OP_MAXPOOL_FWD: {  // in, map, C, out, arg, amax word of out + 1 | 0
       const int64_t* m = c.maps + op[3] * MAPW;
       if (c.dry) return 0;
+      if (op[7] > 0) fc_amax_out_hint(P<unsigned>(c, op[7] - 1));
       return fc_maxpool_fwd(P<const float>(c, op[2]), reinterpret_cast<const int*>(m[3]), m[1], (int)m[2], (int)op[4], P<float>(c, op[5]),
                             P<int>(c, op[6]), st);
     }
@@ -257,6 +261,8 @@ int run_op_impl(Ctx& c, const int64_t* op) {
       const float* in = P<const float>(c, op[2]);
       const float* img = P<const float>(c, op[3]);
       float* out = P<float>(c, op[6]);
+      // word 20: the amax word of `in` + 1 (h3 split; 0: the entry point makes its own pass) — consumed by the ONE call below
+      if (!c.dry && op[20] > 0) fc_conv_amax_hint(P<const unsigned>(c, op[20] - 1), nullptr);
       if (op[4] < 0) {
         const int64_t n = c.dims[op[7]];
         if (!want_ws(c, s, fc_conv_fwd_ws_bytes(n, 1, Cin, Cout, fl))) return 0;
@@ -293,6 +299,7 @@ int run_op_impl(Ctx& c, const int64_t* op) {
       const float eps = (float)as_double(op[5]), mom = (float)as_double(op[10]);
       if (!op[18]) {      // eval mode: the running statistics are the statistics
         if (c.dry) return 0;
+        if (op[21] > 0) fc_amax_out_hint(P<unsigned>(c, op[21] - 1));
         return fc_norm_act_fwd(P<const float>(c, op[2]), nullptr, 0, n, C, P<const float>(c, op[15]), P<const float>(c, op[16]), eps,
                                P<const float>(c, op[6]), P<const float>(c, op[7]), P<const float>(c, op[8]), (int)op[9], P<float>(c, op[11]),
                                st);
@@ -307,6 +314,7 @@ int run_op_impl(Ctx& c, const int64_t* op) {
         if (nbp > 0) part = P<const float>(c, pop[10] - 1);
       }
       if (!want_ws(c, s, fc_bn_train_ws_bytes(n, C))) return 0;
+      if (op[21] > 0) fc_amax_out_hint(P<unsigned>(c, op[21] - 1));         // word 21: amax word of y + 1 | 0 (h3: y feeds a convolution)
       return fc_bn_train_fwd(P<const float>(c, op[2]), n, C, eps, P<const float>(c, op[6]), P<const float>(c, op[7]),
                              P<const float>(c, op[8]), (int)op[9], mom, P<float>(c, op[11]), P<float>(c, op[12]), P<float>(c, op[13]),
                              P<float>(c, op[14]), P<float>(c, op[15]), P<float>(c, op[16]), P<long long>(c, op[17]), part, nbp,
@@ -348,9 +356,11 @@ int run_op_impl(Ctx& c, const int64_t* op) {
                                P<const float>(c, op[6]), P<const float>(c, op[7]), P<const float>(c, op[8]), c.dims[op[9]], (int)op[10],
                                (int)op[11], P<float>(c, op[12]), P<float>(c, op[13]), st);
     }
-    case OP_WGRAD: {  // in, gout, map (-1: dense), gW, n(dim, dense only), Cin, Cout
+    case OP_WGRAD: {  // in, gout, map (-1: dense), gW, n(dim, dense only), Cin, Cout, amax word of in + 1 | 0, of gout + 1 | 0
       const int Cin = (int)op[7], Cout = (int)op[8];
       const int fl = c.flags | WGRAD_X6;
+      if (!c.dry && (op[9] > 0 || op[10] > 0))
+        fc_conv_amax_hint(op[9] > 0 ? P<const unsigned>(c, op[9] - 1) : nullptr, op[10] > 0 ? P<const unsigned>(c, op[10] - 1) : nullptr);
       if (op[4] < 0) {
         const int64_t n = c.dims[op[6]];
         if (!want_ws(c, s, fc_conv_wgrad_ws_bytes(n, 1, Cin, Cout, fl))) return 0;
@@ -381,6 +391,7 @@ int run_op_impl(Ctx& c, const int64_t* op) {
         if (nbp > 0) part = P<const float>(c, pop[10] - 1);
       }
       if (!want_ws(c, s, fc_bn_train_ws_bytes(n, C))) return 0;
+      if (op[19] > 0) fc_amax_out_hint(P<unsigned>(c, op[19] - 1));         // word 19: amax word of gx + 1 | 0
       return fc_bn_train_bwd(P<const float>(c, op[2]), P<const float>(c, op[3]), P<const float>(c, op[4]),
                              op[17] > 0 ? P<const float>(c, op[17] - 1) : nullptr, n, C, P<const float>(c, op[7]), P<const float>(c, op[8]),
                              P<const float>(c, op[9]), eps, P<const float>(c, op[11]), P<const float>(c, op[12]), (int)op[13],
@@ -452,6 +463,15 @@ int run_op_impl(Ctx& c, const int64_t* op) {
                                                                  (int)op[7], P<float>(c, op[8]), P<float>(c, op[9]), P<float>(c, op[10]),
                                                                  P<const float>(c, op[11]), P<float>(c, op[12]));
       FC_CHECK_LAUNCH();
+      return 0;
+    }
+    case OP_AMAX: {  // x, n(dim), C, slot: max |x| over n * C floats -> slot word 0 (fc_amax)
+      if (c.dry) return 0;
+      return fc_amax(P<const float>(c, op[2]), c.dims[op[3]] * op[4], P<unsigned>(c, op[5]), st);
+    }
+    case OP_CLEAR: {  // dst, bytes: zero-fill (the amax words a pass's producers fold into)
+      if (c.dry) return 0;
+      FC_HIP(hipMemsetAsync(P<void>(c, op[2]), 0, (size_t)op[3], st));
       return 0;
     }
     case OP_COPY: {  // dst, src, n(dim), C

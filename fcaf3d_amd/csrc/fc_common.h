@@ -88,3 +88,23 @@ __device__ static inline float4 fc_ld4(const float* p) {          // two 8-byte 
                      __uint_as_float((unsigned)(b >> 32)));
 }
 #endif
+
+// ---- r6: amax slots (csrc/conv_x6.h "h3": max |x| of a convolution operand, the scale of its two-piece fp16 split) ----------------
+// A slot is FC_AMAX_SUB sub-words, one per 64-byte line (FC_AMAX_SLOT_BYTES = 2 KB); the operand's amax is the MAXIMUM of the
+// sub-words.  Producers that fold their output into a slot (norm.hip amax_commit) pick a sub-word by block index, so that the ~10^5
+// waves of an elementwise launch over a 437k-row tensor do not all poll one L2 line (one word: +30 us per launch, r6_notes.md);
+// fc_amax publishes into sub-word 0 and uses words 1, 2 of the first line as scratch.  Slots start zeroed.
+#define FC_AMAX_SUB 32
+#define FC_AMAX_STRIDE 16                                      // dwords between sub-words
+#ifndef FC_AMAX_SLOT_BYTES
+#define FC_AMAX_SLOT_BYTES (FC_AMAX_SUB * FC_AMAX_STRIDE * 4)      // (= include/fcaf3d_hip.h)
+#endif
+static_assert(FC_AMAX_SLOT_BYTES == FC_AMAX_SUB * FC_AMAX_STRIDE * 4, "amax slot layout");
+// every lane of a wave calls this; returns the slot's amax (bit pattern), wave-uniform
+__device__ static inline unsigned fc_amax_read(const unsigned* __restrict__ slot) {
+  const int lane = threadIdx.x & 63;
+  unsigned m = lane < FC_AMAX_SUB ? __hip_atomic_load(slot + lane * FC_AMAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+}

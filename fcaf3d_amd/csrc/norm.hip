@@ -7,6 +7,7 @@
 // MinkowskiMaxPooling / MinkowskiPruning feature paths used at me_resnet.py:22-24,63,
 // BasicBlock (MinkowskiEngine.modules.resnet_block), fcaf3d_neck_with_head.py:53-54,67-71,76,125.
 #include "fc_common.h"
+#include "../../include/fcaf3d_hip.h"
 
 #define MAXSEG 64
 #define MAXBLOCKS 1024       // partial-sum blocks of the two-level reductions
@@ -241,14 +242,34 @@ __device__ static inline float act_bwd_from_pre(float p, int act) {
   return 1.f;
 }
 
+// ---- r6: max |.| of what a kernel writes, for the convolution that will gather it (csrc/conv_x6.h h3: the operand's scale) ----------
+// A producer that is told where (fc_amax_out_hint -> amax_out, a ZEROED slot of FC_AMAX_SUB sub-words) folds the finite elements it
+// stores into one integer atomicMax per wave on its block's sub-word — skipped when that already holds a larger value — instead of
+// the consumer reading the tensor once more (fc_amax).  Integer max: order-independent, bit-reproducible.  EVERY lane of the wave must reach amax_commit.
+__device__ __forceinline__ void amax_fold(unsigned& m, float v) {
+  const unsigned u = __float_as_uint(v) & 0x7fffffffu;
+  m = (u > m && u < 0x7f800000u) ? u : m;
+}
+__device__ __forceinline__ void amax_commit(unsigned m, unsigned* __restrict__ dst) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
+  if ((threadIdx.x & 63) == 0) {
+    unsigned* w = dst + ((blockIdx.x + blockIdx.y) & (FC_AMAX_SUB - 1)) * FC_AMAX_STRIDE;        // this block's sub-word (fc_common.h)
+    if (m > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, m);
+  }
+}
+thread_local unsigned* t_fc_amax_out = nullptr;          // fc_amax_out_hint: consumed by the next producer entry point of this thread
+static inline unsigned* take_amax_out() { unsigned* p = t_fc_amax_out; t_fc_amax_out = nullptr; return p; }
+
 // y = act( (x-mean[seg])*invstd[seg]*gamma + beta (+ residual) ) ; invstd = 1/sqrt(var+eps)
 __global__ void k_norm_act_fwd(const float* __restrict__ x, const int* __restrict__ seg, int seg_stride, int64_t n, int C,
                                const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                               const float* __restrict__ residual, int act, float* __restrict__ y) {
+                               const float* __restrict__ residual, int act, float* __restrict__ y, unsigned* __restrict__ amax_out) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4n = C / 4;
-  if (t >= n * c4n) return;
+  unsigned am = 0u;
+  if (t < n * c4n) {
   int64_t r = t / c4n;
   int c = (int)(t % c4n) * 4;
   int s = seg_of(seg, seg_stride, r);
@@ -268,6 +289,9 @@ __global__ void k_norm_act_fwd(const float* __restrict__ x, const int* __restric
   }
   o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
   *reinterpret_cast<float4*>(y + r * C + c) = o;
+  amax_fold(am, o.x); amax_fold(am, o.y); amax_fold(am, o.z); amax_fold(am, o.w);
+  }
+  if (amax_out) amax_commit(am, amax_out);
 }
 
 // backward pass 1: per (block, seg, channel) partial sums of g' and g'*xhat, g' = gy * act'(y)
@@ -371,10 +395,12 @@ __global__ void k_norm_bwd_apply(const float* __restrict__ x, const float* __res
                                  const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                  const float* __restrict__ sums /*[seg][2][C]*/,
-                                 const float* __restrict__ cnt, int act, float* __restrict__ gx, float* __restrict__ gres) {
+                                 const float* __restrict__ cnt, int act, float* __restrict__ gx, float* __restrict__ gres,
+                                 unsigned* __restrict__ amax_out) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4n = C / 4;
-  if (t >= n * c4n) return;
+  unsigned am = 0u;
+  if (t < n * c4n) {
   int64_t r = t / c4n;
   int c = (int)(t % c4n) * 4;
   int s = seg_of(seg, seg_stride, r);
@@ -407,6 +433,10 @@ __global__ void k_norm_bwd_apply(const float* __restrict__ x, const float* __res
   }
   *reinterpret_cast<float4*>(gx + r * C + c) = *reinterpret_cast<float4*>(o);
   if (gres) *reinterpret_cast<float4*>(gres + r * C + c) = *reinterpret_cast<float4*>(gr);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) amax_fold(am, o[j]);
+  }
+  if (amax_out) amax_commit(am, amax_out);
 }
 
 // ---- max pooling over a (K, n_out) neighbour table ---------------------------------------------
@@ -431,10 +461,11 @@ __global__ void k_maxpool_fwd(const float* __restrict__ in, const int* __restric
 // k2s2 (K == 8), C % 4 == 0: one thread per (output row, 4 channels); the 8 child rows are looked up first, then their
 // 8 x 16 B are in flight together (the scalar kernel above keeps one dependent 4-byte load per lane in flight: 1.6 TB/s)
 __global__ void k_maxpool8_fwd(const float* __restrict__ in, const int* __restrict__ nbr, int64_t n_out, int C,
-                               float* __restrict__ out, int* __restrict__ argrow) {
+                               float* __restrict__ out, int* __restrict__ argrow, unsigned* __restrict__ amax_out) {
   const int c4n = C / 4;
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_out * c4n) return;
+  unsigned am = 0u;
+  if (t < n_out * c4n) {
   const int64_t o = t / c4n;
   const int c = (int)(t % c4n) * 4;
   int idx[8];
@@ -459,6 +490,9 @@ __global__ void k_maxpool8_fwd(const float* __restrict__ in, const int* __restri
   float4 ob = make_float4(arg[0] < 0 ? 0.f : best[0], arg[1] < 0 ? 0.f : best[1], arg[2] < 0 ? 0.f : best[2], arg[3] < 0 ? 0.f : best[3]);
   *reinterpret_cast<float4*>(out + o * C + c) = ob;
   *reinterpret_cast<int4*>(argrow + o * C + c) = make_int4(arg[0], arg[1], arg[2], arg[3]);
+  amax_fold(am, ob.x); amax_fold(am, ob.y); amax_fold(am, ob.z); amax_fold(am, ob.w);
+  }
+  if (amax_out) amax_commit(am, amax_out);
 }
 
 __global__ void k_maxpool_bwd(const float* __restrict__ gout, const int* __restrict__ argrow, int64_t n_out, int C,
@@ -691,7 +725,8 @@ __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __rest
                                 const float* __restrict__ gy2, int64_t n, int C, int64_t rpb, const float* __restrict__ part, int nb,
                                 const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                float* __restrict__ gx, float* __restrict__ gres, float* __restrict__ sums /*[2][C]*/, int CG) {
+                                float* __restrict__ gx, float* __restrict__ gres, float* __restrict__ sums /*[2][C]*/, int CG,
+                                unsigned* __restrict__ amax_out) {
   // r6: grid.y channel windows of CG channels (few rows x many channels — 872 x 512 — used to be 14 blocks of 2 row lanes, 49 us)
   extern __shared__ float sm[];
   const int c0 = blockIdx.y * CG;
@@ -725,6 +760,7 @@ __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __rest
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   int64_t r1 = r0 + rpb;
   if (r1 > n) r1 = n;
+  unsigned am = 0u;
   for (int64_t rb = r0 + rl; rb < r1; rb += 4 * (int64_t)nrl) {      // four rows (x, gy, y of each) in flight per thread
     float xv[4][4], gv[4][4], yv[4][4];
 #pragma unroll
@@ -755,8 +791,11 @@ __global__ void k_bn1_bwd_apply(const float* __restrict__ x, const float* __rest
       }
       *reinterpret_cast<float4*>(gx + r * C + cl * 4) = *reinterpret_cast<float4*>(o);
       if (gres) *reinterpret_cast<float4*>(gres + r * C + cl * 4) = *reinterpret_cast<float4*>(gr);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) amax_fold(am, o[j]);
     }
   }
+  if (amax_out) amax_commit(am, amax_out);
 }
 
 // ================================================================================================
@@ -779,7 +818,8 @@ __global__ void k_bn2_apply(const float* __restrict__ x, int64_t n, int C, int64
                             float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                             const float* __restrict__ residual, int act, float momentum, float* __restrict__ y,
                             float* __restrict__ mean_out, float* __restrict__ var_out, float* __restrict__ cnt_out,
-                            float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt, int CG) {
+                            float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt, int CG,
+                            unsigned* __restrict__ amax_out) {
   // r6: grid.y channel windows of CG channels (see k_bn1_bwd_apply)
   extern __shared__ double smd[];             // [nrl][2][CG]
   const int c0 = blockIdx.y * CG;
@@ -832,6 +872,7 @@ __global__ void k_bn2_apply(const float* __restrict__ x, int64_t n, int C, int64
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   int64_t r1 = r0 + rpb;
   if (r1 > n) r1 = n;
+  unsigned am = 0u;
   for (int64_t rb = r0 + rl; rb < r1; rb += 4 * (int64_t)nrl) {      // four rows in flight per thread
     float v[4][4], rs[4][4];
 #pragma unroll
@@ -853,8 +894,11 @@ __global__ void k_bn2_apply(const float* __restrict__ x, int64_t n, int C, int64
         o[j] = act_fwd(o[j], act);
       }
       *reinterpret_cast<float4*>(y + r * C + cl * 4) = *reinterpret_cast<float4*>(o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) amax_fold(am, o[j]);
     }
   }
+  if (amax_out) amax_commit(am, amax_out);
 }
 
 // many partial blocks: one 256-thread block per 4 channels (64 slices of the table each) adds them (fp64, fixed order) and writes
@@ -1078,8 +1122,9 @@ int fc_bn_act_train_bwd(const float* x, const float* y, const float* gy, int64_t
   float* part = (float*)ws;
   k_norm_bwd_partial<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, nullptr, 0, n, C, 1, mean, var, eps, act, gamma, beta, rpb, part);
   FC_CHECK_LAUNCH();
+  unsigned* ao = take_amax_out();
   k_bn1_bwd_apply<<<(unsigned)nb, threads, sb, stream>>>(x, y, gy, nullptr, n, C, rpb, part, (int)nb, mean, var, eps, gamma, beta, act, gx,
-                                                        gres, sums, C);
+                                                        gres, sums, C, ao);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
@@ -1087,10 +1132,11 @@ int fc_bn_act_train_bwd(const float* x, const float* y, const float* gy, int64_t
 int fc_norm_act_fwd(const float* x, const int* seg, int seg_stride, int64_t n, int C, const float* mean, const float* var,
                     float eps, const float* gamma, const float* beta, const float* residual, int act, float* y,
                     hipStream_t stream) {
+  unsigned* ao = take_amax_out();                // fc_amax_out_hint: max |y| into the caller's (zeroed) word
   if (n < 0 || C < 4 || C % 4 || act < 0 || act > 2) return FC_EINVAL;
   if (n == 0) return FC_OK;
   k_norm_act_fwd<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, seg, seg_stride, n, C, mean, var, eps, gamma,
-                                                                         beta, residual, act, y);
+                                                                         beta, residual, act, y, ao);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
@@ -1106,6 +1152,7 @@ int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* 
                     int nseg, const float* mean, const float* var, const float* cnt, float eps, const float* gamma,
                     const float* beta, int act, float* gx, float* gres, float* sums, void* ws, int64_t ws_bytes,
                     hipStream_t stream) {
+  unsigned* ao = take_amax_out();                // fc_amax_out_hint: max |gx| into the caller's (zeroed) word
   if (n < 0 || nseg < 1 || nseg > MAXSEG || act < 0 || act > 2) return FC_EINVAL;
   int threads; size_t sf, sb;
   if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
@@ -1123,7 +1170,7 @@ int fc_norm_act_bwd(const float* x, const float* y, const float* gy, const int* 
   k_stats_final<<<(unsigned)(nseg * ((2 * C + FIN_CB - 1) / FIN_CB)), FIN_CB * FIN_SL, 0, stream>>>(part, nullptr, nb, nseg, 2 * C, 2, sums, nullptr);
   FC_CHECK_LAUNCH();
   k_norm_bwd_apply<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, y, gy, nullptr, seg, seg_stride, n, C, mean, var, eps,
-                                                                           gamma, beta, sums, cnt, act, gx, gres);
+                                                                           gamma, beta, sums, cnt, act, gx, gres, ao);
   FC_CHECK_LAUNCH();
   return FC_OK;
 }
@@ -1152,13 +1199,18 @@ int fc_bn_train_fwd(const float* x, int64_t n, int C, float eps, const float* ga
                     int act, float momentum, float* y, float* mean, float* var, float* cnt, float* running_mean,
                     float* running_var, long long* num_batches_tracked, const float* part, int64_t nb_part, int groups,
                     int64_t small_elems, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  unsigned* ao = take_amax_out();                // fc_amax_out_hint: max |y| into the caller's (zeroed) word
   if (n < 1 || act < 0 || act > 2) return FC_EINVAL;
   if (!part) {
-    if (n * C <= small_elems)
-      return fc_bn_act_train_fwd(x, n, C, eps, gamma, beta, residual, act, momentum, y, mean, var, cnt, running_mean, running_var,
-                                 num_batches_tracked, ws, ws_bytes, stream);
+    if (n * C <= small_elems) {
+      int rc = fc_bn_act_train_fwd(x, n, C, eps, gamma, beta, residual, act, momentum, y, mean, var, cnt, running_mean, running_var,
+                                   num_batches_tracked, ws, ws_bytes, stream);
+      if (rc == FC_OK && ao) rc = fc_amax(y, n * (int64_t)C, ao, stream);          // (this route's apply kernel does not fold: a pass of its own)
+      return rc;
+    }
     int rc = fc_bn_stats_train(x, n, C, momentum, mean, var, cnt, running_mean, running_var, num_batches_tracked, ws, ws_bytes, stream);
     if (rc) return rc;
+    t_fc_amax_out = ao;
     return fc_norm_act_fwd(x, nullptr, 0, n, C, mean, var, eps, gamma, beta, residual, act, y, stream);
   }
   int threads; size_t sf, sb;
@@ -1171,13 +1223,14 @@ int fc_bn_train_fwd(const float* x, int64_t n, int C, float eps, const float* ga
     if (CG != C && stats_geometry(CG, &threads, &sf, &sb)) return FC_EINVAL;
     const size_t smem = (size_t)(threads / (CG / 4)) * 2 * CG * sizeof(double);
     k_bn2_apply<<<dim3((unsigned)nb, C / CG), threads, smem, stream>>>(x, n, C, rpb, part, (int)nb_part, groups, eps, gamma, beta, residual, act,
-                                                        momentum, y, mean, var, cnt, running_mean, running_var, num_batches_tracked, CG);
+                                                        momentum, y, mean, var, cnt, running_mean, running_var, num_batches_tracked, CG, ao);
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
   k_bn2_finalize<<<(unsigned)((C + FIN_CB - 1) / FIN_CB), FIN_CB * FIN_SL, 0, stream>>>(part, (int)nb_part, C, groups, n, momentum, mean, var, cnt,
                                                                  running_mean, running_var, num_batches_tracked);
   FC_CHECK_LAUNCH();
+  t_fc_amax_out = ao;
   return fc_norm_act_fwd(x, nullptr, 0, n, C, mean, var, eps, gamma, beta, residual, act, y, stream);
 }
 
@@ -1188,6 +1241,7 @@ int fc_bn_train_bwd(const float* x, const float* y, const float* gy, const float
                     const float* var, const float* cnt, float eps, const float* gamma, const float* beta, int act, float* gx,
                     float* gres, float* sums, const float* part, int64_t nb_part, int64_t small_elems, void* ws, int64_t ws_bytes,
                     hipStream_t stream) {
+  unsigned* ao = take_amax_out();                // fc_amax_out_hint: max |gx| into the caller's (zeroed) word
   if (n < 1 || act < 0 || act > 2) return FC_EINVAL;
   int threads; size_t sf, sb;
   if (stats_geometry(C, &threads, &sf, &sb)) return FC_EINVAL;
@@ -1210,25 +1264,32 @@ int fc_bn_train_bwd(const float* x, const float* y, const float* gy, const float
     const int CG = ap_window(n, C);
     if (CG != C && stats_geometry(CG, &threads, &sf, &sb)) return FC_EINVAL;
     k_bn1_bwd_apply<<<dim3((unsigned)nb, C / CG), threads, sb, stream>>>(x, y, gy, gy2, n, C, rpb, p, (int)np, mean, var, eps, gamma, beta, act, gx,
-                                                          gres, sums, CG);
+                                                          gres, sums, CG, ao);
     FC_CHECK_LAUNCH();
     return FC_OK;
   }
   k_stats_final<<<(unsigned)((2 * C + FIN_CB - 1) / FIN_CB), FIN_CB * FIN_SL, 0, stream>>>(p, nullptr, np, 1, 2 * C, 2, sums, nullptr);
   FC_CHECK_LAUNCH();
   k_norm_bwd_apply<<<(unsigned)fc_cdiv(n * (C / 4), 256), 256, 0, stream>>>(x, y, gy, gy2, nullptr, 0, n, C, mean, var, eps, gamma, beta,
-                                                                           sums, cnt, act, gx, gres);
+                                                                           sums, cnt, act, gx, gres, ao);
   FC_CHECK_LAUNCH();
+  return FC_OK;
+}
+
+int fc_amax_out_hint(unsigned* amax_word) {
+  t_fc_amax_out = amax_word;
   return FC_OK;
 }
 
 int fc_maxpool_fwd(const float* in, const int* nbr, int64_t n_out, int K, int C, float* out, int* argrow,
                    hipStream_t stream) {
+  unsigned* ao = take_amax_out();                // fc_amax_out_hint: max |out| into the caller's (zeroed) word
   if (n_out < 0 || K < 1 || C < 1) return FC_EINVAL;
   if (n_out == 0) return FC_OK;
-  if (K == 8 && C % 4 == 0) k_maxpool8_fwd<<<(unsigned)fc_cdiv(n_out * (C / 4), 256), 256, 0, stream>>>(in, nbr, n_out, C, out, argrow);
+  if (K == 8 && C % 4 == 0) k_maxpool8_fwd<<<(unsigned)fc_cdiv(n_out * (C / 4), 256), 256, 0, stream>>>(in, nbr, n_out, C, out, argrow, ao);
   else k_maxpool_fwd<<<(unsigned)fc_cdiv(n_out * C, 256), 256, 0, stream>>>(in, nbr, n_out, K, C, out, argrow);
   FC_CHECK_LAUNCH();
+  if (ao && !(K == 8 && C % 4 == 0)) return fc_amax(out, n_out * (int64_t)C, ao, stream);
   return FC_OK;
 }
 

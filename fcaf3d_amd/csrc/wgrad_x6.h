@@ -53,15 +53,25 @@ __device__ __forceinline__ u32x4 x6_tr_frag(const u32x2* base, int unit) {
   return v;
 }
 
-template <int BMc, int BNc, int KO, bool PAIRS, bool FAST = false>
+// MODE (r6; was the bool FAST): 0 six bf16 products, 1 FAST (plane 0 only), 2 h3: two fp16 pieces per operand, three products
+// (conv_x6.h); amax_a / amax_g: the words holding max |in| / max |gout| (h3 only)
+template <int BMc, int BNc, int KO, bool PAIRS, int MODE = 0>
 __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) void k_wgrad_x6t(
     const float* __restrict__ in, const float* __restrict__ gout, const int* __restrict__ nbr,
     const int* __restrict__ row_index, const int* __restrict__ cnt, float* __restrict__ part, int64_t n_out, int K, int Cin,
-    int Cout, int64_t rows_per_split) {
+    int Cout, int64_t rows_per_split, const unsigned* __restrict__ amax_a, const unsigned* __restrict__ amax_g) {
   constexpr int TM = BMc / 64, TN = BNc / 64;    // 32x32 tiles per wave (waves 2 x 2 over the BMc x BNc tile)
   constexpr int SA = BMc / 32, SG = BNc / 32;    // [32 rows][32 channels] subtiles per offset / of gout: 256 units of 8 B each
-  __shared__ u32x2 As[KO * 3 * SA * 256];        // [offset][plane][channel block][row][8 units]
-  __shared__ u32x2 Gs[3 * SG * 256];             // [plane][channel block][row][8 units]
+  constexpr bool FAST = MODE == 1, H3 = MODE == 2;
+  constexpr int NPL = H3 ? 2 : 3;
+  __shared__ u32x2 As[KO * NPL * SA * 256];      // [offset][plane][channel block][row][8 units]
+  __shared__ u32x2 Gs[NPL * SG * 256];           // [plane][channel block][row][8 units]
+  float h3_sa = 1.f, h3_sg = 1.f, h3_inv = 1.f;
+  if (H3) {
+    h3_sa = h3_scale(fc_amax_read(amax_a));
+    h3_sg = h3_scale(fc_amax_read(amax_g));
+    h3_inv = h3_unscale(h3_sa, h3_sg);
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -144,10 +154,15 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
 #pragma unroll
       for (int p = 0; p < SG; ++p) {
         unsigned q[3][2];
-        WG_SPLIT2(gv[p][0], gv[p][1], q[0][0], q[1][0], q[2][0]);
-        WG_SPLIT2(gv[p][2], gv[p][3], q[0][1], q[1][1], q[2][1]);
+        if (H3) {
+          h3_split2(gv[p][0] * h3_sg, gv[p][1] * h3_sg, q[0][0], q[1][0]);
+          h3_split2(gv[p][2] * h3_sg, gv[p][3] * h3_sg, q[0][1], q[1][1]);
+        } else {
+          WG_SPLIT2(gv[p][0], gv[p][1], q[0][0], q[1][0], q[2][0]);
+          WG_SPLIT2(gv[p][2], gv[p][3], q[0][1], q[1][1], q[2][1]);
+        }
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
           if (fast && pl) break;
           u32x2 v = {q[pl][0], q[pl][1]};
           Gs[(pl * SG + p) * 256 + s_unit] = v;
@@ -158,13 +173,18 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
 #pragma unroll
         for (int p = 0; p < SA; ++p) {
           unsigned q[3][2];
-          WG_SPLIT2(av[o][p][0], av[o][p][1], q[0][0], q[1][0], q[2][0]);
-          WG_SPLIT2(av[o][p][2], av[o][p][3], q[0][1], q[1][1], q[2][1]);
+          if (H3) {
+            h3_split2(av[o][p][0] * h3_sa, av[o][p][1] * h3_sa, q[0][0], q[1][0]);
+            h3_split2(av[o][p][2] * h3_sa, av[o][p][3] * h3_sa, q[0][1], q[1][1]);
+          } else {
+            WG_SPLIT2(av[o][p][0], av[o][p][1], q[0][0], q[1][0], q[2][0]);
+            WG_SPLIT2(av[o][p][2], av[o][p][3], q[0][1], q[1][1], q[2][1]);
+          }
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
+          for (int pl = 0; pl < NPL; ++pl) {
             if (fast && pl) break;
             u32x2 v = {q[pl][0], q[pl][1]};
-            As[((o * 3 + pl) * SA + p) * 256 + s_unit] = v;
+            As[((o * NPL + pl) * SA + p) * 256 + s_unit] = v;
           }
         }
       __syncthreads();
@@ -178,13 +198,39 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
 #pragma unroll
           for (int o = 0; o < KO; ++o)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa1[o][i] = x6_tr_frag(As, ((o * 3) * SA + wr * TM + i) * 256 + b * 128 + f_unit);
+            for (int i = 0; i < TM; ++i) fa1[o][i] = x6_tr_frag(As, ((o * NPL) * SA + wr * TM + i) * 256 + b * 128 + f_unit);
 #pragma unroll
           for (int o = 0; o < KO; ++o)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j) acc[o][i][j] = X6_MFMA(fa1[o][i], fb1[j], acc[o][i][j]);
+        }
+      } else if (H3) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          u32x4 fb[2][TN];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[pl][j] = x6_tr_frag(Gs, (pl * SG + wc * TN + j) * 256 + b * 128 + f_unit);
+          u32x4 fa[KO][2][TM];
+#pragma unroll
+          for (int o = 0; o < KO; ++o)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+              for (int i = 0; i < TM; ++i) fa[o][pl][i] = x6_tr_frag(As, ((o * 2 + pl) * SA + wr * TM + i) * 256 + b * 128 + f_unit);
+#pragma unroll
+          for (int pb = 1; pb >= 0; --pb)
+#pragma unroll
+            for (int pa = 1 - pb; pa >= 0; --pa)
+#pragma unroll
+              for (int o = 0; o < KO; ++o)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                  for (int j = 0; j < TN; ++j) acc[o][i][j] = H3_MFMA(fa[o][pa][i], fb[pb][j], acc[o][i][j]);
         }
       } else
 #pragma unroll
@@ -232,7 +278,7 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
         for (int e = 0; e < 16; ++e) {
           const int row = ci0 + wr * (BMc / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           const int col = co0 + wc * (BNc / 2) + j * 32 + r;
-          dst[(int64_t)row * Cout + col] = acc[o][i][j][e];
+          dst[(int64_t)row * Cout + col] = H3 ? acc[o][i][j][e] * h3_inv : acc[o][i][j][e];
         }
   }
 }

@@ -47,7 +47,7 @@ KEEP_STATE = False
 
 (OP_STEM_FWD, OP_COL_STATS, OP_NORM_FWD, OP_MAXPOOL_FWD, OP_CONV, OP_BN_FWD, OP_UNION_FWD, OP_HEAD_FWD, OP_RECORD, OP_WAIT,
  OP_HEAD_BWD, OP_WGRAD, OP_BN_BWD, OP_NORM_BWD, OP_MAXPOOL_BWD, OP_STEM_WGRAD, OP_GATHER, OP_ADD, OP_SMALL_GRADS,
- OP_PERMUTE_GENT, OP_HEAD_WFIN, OP_COPY, OP_COL_SUM, OP_ROW_SUM) = range(1, 25)
+ OP_PERMUTE_GENT, OP_HEAD_WFIN, OP_COPY, OP_COL_SUM, OP_ROW_SUM, OP_AMAX, OP_CLEAR) = range(1, 27)
 OPW, MAPW = 24, 20
 ALIGN = 256
 S_MAIN, S_HEAD, S_WGRAD = 0, 1, 2
@@ -172,6 +172,29 @@ class NetProgram:
         assert len(w) == OPW, len(w)
         lst.append(w)
 
+    # ---- r6: amax words of the convolutions' operands (csrc/conv_x6.h "h3": the scale of the two-piece fp16 split) ------------
+    # One fc_amax pass per operand TENSOR and stream instead of one per consuming launch: a forward activation's word serves its
+    # forward convolution(s) and, a pass later, their weight gradients; a gradient's word serves the backward-data convolution and the
+    # weight gradient of its layer.  Slots are 2 KB of one persistent buffer (32 sub-words, fc_common.h; fc_amax returns its scratch words to zero).
+    AMAX_SLOTS = 1024
+    AMAX_SLOT_BYTES = 2048           # include/fcaf3d_hip.h FC_AMAX_SLOT_BYTES: 32 sub-words at a 64-byte stride
+
+    def amax_slot(self):
+        if getattr(self, '_amax_buf', None) is None:
+            self._amax_buf = torch.zeros(self.AMAX_SLOTS * self.AMAX_SLOT_BYTES // 4, dtype=torch.int32, device=self.dev)
+            self._amax_used = 0
+            self.keep.append(self._amax_buf)
+        assert self._amax_used < self.AMAX_SLOTS
+        i = self.SA(self._amax_buf.data_ptr() + self.AMAX_SLOT_BYTES * self._amax_used)
+        self._amax_used += 1
+        return i
+
+    def amax_op(self, lst, stream, x, rows, cols):
+        """emit the amax pass of tensor x ((rows, cols) floats) on `stream` -> address index of its word"""
+        slot = self.amax_slot()
+        self.emit(lst, OP_AMAX, stream, x, self.D(rows), cols, slot)
+        return slot
+
     # ---- weights: pre-split images of every kernel, incl. the packed head kernel and the generative convolutions' GEMM form; ONE
     # set per detector, shared by its programs (training / inference, stream configurations, pruned-tail variant)
     def _build_weights(self):
@@ -252,6 +275,7 @@ class NetProgram:
             g2, rows, cols, stream = grad2.pop(t)
             self.emit(Bk, OP_ADD, stream, grad[t], g2, self.D(rows), cols)
             grad_src.pop(grad[t], None)          # added to in place: no longer the plain result of the convolution that wrote it
+            amax_of.pop(grad[t], None)           # ... nor bounded by its producer's amax word
 
         def accumulate(t, g, rows, cols, stream):
             """gradient `g` (a backward tensor) arrives for forward tensor t.  The SECOND contribution is kept aside: if the
@@ -266,6 +290,7 @@ class NetProgram:
                     flush2(t)
                 self.emit(Bk, OP_ADD, stream, grad[t], g, self.D(rows), cols)
                 grad_src.pop(grad[t], None)
+                amax_of.pop(grad[t], None)
 
         def take(t, rows, cols, pair=False):
             """the complete gradient of forward tensor t, for the emitter of the operator that produced t (main stream); pair:
@@ -295,6 +320,23 @@ class NetProgram:
                 self.emit(Bk, OP_WAIT, S_WGRAD, ev)
             self.emit(Bk, OP_WGRAD, wstream(cur), *words)
 
+        AMAX = Fn.X6 and Fn.split_mode() == 2          # the convolutions scale their operands by their amax words (csrc/conv_x6.h h3)
+        amax_f = {}                      # (forward tensor, stream) -> address index of its amax word
+        amax_of = {}                     # tensor -> address index of the amax word its PRODUCER folds into (fc_amax_out_hint)
+        if AMAX:
+            # the words the producers fold into start every pass at zero: one fill per direction, its size patched in below
+            self.amax_slot()             # (slot 0 doubles as the buffer's base address)
+            self.emit(F, OP_CLEAR, S_MAIN, self.SA(self._amax_buf.data_ptr()), 0)
+
+        def fwd_amax(x, rows, cols, stream):
+            if not AMAX:
+                return -1
+            if x in amax_of:
+                return amax_of[x]
+            if (x, stream) not in amax_f:
+                amax_f[(x, stream)] = self.amax_op(F, stream, x, rows, cols)
+            return amax_f[(x, stream)]
+
         producer = {}                    # forward tensor -> (index of the OP_CONV that wrote it, rows, columns)
         grad_src = {}                    # backward tensor -> (index in Bk of the backward-data OP_CONV that wrote it, rows, columns, stream)
 
@@ -303,15 +345,17 @@ class NetProgram:
             Cin, Cout = mod.in_channels, mod.out_channels
             y = self.T(rows_out, Cout)
             m = self.M(mname)
-            self.emit(F, OP_CONV, stream, x, self.IMG(mod.kernel, False), m, 0, y, -1, Cin, Cout)
+            ax = fwd_amax(x, rows_in, Cin, stream)
+            self.emit(F, OP_CONV, stream, x, self.IMG(mod.kernel, False), m, 0, y, -1, Cin, Cout, *([0] * 10), ax + 1)
             producer[y] = (len(F) - 1, rows_out, Cout)
             if tr:
                 def bwd():
                     gy = take(y, rows_out, Cout) if stream == S_MAIN else got(y)
                     gx = self.T(rows_in, Cin, 'b')
-                    self.emit(Bk, OP_CONV, stream, gy, self.IMG(mod.kernel, True), m, 1, gx, -1, Cout, Cin)
+                    ag = (amax_of[gy] if gy in amax_of else self.amax_op(Bk, stream, gy, rows_out, Cout)) if AMAX else -1
+                    self.emit(Bk, OP_CONV, stream, gy, self.IMG(mod.kernel, True), m, 1, gx, -1, Cout, Cin, *([0] * 10), ag + 1)
                     grad_src[gx] = (len(Bk) - 1, rows_in, Cin, stream)
-                    emit_wgrad(stream, x, gy, m, self.G(mod.kernel), -1, Cin, Cout)
+                    emit_wgrad(stream, x, gy, m, self.G(mod.kernel), -1, Cin, Cout, ax + 1, ag + 1)
                     wrote(mod.kernel)
                     accumulate(x, gx, rows_in, Cin, stream)
                 tape.append((stream, bwd))
@@ -321,15 +365,17 @@ class NetProgram:
             """dense GEMM (n, Cin) x (Cin, Cout): the generative transposed convolution, the fused 1x1 heads; gw_dst: the address
             index the (Cin, Cout) weight gradient goes to"""
             y = self.T(rows, Cout)
-            self.emit(F, OP_CONV, stream, x, self.IMG(w_tensor, False), -1, 0, y, self.D(rows), Cin, Cout)
+            ax = fwd_amax(x, rows, Cin, stream)
+            self.emit(F, OP_CONV, stream, x, self.IMG(w_tensor, False), -1, 0, y, self.D(rows), Cin, Cout, *([0] * 10), ax + 1)
             producer[y] = (len(F) - 1, rows, Cout)
             if tr:
                 def bwd():
                     gy = take(y, rows, Cout) if stream == S_MAIN else got(y)
                     gx = self.T(rows, Cin, 'b')
-                    self.emit(Bk, OP_CONV, stream, gy, self.IMG(w_tensor, True), -1, 1, gx, self.D(rows), Cout, Cin)
+                    ag = (amax_of[gy] if gy in amax_of else self.amax_op(Bk, stream, gy, rows, Cout)) if AMAX else -1
+                    self.emit(Bk, OP_CONV, stream, gy, self.IMG(w_tensor, True), -1, 1, gx, self.D(rows), Cout, Cin, *([0] * 10), ag + 1)
                     grad_src[gx] = (len(Bk) - 1, rows, Cin, stream)
-                    emit_wgrad(stream, x, gy, -1, gw_dst, self.D(rows), Cin, Cout)
+                    emit_wgrad(stream, x, gy, -1, gw_dst, self.D(rows), Cin, Cout, ax + 1, ag + 1)
                     if w_tensor is self.packed:
                         head_wgrads[0] += 1
                         if head_wgrads[0] == self.nl - (1 if self.tail0 else 0) and self.wgrad_async:
@@ -358,9 +404,12 @@ class NetProgram:
                 # table: [blocks][2][pcols] floats, blocks <= rows / 16 + 1 (conv.hip fc_stat_rb)
                 F[pi][10] = self.T(prows, pcols // 8, extra=8 * pcols + 256) + 1
                 prod_word = pi + 1
+            ay = -1
+            if AMAX:                     # the apply kernel folds max |y| into this word: a convolution gathering y needs no amax pass
+                ay = amax_of[y] = self.amax_slot()
             self.emit(F, OP_BN_FWD, stream, x, self.D(rows), C, _f(b.eps), self.S(b.weight), self.S(b.bias), -1 if res is None else res, act,
                       _f(b.momentum), y, mean, var, cnt, self.S(b.running_mean), self.S(b.running_var), self.S(b.num_batches_tracked),
-                      1 if tr else 0, prod_word, groups)
+                      1 if tr else 0, prod_word, groups, ay + 1)
             if tr:
                 sums = torch.zeros((2, C), dtype=torch.float32, device=self.dev)
                 si = self.S(sums)
@@ -383,8 +432,11 @@ class NetProgram:
                         Bk[pi][11:20] = [x + 1, mean, var, self.S(b.weight), self.S(b.bias), _f(b.eps), act,
                                          0 if first is None else first + 1, 0 if res is None else y + 1]
                         prod = pi + 1
+                    agx = -1
+                    if AMAX:
+                        agx = amax_of[gx] = self.amax_slot()
                     self.emit(Bk, OP_BN_BWD, stream, x, y if res is not None else -1, gy, self.D(rows), C, mean, var, cnt, _f(b.eps),
-                              self.S(b.weight), self.S(b.bias), act, gx, gres, si, 0 if gy2 is None else gy2 + 1, prod)
+                              self.S(b.weight), self.S(b.bias), act, gx, gres, si, 0 if gy2 is None else gy2 + 1, prod, agx + 1)
                     accumulate(x, gx, rows, C, stream)
                     if res is not None:
                         accumulate(res, gres, rows, C, stream)
@@ -406,7 +458,10 @@ class NetProgram:
         self.relu_outs.append((t_in, 'n1', 64))
         t_pool, arg = self.T('n2', 64), self.T('n2', 64)
         self.pool_arg = (arg, 'n2', 64)
-        self.emit(F, OP_MAXPOOL_FWD, S_MAIN, t_in, self.M('pool'), 64, t_pool, arg)
+        ap = -1
+        if AMAX:
+            ap = amax_of[t_pool] = self.amax_slot()
+        self.emit(F, OP_MAXPOOL_FWD, S_MAIN, t_in, self.M('pool'), 64, t_pool, arg, ap + 1)
         if tr:
             in_sums = self.T('B', 2 * 64, 'b')
             self.in_sums = in_sums
@@ -538,6 +593,12 @@ class NetProgram:
             self.emit(F, OP_RECORD, S_HEAD, EV_HEAD_DONE)
             self.emit(F, OP_WAIT, S_MAIN, EV_HEAD_DONE)
         # ---- backward program -------------------------------------------------------------------------------------------
+        if AMAX:
+            n_fwd_slots = self._amax_used
+            F[0][3] = self.AMAX_SLOT_BYTES * n_fwd_slots                     # the forward pass clears its own words; they stay valid through the backward pass
+            if tr:
+                self.emit(Bk, OP_CLEAR, S_MAIN, self.SA(self._amax_buf.data_ptr() + self.AMAX_SLOT_BYTES * n_fwd_slots), 0)
+                clear_b = len(Bk) - 1
         if tr:
             if self.head_overlap:
                 # the head branches depend on the loss gradients only: their backward is enqueued first, on the head stream, finest
@@ -582,6 +643,8 @@ class NetProgram:
             if self.wgrad_async:
                 self.emit(Bk, OP_RECORD, S_WGRAD, EV_WEND)
                 self.emit(Bk, OP_WAIT, S_MAIN, EV_WEND)
+            if AMAX:
+                Bk[clear_b][3] = self.AMAX_SLOT_BYTES * (self._amax_used - n_fwd_slots)
 
     # ---- per-step tables ---------------------------------------------------------------------------------------------------
     def _finalise(self):
@@ -604,6 +667,7 @@ class NetProgram:
         self._cfg = np.array([Fn.BN_SMALL_ELEMS, Fn.FLAGS, 0, 0], dtype=np.int64)
         self.n_conv_f = int((self.ops_f[:, 0] == OP_CONV).sum())
         self.n_conv_b = int((self.ops_b[:, 0] == OP_CONV).sum()) if len(self.ops_b) else 0
+        self.n_amax = int((self.ops_f[:, 0] == OP_AMAX).sum()) + (int((self.ops_b[:, 0] == OP_AMAX).sum()) if len(self.ops_b) else 0)
         self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
         if self.training:
             # small-gradient descriptor template: (src, dst, C, nseg, stride, 0, 0, 0) per (bias, weight) of every normalisation layer
@@ -687,7 +751,7 @@ class NetProgram:
             # valid (input, output) pairs of every map, as device scalars (read back after the timed region): the FLOPs of a launch
             from .sparse import _rec
             st['pairs'] = {mn[k]: _rec(km._pairs[3].sum() if km._pairs is not None else (km.nbr >= 0).sum()) for k, km in kms.items()}
-            PROBE.append(dict(pairs=st['pairs'], nf=self.n_conv_f, nb=self.n_conv_b))
+            PROBE.append(dict(pairs=st['pairs'], nf=self.n_conv_f, nb=self.n_conv_b, na=self.n_amax))
         return st
 
     def _streams(self):

@@ -109,6 +109,24 @@ CONV_X6 = (1 << 24) | (1 << 26)          # forward / backward-data: split-bf16 k
 WGRAD_X6 = 1 << 24                       # weight gradient: split-bf16 kernels
 
 
+def split_mode():
+    """how the matrix-pipe convolutions cut an fp32 operand right now (csrc/conv.hip fc_get_split_mode): 2 = two fp16 pieces, three
+    products (r6 default), 0 = three bf16 pieces, six products (r3-r5; also while the bf16 fast mode is on)"""
+    return int(L.lib().fc_get_split_mode())
+
+
+def set_split_mode(mode):
+    """switch the operand split (0 / 2).  Weight images are mode-dependent: whoever holds prebuilt ones (runner.TrainStep:
+    `invalidate_images()`, an executor program: `weights_fresh = False`) must rebuild them before the next pass; the per-call images of
+    the module path follow by themselves."""
+    L.call('fc_set_split_mode', int(mode))
+
+
+def set_bf16_fast(on):
+    """the flagged NON-PARITY bf16 fast mode (csrc/conv.hip fc_set_bf16_fast); it reads six-product images: rebuild prebuilt ones"""
+    L.call('fc_set_bf16_fast', 1 if on else 0)
+
+
 def _x6_image(weight, transposed):
     """pre-split image of a (K, Cin, Cout) kernel for the forward launch (transposed=False: reduction Cin, columns Cout) or
     for the backward-data launch on the same kernel (transposed=True: reduction Cout, columns Cin).  Built at every call:

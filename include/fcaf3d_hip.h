@@ -30,9 +30,13 @@ extern "C" {
 
 /* Version of this ABI (No reference counterpart): bumped whenever a prototype or the meaning of a flag bit changes — r5 -> 5
  * (flags bit27 went from "input is pre-split planes" to "flat addressing", fc_x6_planes / fc_conv_x6d removed: ADVICE r5),
- * r6 -> 6 (fc_compact_rows takes the output capacity; fc_plan_*, fc_argsort27, fc_set_split3 added).  A caller built against another
+ * r6 -> 6 (fc_compact_rows takes the output capacity; fc_plan_*, fc_argsort27 added), r6 -> 7 (fc_set_split_mode / fc_get_split_mode / fc_amax /
+ * fc_conv_amax_hint / fc_amax_out_hint added; weight images are mode-dependent and fc_x6_weight_images writes their amax word).  A caller built against another
  * version must not go on: tests/test_cabi.py pins the number the Python host was written for. */
-#define FC_ABI_VERSION 6
+#define FC_ABI_VERSION 7
+#ifndef FC_AMAX_SLOT_BYTES
+#define FC_AMAX_SLOT_BYTES 2048
+#endif
 int fc_abi_version(void);
 
 /* ---- coordinates -------------------------------------------------------------------------- */
@@ -467,6 +471,32 @@ int fc_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * piece of either operand (the operand rounded to nearest bf16; fp32 accumulate) — one MFMA product instead of six.  Default
  * off; `bench.py` reports it as `config.bf16_fast_mode` with "parity": false, never as `value`. */
 int fc_set_bf16_fast(int on);
+
+/* r6: the operand split of the matrix-pipe convolutions (No reference counterpart: MinkowskiEngine multiplies in fp32 FMA, the
+ * call sites are mmdet3d/models/backbones/me_resnet.py:56-62 and every ME.MinkowskiConvolution of fcaf3d_neck_with_head.py:49-71).
+ * mode 2 (default): every fp32 operand as TWO fp16 pieces, scaled by a power of two taken from the operand tensor's max |x|,
+ * three exact products per fp32 product (csrc/conv_x6.h "h3": what is dropped is <= 2^-21 |a b| per product, 2^-25 on average
+ * and unbiased — reductions measure closer to fp64 than an fp32 FMA chain); mode 0: three bf16 pieces, six products (r3-r5).  Process-global; weight images are built in the current mode and
+ * must be read in it (rebuild them after a switch).  fc_get_split_mode: the mode launches use right now (0 while the bf16 fast
+ * mode is on). */
+int fc_set_split_mode(int mode);
+int fc_get_split_mode(void);
+/* max |x| over n floats (x 16-byte aligned) as a bit pattern -> slot[0]; slot = FC_AMAX_SLOT_BYTES (2 048) zero-initialised bytes
+ * owned by the caller: 32 sub-words at a 64-byte stride whose MAXIMUM is the operand's amax (producers spread their folds over
+ * them, fc_amax_out_hint); this pass writes sub-word 0, slot[1..2] are its scratch and return to zero.  Integer atomicMax: order-independent, bit-reproducible.  The mode-2 launches need
+ * this word for their gathered operand(s); No reference counterpart (part of the operand split above, me_resnet.py:56-62). */
+int fc_amax(const float* x, int64_t n, unsigned* slot, hipStream_t stream);
+/* Hands the amax slots (device addresses; an UPPER bound of max |x| is enough) of the operands of the NEXT
+ * fc_conv_fwd* / fc_conv_wgrad* call of the calling thread: amax_in for `in`, amax_gout for `gout` (weight gradients); NULL = the
+ * library computes it itself with one fc_amax pass over the operand (a library-owned slot).  Cleared when that call returns.
+ * No reference counterpart (see fc_set_split_mode; me_resnet.py:56-62). */
+int fc_conv_amax_hint(const unsigned* amax_in, const unsigned* amax_gout);
+/* The other end of the same word: the NEXT fc_bn_train_fwd / fc_bn_train_bwd / fc_norm_act_fwd / fc_norm_act_bwd / fc_bn_act_train_bwd /
+ * fc_maxpool_fwd call of the calling thread also folds max |.| of what it writes (y, gx, out) into the slot at amax_word — one the
+ * caller has ZEROED — from inside its apply kernel (one integer atomicMax per wave), so that the convolution gathering that tensor
+ * needs no fc_amax pass.  Cleared by that call.  No reference counterpart (see fc_set_split_mode; the producers are
+ * ME.MinkowskiBatchNorm / MinkowskiReLU / MinkowskiELU / MinkowskiMaxPooling of me_resnet.py:19-24, fcaf3d_neck_with_head.py:49-71). */
+int fc_amax_out_hint(unsigned* amax_word);
 
 /* ---- launch-list executor (the network body in one call per direction) ------------------------------------ */
 

@@ -57,3 +57,54 @@ def matmul_x6(a, b, block=16):
             upd = pa[i][:, k0:k0 + block].astype(np.float64) @ pb[j][k0:k0 + block].astype(np.float64)
             acc = (acc.astype(np.float64) + upd).astype(np.float32)
     return acc
+
+
+# ---- r6: the two-piece fp16 split ("h3", csrc/conv_x6.h MODE 2) --------------------------------------------------------------------
+# Pins: the scale rule (integer arithmetic on the exponent field of max |x|), (h, l) holds s x to 2^-23 |s x| (one fp32 ulp; exactly
+# for three values in four) whenever both pieces are normal fp16 numbers and to 2^-25 absolute below that, no piece overflows fp16,
+# the three kept products are exact in fp32, and what is dropped is at most 2^-21 of a product (2^-25 on average, unbiased).
+TERMS_H3 = ((0, 1), (1, 0), (0, 0))          # (piece of a, piece of b), the kernels' order inside a 16-channel block
+
+
+def h3_scale(amax):
+    """the kernels' h3_scale: 2^(14 - floor(log2 amax)) from the exponent FIELD of the fp32 amax (clamped to the normal range), so
+    the largest element lands in [2^14, 2^15)"""
+    e = (np.float32(amax).view(np.uint32) >> np.uint32(23)) & np.uint32(0xff)
+    se = int(np.clip(268 - int(e), 1, 254))
+    return np.uint32(se << 23).view(np.float32)
+
+
+def h3_unscale(sa, sb):
+    e = 381 - (int(np.float32(sa).view(np.uint32)) >> 23) - (int(np.float32(sb).view(np.uint32)) >> 23)
+    return np.uint32(int(np.clip(e, 1, 254)) << 23).view(np.float32)
+
+
+def amax_finite(x):
+    """fc_amax: the largest FINITE |x| (0 for an empty / all-non-finite tensor)"""
+    a = np.abs(np.asarray(x, np.float32))
+    a = a[np.isfinite(a)]
+    return np.float32(a.max()) if a.size else np.float32(0)
+
+
+def split2_h(x, s):
+    """fp32 array, power-of-two scale -> (h, l) float16 arrays: h = RN11(s x), l = RN11(s x - h)  (numpy rounds to nearest even, as
+    v_cvt_pk_f16_f32 does; the residual s x - h is exact in fp32)"""
+    xs = np.asarray(x, np.float32) * np.float32(s)
+    with np.errstate(over='ignore'):
+        h = xs.astype(np.float16)
+        r = xs - h.astype(np.float32)
+        lo = r.astype(np.float16)
+    return h, lo
+
+
+def matmul_h3(a, b, block=16):
+    """(M,K) @ (K,N) the way the h3 kernels do it (matmul_x6 with two fp16 pieces per operand, tensor-wide scales, three products)"""
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    sa, sb = h3_scale(amax_finite(a)), h3_scale(amax_finite(b))
+    pa, pb = split2_h(a, sa), split2_h(b, sb)
+    acc = np.zeros((a.shape[0], b.shape[1]), np.float32)
+    for k0 in range(0, a.shape[1], block):
+        for i, j in TERMS_H3:
+            upd = pa[i][:, k0:k0 + block].astype(np.float64) @ pb[j][k0:k0 + block].astype(np.float64)
+            acc = (acc.astype(np.float64) + upd).astype(np.float32)
+    return acc * h3_unscale(sa, sb)

@@ -465,3 +465,60 @@ def test_split_bf16_arithmetic_properties():
     scale = np.abs(ref).max()
     e6, e32 = np.sqrt(((got - ref) ** 2).mean()) / scale, np.sqrt(((plain - ref) ** 2).mean()) / scale
     assert e6 < 3e-7 and e6 <= 1.2 * e32, (e6, e32)
+
+
+def test_two_piece_fp16_split_properties():
+    """oracle/x6_oracle.py h3 — what csrc/conv_x6.h MODE 2 relies on (r6): with the tensor-wide power-of-two scale no piece leaves
+    fp16's range, the pair (h, l) holds the scaled value to 2^-23 relative — ONE fp32 ulp, and exactly for three values in four: the residual
+    s x - h has at most 12 significant bits — where the low piece is normal and to 2^-25 absolute (= 2^-39 of the tensor's maximum)
+    below, the three kept piece products are exact in fp32, the dropped part of a product is at most 2^-21 of it (2^-22 for the
+    low x low product, 2^-23 per residual) and 2^-25 of it on average, with no common sign, and a conv-shaped K = 1728 reduction lands as close to fp64 as plain fp32 accumulation does."""
+    from oracle import x6_oracle as X
+    rng = np.random.default_rng(1)
+    for mag in (1e-30, 3e-7, 1.0, 77.0, 4e3, 1e20, 3e38):
+        x = (rng.standard_normal(20000) * np.exp(2.0 * rng.standard_normal(20000))).astype(np.float32)
+        x = (x / np.abs(x).max() * np.float32(mag)).astype(np.float32)
+        x[:6] = np.float32([0.0, -0.0, mag, -mag, mag * 2.0 ** -20, mag * (1 + 2.0 ** -11)])
+        am = X.amax_finite(x)
+        s = X.h3_scale(am)
+        assert 2.0 ** 14 <= float(am) * float(s) < 2.0 ** 15, (mag, float(am) * float(s))           # scale rule: top element in [2^14, 2^15)
+        assert float(s) == 2.0 ** round(np.log2(float(s)))                                           # a power of two: scaling is exact
+        h, lo = X.split2_h(x, s)
+        assert np.all(np.isfinite(h.astype(np.float32))) and np.all(np.isfinite(lo.astype(np.float32)))
+        xs = x.astype(np.float64) * float(s)
+        err = np.abs(h.astype(np.float64) + lo.astype(np.float64) - xs)
+        normal_lo = np.abs(xs) >= 0.25                  # low piece >= 2^-14: a normal fp16
+        assert np.all(err[normal_lo] <= np.abs(xs[normal_lo]) * 2.0 ** -23)
+        assert np.all(err <= np.maximum(np.abs(xs) * 2.0 ** -23, 2.0 ** -25))
+        assert (err[normal_lo] == 0).mean() >= 0.7                                                   # exact for about three values in four
+        assert np.all(np.abs(lo.astype(np.float64)) <= np.abs(xs) * 2.0 ** -11 + 2.0 ** -25)
+    # piece products exact in fp32; dropped part of a product
+    x = (rng.standard_normal(50000) * np.exp(rng.standard_normal(50000))).astype(np.float32)
+    y = (rng.standard_normal(50000) * 0.05).astype(np.float32)
+    sx, sy = X.h3_scale(X.amax_finite(x)), X.h3_scale(X.amax_finite(y))
+    px, py = X.split2_h(x, sx), X.split2_h(y, sy)
+    keep = np.zeros(len(x), np.float64)
+    for i, j in X.TERMS_H3:
+        p64 = px[i].astype(np.float64) * py[j].astype(np.float64)
+        p32 = px[i].astype(np.float32) * py[j].astype(np.float32)
+        assert np.array_equal(p32.astype(np.float64), p64)                                           # 11 x 11 bits: exact in fp32
+        keep += p64
+    exact = x.astype(np.float64) * float(sx) * y.astype(np.float64) * float(sy)
+    big = (np.abs(x.astype(np.float64) * float(sx)) >= 0.25) & (np.abs(y.astype(np.float64) * float(sy)) >= 0.25)
+    signed = (keep[big] - exact[big]) / exact[big]
+    assert np.abs(signed).max() <= 2.0 ** -21 and np.abs(signed).mean() <= 2.0 ** -24 and abs(signed.mean()) <= 2.0 ** -28, \
+        (np.abs(signed).max(), np.abs(signed).mean(), signed.mean())
+    # unscale
+    assert float(X.h3_unscale(sx, sy)) * float(sx) * float(sy) == 1.0
+    # a conv-shaped reduction: 27 x 64 terms, ReLU-like activations; heavy-tailed gradients
+    for a in (np.maximum(rng.standard_normal((64, 1728)), 0).astype(np.float32),
+              (rng.standard_normal((64, 1728)) * np.exp(2.0 * rng.standard_normal((64, 1728))) * 1e-6).astype(np.float32)):
+        w = (rng.standard_normal((1728, 32)) * 0.05).astype(np.float32)
+        ref = a.astype(np.float64) @ w.astype(np.float64)
+        got = X.matmul_h3(a, w)
+        plain = np.zeros((64, 32), np.float32)
+        for k in range(1728):
+            plain = plain + np.outer(a[:, k], w[k]).astype(np.float32)
+        scale = np.abs(ref).max()
+        e3, e32 = np.sqrt(((got - ref) ** 2).mean()) / scale, np.sqrt(((plain - ref) ** 2).mean()) / scale
+        assert e3 < 3e-7 and e3 <= 1.2 * e32, (e3, e32)

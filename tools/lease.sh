@@ -4,6 +4,7 @@
 # Jobs run in the order given, output under gpurun_out/<tag>/.  A job is one of
 #   bench[:args]     python bench.py [args]            -> bench.json (+ one-line summary)         (FIRST job = driver conditions)
 #   quick[:args]     bench.py without the untimed extras -> quick<i>.json
+#   equick:ENV[:args] the same under environment switches (VAR=VAL,VAR=VAL)
 #   tests[:expr]     pytest -m gpu [-k expr]           -> tests.log
 #   file:<path>      pytest -m gpu <path>              -> tests_<name>.log
 #   smoke            __graft_entry__.smoke()
@@ -12,6 +13,7 @@
 #   pmc:<counters>   rocprofv3 --pmc <counters> over a short bench (own pass, no tracing)
 #   host[:args]      tools/hostprof.py --batches <args>   (default: 8 --lookahead)
 #   py:<script args> python <script args>
+#   sh:<command>     bash -c <command>            -> sh<i>.log (native benches: tools/nbench ...)
 cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=$1; shift
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -30,6 +32,10 @@ for job in "$@"; do
     quick)
       timeout 600 python bench.py --no-cpu-baseline --infer-steps 0 --no-fp32-route --no-extras --no-force-dp $arg > "$O/quick$i.json" 2> "$O/quick$i.err"; rc=$?
       python tools/lease_summary.py "$O/quick$i.json" ;;
+    equick)          # equick:VAR=VAL[,VAR=VAL...][:bench args] — quick with environment switches (A/B sweeps)
+      envs=${arg%%:*}; qargs=""; [ "$envs" != "$arg" ] && qargs=${arg#*:}
+      (export ${envs//,/ }; timeout 600 python bench.py --no-cpu-baseline --infer-steps 0 --no-fp32-route --no-extras --no-force-dp $qargs > "$O/quick$i.json" 2> "$O/quick$i.err"); rc=$?
+      echo "   [$envs]"; python tools/lease_summary.py "$O/quick$i.json" ;;
     tests)
       if [ -n "$arg" ]; then timeout 2400 python -m pytest tests -x -q -m gpu -k "$arg" --durations=8 > "$O/tests$i.log" 2>&1; else
         timeout 2400 python -m pytest tests -x -q -m gpu --durations=8 > "$O/tests$i.log" 2>&1; fi; rc=$?
@@ -51,6 +57,8 @@ for job in "$@"; do
         --infer-steps 0 --no-fp32-route --no-extras --no-force-dp --no-instrument > "$O/pmc$i.json" 2> "$O/pmc$i.err"); rc=$? ;;
     host)
       timeout 600 python tools/hostprof.py --batches ${arg:-8 --lookahead} > "$O/host$i.txt" 2>&1; rc=$?; tail -12 "$O/host$i.txt" ;;
+    sh)
+      timeout 1800 bash -c "$arg" > "$O/sh$i.log" 2>&1; rc=$?; tail -40 "$O/sh$i.log" ;;
     py)
       timeout 1800 python $arg > "$O/py$i.log" 2>&1; rc=$?; tail -25 "$O/py$i.log" ;;
     *) echo "unknown job $job"; rc=64 ;;

@@ -153,7 +153,7 @@ extern "C" int fc_debug_set_prio(int mode);
 int main(int argc, char** argv) {
   int prio = 0;
   int batch = 8, reps = 10, npts = 100000; std::string only, mode = "all", trace_file; bool check = true;
-  int trace_variant = 0, trace_tbl = 0; bool popc_sort = false, s_sweep = false, x6_only = false;
+  int trace_variant = 0, trace_tbl = 0; bool popc_sort = false, s_sweep = false, x6_only = false; bool n64 = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "--batch") batch = atoi(argv[++i]);
@@ -165,6 +165,7 @@ int main(int argc, char** argv) {
     else if (a == "--prio") prio = atoi(argv[++i]);
     else if (a == "--popc-sort") popc_sort = true;
     else if (a == "--s-sweep") s_sweep = true;
+    else if (a == "--n64") n64 = true;
     else if (a == "--x6") x6_only = true;                      // default fp32 routes + the split-bf16 kernel only
     else if (a == "--trace") trace_file = argv[++i];            // needs the FC_TRACE build (tools/nbench_trace)
     else if (a == "--trace-variant") trace_variant = atoi(argv[++i]);
@@ -301,6 +302,7 @@ int main(int argc, char** argv) {
   }
   Dev<float> d_in, d_w, d_wt, d_out, d_ref, d_gout, d_gw, d_gwref; Dev<int> d_nbr, d_sorted, d_oidx, d_pi, d_po, d_pos, d_cnt, d_masks;
   Dev<unsigned char> d_ws, d_img;
+  Dev<unsigned> d_amax; d_amax.alloc(512);
   for (const Case& cs : cases) {
     if (!only.empty() && cs.name.find(only) == std::string::npos) continue;
     const int K = cs.ks * cs.ks * cs.ks, n_in = cs.in->n(), n_out = cs.out->n(), Cin = cs.Cin, Cout = cs.Cout;
@@ -354,7 +356,7 @@ int main(int argc, char** argv) {
             }
           }
       }
-      struct Run { const char* what; int flags; int tbl; bool wt = false; bool img = false; };     // tbl: 0 plain table, 1 mask-sorted, 2 pair lists, 3 live-tile pair lists
+      struct Run { const char* what; int flags; int tbl; bool wt = false; bool img = false; int smode = 0; bool hint = false; };   // smode: fc_set_split_mode (image runs); hint: amax precomputed     // tbl: 0 plain table, 1 mask-sorted, 2 pair lists, 3 live-tile pair lists
       std::vector<Run> runs;
       const int X6 = 1 << 24, WTF = 1 << 23;
       runs.push_back({"plain ", 0, 0});
@@ -375,24 +377,35 @@ int main(int argc, char** argv) {
       runs.push_back({"x6I   ", X6I, 0, false, true});
       if (!cs.dense) { runs.push_back({"x6S   ", X6, 1}); runs.push_back({"x6IS  ", X6I, 1, false, true}); runs.push_back({"x6L   ", X6, 3}); runs.push_back({"x6IL  ", X6I, 3, false, true}); }
       if (Cout == 64) { runs.push_back({"x6 128", X6 | (2 << 4), 0}); runs.push_back({"x6I128", X6I | (2 << 4), 0, false, true}); }
+      // r6: the two-piece fp16 split (mode 2): same launches, image rebuilt in that mode; "+a": the operand's amax word handed in
+      runs.push_back({"h3I   ", X6I, 0, false, true, 2});
+      runs.push_back({"h3I+a ", X6I, 0, false, true, 2, true});
+      if (!cs.dense) { runs.push_back({"h3IS  ", X6I, 1, false, true, 2}); runs.push_back({"h3IS+a", X6I, 1, false, true, 2, true}); runs.push_back({"h3IL  ", X6I, 3, false, true, 2}); runs.push_back({"h3IL+a", X6I, 3, false, true, 2, true}); }
+      if (Cout % 128 == 0 && n64) {      // r6: 64-column tiles on the launches that leave CUs empty with 128-column tiles
+        runs.push_back({"x6I n64", X6I | (1 << 6), 0, false, true});
+        if (!cs.dense) { runs.push_back({"x6ISn64", X6I | (1 << 6), 1, false, true}); runs.push_back({"x6ILn64", X6I | (1 << 6), 3, false, true}); }
+      }
       static const char* snames[] = {"S=1", "S=2", "S=3", "S=4", "S=5", "S=6", "S=7", "S=8", "S=9", "S=10", "S=12", "S=14"};
       static const int svals[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14};
       if (s_sweep) for (int q = 0; q < 12; ++q) runs.push_back({snames[q], svals[q] << 8, cs.dense ? 0 : 1});
       for (const Run& r : runs) {
         const int fl = r.flags;
         const float* wp = r.img ? (const float*)d_img.p : (r.wt ? d_wt.p : d_w.p);
+        if (r.img) { FC(fc_set_split_mode(r.smode)); FC(fc_x6_weight_image(d_w.p, d_img.p, K, Cin, Cout, 0, 0)); }
+        const unsigned* hint = nullptr;
+        if (r.hint) { CK(hipMemset(d_amax.p, 0, 2048)); FC(fc_amax(d_in.p, (int64_t)n_in * Cin, d_amax.p, 0)); hint = d_amax.p; }
         std::function<void()> fn;
         if (r.tbl == 3) {
           int64_t wb = ws_for(fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout));
           std::vector<int> hc = d_cnt.down(K); int64_t live = 0; for (int v : hc) live += (v + 127) / 128;
-          fn = [&, wb, fl, live, wp]() { FC(fc_conv_fwd_pairs_tiles(d_in.p, wp, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, live, fl, d_ws.p, wb, 0)); };
+          fn = [&, wb, fl, live, wp, hint]() { if (hint) FC(fc_conv_amax_hint(hint, nullptr)); FC(fc_conv_fwd_pairs_tiles(d_in.p, wp, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, live, fl, d_ws.p, wb, 0)); };
         } else if (r.tbl == 2) {
           int64_t wb = ws_for(fc_conv_fwd_pairs_ws_bytes(n_out, K, Cout));
-          fn = [&, wb, fl, wp]() { FC(fc_conv_fwd_pairs(d_in.p, wp, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
+          fn = [&, wb, fl, wp, hint]() { if (hint) FC(fc_conv_amax_hint(hint, nullptr)); FC(fc_conv_fwd_pairs(d_in.p, wp, d_pi.p, d_cnt.p, d_pos.p, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
         } else {
           int64_t wb = ws_for(fc_conv_fwd_ws_bytes(n_out, K, Cin, Cout, fl));
           const int* tab = r.tbl ? d_sorted.p : d_nbr.p; const int* oi = r.tbl ? d_oidx.p : nullptr;
-          fn = [&, wb, fl, tab, oi, wp]() { FC(fc_conv_fwd(d_in.p, wp, tab, oi, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
+          fn = [&, wb, fl, tab, oi, wp, hint]() { if (hint) FC(fc_conv_amax_hint(hint, nullptr)); FC(fc_conv_fwd(d_in.p, wp, tab, oi, d_out.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
         }
         CK(hipMemset(d_out.p, 0xff, (size_t)n_out * Cout * 4));
         fn(); CK(hipDeviceSynchronize());
@@ -460,6 +473,8 @@ int main(int argc, char** argv) {
         for (int pairs = (s_sweep && !cs.dense ? 1 : 0); pairs < (cs.dense ? 1 : 2); ++pairs) {
           if (reg == 3 && pairs) continue;
           if (x6_only && (reg == 2 || reg == 3)) continue;
+          for (int smode = 0; smode <= (reg == 4 ? 2 : 0); smode += 2) {
+          FC(fc_set_split_mode(smode));
           const int fl = ((reg == 2) << 16) | ((reg == 3) << 30) | ((reg == 4) << 24) | (fsw << 8);
           int64_t wb = ws_for(fc_conv_wgrad_ws_bytes(n_out, K, Cin, Cout, fl));
           std::function<void()> fn;
@@ -470,8 +485,9 @@ int main(int argc, char** argv) {
           double err = -1;
           if (check) err = max_rel_err(d_gw.down(hw.size()), ref);
           double us = time_us(reps, fn);
-          printf("   wgrad %s %s S=%-2d %9.1f us %7.1f TF  err %.2e%s\n", reg == 2 ? "ldsr1" : reg == 3 ? "m-r1 " : reg == 4 ? "x6   " : "lds ", pairs ? "pairs" : "table", fsw, us, gflop / us * 1e3, err, (check && !(err < 2e-4)) ? "  <-- MISMATCH" : "");
+          printf("   wgrad %s %s S=%-2d %9.1f us %7.1f TF  err %.2e%s\n", reg == 2 ? "ldsr1" : reg == 3 ? "m-r1 " : reg == 4 ? (smode == 2 ? "h3   " : "x6   ") : "lds ", pairs ? "pairs" : "table", fsw, us, gflop / us * 1e3, err, (check && !(err < 2e-4)) ? "  <-- MISMATCH" : "");
           fflush(stdout);
+          }
         }
     }
   }
