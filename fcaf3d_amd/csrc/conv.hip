@@ -73,6 +73,12 @@ extern "C" int fc_set_split_mode(int mode) {
   return FC_OK;
 }
 extern "C" int fc_get_split_mode(void) { return split_mode(); }
+static int g_h3r = -1;                           // which h3 launches run the register-operand kernel (launch_conv_mfma)
+extern "C" int fc_debug_set_h3r(int mode) {
+  if (mode < 0 || mode > 2) return FC_EINVAL;
+  g_h3r = mode;
+  return FC_OK;
+}
 
 #include "conv_x6.h"
 #include "wgrad_x6.h"
@@ -1427,9 +1433,12 @@ static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in
   if (pipe == 4) wt = false;                     // a weight image already is the operator of its direction
   if (wt && !nbr) return FC_EINVAL;              // transposed weights: neighbour-table / pair-list launches only
   if (wt && pipe == 2) pipe = 0;                 // the LDS-DMA image cannot be transposed in flight
-  // r6: h3 launches on 128-row tiles take the register-operand kernel (conv_h3r.h; FC_H3R=0: the LDS-staged k_conv_x6 MODE 2, A/B)
-  static const bool h3r = !(getenv("FC_H3R") && atoi(getenv("FC_H3R")) == 0);
-  if (h3 && h3r && bm == 128 && !g_bf16_fast) {
+  // r6: h3 launches on 128 x 128 tiles take the register-operand kernel (conv_h3r.h): +1...11 % per launch there (tools/nbench, same
+  // box), while the 64-column tiles LOSE 7-14 % on the 441k-row maps — a lane-per-row load touches 32 cache lines per instruction
+  // where the LDS staging touches 8, and those launches are bound by the gather.  FC_H3R / fc_debug_set_h3r: 0 never, 1 (default)
+  // 128-column tiles, 2 every 128-row tile.
+  if (g_h3r < 0) g_h3r = getenv("FC_H3R") ? atoi(getenv("FC_H3R")) : 1;
+  if (h3 && bm == 128 && !g_bf16_fast && (g_h3r == 2 || (g_h3r == 1 && bn == 128))) {
 #define FC_LAUNCH_H3R(BN_)                                                                                               \
   do {                                                                                                                  \
     if (nbr && bufok) k_conv_h3r<BN_, true, true><<<grid, 256, 0, stream>>>(in, W, nbr, out_index, cnt, dst, n_rows, K, Cin, Cout, e6);       \

@@ -131,7 +131,9 @@ STRUCTURED_MAPS = os.environ.get('FC_STRUCTURED_MAPS', '1') != '0'   # generated
 PAIRS_DENSE = os.environ.get('FC_PAIRS_DENSE', '0') != '0'   # pair lists (exact work) also on small dense maps (77 % occupied at 6.9k rows)
 WGRAD_PAIRS = os.environ.get('FC_WGRAD_PAIRS', '1') != '0'    # weight gradients reduce over exact pair lists there
 # ... and with at most this many result rows the convolution itself runs per offset over the pair lists
-PAIR_CONV_ROWS = int(os.environ.get('FC_PAIR_CONV_ROWS', '16384'))
+# (r6, three-product kernels: 8 192 — the 14.7k-row level on its mask-sorted table — 462.9 scenes/s against 456.1 at 16 384 and 452.5 at
+# 2 048, same box; the six-product kernels of r3-r5 were level at 16 384 / 8 192: profiles/r5_notes.md section 7)
+PAIR_CONV_ROWS = int(os.environ.get('FC_PAIR_CONV_ROWS', '8192'))
 _offs_cache = {}
 
 

@@ -497,6 +497,10 @@ int fc_conv_amax_hint(const unsigned* amax_in, const unsigned* amax_gout);
  * needs no fc_amax pass.  Cleared by that call.  No reference counterpart (see fc_set_split_mode; the producers are
  * ME.MinkowskiBatchNorm / MinkowskiReLU / MinkowskiELU / MinkowskiMaxPooling of me_resnet.py:19-24, fcaf3d_neck_with_head.py:49-71). */
 int fc_amax_out_hint(unsigned* amax_word);
+/* A/B switch (No reference counterpart; tests and tools/nbench): which mode-2 convolution launches on 128-row tiles run the
+ * register-operand kernel csrc/conv_h3r.h — 0 none, 1 those on 128-column tiles (default), 2 all.  Results are bit-identical either
+ * way (the statistics tables agree to rounding: other summation order). */
+int fc_debug_set_h3r(int mode);
 
 /* ---- launch-list executor (the network body in one call per direction) ------------------------------------ */
 

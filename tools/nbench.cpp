@@ -381,6 +381,7 @@ int main(int argc, char** argv) {
       runs.push_back({"h3I   ", X6I, 0, false, true, 2});
       runs.push_back({"h3I+a ", X6I, 0, false, true, 2, true});
       if (!cs.dense) { runs.push_back({"h3IS  ", X6I, 1, false, true, 2}); runs.push_back({"h3IS+a", X6I, 1, false, true, 2, true}); runs.push_back({"h3IL  ", X6I, 3, false, true, 2}); runs.push_back({"h3IL+a", X6I, 3, false, true, 2, true}); }
+      if (Cout == 64) runs.push_back({"h3I256+a", X6I | (3 << 4), 0, false, true, 2, true});       // 256 x 64 tiles
       if (Cout % 128 == 0 && n64) {      // r6: 64-column tiles on the launches that leave CUs empty with 128-column tiles
         runs.push_back({"x6I n64", X6I | (1 << 6), 0, false, true});
         if (!cs.dense) { runs.push_back({"x6ISn64", X6I | (1 << 6), 1, false, true}); runs.push_back({"x6ILn64", X6I | (1 << 6), 3, false, true}); }
