@@ -408,7 +408,7 @@ class ConvProbe:
                             pr = float(p_.item()) if p_ is not None else float(n_out)
                             fh.write(json.dumps(dict(shape=shp, pairs=pr, gflop=pr * fpp / 1e9, us=s_.elapsed_time(e_) * 1e3)) + '\n')
         traffic, traffic_src = None, None
-        for tname in ('r5_traffic.json', 'r4_traffic.json'):          # PMC passes cannot run inside the timed region: committed rocprofv3 result
+        for tname in ('r6_traffic.json', 'r5_traffic.json', 'r4_traffic.json'):          # PMC passes cannot run inside the timed region: committed rocprofv3 result
             tj = os.path.join(ROOT, 'profiles', tname)
             if os.path.exists(tj):
                 t = json.load(open(tj))

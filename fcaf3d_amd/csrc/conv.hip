@@ -1605,7 +1605,7 @@ int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int trans
   const int64_t total = (int64_t)K * (R / 32) * (C / 64) * 256;
   const unsigned nb = (unsigned)fc_cdiv(total, 256);
   if (split_mode() == 2) {                       // h3: max |W| into the image's amax word, then the fp16 pieces
-    FC_HIP(hipMemsetAsync((char*)img + 4 * X6_IMG_AMAX_WORD, 0, 4, stream));
+    FC_HIP(hipMemsetAsync((char*)img + 4 * X6_IMG_AMAX_WORD, 0, FC_AMAX_SLOT_BYTES, stream));
     k_x6_weight_image<3><<<nb, 256, 0, stream>>>(W, (u32x4*)img, K, R, C, transposed);
     k_x6_weight_image<2><<<nb, 256, 0, stream>>>(W, (u32x4*)img, K, R, C, transposed);
   } else {
@@ -1619,7 +1619,7 @@ int fc_x6_weight_images(const int64_t* desc, int n, int64_t total_blocks, hipStr
   if (!desc || n < 1 || total_blocks < 1 || total_blocks > 0x7fffffffll) return FC_EINVAL;
   const long long* d = reinterpret_cast<const long long*>(desc);
   if (split_mode() == 2) {
-    k_x6_weight_images<4><<<(unsigned)fc_cdiv(n, 256), 256, 0, stream>>>(d, n);
+    k_x6_weight_images<4><<<(unsigned)fc_cdiv(n, 4), 256, 0, stream>>>(d, n);
     k_x6_weight_images<3><<<(unsigned)total_blocks, 256, 0, stream>>>(d, n);
     k_x6_weight_images<2><<<(unsigned)total_blocks, 256, 0, stream>>>(d, n);
   } else {

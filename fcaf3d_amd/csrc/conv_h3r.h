@@ -9,7 +9,7 @@
 // in registers and hand them to the matrix pipe: no LDS write, no LDS read, no barrier for the rows.  Only the weight pieces — shared
 // by the four waves — go through LDS, double-buffered: ONE barrier per stage.
 // Same pieces, same products in the same order per accumulator as k_conv_x6<..., MODE 2>: results are BIT-IDENTICAL
-// (tests/test_gpu_ops.py::test_register_operand_kernel_is_bit_identical); same grid, pair mode, offset split, epilogues.
+// (tests/test_gpu_h3.py::test_register_operand_kernel_is_bit_identical); same grid, pair mode, offset split, epilogues.
 #pragma once
 
 template <int BN, bool HAS_NBR, bool BUF>
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 3) void k_conv_h3r(
   }
   const int64_t m0 = bx * BM;
   const float h3_sa = h3_scale(fc_amax_read(epi.amax_in));
-  const float h3_inv = h3_unscale(h3_sa, h3_scale(reinterpret_cast<const unsigned*>(W)[X6_IMG_AMAX_WORD]));
+  const float h3_inv = h3_unscale(h3_sa, h3_scale(fc_amax_read(reinterpret_cast<const unsigned*>(W) + X6_IMG_AMAX_WORD)));
 
   f32x16 acc[TN];
 #pragma unroll

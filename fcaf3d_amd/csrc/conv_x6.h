@@ -87,7 +87,8 @@ __device__ __forceinline__ void x6_split2(float x0, float x1, unsigned& p0, unsi
 // fields — nothing but integer arithmetic on the host or the device decides a scale, so runs are bit-reproducible.
 typedef _Float16 x6_f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-#define X6_IMG_AMAX_WORD 2048          // dword index in a weight image: plane 2, row 0, chunk 0 of the first (k, slab, group) block
+#define X6_IMG_AMAX_WORD 2048          // dword index in a weight image: plane 2, row 0, chunk 0 of the first (k, slab, group) block —
+                                       // the first of FC_AMAX_SUB sub-words at FC_AMAX_STRIDE (an amax slot, fc_common.h, inside the unused plane)
 __device__ __forceinline__ float h3_scale(unsigned amax_bits) {       // 2^(14 - floor(log2 amax)), clamped to the normal range
   int se = 268 - (int)((amax_bits >> 23) & 0xffu);
   se = se > 254 ? 254 : (se < 1 ? 1 : se);
@@ -147,8 +148,7 @@ __device__ __forceinline__ void x6_weight_image_unit(const float* __restrict__ W
 // h3 image: planes 0 / 1 hold the fp16 pieces of sw W, plane 2 is unused (its first word holds max |W|: X6_IMG_AMAX_WORD, written
 // by the amax pass that runs before this one)
 __device__ __forceinline__ void h3_weight_image_unit(const float* __restrict__ W, u32x4* __restrict__ img, int64_t t, int R, int C,
-                                                     int transposed) {
-  const float sw = h3_scale(reinterpret_cast<const unsigned*>(img)[X6_IMG_AMAX_WORD]);
+                                                     int transposed, float sw) {
   const int chunk = (int)(t & 3), c = (int)((t >> 2) & 63);
   const int64_t blk = t >> 8;
   const int g = (int)(blk % (C / 64));
@@ -185,11 +185,15 @@ __device__ __forceinline__ unsigned h3_weight_unit_amax(const float* __restrict_
   }
   return m;
 }
-__device__ __forceinline__ void h3_block_amax(unsigned m, unsigned* __restrict__ dst) {      // 256 threads -> one atomicMax
+// a wave's maximum -> the sub-word of its block in the image's amax slot (striped, and skipped when the sub-word already holds as
+// much: with ONE word per image the 4 waves x 69k blocks of the weight pass polled ~100 L2 lines and the pass took 0.62 ms)
+__device__ __forceinline__ void h3_block_amax(unsigned m, unsigned* __restrict__ slot) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
-  // (skipped when the word already holds as much: 4 waves x 69k blocks on ~100 words cost the weight pass 0.7 ms per step without)
-  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, m);
+  if ((threadIdx.x & 63) == 0) {
+    unsigned* w = slot + (blockIdx.x & (FC_AMAX_SUB - 1)) * FC_AMAX_STRIDE;
+    if (m > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, m);
+  }
 }
 
 // MODE: 0 six bf16 products, 2 three fp16 products (amax pass: MODE 3)
@@ -198,9 +202,12 @@ __global__ void k_x6_weight_image(const float* __restrict__ W, u32x4* __restrict
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (k, slab, group, column, chunk)
   const bool live = t < (int64_t)K * (R / 32) * (C / 64) * 256;
   if (MODE == 3) { h3_block_amax(live ? h3_weight_unit_amax(W, t, R, C, transposed) : 0u, reinterpret_cast<unsigned*>(img) + X6_IMG_AMAX_WORD); return; }
-  if (!live) return;
-  if (MODE == 2) h3_weight_image_unit(W, img, t, R, C, transposed);
-  else x6_weight_image_unit(W, img, t, R, C, transposed);
+  if (MODE == 2) {
+    const float sw = h3_scale(fc_amax_read(reinterpret_cast<const unsigned*>(img) + X6_IMG_AMAX_WORD));      // (every lane)
+    if (live) h3_weight_image_unit(W, img, t, R, C, transposed, sw);
+    return;
+  }
+  if (live) x6_weight_image_unit(W, img, t, R, C, transposed);
 }
 #if 0
 __global__ void k_x6_weight_image(const float* __restrict__ W, u32x4* __restrict__ img, int K, int R, int C, int transposed) {
@@ -212,11 +219,13 @@ __global__ void k_x6_weight_image(const float* __restrict__ W, u32x4* __restrict
 // Images of MANY kernels in one launch (every convolution of a model, both directions, after an optimizer step):
 // desc[e] = {W, img, K, R, C, transposed, first block, -}; an entry owns the blocks [first block, first block of e + 1) and
 // K (R / 32) (C / 64) of them are live (256 threads = one (k, slab, group) unit each).
-template <int MODE>           // 0 / 2: the image pass of that mode; 3: the amax pass of h3; 4: zero the amax words (one thread per entry)
+// desc word 7 (h3): the address of ANOTHER image of the same weights (the forward image, for a backward-data entry) whose amax slot
+// this entry shares — it skips the amax pass, scales by that slot and copies it into its own — or 0.
+template <int MODE>           // 0 / 2: the image pass of that mode; 3: the amax pass of h3; 4: zero the amax slots (one wave per entry)
 __global__ void k_x6_weight_images(const long long* __restrict__ desc, int n) {
   if (MODE == 4) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) reinterpret_cast<unsigned*>(desc[8 * e + 1])[X6_IMG_AMAX_WORD] = 0u;
+    const int e = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (e < n && l < FC_AMAX_SUB) reinterpret_cast<unsigned*>(desc[8 * e + 1])[X6_IMG_AMAX_WORD + l * FC_AMAX_STRIDE] = 0u;
     return;
   }
   int lo = 0, hi = n - 1;
@@ -231,10 +240,19 @@ __global__ void k_x6_weight_images(const long long* __restrict__ desc, int n) {
   const bool live = t < (int64_t)K * (R / 32) * (C / 64) * 256;
   const float* W = reinterpret_cast<const float*>(d[0]);
   u32x4* img = reinterpret_cast<u32x4*>(d[1]);
-  if (MODE == 3) { h3_block_amax(live ? h3_weight_unit_amax(W, t, R, C, (int)d[5]) : 0u, reinterpret_cast<unsigned*>(img) + X6_IMG_AMAX_WORD); return; }
-  if (!live) return;
-  if (MODE == 2) h3_weight_image_unit(W, img, t, R, C, (int)d[5]);
-  else x6_weight_image_unit(W, img, t, R, C, (int)d[5]);
+  if (MODE == 3) {
+    if (d[7]) return;                           // shares its sibling's slot
+    h3_block_amax(live ? h3_weight_unit_amax(W, t, R, C, (int)d[5]) : 0u, reinterpret_cast<unsigned*>(img) + X6_IMG_AMAX_WORD);
+    return;
+  }
+  if (MODE == 2) {
+    const unsigned* slot = d[7] ? reinterpret_cast<const unsigned*>(d[7]) + X6_IMG_AMAX_WORD : reinterpret_cast<const unsigned*>(img) + X6_IMG_AMAX_WORD;
+    const unsigned am = fc_amax_read(slot);     // (every lane)
+    if (d[7] && b == d[6] && threadIdx.x == 0) reinterpret_cast<unsigned*>(img)[X6_IMG_AMAX_WORD] = am;      // own slot: sub-word 0 (the rest stays zero)
+    if (live) h3_weight_image_unit(W, img, t, R, C, (int)d[5], h3_scale(am));
+    return;
+  }
+  if (live) x6_weight_image_unit(W, img, t, R, C, (int)d[5]);
 }
 
 #define X6_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
   float h3_sa = 1.f, h3_inv = 1.f;               // h3: scale of the gathered operand, 1 / (sa sw) for the epilogue
   if (H3) {
     h3_sa = h3_scale(fc_amax_read(epi.amax_in));
-    h3_inv = h3_unscale(h3_sa, h3_scale(reinterpret_cast<const unsigned*>(W)[X6_IMG_AMAX_WORD]));
+    h3_inv = h3_unscale(h3_sa, h3_scale(fc_amax_read(reinterpret_cast<const unsigned*>(W) + X6_IMG_AMAX_WORD)));
   }
 
   f32x16 acc[TM][TN];

@@ -662,7 +662,8 @@ class WeightImages:
                 o, nb, K, R, C = pair[tr]
                 v = self.buf[o:o + nb]
                 views.append(v)
-                desc += [w.data_ptr(), v.data_ptr(), K, R, C, tr, blk, 0]
+                # word 7 (h3 split): a backward-data image shares the amax slot of its forward image (the same weights): no second pass
+                desc += [w.data_ptr(), v.data_ptr(), K, R, C, tr, blk, views[0].data_ptr() if (tr == 1 and views[0] is not None) else 0]
                 blk += K * (R // 32) * (C // 64)
             K = 1 if w.dim() == 2 else w.shape[0]
             self.table[(w.data_ptr(), K, w.shape[-2], w.shape[-1])] = tuple(views)

@@ -189,7 +189,9 @@ int fc_x6_weight_image(const float* W, void* img, int K, int R, int C, int trans
 /* The images of many kernels in ONE launch (all convolutions of a model — me_resnet.py:56-62, fcaf3d_neck_with_head.py:52,60-69 —
  * both directions, right after the optimizer step: the reference's optimizer hook, mmcv OptimizerHook.after_train_iter, is where
  * its weights change): `desc` is a DEVICE array
- * of n entries of 8 int64 {W pointer, image pointer, K, R, C, transposed, first block, 0}; entry e owns the blocks from its
+ * of n entries of 8 int64 {W pointer, image pointer, K, R, C, transposed, first block, sibling}; sibling (split mode 2): 0, or
+ * the address of another image of the SAME weights listed earlier (the forward image of a backward-data entry) whose amax slot
+ * this entry shares instead of making its own pass over W; entry e owns the blocks from its
  * first block up to the next entry's, K (R / 32) (C / 64) of them; total_blocks = the last entry's first block + its blocks. */
 int fc_x6_weight_images(const int64_t* desc, int n, int64_t total_blocks, hipStream_t stream);
 

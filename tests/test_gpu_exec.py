@@ -159,13 +159,16 @@ def test_train_step_through_the_executor_equals_module_path():
     # same sums in another order, gradients equal to 2e-5 in the one-step test above).  Hence: at most 1 element in 100 of a tensor
     # further apart than 1e-4 (a thirtieth of what an element can move; measured: 4 of 512 in the worst tensor, a BatchNorm bias of
     # the deepest stage), and none further than 6e-3.
+    # (r6: counted per tensor as "at most one element, or 1 in 100" — ONE flipped element of a 64-channel BatchNorm bias is 1.6 % of it)
     worst_frac, worst_abs = 0.0, 0.0
     for k, p in out[False][1].items():
         d = (out[True][1][k].double() - p.double()).abs()
-        worst_frac = max(worst_frac, float((d > 1e-4).double().mean()))
+        n_far = int((d > 1e-4).sum())
+        assert n_far <= max(1, d.numel() // 100), (k, n_far, d.numel())
+        worst_frac = max(worst_frac, n_far / d.numel())
         worst_abs = max(worst_abs, float(d.max()))
     print(f'parameters after 3 steps: largest difference {worst_abs:.2e}, largest fraction of a tensor beyond 1e-4: {worst_frac:.2e}')
-    assert worst_frac <= 1e-2 and worst_abs <= 6e-3, (worst_frac, worst_abs)
+    assert worst_abs <= 6e-3, (worst_frac, worst_abs)
 
 
 def test_pruning_falls_back_to_the_module_path():

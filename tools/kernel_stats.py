@@ -10,8 +10,8 @@ def family(n):
     n = n.replace('void ', '')
     if n.startswith('(anonymous namespace)::'):
         n = n[len('(anonymous namespace)::'):]
-    if n.startswith('k_conv_x6'):
-        return 'conv fwd/dgrad: k_conv_x6'
+    if n.startswith(('k_conv_x6', 'k_conv_h3r')):
+        return 'conv fwd/dgrad: k_conv_x6 / k_conv_h3r'
     if n.startswith('k_wgrad_x6'):
         return 'weight gradient: k_wgrad_x6'
     if n.startswith(('k_wgrad', 'k_stem_wgrad')):
@@ -20,6 +20,10 @@ def family(n):
         return 'normalisation (k_bn*, k_norm*, k_stats*)'
     if n.startswith(('k_sum_pairs', 'k_sum_parts')):
         return 'fixed-order sums of split launches (k_sum_pairs / k_sum_parts)'
+    if n.startswith('k_amax'):
+        return 'amax passes of convolution operands (k_amax)'
+    if n.startswith(('k_plan', 'k_radix')):
+        return 'coordinates / maps'
     if n.startswith('k_x6_weight'):
         return 'weight images (k_x6_weight_image[s])'
     if n.startswith(('k_hash', 'k_unique', 'k_kernel_map', 'k_map_', 'k_gen_', 'k_union', 'k_child', 'k_nbr', 'k_permute_nbr', 'k_pairs_', 'k_scan',

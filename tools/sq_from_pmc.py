@@ -11,7 +11,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-FAMILIES = ('k_conv_x6', 'k_wgrad_x6t', 'k_sum_pairs', 'k_sum_parts', 'k_bn2_apply', 'k_norm_bwd_apply', 'k_bn1_bwd_apply', 'k_norm_act_fwd')
+FAMILIES = ('k_conv_x6', 'k_conv_h3r', 'k_wgrad_x6t', 'k_sum_pairs', 'k_sum_parts', 'k_bn2_apply', 'k_norm_bwd_apply', 'k_bn1_bwd_apply', 'k_norm_act_fwd')
 
 
 STATIC, TIMES, SHAPE_TIMES = {}, {}, {}

@@ -33,7 +33,7 @@ def per_template(path, counter, match):
 
 def main():
     fetch_csv, write_csv, out = sys.argv[1:4]
-    match = ('k_conv_mfma', 'k_conv_glds', 'k_conv_x6')        # the forward / backward-data family
+    match = ('k_conv_mfma', 'k_conv_glds', 'k_conv_x6', 'k_conv_h3r')        # the forward / backward-data family
     f, nf = per_kernel(fetch_csv, 'FETCH_SIZE', match)
     w, nw = per_kernel(write_csv, 'WRITE_SIZE', match)
     fetch_b = 2.0 * f * 1024 / max(nf, 1)        # KB -> B, x2 gfx950 correction
@@ -42,7 +42,7 @@ def main():
     templates = {k: dict(launches=ft[k][1], fetch_MB_per_launch=round(2.0 * ft[k][0] * 1024 / ft[k][1] / 1e6, 2),
                          write_MB_per_launch=round(wt.get(k, [0.0, 1])[0] * 1024 / max(wt.get(k, [0.0, 1])[1], 1) / 1e6, 2)) for k in ft}
     from fcaf3d_amd.build import source_hash
-    json.dump(dict(kernel_source_sha16=source_hash(), per_template=templates, kernel='k_conv_x6 + k_conv_mfma* + k_conv_glds', launches_fetch_pass=nf, launches_write_pass=nw,
+    json.dump(dict(kernel_source_sha16=source_hash(), per_template=templates, kernel='k_conv_x6 + k_conv_h3r + k_conv_mfma* + k_conv_glds', launches_fetch_pass=nf, launches_write_pass=nw,
                    fetch_bytes_per_launch=round(fetch_b), write_bytes_per_launch=round(write_b),
                    hbm_bytes_per_launch=round(fetch_b + write_b),
                    method='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py; FETCH_SIZE x2 '
