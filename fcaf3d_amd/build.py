@@ -9,6 +9,10 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libfcaf3d_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wno-unused-result']
+# r6: no SLP vectorisation in the MFMA kernels' files — the vectoriser packs the split arithmetic of adjacent channels into v_pk_mul_f32 /
+# v_pk_fma_f32 / v_pk_add_f32, and beside MFMAs a packed fp32 instruction costs more than the two scalar ones it replaces
+# (MI355X_MICROARCH.md "price of one filler beside MFMAs"): 454.9 / 453.8 -> 462.5 / 463.2 scenes/s (ABAB, one box), conv operator 93.2 -> 89.7 us
+FILE_FLAGS = {'conv.hip': ['-fno-slp-vectorize'], 'norm.hip': ['-fno-slp-vectorize']}
 
 
 def _sources():
@@ -43,7 +47,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(CSRC, s[:-4] + '.o')
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ['-c', src, '-o', obj])
+            jobs.append([HIPCC] + FLAGS + FILE_FLAGS.get(s, []) + ['-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:

@@ -2314,6 +2314,9 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
                    (wgrad_multi_ok(n_out, K, Cin, Cout, flags, dense_table) ||
                     (cnt && (Cin % 128 == 0 || Cout % 128 == 0 || wgrad_tr64())) || (!nbr && !cnt && wgrad_tr64()));
   const bool h3 = x6t && split_mode() == 2;
+  // buffer addressing of both operands (wgrad_x6.h): below 2 GB each, row indices below 2^24; flags bit27: flat addresses (A/B, tests)
+  const int wbuf = (!(flags & (1 << 27)) && (uint64_t)n_in * (uint64_t)Cin * 4u < (1ull << 31) - 4096u && (uint64_t)n_out * (uint64_t)Cout * 4u < (1ull << 31) - 4096u &&
+                    n_in < (1 << 24) && n_out < (1 << 24)) ? 1 : 0;
   const unsigned *am_a = nullptr, *am_g = nullptr;
   if (h3) {
     int rc = operand_amax(in, n_in * (int64_t)Cin, 0, stream, &am_a);
@@ -2327,12 +2330,12 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     const int bn = (Cout % 128 == 0) ? 128 : 64;
     dim3 grid((unsigned)S, (unsigned)((K / WGRAD_KO) * (Cin / 64) * (Cout / bn)));
     if (flags & (1 << 24)) {                     // split-bf16 (wgrad_x6.h)
-      if (g_bf16_fast && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false, 1><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr);
-      else if (g_bf16_fast) k_wgrad_x6t<64, 64, WGRAD_KO, false, 1><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr);
-      else if (h3 && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false, 2><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, am_a, am_g);
-      else if (h3) k_wgrad_x6t<64, 64, WGRAD_KO, false, 2><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, am_a, am_g);
-      else if (bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr);
-      else k_wgrad_x6t<64, 64, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr);
+      if (g_bf16_fast && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false, 1><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr, wbuf);
+      else if (g_bf16_fast) k_wgrad_x6t<64, 64, WGRAD_KO, false, 1><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr, wbuf);
+      else if (h3 && bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false, 2><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, am_a, am_g, wbuf);
+      else if (h3) k_wgrad_x6t<64, 64, WGRAD_KO, false, 2><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, am_a, am_g, wbuf);
+      else if (bn == 128) k_wgrad_x6t<64, 128, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr, wbuf);
+      else k_wgrad_x6t<64, 64, WGRAD_KO, false><<<grid, 256, 0, stream>>>(in, gout, nbr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr, wbuf);
     } else
     if (bn == 128) k_wgrad_multi<128, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
     else k_wgrad_multi<64, WGRAD_KO><<<grid, 256, 0, stream>>>(in, gout, nbr, part, n_out, K, Cin, Cout, rps);
@@ -2347,9 +2350,9 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
 #define FC_WX6(BM_, BN_)                                                                                                             \
   do {                                                                                                                               \
-    if (g_bf16_fast) k_wgrad_x6t<BM_, BN_, 1, true, 1><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps, nullptr, nullptr); \
-    else if (h3) k_wgrad_x6t<BM_, BN_, 1, true, 2><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps, am_a, am_g); \
-    else k_wgrad_x6t<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps, nullptr, nullptr); \
+    if (g_bf16_fast) k_wgrad_x6t<BM_, BN_, 1, true, 1><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps, nullptr, nullptr, wbuf); \
+    else if (h3) k_wgrad_x6t<BM_, BN_, 1, true, 2><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps, am_a, am_g, wbuf); \
+    else k_wgrad_x6t<BM_, BN_, 1, true><<<grid, 256, 0, stream>>>(in, gout, nbr, row_index, cnt, part, n_out, K, Cin, Cout, rps, nullptr, nullptr, wbuf); \
   } while (0)
     if (bm == 128 && bn == 128) FC_WX6(128, 128);
     else if (bm == 128) FC_WX6(128, 64);
@@ -2364,9 +2367,9 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
     dim3 grid((unsigned)S, (unsigned)(K * (Cin / bm) * (Cout / bn)));
 #define FC_WX6D(BM_, BN_)                                                                                                              \
   do {                                                                                                                                \
-    if (g_bf16_fast) k_wgrad_x6t<BM_, BN_, 1, false, 1><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr); \
-    else if (h3) k_wgrad_x6t<BM_, BN_, 1, false, 2><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, am_a, am_g); \
-    else k_wgrad_x6t<BM_, BN_, 1, false><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr);   \
+    if (g_bf16_fast) k_wgrad_x6t<BM_, BN_, 1, false, 1><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr, wbuf); \
+    else if (h3) k_wgrad_x6t<BM_, BN_, 1, false, 2><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, am_a, am_g, wbuf); \
+    else k_wgrad_x6t<BM_, BN_, 1, false><<<grid, 256, 0, stream>>>(in, gout, nullptr, nullptr, nullptr, part, n_out, K, Cin, Cout, rps, nullptr, nullptr, wbuf);   \
   } while (0)
     if (bm == 128 && bn == 128) FC_WX6D(128, 128);
     else if (bm == 128) FC_WX6D(128, 64);

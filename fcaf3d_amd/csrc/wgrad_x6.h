@@ -59,7 +59,7 @@ template <int BMc, int BNc, int KO, bool PAIRS, int MODE = 0>
 __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) void k_wgrad_x6t(
     const float* __restrict__ in, const float* __restrict__ gout, const int* __restrict__ nbr,
     const int* __restrict__ row_index, const int* __restrict__ cnt, float* __restrict__ part, int64_t n_out, int K, int Cin,
-    int Cout, int64_t rows_per_split, const unsigned* __restrict__ amax_a, const unsigned* __restrict__ amax_g) {
+    int Cout, int64_t rows_per_split, const unsigned* __restrict__ amax_a, const unsigned* __restrict__ amax_g, int buf) {
   constexpr int TM = BMc / 64, TN = BNc / 64;    // 32x32 tiles per wave (waves 2 x 2 over the BMc x BNc tile)
   constexpr int SA = BMc / 32, SG = BNc / 32;    // [32 rows][32 channels] subtiles per offset / of gout: 256 units of 8 B each
   constexpr bool FAST = MODE == 1, H3 = MODE == 2;
@@ -118,7 +118,28 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
       ig = row < r_end ? (PAIRS ? row_index[(int64_t)k0 * n_out + rc] : (int)rc) : -1;
     };
     f32x4 av[KO][SA], gv[SG];
+    // buf (r6; both operands below 2 GB, fewer than 2^24 rows): rows through buffer descriptors — a 32-bit byte offset per row (24-bit
+    // multiply-add), an absent row = an offset past the descriptor's range (the load returns zeros) — instead of a 64-bit address
+    // per row and stage (v_mad_u64_u32 + v_lshl_add_u64 per operand: ~30 of the stage's ~200 VALU instructions, and on this SIMD a
+    // wave's VALU time ADDS to the other wave's matrix time: 2 x (1 152 + 840) clocks per stage measured as 4 037)
+    constexpr unsigned WG_DEAD = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, (int)WG_DEAD, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)WG_DEAD, 0x00020000);
+    const unsigned g_row_bytes = (unsigned)Cout * 4u, a_row_bytes = (unsigned)Cin * 4u;
+    const unsigned g_col_bytes = (unsigned)(co0 + s_c4) * 4u, a_col_bytes = (unsigned)(ci0 + s_c4) * 4u;
     auto load_rows = [&]() {                     // rows of the stage whose indices sit in ia / ig
+      if (buf) {
+        const unsigned og = ig >= 0 ? __umul24((unsigned)ig, g_row_bytes) + g_col_bytes : WG_DEAD;
+#pragma unroll
+        for (int p = 0; p < SG; ++p) gv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)(og + 128u * p), 0, 0));
+#pragma unroll
+        for (int o = 0; o < KO; ++o) {
+          const unsigned oa = ia[o] >= 0 ? __umul24((unsigned)ia[o], a_row_bytes) + a_col_bytes : WG_DEAD;
+#pragma unroll
+          for (int p = 0; p < SA; ++p) av[o][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (int)(oa + 128u * p), 0, 0));
+        }
+        return;
+      }
       const float* gp = ig >= 0 ? gout + (int64_t)ig * Cout + co0 + s_c4 : g_zero_row + s_c4;
 #pragma unroll
       for (int p = 0; p < SG; ++p) {

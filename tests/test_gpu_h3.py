@@ -99,7 +99,8 @@ def test_three_product_route_against_fp64_and_the_six_product_route(xs, gs):
 def test_register_operand_kernel_is_bit_identical(n_points, Cin, Cout, q):
     """csrc/conv_h3r.h: the gathered operand split in registers (one row per lane) instead of staged through LDS — the same pieces
     and products in the same order per accumulator: forward and backward-data bit for bit (dense tables, mask-sorted tables, pair
-    lists, ragged tiles; buffer and flat addressing); the statistics epilogue agrees to rounding (other summation order)."""
+    lists, ragged tiles; buffer and flat addressing); the statistics epilogue agrees to rounding (other summation order).  The weight
+    gradient rides along: k_wgrad_x6t reads its rows through buffer descriptors or flat addresses (flags bit27) — the same bits."""
     from fcaf3d_amd import _lib as L
     import fcaf3d_amd.functional as Fn
     from tests.test_gpu_ops import _stats_case
@@ -113,18 +114,19 @@ def test_register_operand_kernel_is_bit_identical(n_points, Cin, Cout, q):
             for flat in (False, True):
                 L.call('fc_debug_set_h3r', mode)
                 Fn.FLAGS = f0 | ((1 << 27) if flat else 0)
-                xx = x.clone().requires_grad_(True)
-                y, tab = Fn.sparse_conv(xx, w, km, cm.n, True, want_stats=True)
+                xx, ww = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+                y, tab = Fn.sparse_conv(xx, ww, km, cm.n, True, want_stats=True)
                 y.backward(g)
-                res[(mode, flat)] = (y.detach().clone(), xx.grad.clone(), None if tab is None else tab.clone())
+                res[(mode, flat)] = (y.detach().clone(), xx.grad.clone(), None if tab is None else tab.clone(), ww.grad.clone())
     finally:
         Fn.FLAGS = f0
         L.call('fc_debug_set_h3r', 1)
     ref = res[(0, False)]
     assert torch.isfinite(ref[0]).all() and float(ref[0].abs().max()) > 0
-    for key, (y, gx, tab) in res.items():
+    for key, (y, gx, tab, gw) in res.items():
         assert torch.equal(y, ref[0]), ('forward', key)
         assert torch.equal(gx, ref[1]), ('backward data', key)
+        assert torch.equal(gw, ref[3]), ('backward weights (buffer / flat addressing of k_wgrad_x6t)', key)
         if tab is not None:
             a, b = tab.double().sum(0), ref[2].double().sum(0)
             assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), ('statistics', key)

@@ -53,7 +53,7 @@ for job in "$@"; do
       python tools/lease_summary.py "$O/$kind.json"; head -25 "$O/${kind}_kernel_stats.csv" | cut -c1-160
       find "$O/$kind" -name '*kernel_trace.csv' -size +40M -delete ;;
     pmc)
-      (cd /tmp && timeout 900 rocprofv3 --pmc $arg -d "$O/pmc_${arg// /_}" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline \
+      (cd /tmp && timeout 900 rocprofv3 --pmc $arg --output-format csv -d "$O/pmc_${arg// /_}" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline \
         --infer-steps 0 --no-fp32-route --no-extras --no-force-dp --no-instrument > "$O/pmc$i.json" 2> "$O/pmc$i.err"); rc=$? ;;
     host)
       timeout 600 python tools/hostprof.py --batches ${arg:-8 --lookahead} > "$O/host$i.txt" 2>&1; rc=$?; tail -12 "$O/host$i.txt" ;;

@@ -474,9 +474,9 @@ int main(int argc, char** argv) {
         for (int pairs = (s_sweep && !cs.dense ? 1 : 0); pairs < (cs.dense ? 1 : 2); ++pairs) {
           if (reg == 3 && pairs) continue;
           if (x6_only && (reg == 2 || reg == 3)) continue;
-          for (int smode = 0; smode <= (reg == 4 ? 2 : 0); smode += 2) {
-          FC(fc_set_split_mode(smode));
-          const int fl = ((reg == 2) << 16) | ((reg == 3) << 30) | ((reg == 4) << 24) | (fsw << 8);
+          for (int smode = 0; smode <= (reg == 4 ? 3 : 0); smode += (smode == 2 ? 1 : 2)) {       // 3: mode 2 with flat addresses (flags bit27)
+          FC(fc_set_split_mode(smode == 3 ? 2 : smode));
+          const int fl = ((reg == 2) << 16) | ((reg == 3) << 30) | ((reg == 4) << 24) | (fsw << 8) | ((smode == 3) << 27);
           int64_t wb = ws_for(fc_conv_wgrad_ws_bytes(n_out, K, Cin, Cout, fl));
           std::function<void()> fn;
           if (pairs) fn = [&, wb, fl]() { FC(fc_conv_wgrad_pairs(d_in.p, d_gout.p, d_pi.p, d_po.p, d_cnt.p, d_gw.p, n_in, n_out, K, Cin, Cout, fl, d_ws.p, wb, 0)); };
@@ -486,7 +486,7 @@ int main(int argc, char** argv) {
           double err = -1;
           if (check) err = max_rel_err(d_gw.down(hw.size()), ref);
           double us = time_us(reps, fn);
-          printf("   wgrad %s %s S=%-2d %9.1f us %7.1f TF  err %.2e%s\n", reg == 2 ? "ldsr1" : reg == 3 ? "m-r1 " : reg == 4 ? (smode == 2 ? "h3   " : "x6   ") : "lds ", pairs ? "pairs" : "table", fsw, us, gflop / us * 1e3, err, (check && !(err < 2e-4)) ? "  <-- MISMATCH" : "");
+          printf("   wgrad %s %s S=%-2d %9.1f us %7.1f TF  err %.2e%s\n", reg == 2 ? "ldsr1" : reg == 3 ? "m-r1 " : reg == 4 ? (smode == 3 ? "h3flt" : smode == 2 ? "h3   " : "x6   ") : "lds ", pairs ? "pairs" : "table", fsw, us, gflop / us * 1e3, err, (check && !(err < 2e-4)) ? "  <-- MISMATCH" : "");
           fflush(stdout);
           }
         }
