@@ -1409,7 +1409,8 @@ static int launch_conv_mfma(int pipe, int bm, int bn, dim3 grid, const float* in
   if (epi && (pipe < 3 || bm < 128 || cnt || grid.z != 1)) return FC_EINVAL;      // the statistics epilogue lives in k_conv_x6
   // buffer addressing (k_conv_x6 BUF; gathering launches on a weight image): the gathered operand must end below the 2 GB its
   // descriptor spans; n_in < 0: the caller asks for (flags bit27) or only knows flat addresses
-  const bool bufok = nbr && n_in >= 0 && (uint64_t)n_in * (uint64_t)Cin * 4u < (1ull << 31) - 4096u;
+  const bool bufok = nbr && n_in >= 0 && (uint64_t)n_in * (uint64_t)Cin * 4u < (1ull << 31) - 4096u &&
+                     (uint64_t)K * (uint64_t)n_rows * 4u < (1ull << 31) - 4096u;      // (r6: the neighbour table goes through a descriptor too)
   X6Epi e6 = {};
   if (epi) e6 = *epi;
   const bool h3 = pipe == 4 && bm >= 128 && split_mode() == 2;
@@ -2316,7 +2317,7 @@ static int conv_wgrad_impl(const float* in, const float* gout, const int* nbr, c
   const bool h3 = x6t && split_mode() == 2;
   // buffer addressing of both operands (wgrad_x6.h): below 2 GB each, row indices below 2^24; flags bit27: flat addresses (A/B, tests)
   const int wbuf = (!(flags & (1 << 27)) && (uint64_t)n_in * (uint64_t)Cin * 4u < (1ull << 31) - 4096u && (uint64_t)n_out * (uint64_t)Cout * 4u < (1ull << 31) - 4096u &&
-                    n_in < (1 << 24) && n_out < (1 << 24)) ? 1 : 0;
+                    n_in < (1 << 24) && n_out < (1 << 24) && (uint64_t)K * (uint64_t)n_out * 4u < (1ull << 31) - 4096u) ? 1 : 0;
   const unsigned *am_a = nullptr, *am_g = nullptr;
   if (h3) {
     int rc = operand_amax(in, n_in * (int64_t)Cin, 0, stream, &am_a);

@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 3) void k_conv_h3r(
     int vcur, vnxt;
     const int rows_here = (int)((n_out - m0) < BM ? (n_out - m0) : BM);
     const int lrow = wave * 32 + r;               // this lane's row of the tile
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(nbr), 0, 0x7fffffff, 0x00020000);
+    const unsigned irow = (lrow < rows_here ? (unsigned)(m0 + lrow) : 0u) * 4u;
     auto fetch_idx = [&](int kk) -> int {
+      if (BUF && HAS_NBR) return (int)__builtin_amdgcn_raw_buffer_load_b32(rn, (int)irow, (int)((unsigned)kk * (unsigned)n_out * 4u), 0);
       const int64_t row = lrow < rows_here ? m0 + lrow : 0;
       return HAS_NBR ? nbr[(int64_t)kk * n_out + row] : (int)row;
     };
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 3) void k_conv_h3r(
         unsigned p0[4], p1[4];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          h3_split2(av[2 * b + q][0] * h3_sa, av[2 * b + q][1] * h3_sa, p0[2 * q], p1[2 * q]);
-          h3_split2(av[2 * b + q][2] * h3_sa, av[2 * b + q][3] * h3_sa, p0[2 * q + 1], p1[2 * q + 1]);
+          h3_split2s(av[2 * b + q][0], av[2 * b + q][1], h3_sa, p0[2 * q], p1[2 * q]);
+          h3_split2s(av[2 * b + q][2], av[2 * b + q][3], h3_sa, p0[2 * q + 1], p1[2 * q + 1]);
         }
         fa[b][0] = u32x4{p0[0], p0[1], p0[2], p0[3]};
         fa[b][1] = u32x4{p1[0], p1[1], p1[2], p1[3]};

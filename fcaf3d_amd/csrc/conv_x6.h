@@ -111,6 +111,27 @@ __device__ __forceinline__ void h3_split2(float x0, float x1, unsigned& p0, unsi
   p1 = h3_rn2(r0, r1);
 }
 
+// (-DFC_H3_SPLIT_MIX, not the default — see below.)  The same two pieces from UNSCALED inputs in five instructions per pair instead of eight: v_fma_mixlo / mixhi_f16 round
+// fma(x, s, -0) = s x to fp16 straight into the halves of p0, v_fma_mix_f32 forms the residual fma(x, s, -h) = s x - h exactly in
+// fp32 from the fp16 half (no conversion back), one packed conversion makes p1.  Bit for bit h3_split2(s x0, s x1, ...)
+// (scratch/mix_probe.hip: 4.2 M heavy-tailed values at three scales, signed zeros included).  On this SIMD a wave's VALU time adds
+// to its neighbours' matrix time, and the split is most of the staging's VALU (r6_notes.md section 9).
+__device__ __forceinline__ void h3_split2s(float x0, float x1, float s, unsigned& p0, unsigned& p1) {
+#ifndef FC_H3_SPLIT_MIX                        // default: the conversion-based sequence.  Measured (ABAB, one box): the five-instruction
+  h3_split2(x0 * s, x1 * s, p0, p1);           // mix sequence below runs the step at 476.2 / 476.4 scenes/s against 478.5 / 478.1 — like the
+  return;                                      // packed fp32 instructions, VOP3P mix instructions are no bargain beside MFMAs
+#endif
+  unsigned h = 0u;
+  const float nz = -0.0f;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "+v"(h) : "v"(x0), "v"(s), "s"(nz));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(h) : "v"(x1), "v"(s), "s"(nz));
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(s), "v"(h));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(s), "v"(h));
+  p0 = h;
+  p1 = h3_rn2(r0, r1);
+}
+
 // Weight slab in LDS and in a pre-split weight image: per 64-column group three planes of 64 rows x 64 B.  Column c of the
 // group lives in row (c % 2) * 32 + c / 2: a wave's sub-tile j reads rows j * 32 + r = the INTERLEAVED columns 2 r + j
 // (8-byte output stores).  16-byte unit index of (group-local column c, plane, chunk):
@@ -158,10 +179,10 @@ __device__ __forceinline__ void h3_weight_image_unit(const float* __restrict__ W
   const float* Wk = W + (int64_t)k * R * C;
   float x[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) x[e] = sw * (transposed ? Wk[(int64_t)col * R + r0 + e] : Wk[(int64_t)(r0 + e) * C + col]);
+  for (int e = 0; e < 8; ++e) x[e] = transposed ? Wk[(int64_t)col * R + r0 + e] : Wk[(int64_t)(r0 + e) * C + col];
   unsigned p[2][4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) h3_split2(x[2 * e], x[2 * e + 1], p[0][e], p[1][e]);
+  for (int e = 0; e < 4; ++e) h3_split2s(x[2 * e], x[2 * e + 1], sw, p[0][e], p[1][e]);
 #pragma unroll
   for (int pl = 0; pl < 2; ++pl) {
     u32x4 v = {p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
@@ -423,9 +444,19 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
     int vcur[AR], vnxt[AR];
     // tile rows past the end read the table's first row and are masked at the gather (their index is forced to -1)
     const int rows_here = (int)((n_out - m0) < BM ? (n_out - m0) : BM);
+    // BUF: the neighbour table through a buffer descriptor too — a lane's row is a constant 32-bit byte offset, the kernel offset a
+    // SCALAR one: no 64-bit address per row and offset (hipcc speculated that arithmetic into every stage: ~20 of ~74 VALU)
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(nbr), 0, 0x7fffffff, 0x00020000);
+    unsigned irow[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) irow[i] = (a_r + 32 * i < rows_here ? (unsigned)(m0 + a_r + 32 * i) : 0u) * 4u;
     auto fetch_idx = [&](int kk, int (&v)[AR]) {
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
+        if (BUF && BSRC == 2 && HAS_NBR) {
+          v[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rn, (int)irow[i], (int)((unsigned)kk * (unsigned)n_out * 4u), 0);
+          continue;
+        }
         const int lr = a_r + 32 * i;
         const int64_t row = lr < rows_here ? m0 + lr : 0;
         v[i] = HAS_NBR ? nbr[(int64_t)kk * n_out + row] : (int)row;
@@ -528,8 +559,8 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (BN == 64 ? 4 : 3)) void k_con
         const int row = a_r + 32 * i;
         unsigned p[3][2];
         if (H3) {
-          h3_split2(av[i][0] * h3_sa, av[i][1] * h3_sa, p[0][0], p[1][0]);
-          h3_split2(av[i][2] * h3_sa, av[i][3] * h3_sa, p[0][1], p[1][1]);
+          h3_split2s(av[i][0], av[i][1], h3_sa, p[0][0], p[1][0]);
+          h3_split2s(av[i][2], av[i][3], h3_sa, p[0][1], p[1][1]);
         } else {
           x6_split2(av[i][0], av[i][1], p[0][0], p[1][0], p[2][0]);
           x6_split2(av[i][2], av[i][3], p[0][1], p[1][1], p[2][1]);

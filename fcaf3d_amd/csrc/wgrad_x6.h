@@ -106,16 +106,22 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
     const int s_row = 8 * wave + (lane >> 3), s_c4 = (lane & 7) * 4;
     const int s_unit = s_row * 8 + (lane & 7);
     int ia[KO], ig;
+    // buf: the index tables through buffer descriptors as well (row -> 32-bit byte offset, kernel offset -> scalar offset)
+    const __amdgpu_buffer_rsrc_t rnb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(nbr), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrx = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(row_index), 0, 0x7fffffff, 0x00020000);
     auto fetch_idx = [&](int64_t rb) {
       const int64_t row = rb + s_row;
       const int64_t rc = row < r_end ? row : r_end - 1;
 #pragma unroll
       for (int o = 0; o < KO; ++o) {
         const int kk = k0 + o < K ? k0 + o : K - 1;
-        const int t = nbr ? nbr[(int64_t)kk * n_out + rc] : (int)rc;        // no table: the dense GEMM over the rows themselves
+        int t;
+        if (buf && nbr) t = (int)__builtin_amdgcn_raw_buffer_load_b32(rnb, (int)((unsigned)rc * 4u), (int)((unsigned)kk * (unsigned)n_out * 4u), 0);
+        else t = nbr ? nbr[(int64_t)kk * n_out + rc] : (int)rc;        // no table: the dense GEMM over the rows themselves
         ia[o] = (row < r_end && k0 + o < K) ? t : -1;
       }
-      ig = row < r_end ? (PAIRS ? row_index[(int64_t)k0 * n_out + rc] : (int)rc) : -1;
+      if (PAIRS && buf) ig = row < r_end ? (int)__builtin_amdgcn_raw_buffer_load_b32(rrx, (int)((unsigned)rc * 4u), (int)((unsigned)k0 * (unsigned)n_out * 4u), 0) : -1;
+      else ig = row < r_end ? (PAIRS ? row_index[(int64_t)k0 * n_out + rc] : (int)rc) : -1;
     };
     f32x4 av[KO][SA], gv[SG];
     // buf (r6; both operands below 2 GB, fewer than 2^24 rows): rows through buffer descriptors — a 32-bit byte offset per row (24-bit
@@ -176,8 +182,8 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
       for (int p = 0; p < SG; ++p) {
         unsigned q[3][2];
         if (H3) {
-          h3_split2(gv[p][0] * h3_sg, gv[p][1] * h3_sg, q[0][0], q[1][0]);
-          h3_split2(gv[p][2] * h3_sg, gv[p][3] * h3_sg, q[0][1], q[1][1]);
+          h3_split2s(gv[p][0], gv[p][1], h3_sg, q[0][0], q[1][0]);
+          h3_split2s(gv[p][2], gv[p][3], h3_sg, q[0][1], q[1][1]);
         } else {
           WG_SPLIT2(gv[p][0], gv[p][1], q[0][0], q[1][0], q[2][0]);
           WG_SPLIT2(gv[p][2], gv[p][3], q[0][1], q[1][1], q[2][1]);
@@ -195,8 +201,8 @@ __global__ __launch_bounds__(256, (KO * (BMc / 64) * (BNc / 64) >= 6) ? 2 : 3) v
         for (int p = 0; p < SA; ++p) {
           unsigned q[3][2];
           if (H3) {
-            h3_split2(av[o][p][0] * h3_sa, av[o][p][1] * h3_sa, q[0][0], q[1][0]);
-            h3_split2(av[o][p][2] * h3_sa, av[o][p][3] * h3_sa, q[0][1], q[1][1]);
+            h3_split2s(av[o][p][0], av[o][p][1], h3_sa, q[0][0], q[1][0]);
+            h3_split2s(av[o][p][2], av[o][p][3], h3_sa, q[0][1], q[1][1]);
           } else {
             WG_SPLIT2(av[o][p][0], av[o][p][1], q[0][0], q[1][0], q[2][0]);
             WG_SPLIT2(av[o][p][2], av[o][p][3], q[0][1], q[1][1], q[2][1]);
