@@ -11,6 +11,7 @@
 #   trace            rocprofv3 --kernel-trace --stats over a short bench -> trace/ + kernel_stats
 #   trace1           the same with every kernel on ONE stream (--no-wgrad-overlap, FC_MAP_SYNC=1)
 #   pmc:<counters>   rocprofv3 --pmc <counters> over a short bench (own pass, no tracing)
+#   pmcfold:<tag>    FETCH / WRITE traffic passes + three SQ counter passes, folded -> <tag>_traffic.json, <tag>_conv_pmc.{json,md}
 #   host[:args]      tools/hostprof.py --batches <args>   (default: 8 --lookahead)
 #   py:<script args> python <script args>
 #   sh:<command>     bash -c <command>            -> sh<i>.log (native benches: tools/nbench ...)
@@ -55,6 +56,23 @@ for job in "$@"; do
     pmc)
       (cd /tmp && timeout 900 rocprofv3 --pmc $arg --output-format csv -d "$O/pmc_${arg// /_}" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline \
         --infer-steps 0 --no-fp32-route --no-extras --no-force-dp --no-instrument > "$O/pmc$i.json" 2> "$O/pmc$i.err"); rc=$? ;;
+    pmcfold)         # pmcfold:<tag> — the round's counter passes on ONE build: FETCH_SIZE, WRITE_SIZE (own passes, MI355X_MICROARCH.md) and three
+                     # passes of <= 9 SQ counters, each with --kernel-trace only; folded on the box, the raw collections deleted
+      B="--no-cpu-baseline --infer-steps 0 --no-force-dp --no-fp32-route --no-extras --no-instrument --steps 3 --warmup 1"
+      P1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
+      P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS"
+      P3="SQ_INSTS_VMEM_RD SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_SALU SQ_WAVES SQ_INST_LEVEL_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_VMEM_WR"
+      rc=0; j=0
+      for P in "FETCH_SIZE" "WRITE_SIZE" "$P1" "$P2" "$P3"; do
+        j=$((j + 1))
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$O/pmcpass$j" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" $B > "$O/pmcpass$j.log" 2>&1) || rc=$?
+        echo "   pass $j ($P): rc=$rc"
+      done
+      F=$(find "$O/pmcpass1" -name "*counter_collection.csv" | head -1); W=$(find "$O/pmcpass2" -name "*counter_collection.csv" | head -1)
+      python tools/traffic_from_pmc.py "$F" "$W" "$O/${arg}_traffic.json" > "$O/traffic.log" 2>&1 || rc=$?
+      python tools/sq_from_pmc.py "$O/${arg}_conv_pmc.json" "$O/${arg}_conv_pmc_table.md" $(find "$O/pmcpass3" "$O/pmcpass4" "$O/pmcpass5" -name "*counter_collection.csv" | sort) > "$O/sq.log" 2>&1 || rc=$?
+      rm -rf "$O"/pmcpass[1-5]
+      tail -4 "$O/traffic.log" | cut -c1-200 ;;
     host)
       timeout 600 python tools/hostprof.py --batches ${arg:-8 --lookahead} > "$O/host$i.txt" 2>&1; rc=$?; tail -12 "$O/host$i.txt" ;;
     sh)
