@@ -278,7 +278,7 @@ def _check_profile_take(tag, must_match_source):
     spec.loader.exec_module(ks)
     md = open(os.path.join(root, 'profiles', f'{tag}_kernel_stats.md')).read()
     for name in (f'{tag}_kernel_stats.csv', f'{tag}_kernel_stats_no_overlap.csv'):
-        assert ks.table(os.path.join(root, 'profiles', name), float(meta['steps_profiled'])) in md, name
+        assert ks.table(os.path.join(root, 'profiles', name), float(meta['steps_profiled']), anon=bool(meta.get('anon_names'))) in md, name
     bench_line = json.load(open(os.path.join(root, 'profiles', f'{tag}_bench_n1.json')))
     assert bench_line['config']['kernel_source_sha16'] == meta['kernel_source_sha16']
     return meta, bench_line
