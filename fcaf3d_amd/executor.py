@@ -1000,9 +1000,15 @@ def program_for(det, training, tail0=False):
         return None
     key = (bool(training), bool(Fn.WGRAD_ASYNC), bool(nh.head_overlap), bool(tail0))
     fuse = bool(Fn.BN_FUSE)                    # changes the emitted program (statistics tables, producer words): part of the cache key
+    # ... and so does the operand split (r6): the three-product route's program carries amax slots, hint words and clear operators,
+    # and the weight images are mode-dependent
+    mode = Fn.split_mode() if Fn.X6 else -1
     cache = det.__dict__.setdefault('_programs', {})
     sig = NetProgram.signature(det)
-    prog = cache.get(key + (fuse,))
+    prog = cache.get(key + (fuse, mode))
     if prog is None or prog._sig != sig:
-        prog = cache[key + (fuse,)] = NetProgram(det, *key)
+        prog = cache[key + (fuse, mode)] = NetProgram(det, *key)
+    if getattr(prog.w, 'split_mode', mode) != mode:      # the shared images were built in the other mode
+        prog.w.fresh = False
+    prog.w.split_mode = mode
     return prog
