@@ -505,6 +505,7 @@ def hbm_steps(args, exec_on):
 
 LAST_HOST_S = 0.0
 LAST_WAIT_S = 0.0
+LAST_CPU_S = 0.0
 
 
 def gpu_local_cpus(dev_index):
@@ -558,6 +559,27 @@ def host_state():
     return dict(loadavg=la, cpus=len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count())
 
 
+def thread_cpu_snapshot():
+    """{tid: (comm, cpu seconds)} of every thread of this process (/proc/self/task): who burns the CPU time `process_cpu_ms_per_step` reports"""
+    out = {}
+    try:
+        tck = os.sysconf('SC_CLK_TCK')
+        for tid in os.listdir('/proc/self/task'):
+            try:
+                st = open(f'/proc/self/task/{tid}/stat').read()
+                comm = st[st.index('(') + 1:st.rindex(')')]
+                f = st[st.rindex(')') + 2:].split()
+                out[tid] = (comm, (int(f[11]) + int(f[12])) / tck)
+            except (OSError, ValueError, IndexError):
+                pass
+    except (OSError, ValueError):
+        pass
+    return out
+
+
+LAST_THREADS = None
+
+
 def timed_region(fn, n, world, dev):
     """barrier + synchronize | n calls | synchronize + barrier; returns the MAX over ranks of the elapsed seconds"""
     if world > 1:
@@ -565,6 +587,8 @@ def timed_region(fn, n, world, dev):
     torch.cuda.synchronize()
     import fcaf3d_amd._lib as L
     w0 = L.HOST_WAIT[0]
+    th0 = thread_cpu_snapshot()
+    c0 = time.process_time()
     t0 = time.perf_counter()
     last = None
     for i in range(n):
@@ -573,6 +597,18 @@ def timed_region(fn, n, world, dev):
     LAST_HOST_S = time.perf_counter() - t0       # the host has ENQUEUED all n calls (diagnostic: close to the region's time = host-bound)
     LAST_WAIT_S = L.HOST_WAIT[0] - w0            # ... of which it was blocked on the device by design (run-ahead bound, staging ring, lookahead plan)
     torch.cuda.synchronize()
+    global LAST_CPU_S
+    LAST_CPU_S = time.process_time() - c0        # CPU time of ALL threads of the process over the region (spinning waits show here)
+    global LAST_THREADS
+    th1 = thread_cpu_snapshot()
+    agg = {}
+    plan_tids = {str(t.native_id) for t in __import__('threading').enumerate() if t.name.startswith('fc-plan')}
+    for tid, (comm, c1) in th1.items():
+        d = c1 - th0.get(tid, (comm, 0.0))[1]
+        if d > 0:
+            name = 'main' if tid == str(os.getpid()) else ('fc-plan' if tid in plan_tids else comm + ' (other)')
+            agg[name] = agg.get(name, 0.0) + d
+    LAST_THREADS = {k: round(v / n * 1e3, 2) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:6]}
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
@@ -707,6 +743,7 @@ def main():
     host_main = dict(host_enqueue_ms_per_step=round(LAST_HOST_S / args.steps * 1e3, 3),
                      host_blocked_ms_per_step=round(LAST_WAIT_S / args.steps * 1e3, 3),
                      host_busy_ms_per_step=round((LAST_HOST_S - LAST_WAIT_S) / args.steps * 1e3, 3),
+                     process_cpu_ms_per_step=round(LAST_CPU_S / args.steps * 1e3, 3), thread_cpu_ms_per_step=LAST_THREADS,
                      phases_ms_per_step=[round((b - a) / args.steps * 1e3, 3) for a, b in zip(ph0, trainer.phase_s)],
                      micro=host_micro(dev), pinned_to_gpu_numa_node=pinned, after=host_state())
     final_loss = float(loss.item())
