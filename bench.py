@@ -35,6 +35,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--settle-seconds', type=float, default=45.0,
+                    help='after the warm-up steps: further UNTIMED steps (windows of 4) for at most this long while the host, not the GPU, '
+                         'sets the step time — the first minute of a fresh box (profiles/r6_notes.md section 13); 0 = off.  Reported in config.host.settle')
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step (reference samples_per_gpu=8)')
     ap.add_argument('--workload', default='scannet-100k', choices=['plumbing-20k', 'scannet-100k', 'sunrgbd-100k', 's3dis-500k'])
     ap.add_argument('--voxel-size', type=float, default=0.02)
@@ -720,6 +723,37 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    # r6: settling.  The FIRST process on a fresh box can spend its first ~minute with the host's launch path 4-5x slower than ever after
+    # (20-23 ms of host work per step instead of 4-5, kernels at their usual speed: r6_notes.md section 13 — 3 of ~40 leases this round;
+    # every later process on the box is normal, and so is this one after that minute).  That is the box waking up, not the step:
+    # while the host's enqueue time of forward + backward exceeds half of the step's wall time, keep stepping UNTIMED (windows of 4
+    # steps, at most --settle-seconds), every rank in lockstep; what was done is reported in config.host.settle.
+    settle = dict(windows=0, extra_untimed_steps=0, seconds=0.0, host_share_first=None, host_share_last=None)
+    if args.settle_seconds > 0 and not args.breakdown:
+        t_settle = time.perf_counter()
+        k = args.warmup
+        while True:
+            torch.cuda.synchronize()
+            p0, w0 = list(trainer.phase_s), time.perf_counter()
+            for j in range(4):
+                step(k + j, prefetch=j < 3)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - w0
+            share = ((trainer.phase_s[1] - p0[1]) + (trainer.phase_s[2] - p0[2])) / max(wall, 1e-9)
+            k += 4
+            settle['windows'] += 1
+            settle['extra_untimed_steps'] += 4
+            if settle['host_share_first'] is None:
+                settle['host_share_first'] = round(share, 3)
+            settle['host_share_last'] = round(share, 3)
+            slow = 1.0 if share > 0.5 else 0.0
+            if world > 1:
+                t = torch.tensor([slow], device=dev)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                slow = float(t.item())
+            if slow == 0.0 or time.perf_counter() - t_settle > args.settle_seconds:
+                break
+        settle['seconds'] = round(time.perf_counter() - t_settle, 2)
     if exec_on and probe:
         # the probed step of the timed region runs the executor's ONE-STREAM program: build its operator list now, not inside
         # the timed region (r4: ~20 ms of host work that the first 20-step line carried as +1 ms per step)
@@ -743,7 +777,7 @@ def main():
     host_main = dict(host_enqueue_ms_per_step=round(LAST_HOST_S / args.steps * 1e3, 3),
                      host_blocked_ms_per_step=round(LAST_WAIT_S / args.steps * 1e3, 3),
                      host_busy_ms_per_step=round((LAST_HOST_S - LAST_WAIT_S) / args.steps * 1e3, 3),
-                     process_cpu_ms_per_step=round(LAST_CPU_S / args.steps * 1e3, 3), thread_cpu_ms_per_step=LAST_THREADS,
+                     process_cpu_ms_per_step=round(LAST_CPU_S / args.steps * 1e3, 3), thread_cpu_ms_per_step=LAST_THREADS, settle=settle,
                      phases_ms_per_step=[round((b - a) / args.steps * 1e3, 3) for a, b in zip(ph0, trainer.phase_s)],
                      micro=host_micro(dev), pinned_to_gpu_numa_node=pinned, after=host_state())
     final_loss = float(loss.item())
@@ -982,7 +1016,11 @@ def main():
                                          'host_busy = the difference = the host\'s own work per step (r5: 17.5 of 20.5 ms, the step was host-bound '
                                          'whenever that grew); phases_ms_per_step: [run-ahead bound + prefetch, forward_train enqueue, backward enqueue, '
                                          'all-reduce finish + clip + AdamW + weight images]; micro: a pure-Python loop, a torch launch, a launch + event '
-                                         'round trip, taken right after the region; loadavg / usable CPUs when the process started and after the timed region'),
+                                         'round trip, taken right after the region; loadavg / usable CPUs when the process started and after the timed region; '
+                                         'process_cpu / thread_cpu_ms_per_step: CPU time of the process and of its busiest threads over the region (spinning '
+                                         'waits included); settle: UNTIMED steps run after the --warmup steps, in windows of 4, while the host\'s forward + '
+                                         'backward enqueue time exceeded half of the step\'s wall time (host_share; a fresh box\'s first minute) — at most '
+                                         '--settle-seconds; one window is always run'),
                        'coordinate_phase': ('native plan (csrc/plan.hip: fc_plan_levels + fc_plan_maps, 2 read-backs per step)' +
                                             (', the NEXT batch planned on a worker thread beside the current step (plan.Lookahead); exactly '
                                              f'{args.steps} plans inside the timed region' if lookahead else ', in line')),

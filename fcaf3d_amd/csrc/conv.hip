@@ -80,6 +80,7 @@ extern "C" int fc_debug_set_h3r(int mode) {
   return FC_OK;
 }
 
+#include <mutex>
 #include "conv_x6.h"
 #include "wgrad_x6.h"
 #include "conv_h3r.h"
@@ -129,10 +130,12 @@ __global__ __launch_bounds__(256) void k_amax(const f32x4* __restrict__ x, int64
 constexpr int AMAX_RING = 2048;
 static unsigned* g_amax_ring[16] = {};
 static unsigned g_amax_next[16] = {};
+static std::mutex g_amax_ring_mu;
 static int amax_ring_slot(unsigned** slot) {
   int dev = 0;
   FC_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return FC_EINVAL;
+  std::lock_guard<std::mutex> lock(g_amax_ring_mu);          // (two threads' first calls must not both create the ring)
   if (!g_amax_ring[dev]) {
     FC_HIP(hipMalloc((void**)&g_amax_ring[dev], (size_t)AMAX_RING * FC_AMAX_SLOT_BYTES));
     FC_HIP(hipMemset(g_amax_ring[dev], 0, (size_t)AMAX_RING * FC_AMAX_SLOT_BYTES));

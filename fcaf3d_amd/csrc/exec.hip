@@ -346,6 +346,7 @@ int run_op_impl(Ctx& c, const int64_t* op) {
       if (op[13] < 0) {    // with the scale / class-bias reductions of this level (fc_head_split_bwd_sums)
         const int64_t n = c.dims[op[9]];
         if (!want_ws(c, s, fc_head_split_bwd_sums_ws_bytes(n))) return 0;
+        if (op[16] > 0) fc_amax_out_hint(P<unsigned>(c, op[16] - 1));         // word 16: amax slot of gy + 1 | 0
         return fc_head_split_bwd_sums(P<const float>(c, op[2]), (int)op[3], P<const float>(c, op[4]), P<const float>(c, op[5]),
                                       P<const float>(c, op[6]), P<const float>(c, op[7]), P<const float>(c, op[8]), n, (int)op[10],
                                       (int)op[11], P<float>(c, op[12]), P<float>(c, op[15]), P<float>(c, op[14]), c.ws[s],

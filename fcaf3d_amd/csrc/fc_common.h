@@ -108,3 +108,27 @@ __device__ static inline unsigned fc_amax_read(const unsigned* __restrict__ slot
   for (int off = 16; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
   return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
 }
+
+// producers' side of a slot (norm.hip, head.hip): fold what a thread stores, then ONE atomicMax per block on the block's sub-word.
+// EVERY thread of the block must reach amax_commit (it holds a __syncthreads).
+__device__ __forceinline__ void amax_fold(unsigned& m, float v) {
+  const unsigned u = __float_as_uint(v) & 0x7fffffffu;
+  m = (u > m && u < 0x7f800000u) ? u : m;
+}
+// (one atomic per BLOCK: same-line atomics serialise at ~35 ns each in the L2 — with one per wave a 7 us launch of 1 840 blocks carried
+// 230 of them per sub-word = +8 us)
+__device__ __forceinline__ void amax_commit(unsigned m, unsigned* __restrict__ dst) {
+  __shared__ unsigned s_am[16];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
+  if ((threadIdx.x & 63) == 0) s_am[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (int)((blockDim.x + 63) >> 6);
+    for (int w = 1; w < nw; ++w) m = s_am[w] > m ? s_am[w] : m;
+    unsigned* wd = dst + ((blockIdx.x + blockIdx.y) & (FC_AMAX_SUB - 1)) * FC_AMAX_STRIDE;        // this block's sub-word (fc_common.h)
+    if (m > __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(wd, m);
+  }
+}
+extern thread_local unsigned* t_fc_amax_out;           // set by fc_amax_out_hint (norm.hip), consumed by the next producer entry point of the thread
+static inline unsigned* take_amax_out() { unsigned* p = t_fc_amax_out; t_fc_amax_out = nullptr; return p; }

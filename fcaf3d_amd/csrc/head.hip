@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256) void k_head_split_bwd_sums(const float* __rest
                                                              const float* __restrict__ bbox, const float* __restrict__ g_cent,
                                                              const float* __restrict__ g_bbox, const float* __restrict__ g_cls,
                                                              int64_t n, int n_reg, int n_cls, float* __restrict__ gy,
-                                                             float* __restrict__ part) {
+                                                             float* __restrict__ part, unsigned* __restrict__ amax_out) {
   __shared__ float red[4][65];
+  unsigned am = 0u;                              // r6: max |gy| for the backward-data GEMM that gathers it (fc_amax_out_hint)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t base = (int64_t)blockIdx.x * HEAD_RPB;
   const float sc = scale[0];
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void k_head_split_bwd_sums(const float* __rest
         g = e * sc;
         s = e * yy[u];
       }
-      if (lane < ld) gy[row * ld + lane] = g;
+      if (lane < ld) { gy[row * ld + lane] = g; amax_fold(am, g); }
       ag += g;
       as += s;
     }
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256) void k_head_split_bwd_sums(const float* __rest
   __syncthreads();
   if (threadIdx.x < 65)
     part[(int64_t)blockIdx.x * 65 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (amax_out) amax_commit(am, amax_out);
 }
 
 // block b < n_cls: gbias[b] = sum over the partial blocks of column 1 + n_reg + b; block n_cls: gscale[0] = sum of entry 64
@@ -153,6 +155,7 @@ int64_t fc_head_split_bwd_sums_ws_bytes(int64_t n) { return fc_cdiv(n > 0 ? n : 
 int fc_head_split_bwd_sums(const float* y, int ld, const float* scale_dev, const float* bbox_pred, const float* g_centerness,
                            const float* g_bbox, const float* g_cls, int64_t n, int n_reg, int n_cls, float* gy, float* gbias,
                            float* gscale, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  unsigned* ao = take_amax_out();                // fc_amax_out_hint: max |gy| into the caller's (zeroed) slot
   if (n < 0 || ld < 1 || ld > 64 || n_reg < 6 || n_cls < 1 || 1 + n_reg + n_cls > ld) return FC_EINVAL;
   if (ws_bytes < fc_head_split_bwd_sums_ws_bytes(n)) return FC_EWS;
   if (n == 0) {
@@ -163,7 +166,7 @@ int fc_head_split_bwd_sums(const float* y, int ld, const float* scale_dev, const
   const int64_t nb = fc_cdiv(n, HEAD_RPB);
   float* part = (float*)ws;
   k_head_split_bwd_sums<<<(unsigned)nb, 256, 0, stream>>>(y, ld, scale_dev, bbox_pred, g_centerness, g_bbox, g_cls, n, n_reg, n_cls,
-                                                         gy, part);
+                                                         gy, part, ao);
   FC_CHECK_LAUNCH();
   k_head_sums_final<<<(unsigned)(n_cls + 1), 256, 0, stream>>>(part, nb, n_reg, n_cls, gbias, gscale);
   FC_CHECK_LAUNCH();

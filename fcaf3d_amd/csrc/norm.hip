@@ -244,22 +244,9 @@ __device__ static inline float act_bwd_from_pre(float p, int act) {
 
 // ---- r6: max |.| of what a kernel writes, for the convolution that will gather it (csrc/conv_x6.h h3: the operand's scale) ----------
 // A producer that is told where (fc_amax_out_hint -> amax_out, a ZEROED slot of FC_AMAX_SUB sub-words) folds the finite elements it
-// stores into one integer atomicMax per wave on its block's sub-word — skipped when that already holds a larger value — instead of
+// stores into one integer atomicMax per block on its block's sub-word — skipped when that already holds a larger value — instead of
 // the consumer reading the tensor once more (fc_amax).  Integer max: order-independent, bit-reproducible.  EVERY lane of the wave must reach amax_commit.
-__device__ __forceinline__ void amax_fold(unsigned& m, float v) {
-  const unsigned u = __float_as_uint(v) & 0x7fffffffu;
-  m = (u > m && u < 0x7f800000u) ? u : m;
-}
-__device__ __forceinline__ void amax_commit(unsigned m, unsigned* __restrict__ dst) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
-  if ((threadIdx.x & 63) == 0) {
-    unsigned* w = dst + ((blockIdx.x + blockIdx.y) & (FC_AMAX_SUB - 1)) * FC_AMAX_STRIDE;        // this block's sub-word (fc_common.h)
-    if (m > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, m);
-  }
-}
-thread_local unsigned* t_fc_amax_out = nullptr;          // fc_amax_out_hint: consumed by the next producer entry point of this thread
-static inline unsigned* take_amax_out() { unsigned* p = t_fc_amax_out; t_fc_amax_out = nullptr; return p; }
+thread_local unsigned* t_fc_amax_out = nullptr;          // fc_amax_out_hint: consumed by the next producer entry point of this thread (fc_common.h)
 
 // y = act( (x-mean[seg])*invstd[seg]*gamma + beta (+ residual) ) ; invstd = 1/sqrt(var+eps)
 __global__ void k_norm_act_fwd(const float* __restrict__ x, const int* __restrict__ seg, int seg_stride, int64_t n, int C,

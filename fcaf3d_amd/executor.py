@@ -582,8 +582,11 @@ class NetProgram:
                     # ... with d loss / d scale of this level and this level's share of the class-bias gradient (column sums of
                     # d loss / d cls_score; summed over the levels by OP_HEAD_WFIN) out of the same pass (r5: they were single-block
                     # reductions over every location, k_col_sum: 0.35 ms per step on the dependent chain)
+                    agy = -1
+                    if AMAX:                 # the kernel folds max |gy| for the backward-data GEMM behind it
+                        agy = amax_of[gy] = self.amax_slot()
                     self.emit(Bk, OP_HEAD_BWD, hs, y, 64, self.S(nh.scales[lvl].scale), outs[1], gin[0], gin[1], gin[2], self.D(rows), n_reg,
-                              n_cls, gy, -1, self.G(nh.scales[lvl].scale), self.SA(bias_part[lvl].data_ptr()))
+                              n_cls, gy, -1, self.G(nh.scales[lvl].scale), self.SA(bias_part[lvl].data_ptr()), agy + 1)
                     wrote(nh.scales[lvl].scale)
                     grad[y] = gy
                 tape.append((hs, bwd_head))

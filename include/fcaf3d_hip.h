@@ -494,8 +494,8 @@ int fc_amax(const float* x, int64_t n, unsigned* slot, hipStream_t stream);
  * No reference counterpart (see fc_set_split_mode; me_resnet.py:56-62). */
 int fc_conv_amax_hint(const unsigned* amax_in, const unsigned* amax_gout);
 /* The other end of the same word: the NEXT fc_bn_train_fwd / fc_bn_train_bwd / fc_norm_act_fwd / fc_norm_act_bwd / fc_bn_act_train_bwd /
- * fc_maxpool_fwd call of the calling thread also folds max |.| of what it writes (y, gx, out) into the slot at amax_word — one the
- * caller has ZEROED — from inside its apply kernel (one integer atomicMax per wave), so that the convolution gathering that tensor
+ * fc_maxpool_fwd / fc_head_split_bwd_sums call of the calling thread also folds max |.| of what it writes (y, gx, out) into the slot at amax_word — one the
+ * caller has ZEROED — from inside its apply kernel (one integer atomicMax per block), so that the convolution gathering that tensor
  * needs no fc_amax pass.  Cleared by that call.  No reference counterpart (see fc_set_split_mode; the producers are
  * ME.MinkowskiBatchNorm / MinkowskiReLU / MinkowskiELU / MinkowskiMaxPooling of me_resnet.py:19-24, fcaf3d_neck_with_head.py:49-71). */
 int fc_amax_out_hint(unsigned* amax_word);

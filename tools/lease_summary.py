@@ -9,10 +9,10 @@ except Exception as e:                     # noqa
     sys.exit(0)
 c, r = d['config'], d.get('roofline') or {}
 h = c.get('host') or {}
-print('   phases', h.get('phases_ms_per_step'), 'micro', h.get('micro'), 'pinned', h.get('pinned_to_gpu_numa_node'))
+print('   phases', h.get('phases_ms_per_step'), 'micro', h.get('micro'), 'pinned', h.get('pinned_to_gpu_numa_node'), 'settle', h.get('settle'))
 print(f"value {d['value']} scenes/s  {d['ms_per_step']} ms/step  host_enqueue {h.get('host_enqueue_ms_per_step')} (busy {h.get('host_busy_ms_per_step')}, cpu {h.get('process_cpu_ms_per_step')} {h.get('thread_cpu_ms_per_step')})  load {((h.get('at_start') or {}).get('loadavg'))}"
       f"  roofline {r.get('achieved')} {r.get('frac')} {r.get('avg_launch_us')} us  sha {c.get('kernel_source_sha16')}")
-for k in ('fwd_bwd_only', 'forced_dp_n1', 'config4_per_gpu', 'bf16_fast_mode', 'split3_mode', 'literal_1cm', 'two_scales', 'sunrgbd', 's3dis', 'fp32_mfma_route',
+for k in ('fwd_bwd_only', 'forced_dp_n1', 'config4_per_gpu', 'bf16_fast_mode', 'literal_1cm', 'two_scales', 'sunrgbd', 's3dis', 'fp32_mfma_route',
           'inference', 'inference_pipelined'):
     v = c.get(k)
     if isinstance(v, dict):
