@@ -49,16 +49,16 @@ for job in "$@"; do
     trace|trace1)
       extra=""; [ "$kind" = trace1 ] && extra="--no-wgrad-overlap"
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$kind" -o k -- python "$GRAFT_REPO_ROOT/bench.py" --steps 6 --warmup 3 --no-cpu-baseline \
-        --infer-steps 0 --no-fp32-route --no-extras --no-force-dp --no-instrument $extra $arg > "$O/$kind.json" 2> "$O/$kind.err"); rc=$?
+        --infer-steps 0 --no-fp32-route --no-extras --no-force-dp --no-instrument --settle-seconds 0 $extra $arg > "$O/$kind.json" 2> "$O/$kind.err"); rc=$?
       cp "$(find "$O/$kind" -name '*kernel_stats.csv' | head -1)" "$O/${kind}_kernel_stats.csv" 2>> "$O/$kind.err"
       python tools/lease_summary.py "$O/$kind.json"; head -25 "$O/${kind}_kernel_stats.csv" | cut -c1-160
       find "$O/$kind" -name '*kernel_trace.csv' -size +40M -delete ;;
     pmc)
       (cd /tmp && timeout 900 rocprofv3 --pmc $arg --output-format csv -d "$O/pmc_${arg// /_}" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline \
-        --infer-steps 0 --no-fp32-route --no-extras --no-force-dp --no-instrument > "$O/pmc$i.json" 2> "$O/pmc$i.err"); rc=$? ;;
+        --infer-steps 0 --no-fp32-route --no-extras --no-force-dp --no-instrument --settle-seconds 0 > "$O/pmc$i.json" 2> "$O/pmc$i.err"); rc=$? ;;
     pmcfold)         # pmcfold:<tag> — the round's counter passes on ONE build: FETCH_SIZE, WRITE_SIZE (own passes, MI355X_MICROARCH.md) and three
                      # passes of <= 9 SQ counters, each with --kernel-trace only; folded on the box, the raw collections deleted
-      B="--no-cpu-baseline --infer-steps 0 --no-force-dp --no-fp32-route --no-extras --no-instrument --steps 3 --warmup 1"
+      B="--no-cpu-baseline --infer-steps 0 --no-force-dp --no-fp32-route --no-extras --no-instrument --settle-seconds 0 --steps 3 --warmup 1"
       P1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
       P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS"
       P3="SQ_INSTS_VMEM_RD SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_SALU SQ_WAVES SQ_INST_LEVEL_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_VMEM_WR"
