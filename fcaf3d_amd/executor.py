@@ -545,6 +545,8 @@ class NetProgram:
                 u = self.T(g_rows, Ci)
                 rows_i = self.DY(f'rows{i}')
                 self.emit(F, OP_UNION_FWD, S_MAIN, t, fb, rows_i, self.D(g_rows), self.D(fb_rows), self.D(g_rows), Ci, u)
+                if AMAX:                 # no producer folds a union: ONE pass here, before the head branch forks, serves both streams' consumers
+                    amax_of[u] = self.amax_op(F, S_MAIN, u, g_rows, Ci)
                 if tr:
                     def bwd_union(u=u, t=t, fb=fb, fb_rows=fb_rows, rows_i=rows_i, g_rows=g_rows, Ci=Ci):
                         gu = take(u, g_rows, Ci)
