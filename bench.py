@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--levels', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-points', type=int, default=0, help='points of the cpu_baseline sample scene (0 = same as workload)')
+    ap.add_argument('--reserve-gb', type=float, default=64.0, help='device memory taken into the caching allocator before the first step (runner.reserve_device_memory); 0: none')
+    ap.add_argument('--sample-main-thread', action='store_true', help='tools/wchan.py over the timed region: what the main thread did when it was not running (config.host.steps.main_thread)')
     ap.add_argument('--no-instrument', action='store_true', help='skip per-kernel HIP events (roofline = null)')
     ap.add_argument('--probe-every', type=int, default=20, help='HIP events bracket the conv launches of every n-th timed step '
                     '(each event pair is a pipeline bubble: sampling keeps the probe from slowing the thing it measures)')
@@ -95,9 +97,9 @@ def run_extra(args, key, dev, steps):
     dt, loss = timed_region(lambda i: tr(batches[i % 2], batches[(i + 1) % 2] if (i < steps - 1 and not args.no_lookahead) else None)[0], steps, 1, dev)
     out = dict(workload=f'{wl}, voxel {vs} m, {lv} levels', scenes_per_step=bs, steps=steps, ms_per_step=round(dt / steps * 1e3, 3),
                value=round(bs * steps / dt, 3), unit='scenes/s', final_loss=round(float(loss), 4),
-               host_enqueue_ms_per_step=round(LAST_HOST_S / steps * 1e3, 3))
-    del tr, model, batches
-    torch.cuda.empty_cache()
+               host_enqueue_ms_per_step=round(LAST_HOST_S / steps * 1e3, 3), host_busy_ms_per_step=round((LAST_HOST_S - LAST_WAIT_S) / steps * 1e3, 3),
+               calls=LAST_STEPS)
+    del tr, model, batches             # (no empty_cache(): the allocator keeps what it holds — see --reserve-gb)
     return out
 
 
@@ -581,6 +583,54 @@ def thread_cpu_snapshot():
 
 
 LAST_THREADS = None
+SAMPLE_MAIN_THREAD = False
+LAST_STEPS = None           # per-call enqueue times of the last timed region and what the kernel did to the process meanwhile
+
+
+GC_LOG = []                 # (generation, seconds) of every garbage collection of the interpreter since install_gc_log()
+
+
+def install_gc_log():
+    """time every collection of CPython's cyclic collector (gc.callbacks): a FULL collection walks every tracked object of the
+    process — tens of milliseconds with torch imported — on whichever thread allocated last, holding the GIL"""
+    import gc
+    t = [0.0]
+
+    def cb(phase, info):
+        if phase == 'start':
+            t[0] = time.perf_counter()
+        else:
+            GC_LOG.append((info['generation'], time.perf_counter() - t[0]))
+    gc.callbacks.append(cb)
+
+
+def sched_snapshot():
+    """what the kernel did to this process: context switches and page faults (getrusage) and, where the files are readable, the CPU
+    quota of the box's cgroup (cpu.stat: periods in which the group was THROTTLED) and the CPU pressure of the host (PSI)"""
+    import resource
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    out = dict(nvcsw=ru.ru_nvcsw, nivcsw=ru.ru_nivcsw, majflt=ru.ru_majflt, minflt=ru.ru_minflt)
+    try:
+        for ln in open('/sys/fs/cgroup/cpu.stat'):
+            k, v = ln.split()
+            if k in ('nr_periods', 'nr_throttled', 'throttled_usec'):
+                out[k] = int(v)
+    except (OSError, ValueError):
+        pass
+    try:                                           # the caching allocator: device allocations (hipMalloc) and frees, bytes it holds
+        ms = torch.cuda.memory_stats()
+        out['device_mallocs'] = int(ms.get('num_device_alloc', ms.get('segment.all.allocated', 0)))
+        out['device_frees'] = int(ms.get('num_device_free', ms.get('segment.all.freed', 0)))
+        out['reserved_MB'] = int(ms.get('reserved_bytes.all.current', 0)) >> 20
+        out['alloc_retries'] = int(ms.get('num_alloc_retries', 0))
+    except Exception:                              # noqa: no device
+        pass
+    try:
+        some = open('/proc/pressure/cpu').readline().split()
+        out['psi_cpu_some_total_us'] = int(some[-1].split('=')[1])
+    except (OSError, ValueError, IndexError):
+        pass
+    return out
 
 
 def timed_region(fn, n, world, dev):
@@ -591,17 +641,44 @@ def timed_region(fn, n, world, dev):
     import fcaf3d_amd._lib as L
     w0 = L.HOST_WAIT[0]
     th0 = thread_cpu_snapshot()
+    sampler = None
+    if SAMPLE_MAIN_THREAD:
+        import subprocess
+        import tempfile
+        sfile = os.path.join(tempfile.gettempdir(), f'fc_wchan_{os.getpid()}.json')
+        sampler = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'wchan.py'),
+                                    str(os.getpid()), str(os.getpid()), sfile])
+        time.sleep(0.3)
+        sampler.send_signal(__import__('signal').SIGUSR1)
+    s0 = sched_snapshot()
+    g0 = len(GC_LOG)
     c0 = time.process_time()
     t0 = time.perf_counter()
     last = None
+    marks = [t0]
     for i in range(n):
         last = fn(i)
-    global LAST_HOST_S, LAST_WAIT_S
+        marks.append(time.perf_counter())
+    global LAST_HOST_S, LAST_WAIT_S, LAST_STEPS
     LAST_HOST_S = time.perf_counter() - t0       # the host has ENQUEUED all n calls (diagnostic: close to the region's time = host-bound)
     LAST_WAIT_S = L.HOST_WAIT[0] - w0            # ... of which it was blocked on the device by design (run-ahead bound, staging ring, lookahead plan)
     torch.cuda.synchronize()
     global LAST_CPU_S
     LAST_CPU_S = time.process_time() - c0        # CPU time of ALL threads of the process over the region (spinning waits show here)
+    s1 = sched_snapshot()
+    per = sorted((b - a) * 1e3 for a, b in zip(marks, marks[1:]))
+    LAST_STEPS = dict(call_ms_min=round(per[0], 2), call_ms_median=round(per[len(per) // 2], 2), call_ms_max=round(per[-1], 2),
+                      calls_over_twice_the_median=sum(1 for x in per if x > 2 * per[len(per) // 2]),
+                      kernel={k: s1[k] - s0[k] for k in s1 if k in s0},
+                      gc={f'gen{g}': [sum(1 for x in GC_LOG[g0:] if x[0] == g), round(sum(x[1] for x in GC_LOG[g0:] if x[0] == g) * 1e3, 2)]
+                          for g in (0, 1, 2)})
+    if sampler is not None:
+        sampler.terminate()
+        try:
+            sampler.wait(timeout=5)
+            LAST_STEPS['main_thread'] = json.load(open(sfile))
+        except Exception as e:                   # noqa: a diagnostic
+            LAST_STEPS['main_thread'] = dict(error=str(e))
     global LAST_THREADS
     th1 = thread_cpu_snapshot()
     agg = {}
@@ -624,6 +701,7 @@ def timed_region(fn, n, world, dev):
 
 def main():
     args = parse()
+    install_gc_log()
     host0 = host_state()
     # stdout carries ONE line, the JSON result: everything else that writes to file descriptor 1 during the run (RCCL's
     # version banner, library warnings) goes to stderr
@@ -678,6 +756,14 @@ def main():
     # the reference's recipe (configs/fcaf3d/fcaf3d.py:30-33): AdamW 1e-3 / 1e-4, grad-clip 10, step LR — fcaf3d_amd/runner.py
     trainer = TrainStep.from_config(model, cfg)
     batches = make_batches(args, rank, dev)
+    # r6: the caching allocator's pools (one per stream) are filled before the first step — no device allocation inside a timed step
+    reserved = 0
+    if args.reserve_gb > 0:
+        import fcaf3d_amd.sparse as SPm
+        from fcaf3d_amd.runner import reserve_device_memory
+        reserved = reserve_device_memory(args.reserve_gb, dev, streams=[
+            (torch.cuda.current_stream(dev), 0.5), (SPm.map_stream(dev), 0.25), (Fn.wgrad_stream(dev), 0.125),
+            (model.neck_with_head._head_stream(dev), 0.125)], chunk_gb=8)
 
     probe = None
     bd = None
@@ -761,6 +847,12 @@ def main():
         Fn.WGRAD_ASYNC, model.neck_with_head.head_overlap = False, False
         EX.program_for(model, True)
         Fn.WGRAD_ASYNC, model.neck_with_head.head_overlap = wa0, ho0
+    if exec_on and probe and args.warmup > 0:
+        # ... and run it once, untimed, brackets and all (r6: the first probed step of a process creates a few hundred HIP events and
+        # whatever pools the runtime keeps behind them — 36 MB of fresh host memory, 20-120 ms — and it was step 8 of the timed region)
+        step(args.warmup, 'time')
+        probe.exec_records()
+        probe.timed, probe.exec_steps = {}, []
     if bd:
         torch.cuda.synchronize()
         bd.rec.clear()
@@ -772,14 +864,17 @@ def main():
     # synchronise, so its brackets are the kernels' own time (r5: 135 -> ~125 us per operator against 122 us in the trace)
     pe = max(args.probe_every, 1)
     ph0 = list(trainer.phase_s)
+    global SAMPLE_MAIN_THREAD
+    SAMPLE_MAIN_THREAD = bool(args.sample_main_thread) and rank == 0          # (stays on for the extras' regions: a diagnostic run)
     dt, loss = timed_region(lambda i: step(args.warmup + i, 'time' if (args.steps - 1 - i) % pe == 0 else None, prefetch=i < args.steps - 1),
                             args.steps, world, dev)
     host_main = dict(host_enqueue_ms_per_step=round(LAST_HOST_S / args.steps * 1e3, 3),
                      host_blocked_ms_per_step=round(LAST_WAIT_S / args.steps * 1e3, 3),
                      host_busy_ms_per_step=round((LAST_HOST_S - LAST_WAIT_S) / args.steps * 1e3, 3),
-                     process_cpu_ms_per_step=round(LAST_CPU_S / args.steps * 1e3, 3), thread_cpu_ms_per_step=LAST_THREADS, settle=settle,
+                     process_cpu_ms_per_step=round(LAST_CPU_S / args.steps * 1e3, 3), thread_cpu_ms_per_step=LAST_THREADS, steps=LAST_STEPS, settle=settle,
                      phases_ms_per_step=[round((b - a) / args.steps * 1e3, 3) for a, b in zip(ph0, trainer.phase_s)],
-                     micro=host_micro(dev), pinned_to_gpu_numa_node=pinned, after=host_state())
+                     micro=host_micro(dev), pinned_to_gpu_numa_node=pinned, after=host_state(),
+                     allocator_reserve_GB=round(reserved / 2 ** 30, 1))
     final_loss = float(loss.item())
     dp_log = getattr(trainer.averager, 'log', None)
     trainer.averager.log = None
@@ -886,7 +981,8 @@ def main():
             for i in range(3):
                 step(i)
             dtf, _ = timed_region(lambda i: step(i, prefetch=i < 9), 10, 1, dev)
-            forced = dict(steps=10, ms_per_step=round(dtf / 10 * 1e3, 3), value=round(args.batch * 10 / dtf, 3), unit='scenes/s',
+            forced = dict(steps=10, ms_per_step=round(dtf / 10 * 1e3, 3), value=round(args.batch * 10 / dtf, 3), unit='scenes/s', calls=LAST_STEPS,
+                          host_busy_ms_per_step=round((LAST_HOST_S - LAST_WAIT_S) / 10 * 1e3, 3),
                           buckets=len(trainer.averager.buckets), what='the same step with the gradient averager active in a 1-rank RCCL group')
             if args.workload == 'scannet-100k' and args.batch >= 2:
                 # BASELINE config 4 as ONE of its 8 GPUs sees it: 2 scenes per step (global batch 16 / 8), through the data-parallel
@@ -1020,7 +1116,9 @@ def main():
                                          'process_cpu / thread_cpu_ms_per_step: CPU time of the process and of its busiest threads over the region (spinning '
                                          'waits included); settle: UNTIMED steps run after the --warmup steps, in windows of 4, while the host\'s forward + '
                                          'backward enqueue time exceeded half of the step\'s wall time (host_share; a fresh box\'s first minute) — at most '
-                                         '--settle-seconds; one window is always run'),
+                                         '--settle-seconds; one window is always run; steps: host time of the timed region\'s calls (min / median / max; calls above twice the '
+                                         'median) and what the kernel did to the process over the region — voluntary / involuntary context switches, page '
+                                         'faults, periods in which the box\'s cgroup was CPU-throttled (cpu.stat), CPU pressure of the host (PSI, us)'),
                        'coordinate_phase': ('native plan (csrc/plan.hip: fc_plan_levels + fc_plan_maps, 2 read-backs per step)' +
                                             (', the NEXT batch planned on a worker thread beside the current step (plan.Lookahead); exactly '
                                              f'{args.steps} plans inside the timed region' if lookahead else ', in line')),

@@ -242,8 +242,49 @@ __global__ void k_x6_weight_image(const float* __restrict__ W, u32x4* __restrict
 // K (R / 32) (C / 64) of them are live (256 threads = one (k, slab, group) unit each).
 // desc word 7 (h3): the address of ANOTHER image of the same weights (the forward image, for a backward-data entry) whose amax slot
 // this entry shares — it skips the amax pass, scales by that slot and copies it into its own — or 0.
+// r6 (last take): the image pass stages its unit's 32 x 64 weights through LDS — 16-byte loads along the rows of W as they lie
+// (256 B per row of a forward kernel, 128 B per row of a transposed one), the transpose in LDS — and the amax pass reads its unit's
+// 2 048 weights flat (the maximum does not care which): per-thread strided dword loads had the passes at 3.2 / 2.0 TB/s.
+// (Tried and dropped: four units per thread block with the first-block column of desc in LDS, 394 -> 507 us per build — the passes
+// live on blocks in flight, not on the eight scalar loads of the search.)
+#define X6_IMG_LD 65
+__device__ __forceinline__ void h3_weight_image_unit_lds(const float* __restrict__ W, u32x4* __restrict__ img, int64_t blk, int R, int C,
+                                                         int transposed, float sw, float* __restrict__ tile /*[32][X6_IMG_LD]*/) {
+  const int g = (int)(blk % (C / 64));
+  const int slab = (int)((blk / (C / 64)) % (R / 32));
+  const int k = (int)(blk / ((int64_t)(C / 64) * (R / 32)));
+  const float* Wk = W + (int64_t)k * R * C;
+  const int tid = threadIdx.x;
+  if (!transposed) {                             // rows slab * 32 + r, columns g * 64 + c: 16 lanes x 16 B per row
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = p * 16 + (tid >> 4), c4 = (tid & 15) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(Wk + (int64_t)(slab * 32 + r) * C + g * 64 + c4);
+      tile[r * X6_IMG_LD + c4] = v.x; tile[r * X6_IMG_LD + c4 + 1] = v.y; tile[r * X6_IMG_LD + c4 + 2] = v.z; tile[r * X6_IMG_LD + c4 + 3] = v.w;
+    }
+  } else {                                       // W[k] is (C, R): row g * 64 + c, elements slab * 32 + r: 8 lanes x 16 B per row
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int c = p * 32 + (tid >> 3), r4 = (tid & 7) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(Wk + (int64_t)(g * 64 + c) * R + slab * 32 + r4);
+      tile[r4 * X6_IMG_LD + c] = v.x; tile[(r4 + 1) * X6_IMG_LD + c] = v.y; tile[(r4 + 2) * X6_IMG_LD + c] = v.z; tile[(r4 + 3) * X6_IMG_LD + c] = v.w;
+    }
+  }
+  __syncthreads();
+  const int chunk = tid & 3, c = (tid >> 2) & 63;
+  unsigned p[2][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    h3_split2s(tile[(chunk * 8 + 2 * e) * X6_IMG_LD + c], tile[(chunk * 8 + 2 * e + 1) * X6_IMG_LD + c], sw, p[0][e], p[1][e]);
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+    u32x4 v = {p[pl][0], p[pl][1], p[pl][2], p[pl][3]};
+    img[blk * X6_GROUP_U16 + x6_bslot(c, pl, chunk)] = v;
+  }
+}
+
 template <int MODE>           // 0 / 2: the image pass of that mode; 3: the amax pass of h3; 4: zero the amax slots (one wave per entry)
-__global__ void k_x6_weight_images(const long long* __restrict__ desc, int n) {
+__global__ __launch_bounds__(256) void k_x6_weight_images(const long long* __restrict__ desc, int n) {
   if (MODE == 4) {
     const int e = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6), l = threadIdx.x & 63;
     if (e < n && l < FC_AMAX_SUB) reinterpret_cast<unsigned*>(desc[8 * e + 1])[X6_IMG_AMAX_WORD + l * FC_AMAX_STRIDE] = 0u;
@@ -258,19 +299,36 @@ __global__ void k_x6_weight_images(const long long* __restrict__ desc, int n) {
   const long long* d = desc + 8 * lo;
   const int K = (int)d[2], R = (int)d[3], C = (int)d[4];
   const int64_t t = (b - d[6]) * 256 + threadIdx.x;
-  const bool live = t < (int64_t)K * (R / 32) * (C / 64) * 256;
+  const bool live = t < (int64_t)K * (R / 32) * (C / 64) * 256;            // (block-uniform: a unit is 256 threads)
   const float* W = reinterpret_cast<const float*>(d[0]);
   u32x4* img = reinterpret_cast<u32x4*>(d[1]);
+  const bool vec = (reinterpret_cast<uintptr_t>(W) & 15) == 0;
   if (MODE == 3) {
     if (d[7]) return;                           // shares its sibling's slot
-    h3_block_amax(live ? h3_weight_unit_amax(W, t, R, C, (int)d[5]) : 0u, reinterpret_cast<unsigned*>(img) + X6_IMG_AMAX_WORD);
+    unsigned m = 0u;
+    if (live && vec) {                          // the unit's 256 x 8 weights, flat
+      const float4* w4 = reinterpret_cast<const float4*>(W + t * 8);
+      const float4 x0 = w4[0], x1 = w4[1];
+      const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned v = __float_as_uint(xs[e]) & 0x7fffffffu;
+        m = (v > m && v < 0x7f800000u) ? v : m;  // finite weights only (k_amax)
+      }
+    } else if (live) {
+      m = h3_weight_unit_amax(W, t, R, C, (int)d[5]);
+    }
+    h3_block_amax(m, reinterpret_cast<unsigned*>(img) + X6_IMG_AMAX_WORD);
     return;
   }
   if (MODE == 2) {
+    __shared__ float tile[32 * X6_IMG_LD];
     const unsigned* slot = d[7] ? reinterpret_cast<const unsigned*>(d[7]) + X6_IMG_AMAX_WORD : reinterpret_cast<const unsigned*>(img) + X6_IMG_AMAX_WORD;
     const unsigned am = fc_amax_read(slot);     // (every lane)
     if (d[7] && b == d[6] && threadIdx.x == 0) reinterpret_cast<unsigned*>(img)[X6_IMG_AMAX_WORD] = am;      // own slot: sub-word 0 (the rest stays zero)
-    if (live) h3_weight_image_unit(W, img, t, R, C, (int)d[5], h3_scale(am));
+    if (!live) return;
+    if (vec) h3_weight_image_unit_lds(W, img, t >> 8, R, C, (int)d[5], h3_scale(am), tile);
+    else h3_weight_image_unit(W, img, t, R, C, (int)d[5], h3_scale(am));
     return;
   }
   if (live) x6_weight_image_unit(W, img, t, R, C, (int)d[5]);

@@ -118,7 +118,7 @@ template <typename J> __device__ __forceinline__ int batch_find(const Batch<J>& 
 }
 
 // ---- stage 1 kernels: device-resident counts ---------------------------------------------------------------------------------
-// meta (device ints): per set s: [8s + 0] rows, [8s + 2] range flag, [8s + 3] finished blocks of the flag pass; then rows per (set, scene).
+// meta (device ints): per set s: [8s + 0] rows, [8s + 2] range flag; then rows per (set, scene).
 constexpr int METAW = 8;
 constexpr int CH = 32;              // scenes per launch of the point kernel
 struct SceneArgs { const float* p[CH]; int n[CH]; int off[CH]; int b0, stride, nfeat; float vs, feat_div; };
@@ -190,17 +190,17 @@ __global__ void k_plan_insert(const int4* __restrict__ coords, int64_t n, unsign
   hash_insert(keys, vals, mask, c, (int)i, slot);
 }
 
-// winners: flags + the count of every 256-row sub-block; the LAST block to finish scans the block counts (exclusive, in place)
-// and writes the set's row count -> meta_s[0]
-__global__ __launch_bounds__(256) void k_plan_flags_scan(const int* __restrict__ slot, const int* __restrict__ vals, const int* __restrict__ n_dev,
-                                                         int64_t n_host, unsigned char* __restrict__ flags, int* __restrict__ blocksums,
-                                                         int* __restrict__ meta_s) {
-  __shared__ int ws[4];
-  __shared__ int last_s, carry_s;
+// winners: flags + the count of every 256-row sub-block (blocksums, what k_plan_finalize works in) and of every 1 024-row block
+// (coarse).  No scan here: every block of k_plan_finalize adds up the (L2-resident, <= a few thousand) counts in front of it — and all
+// of them, for the set's row count — itself.  (Until r6's last take the LAST block to finish scanned the counts in place: a
+// device-scope fence and a same-line atomic per block, 28 us for an EMPTY set and ~60 of the ~100 us of a full one.)
+__global__ __launch_bounds__(256) void k_plan_flags(const int* __restrict__ slot, const int* __restrict__ vals, const int* __restrict__ n_dev,
+                                                    int64_t n_host, unsigned char* __restrict__ flags, int* __restrict__ blocksums,
+                                                    int* __restrict__ coarse) {
   const int64_t n = n_dev ? *n_dev : n_host;
+  if ((int64_t)blockIdx.x * 1024 >= n) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   __shared__ int wsr[4][4];
-  // 1 024 rows per block, as four sub-blocks of 256 (the unit k_plan_finalize works in: blocksums holds one entry per sub-block);
   // the four dependent read pairs of a thread (slot, table value) are issued together
   int f[4];
 #pragma unroll
@@ -218,60 +218,56 @@ __global__ __launch_bounds__(256) void k_plan_flags_scan(const int* __restrict__
   __syncthreads();
   if (threadIdx.x < 4) {
     const int r = threadIdx.x;
-    __hip_atomic_store(&blocksums[4 * blockIdx.x + r], wsr[r][0] + wsr[r][1] + wsr[r][2] + wsr[r][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    blocksums[4 * blockIdx.x + r] = wsr[r][0] + wsr[r][1] + wsr[r][2] + wsr[r][3];
+  } else if (threadIdx.x == 64) {
+    int t = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t += wsr[r][0] + wsr[r][1] + wsr[r][2] + wsr[r][3];
+    coarse[blockIdx.x] = t;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    last_s = atomicAdd(&meta_s[3], 1) == (int)gridDim.x - 1;
-    carry_s = 0;
-  }
-  __syncthreads();
-  if (!last_s) return;
-  __threadfence();
-  const int nb = 4 * (int)gridDim.x;
-  for (int start = 0; start < nb; start += 256) {
-    const int i = start + threadIdx.x;
-    const int v = i < nb ? fc_ld(&blocksums[i]) : 0;
-    int x = v;                                    // inclusive scan inside the wave
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(x, o, 64);
-      if (lane >= o) x += t;
-    }
-    if (lane == 63) ws[w] = x;
-    __syncthreads();
-    int pre = carry_s;
-    for (int k = 0; k < w; ++k) pre += ws[k];
-    if (i < nb) blocksums[i] = pre + x - v;
-    __syncthreads();
-    if (threadIdx.x == 255) carry_s = pre + x;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) meta_s[0] = carry_s;
 }
 
 // positions + the set itself: winner row i -> out row p: coordinates (with its feature row for level 0), table value = p,
 // rows-per-scene counters (rows of one scene are consecutive: one atomic per wave and scene) — and, fused, the hash insert of the
 // NEXT set of the chain: row p of this set, quantised to the next stride, goes into the next table with value p (first occurrence
-// = smallest p, as an insert pass over the finished set would give)
+// = smallest p, as an insert pass over the finished set would give).  The block's first output row = the winners in front of it =
+// the coarse counts of the 1 024-row blocks before its own + the sub-block counts inside that one; the set's row count (the next
+// table's mask; block 0 leaves it in meta_s[0] for the kernels behind) = all coarse counts.
 __global__ __launch_bounds__(256) void k_plan_finalize(const int4* __restrict__ coords, const int* __restrict__ n_dev, int64_t n_host, int q,
                                                        const unsigned char* __restrict__ flags, const int* __restrict__ blocksums,
-                                                       const int* __restrict__ slot, int* vals, int4* __restrict__ out_coords,
-                                                       const float* __restrict__ feats_in, float* __restrict__ feats_out, int nfeat,
-                                                       int* __restrict__ scene_cnt, int B, const int* __restrict__ meta_s,
-                                                       unsigned long long* next_keys, int* next_vals, int* __restrict__ next_slot) {
+                                                       const int* __restrict__ coarse, const int* __restrict__ slot, int* vals,
+                                                       int4* __restrict__ out_coords, const float* __restrict__ feats_in,
+                                                       float* __restrict__ feats_out, int nfeat, int* __restrict__ scene_cnt, int B,
+                                                       int* __restrict__ meta_s, unsigned long long* next_keys, int* next_vals,
+                                                       int* __restrict__ next_slot) {
   __shared__ int ws[4];
+  __shared__ int red[2][4];
   const int64_t n = n_dev ? *n_dev : n_host;
   const int64_t base = (int64_t)blockIdx.x * 256;
   if (base >= n) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const unsigned long long nmask = next_keys ? table_mask(meta_s[0]) : 0ull;
   const int64_t i = base + threadIdx.x;
   const int f = i < n ? (int)flags[i] : 0;
   const unsigned long long bal = __ballot(f);
   if (lane == 0) ws[w] = __popcll(bal);
+  const int nc = (int)((n + 1023) >> 10), mine = (int)(blockIdx.x >> 2);
+  int before = 0, all = 0;
+  for (int j = threadIdx.x; j < nc; j += 256) {
+    const int v = coarse[j];
+    all += v;
+    if (j < mine) before += v;
+  }
+  if (threadIdx.x < (int)(blockIdx.x & 3)) before += blocksums[4 * mine + threadIdx.x];
+  for (int o = 32; o > 0; o >>= 1) {
+    before += __shfl_xor(before, o, 64);
+    all += __shfl_xor(all, o, 64);
+  }
+  if (lane == 0) { red[0][w] = before; red[1][w] = all; }
   __syncthreads();
-  int pre = blocksums[blockIdx.x];
+  int pre = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  const int total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) meta_s[0] = total;
+  const unsigned long long nmask = next_keys ? table_mask(total) : 0ull;
   for (int k = 0; k < w; ++k) pre += ws[k];
   int b = -1;
   if (f) {
@@ -609,7 +605,7 @@ static int64_t stage1_layout(int64_t T, int B, int nl, int nfeat, char* base, vo
   p[i++] = a.arr<float>((int64_t)nfeat * T);                    // 1 feats_raw
   p[i++] = a.arr<int>(T);                                       // 2 slot (even sets)
   p[i++] = a.take(T);                                           // 3 flags
-  p[i++] = a.arr<int>(4 * fc_cdiv(T > 0 ? T : 1, 1024) + 4);    // 4 blocksums (one per 256 rows)
+  p[i++] = a.arr<int>(5 * fc_cdiv(T > 0 ? T : 1, 1024) + 8);    // 4 blocksums (one per 256 rows), then one per 1 024 rows
   p[i++] = a.arr<int>((int64_t)METAW * S + (int64_t)S * B + 64); // 5 meta
   p[i++] = a.arr<float>((int64_t)nfeat * T);                    // 6 F0
   p[i++] = a.arr<int>(T);                                       // 7 slot (odd sets)
@@ -639,6 +635,7 @@ int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int6
   int* slots[2] = {(int*)p[2], (int*)p[7]};
   unsigned char* flags = (unsigned char*)p[3];
   int* blocksums = (int*)p[4];
+  int* coarse = blocksums + 4 * fc_cdiv(T > 0 ? T : 1, 1024) + 4;
   int* meta = (int*)p[5];
   float* F0 = (float*)p[6];
   const int64_t cap0 = next_pow2(T > 0 ? 2 * T : 2);
@@ -703,13 +700,13 @@ int fc_plan_levels(const int64_t* cfg, const int64_t* scenes, void* arena1, int6
       const size_t pp0 = g_pp.size();
       {
         Bracket br(probe, PK_FLAGS, 0.0, stream);        // bytes are filled in after the read-back (they depend on the live counts)
-        k_plan_flags_scan<<<gB, 256, 0, stream>>>(slots[s & 1], vals, n_in_dev, T, flags, blocksums, meta_s);
+        k_plan_flags<<<gB, 256, 0, stream>>>(slots[s & 1], vals, n_in_dev, T, flags, blocksums, coarse);
         FC_CHECK_LAUNCH();
       }
       if (probe) stage1_pp[s] = pp0;
       const bool more = s + 1 < S;
       Bracket br(probe, PK_FINALIZE, 0.0, stream);
-      k_plan_finalize<<<gF, 256, 0, stream>>>(src, n_in_dev, T, 1 << s, flags, blocksums, slots[s & 1], vals, (int4*)p[10 + s],
+      k_plan_finalize<<<gF, 256, 0, stream>>>(src, n_in_dev, T, 1 << s, flags, blocksums, coarse, slots[s & 1], vals, (int4*)p[10 + s],
                                              s == 0 ? feats_raw : nullptr, s == 0 ? F0 : nullptr, nfeat,
                                              meta + METAW * S + (int64_t)s * B, B, meta_s, more ? keys_all + cap0 * (s + 1) : nullptr,
                                              more ? vals_all + cap0 * (s + 1) : nullptr, slots[(s + 1) & 1]);

@@ -146,12 +146,42 @@ def build_lr_updater(optimizer, cfg):
 def parse_losses(losses):
     """mmdet BaseDetector._parse_losses: every entry is reduced to a scalar (a tensor by its mean, a list of tensors by
     the sum of their means) and the training loss is the sum of the entries whose key contains 'loss'."""
+    def mean(t):                     # the mean of a 0-dim tensor is the tensor: no reduction launch, none in its backward
+        return t if t.dim() == 0 else t.mean()
     total = None
     for k, v in losses.items():
         if 'loss' in k:
-            v = v.mean() if torch.is_tensor(v) else sum(x.mean() for x in v)
+            v = mean(v) if torch.is_tensor(v) else sum(mean(x) for x in v)
             total = v if total is None else total + v
     return total
+
+
+def reserve_device_memory(gigabytes, device=None, streams=None, chunk_gb=8):
+    """Take `gigabytes` of device memory into torch's caching allocator up front (as chunk_gb blocks, released to the cache at once:
+    later requests are carved out of them).  A training step asks the allocator for its arenas (the coordinate phase's tables, the
+    executor's activations and workspaces) every step; which cached block fits depends on how far the host runs ahead of the GPU, and a
+    step that finds none goes to the driver — a device allocation of a few hundred MB takes 20-120 ms on this stack, inside the step
+    (profiles/r6_notes.md section 14: every "slow first process" of r5 / r6 was one to five such calls inside the 20 timed steps).  On a
+    288 GB device holding back a few tens of GB removes them.
+    The allocator keeps one pool PER STREAM: `streams` = [(stream, share)] splits the reserve over the streams the step allocates under
+    (default: the current stream 1/2, the coordinate stream 1/4, the weight-gradient stream 1/4).  Returns the bytes reserved (at most
+    a quarter of what is free)."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if streams is None:
+        from . import functional as Fn
+        from . import sparse as SP
+        streams = [(torch.cuda.current_stream(dev), 0.5), (SP.map_stream(dev), 0.25), (Fn.wgrad_stream(dev), 0.25)]
+    free, _ = torch.cuda.mem_get_info(dev)
+    budget = min(float(gigabytes), free / 4 / 2 ** 30)
+    tot = sum(w for _, w in streams) or 1.0
+    got = 0
+    for st, w in streams:
+        n = int(budget * w / tot // chunk_gb)
+        with torch.cuda.stream(st):
+            blocks = [torch.empty(chunk_gb << 30, dtype=torch.uint8, device=dev) for _ in range(max(n, 0))]
+            got += sum(b.numel() for b in blocks)
+            del blocks
+    return got
 
 
 class TrainStep:

@@ -29,50 +29,70 @@ def main():
     model.async_maps = True
     model.inputs_resident = True
     Fn.WGRAD_ASYNC = not args.no_wgrad_overlap
+    model.spatial_sort = args.spatial_sort
     tr = TrainStep.from_config(model, cfg)
     batches = bench.make_batches(args, 0, dev)
-    names = ['forward (extract_feat)', 'loss', 'backward', 'optimizer', 'gap to next step']
-    marks = []
+    names = ['forward + loss', 'backward', 'optimizer (clip + AdamW)', 'gap to next step']
+    marks, cur = [], [None]
 
-    def ev():
+    def ev(stream=None):
         e = torch.cuda.Event(enable_timing=True)
-        e.record()
+        e.record(stream) if stream is not None else e.record()
         return e
 
-    def step(i, rec):
-        b = batches[i % 2]
-        m = [ev()] if rec else None
-        tr.optimizer.zero_grad(set_to_none=True)
-        x = model.extract_feat(b['points'], b['img_metas'], (b['gt_bboxes_3d'], b['gt_labels_3d']))
-        x = [list(v) for v in x]
-        if rec: m.append(ev())
-        losses = model.neck_with_head.loss(*x, b['gt_bboxes_3d'], b['gt_labels_3d'], b['img_metas'])
-        loss = parse_losses(losses)
-        if rec: m.append(ev())
-        loss.backward()
-        tr.averager.finish()
-        if rec: m.append(ev())
-        tr.optimizer.step(tr.max_norm)
-        if rec:
-            m.append(ev())
-            marks.append(m)
+    # boundaries of TrainStep.__call__ (runner.py:223): after the run-ahead bound, after forward_train + parse_losses, after
+    # loss.backward(), at return — recorded on the main stream; the step itself is TrainStep's, lookahead included
+    import fcaf3d_amd.runner as R
+    bound0, parse0, fin0 = tr._bound_run_ahead, R.parse_losses, tr.averager.finish
 
-    for i in range(4):
+    def bound(*a, **k):
+        bound0(*a, **k)
+        if cur[0] is not None:
+            cur[0].append(ev())
+
+    def parse(losses):
+        r = parse0(losses)
+        if cur[0] is not None:
+            cur[0].append(ev())
+        return r
+
+    def fin():
+        if cur[0] is not None:
+            cur[0].append(ev())
+        return fin0()
+    tr._bound_run_ahead, R.parse_losses, tr.averager.finish = bound, parse, fin
+    side = Fn.wgrad_stream(dev)
+    img = []
+
+    def step(i, rec):
+        cur[0] = [] if rec else None
+        tr(batches[i % 2], next_batch=batches[(i + 1) % 2] if not args.no_lookahead else None)
+        if rec:
+            cur[0].append(ev())
+            img.append(ev(side))                 # the weight images of the next step are ready (weight-gradient stream)
+            marks.append(cur[0])
+
+    for i in range(6):
         step(i, False)
     torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
     for i in range(steps):
         step(i, True)
     torch.cuda.synchronize()
-    tot = [0.0] * 5
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    tot = [0.0] * 4
     for j, m in enumerate(marks):
-        for k in range(4):
+        assert len(m) == 4, len(m)
+        for k in range(3):
             tot[k] += m[k].elapsed_time(m[k + 1])
         if j + 1 < len(marks):
-            tot[4] += m[4].elapsed_time(marks[j + 1][0])
+            tot[3] += m[3].elapsed_time(marks[j + 1][0])
     n = len(marks)
-    for k in range(5):
-        print(f'{names[k]:28s} {tot[k] / (n if k < 4 else n - 1):8.3f} ms')
-    print(f'{"sum":28s} {sum(tot[:4]) / n + tot[4] / (n - 1):8.3f} ms')
+    for k in range(4):
+        print(f'{names[k]:28s} {tot[k] / (n if k < 3 else n - 1):8.3f} ms')
+    print(f'{"sum":28s} {sum(tot[:3]) / n + tot[3] / (n - 1):8.3f} ms   (wall {wall:.3f} ms per step)')
+    print(f'{"images ready after step end":28s} {sum(m[3].elapsed_time(e) for m, e in zip(marks, img)) / n:8.3f} ms')
 
 
 if __name__ == '__main__':
