@@ -761,7 +761,8 @@ def main():
     if args.reserve_gb > 0:
         import fcaf3d_amd.sparse as SPm
         from fcaf3d_amd.runner import reserve_device_memory
-        reserved = reserve_device_memory(args.reserve_gb, dev, streams=[
+        sharers = -(-world // torch.cuda.device_count()) if os.environ.get('FC_DIST_BACKEND') == 'gloo' else 1     # smoke mode: ranks per GPU
+        reserved = reserve_device_memory(args.reserve_gb / sharers, dev, streams=[
             (torch.cuda.current_stream(dev), 0.5), (SPm.map_stream(dev), 0.25), (Fn.wgrad_stream(dev), 0.125),
             (model.neck_with_head._head_stream(dev), 0.125)], chunk_gb=8)
 
@@ -847,12 +848,14 @@ def main():
         Fn.WGRAD_ASYNC, model.neck_with_head.head_overlap = False, False
         EX.program_for(model, True)
         Fn.WGRAD_ASYNC, model.neck_with_head.head_overlap = wa0, ho0
-    if exec_on and probe and args.warmup > 0:
+    if exec_on and args.warmup > 0 and not args.no_instrument:
         # ... and run it once, untimed, brackets and all (r6: the first probed step of a process creates a few hundred HIP events and
-        # whatever pools the runtime keeps behind them — 36 MB of fresh host memory, 20-120 ms — and it was step 8 of the timed region)
-        step(args.warmup, 'time')
-        probe.exec_records()
-        probe.timed, probe.exec_steps = {}, []
+        # whatever pools the runtime keeps behind them — 36 MB of fresh host memory, 20-120 ms — and it was step 8 of the timed region).
+        # EVERY rank steps (the step holds collectives; the condition is a function of the flags only), rank 0 with its probe
+        step(args.warmup, 'time' if probe else None)
+        if probe:
+            probe.exec_records()
+            probe.timed, probe.exec_steps = {}, []
     if bd:
         torch.cuda.synchronize()
         bd.rec.clear()

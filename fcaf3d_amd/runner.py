@@ -178,7 +178,12 @@ def reserve_device_memory(gigabytes, device=None, streams=None, chunk_gb=8):
     for st, w in streams:
         n = int(budget * w / tot // chunk_gb)
         with torch.cuda.stream(st):
-            blocks = [torch.empty(chunk_gb << 30, dtype=torch.uint8, device=dev) for _ in range(max(n, 0))]
+            blocks = []
+            try:
+                for _ in range(max(n, 0)):
+                    blocks.append(torch.empty(chunk_gb << 30, dtype=torch.uint8, device=dev))
+            except torch.OutOfMemoryError:         # somebody else took the memory meanwhile (several processes on one device): keep what there is
+                pass
             got += sum(b.numel() for b in blocks)
             del blocks
     return got

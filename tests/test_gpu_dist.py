@@ -210,7 +210,7 @@ def test_bench_n_ranks_on_one_gpu_prints_the_contract_line(ranks, batch):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', str(ranks), '--steps', '3', '--warmup', '2',
            '--batch', str(batch), '--no-cpu-baseline', '--infer-steps', '0', '--no-extras', '--no-fp32-route']
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
