@@ -13,6 +13,7 @@ depend on the input points only): ctypes releases the GIL for the duration of th
 plan are waited for off the step's critical path.
 """
 import threading
+import weakref
 
 import numpy as np
 import torch
@@ -187,8 +188,8 @@ class Planner:
                 lazy['_vals'] = (int(o[S_VALS]), (cap,), torch.int32)
             else:
                 cm._keys = cm._vals = None
-            cm.__dict__.update(_lazy=lazy, _arenas=ar, stride=stride, batch_size=B, n=n, _kmaps={}, _strided={}, _unions={}, _generated=None,
-                               _perm=None, _order=None, dense_hint=s >= S0, _gen_parent=None, _grouped=True)
+            cm.__dict__.update(_lazy=lazy, _arenas=ar, stride=stride, batch_size=B, n=n, _kmaps=weakref.WeakKeyDictionary(), _strided={},
+                               _unions=weakref.WeakKeyDictionary(), _generated=None, _perm=None, _order=None, dense_hint=s >= S0, _grouped=True)
             if s < S0:
                 cm._counts = [int(v) for v in scene_cnt[s]]
             else:
@@ -208,8 +209,7 @@ class Planner:
             km = SP.KernelMap.__new__(SP.KernelMap)
             fl = int(o[MW_FLAGS])
             lazy = {'nbr': (int(o[MW_NBR]), (K, n_out), torch.int32)}
-            d = dict(n_in=n_in, n_out=n_out, K=K, sort_rows=bool(fl & 1), use_pairs=bool(fl & 2), _out_map=sets[int(o[MW_OUT])],
-                     _arenas=ar, _desc={})
+            d = dict(n_in=n_in, n_out=n_out, K=K, sort_rows=bool(fl & 1), use_pairs=bool(fl & 2), _arenas=ar, _desc={})
             conv = m >= 2
             if conv:
                 if o[MW_PI]:
@@ -243,7 +243,7 @@ class Planner:
             d['_lazy'] = lazy
             km.__dict__.update(d)
             ks = {27: 3, 8: 2, 1: 1}[K]
-            sets[int(o[MW_IN])]._kmaps[(id(km._out_map), ks)] = km
+            sets[int(o[MW_IN])]._kmaps.setdefault(sets[int(o[MW_OUT])], {})[ks] = km      # (weak key: sparse.CoordMap.__init__)
             maps.append(km)
         structured = bool(out[H_STRUCT])
         prune = int(out[H_PRUNE])
@@ -252,7 +252,7 @@ class Planner:
             for g in range(S0, S):
                 i = nl - 2 - (g - S0)
                 rows = ar.view(int(out[HDR + SETW * g + S_ROWS]), (sets[3 + i].n,))
-                sets[3 + i]._unions[id(sets[g])] = (sets[g], rows, True, sets[g])
+                sets[3 + i]._unions[sets[g]] = (sets[g], rows, True)
             if prune < 0:
                 head_maps = [sets[S0 - 1 + (nl - 1 - l)] if l < nl - 1 else sets[S0 - 1] for l in range(nl)]
         sp = StepPlan()

@@ -8,6 +8,7 @@ oracle's, so parity is checked row for row.
 """
 import itertools
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -330,15 +331,28 @@ class CoordMap(_Lazy):
         self.stride = stride
         self.batch_size = batch_size
         self.n = coords.shape[0]
-        self._kmaps = {}
+        # caches keyed by the OTHER set — weakly, and holding nothing that leads back here: a set, its kernel maps and the arenas they
+        # view must die by reference count when the step lets go of them.  (r6: `_kmaps[(id(out), k)]` with `km._out_map = out` to keep
+        # the id unique, parent <-> generated child and `_unions[id(other)] = (self, ...)` were cycles; the cyclic collector got to
+        # them generations late — 0.66 GB of arenas per step waiting for it, +37 MB per step for good over 1 000 steps.)
+        self._kmaps = weakref.WeakKeyDictionary()       # out_map -> {kernel_size: KernelMap}
         self._strided = {}
-        self._unions = {}
+        self._unions = weakref.WeakKeyDictionary()      # other -> (union set | None = this set, rows, swapped)
         self._generated = None
         self._perm = None
         self._counts = None
         self._order = None
         self.dense_hint = False         # True for generated children sets and their unions
-        self._gen_parent = None         # generated children set: the set it was generated from (rows 8i + k)
+        self._gen_parent = None         # generated children set: the set it was generated from (rows 8i + k); held weakly
+
+    @property
+    def _gen_parent(self):
+        r = self.__dict__.get('_gen_parent_ref')
+        return r() if r is not None else None
+
+    @_gen_parent.setter
+    def _gen_parent(self, par):
+        self.__dict__['_gen_parent_ref'] = weakref.ref(par) if par is not None else None
 
     # ---- voxel hash: built on demand for generated sets (their maps come from the parent level, see generate()) ----
     def _ensure_table(self):
@@ -424,8 +438,8 @@ class CoordMap(_Lazy):
 
     def kernel_map(self, out_map, kernel_size):
         """KernelMap from this (input) set to `out_map`, offsets in units of this set's stride."""
-        key = (id(out_map), kernel_size)
-        km = self._kmaps.get(key)
+        per_out = self._kmaps.get(out_map)
+        km = per_out.get(kernel_size) if per_out is not None else None
         if km is None:
             offs = kernel_offsets(kernel_size, self.stride, self.coords.device)
             K = offs.shape[0]
@@ -437,7 +451,6 @@ class CoordMap(_Lazy):
                 L.call('fc_kernel_map', L.ptr(out_map.coords), out_map.n, L.ptr(self.keys), L.ptr(self.vals), self.cap,
                        L.ptr(offs), K, L.ptr(nbr), L.stream())
             km = KernelMap(nbr, self.n, out_map.n)
-            km._out_map = out_map            # keep alive so id() stays unique
             # generated / union sets are ~94 % dense (2x2x2 blocks): nothing to skip there
             # ... and below ~8k rows the masks do not group well enough to pay for themselves (tools/convbench.py)
             # (r2: the generated / union sets are 77 % / 88 % / 94 % occupied; mask order would issue 1.10x / 1.02x / 1.00x the
@@ -448,7 +461,7 @@ class CoordMap(_Lazy):
             km.sort_rows = (SORT_ROWS and K == 27 and out_map.n >= SORT_MIN_ROWS
                             and (SORT_DENSE or not dense or out_map.n <= SORT_DENSE_MAX_ROWS))
             km.use_pairs = WGRAD_PAIRS and K == 27 and (not dense or (PAIRS_DENSE and out_map.n <= PAIR_CONV_ROWS))
-            self._kmaps[key] = km
+            self._kmaps.setdefault(out_map, {})[kernel_size] = km
         return km
 
     def union(self, other):
@@ -458,8 +471,9 @@ class CoordMap(_Lazy):
                          generated children set) -> the union IS other's set and other's map (with its cached
                          kernel maps) is reused; rows[i] = row in `other` of self's row i."""
         assert self.stride == other.stride
-        if id(other) in self._unions:
-            return self._unions[id(other)][:3]
+        ent = self._unions.get(other)
+        if ent is not None:
+            return (self if ent[0] is None else ent[0]), ent[1], ent[2]
         dev = self.coords.device
         if other._gen_parent is not None and STRUCTURED_MAPS:
             # `other` is a generated children set: where each of MY voxels sits in it follows from its parent level's hash
@@ -472,7 +486,7 @@ class CoordMap(_Lazy):
                    L.ptr(rows), L.ptr(found), L.stream())
             if int(found.item()) == self.n:
                 _rec(rows)
-                self._unions[id(other)] = (other, rows, True, other)
+                self._unions[other] = (other, rows, True)
                 return other, rows, True
 
         def probe(q, table):
@@ -497,7 +511,7 @@ class CoordMap(_Lazy):
             cm.dense_hint = other.dense_hint
             rows = row_b
         _rec(rows)
-        self._unions[id(other)] = (cm, rows, swapped, other)       # keep `other` alive so id() stays unique
+        self._unions[other] = (None if cm is self else cm, rows, swapped)
         return cm, rows, swapped
 
     def pruned(self, kept):

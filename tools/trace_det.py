@@ -59,7 +59,7 @@ def main():
                 continue
             seen.add(id(cm))
             sums.append(cm.coords.double().sum() + cm.n)
-            for km in cm._kmaps.values():
+            for km in (k for per in cm._kmaps.values() for k in per.values()):
                 sums.append(km.nbr.double().sum())
                 for attr in ('nbr_t',):
                     v = getattr(km, attr, None)
@@ -77,7 +77,7 @@ def main():
             for cm in out:
                 if id(cm) not in seen:
                     seen.add(id(cm)); sums.append(cm.coords.double().sum() + cm.n)
-                    for km in cm._kmaps.values():
+                    for km in (k for per in cm._kmaps.values() for k in per.values()):
                         sums.append(km.nbr.double().sum())
         rec.append((f'maps ({len(sums)} tensors)', torch.stack([torch.stack(sums).sum(), torch.stack(sums).abs().max()])))
         return out
