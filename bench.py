@@ -92,8 +92,8 @@ def run_extra(args, key, dev, steps):
     Fn.WGRAD_ASYNC = not args.no_wgrad_overlap
     tr = TrainStep.from_config(model, cfg)
     batches = make_batches(a, 0, dev)
-    for i in range(2):
-        tr(batches[i % 2])
+    for i in range(4):                  # warm-up with the timed region's own pattern (lookahead: two plans' arenas alive): the allocator's pools fill here
+        tr(batches[i % 2], batches[(i + 1) % 2] if (i < 3 and not args.no_lookahead) else None)
     dt, loss = timed_region(lambda i: tr(batches[i % 2], batches[(i + 1) % 2] if (i < steps - 1 and not args.no_lookahead) else None)[0], steps, 1, dev)
     out = dict(workload=f'{wl}, voxel {vs} m, {lv} levels', scenes_per_step=bs, steps=steps, ms_per_step=round(dt / steps * 1e3, 3),
                value=round(bs * steps / dt, 3), unit='scenes/s', final_loss=round(float(loss), 4),
