@@ -228,3 +228,41 @@ def test_argsort27_is_the_stable_argsort(n):
         L.call('fc_argsort27', L.ptr(keys), n, L.ptr(order), L.ptr(ws), ws.numel(), L.stream())
         want = torch.sort(keys, stable=True).indices.to(torch.int32)
         assert torch.equal(order, want)
+
+
+@pytest.mark.parametrize('native', [True, False])
+def test_a_step_leaves_no_device_memory_to_the_cyclic_collector(native):
+    """coordinate sets, kernel maps and the arenas they view are freed by reference count when a step ends (sparse.CoordMap: caches
+    keyed weakly by the other set, a generated set holds its parent weakly): with CPython's cyclic collector OFF the allocated device
+    memory does not grow from step to step — r6 found 0.66 GB per 8-scene step waiting for a collection (three reference cycles), and
+    +36.8 GB reserved over 1 000 steps; both coordinate paths (the native plan and the per-operator phase)"""
+    import gc
+    dev = _dev()
+    det = _build(levels=4).to(dev).train()
+    pts, gtb, gtl = _batch((41, 42), dev, 30000)
+    batch = dict(points=pts, gt_bboxes_3d=gtb, gt_labels_3d=gtl, img_metas=[dict(box_type_3d=fa.DepthInstance3DBoxes)] * 2)
+
+    def step():
+        det.zero_grad(set_to_none=True)
+        losses = det(return_loss=True, **batch)
+        sum(losses.values()).backward()
+    PL.ENABLED = native
+    try:
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()
+        try:
+            step()
+            torch.cuda.synchronize()
+            m0 = torch.cuda.memory_allocated()
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            m1 = torch.cuda.memory_allocated()
+        finally:
+            gc.enable()
+    finally:
+        PL.ENABLED = True
+    assert m1 - m0 <= 4 << 20, f'{(m1 - m0) / 2 ** 20:.1f} MB of device memory per 4 steps are held by reference cycles'
