@@ -37,7 +37,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--settle-seconds', type=float, default=45.0,
                     help='after the warm-up steps: further UNTIMED steps (windows of 4) for at most this long while the host, not the GPU, '
-                         'sets the step time — the first minute of a fresh box (profiles/r6_notes.md section 13); 0 = off.  Reported in config.host.settle')
+                         'sets the step time (a guard: since the allocator reserve and the warmed probed step — profiles/r6_notes.md section 14 — no run needed more than the one window that always runs); 0 = off.  Reported in config.host.settle')
     ap.add_argument('--batch', type=int, default=8, help='scenes per GPU per step (reference samples_per_gpu=8)')
     ap.add_argument('--workload', default='scannet-100k', choices=['plumbing-20k', 'scannet-100k', 'sunrgbd-100k', 's3dis-500k'])
     ap.add_argument('--voxel-size', type=float, default=0.02)
@@ -810,11 +810,11 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    # r6: settling.  The FIRST process on a fresh box can spend its first ~minute with the host's launch path 4-5x slower than ever after
-    # (20-23 ms of host work per step instead of 4-5, kernels at their usual speed: r6_notes.md section 13 — 3 of ~40 leases this round;
-    # every later process on the box is normal, and so is this one after that minute).  That is the box waking up, not the step:
-    # while the host's enqueue time of forward + backward exceeds half of the step's wall time, keep stepping UNTIMED (windows of 4
-    # steps, at most --settle-seconds), every rank in lockstep; what was done is reported in config.host.settle.
+    # r6: settling.  Some first processes ran with 20-23 ms of host time per step instead of 4-5 at unchanged kernel times; read at first
+    # as the box waking up, it was device allocations and first-use costs inside the steps (r6_notes.md section 14: removed at the root
+    # by --reserve-gb, the warmed probed step below and the cycle-free coordinate objects).  The guard stays: while the host's enqueue
+    # time of forward + backward exceeds half of the step's wall time, keep stepping UNTIMED (windows of 4 steps, at most
+    # --settle-seconds), every rank in lockstep; what was done is reported in config.host.settle.
     settle = dict(windows=0, extra_untimed_steps=0, seconds=0.0, host_share_first=None, host_share_last=None)
     if args.settle_seconds > 0 and not args.breakdown:
         t_settle = time.perf_counter()
@@ -1118,7 +1118,7 @@ def main():
                                          'round trip, taken right after the region; loadavg / usable CPUs when the process started and after the timed region; '
                                          'process_cpu / thread_cpu_ms_per_step: CPU time of the process and of its busiest threads over the region (spinning '
                                          'waits included); settle: UNTIMED steps run after the --warmup steps, in windows of 4, while the host\'s forward + '
-                                         'backward enqueue time exceeded half of the step\'s wall time (host_share; a fresh box\'s first minute) — at most '
+                                         'backward enqueue time exceeded half of the step\'s wall time (host_share) — at most '
                                          '--settle-seconds; one window is always run; steps: host time of the timed region\'s calls (min / median / max; calls above twice the '
                                          'median) and what the kernel did to the process over the region — voluntary / involuntary context switches, page '
                                          'faults, periods in which the box\'s cgroup was CPU-throttled (cpu.stat), CPU pressure of the host (PSI, us)'),
