@@ -306,13 +306,52 @@ __global__ void k_plan_kernel_maps(Batch<KMapJob> bt) {
   j.nbr[(int64_t)k * j.n_out + o] = fc_lookup(j.keys, j.vals, j.mask, fc_pack(c.x, c.y + dx, c.z + dy, c.w + dz));
 }
 
+// kernel maps from a set of stride s onto the set of stride 2 s (the stem's and the levels' k3 s2 convolutions, the k2 s2 max-pool),
+// built from the INPUT side (r6, last take): row i of the input lies at offset k of output row o exactly when out = in - offset_k is a
+// voxel of the output set — per axis ONE candidate output if the coordinate is a multiple of 2 s (offset 0), two if not (offsets
+// +s / -s), one for the k2 kernel — so 1 ... 8 probes of the OUTPUT set's table per input row (3.4 on average) instead of 27 probes
+// of the input table per output row, 14 % of which hit: the stem's map 18.9 M probes -> 2.7 M.  The table (pre-filled with -1 by the
+// launch in front) gets nbr[k][o] = i; every entry has one writer (input rows are unique voxels).  Same tables bit for bit.
+struct SMapJob { const int4* ic; const unsigned long long* okeys; const int* ovals; unsigned long long omask; int* nbr; int64_t n_in, n_out; int ks, stride, nbx; };
+__global__ void k_plan_strided_maps(Batch<SMapJob> bt) {
+  int64_t lb;
+  const SMapJob& j = bt.j[batch_find(bt, blockIdx.x, &lb)];
+  // eight threads per input row, one per candidate (a, b, c): the probes of a row are in flight together
+  const int64_t t = lb * 256 + threadIdx.x;
+  const int64_t i = t >> 3;
+  if (i >= j.n_in) return;
+  const int a = (int)t & 1, b = ((int)t >> 1) & 1, c = ((int)t >> 2) & 1;
+  const int4 p = j.ic[i];
+  const int s = j.stride, s2 = 2 * j.stride, ks = j.ks;
+  const int pc[3] = {p.y, p.z, p.w};
+  int nc[3], cc[3][2], ki[3][2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int q = fc_floor_div(pc[d], s2) * s2, r = pc[d] - q;      // r = 0 or s
+    cc[d][0] = q; cc[d][1] = q + s2;
+    if (ks == 2) { nc[d] = 1; ki[d][0] = r / s; ki[d][1] = 0; }     // offsets {0, s}: out = q
+    else if (r == 0) { nc[d] = 1; ki[d][0] = 1; ki[d][1] = 0; }     // offset 0
+    else { nc[d] = 2; ki[d][0] = 2; ki[d][1] = 0; }                 // out = q: offset +s (index 2); out = q + 2 s: offset -s (index 0)
+  }
+  if (a >= nc[0] || b >= nc[1] || c >= nc[2]) return;
+  const int o = fc_lookup(j.okeys, j.ovals, j.omask, fc_pack(p.x, cc[0][a], cc[1][b], cc[2][c]));
+  if (o >= 0) j.nbr[(int64_t)(ki[0][a] + ks * ki[1][b] + ks * ks * ki[2][c]) * j.n_out + o] = (int)i;
+}
+
 // row copies / fills of (K, n) tables.  mode 0: dst[k] = src[K - 1 - k] — the transposed table of a map of a set onto ITSELF with
 // a centred odd kernel (offset k reversed is offset K - 1 - k: identical to fc_kernel_map_transpose); mode 1: dst = -1;
-// mode 2: scatter dst[k][src[k][o]] = o (src (K, n), dst (K, n2)) — fc_kernel_map_transpose's second half
+// mode 2: scatter dst[k][src[k][o]] = o (src (K, n), dst (K, n2)) — fc_kernel_map_transpose's second half; mode 3: dst = -1 as one flat
+// run of K n entries, 16 bytes per thread
 struct RowJob { const int* src; int* dst; int64_t n, n2; int K, mode, nbx; };
 __global__ void k_plan_rows(Batch<RowJob> bt) {
   int64_t lb;
   const RowJob& j = bt.j[batch_find(bt, blockIdx.x, &lb)];
+  if (j.mode == 3) {                                 // dst[0 .. K n) = -1, four entries per thread (dst is 16-byte aligned: bump allocator)
+    const int64_t tot = (int64_t)j.K * j.n, e = (lb * 256 + threadIdx.x) * 4;
+    if (e + 3 < tot) *reinterpret_cast<int4*>(j.dst + e) = make_int4(-1, -1, -1, -1);
+    else for (int64_t q = e; q < tot; ++q) j.dst[q] = -1;
+    return;
+  }
   const int k = (int)(lb / j.nbx);
   const int64_t i = (lb % j.nbx) * 256 + threadIdx.x;
   if (i >= j.n) return;
@@ -813,7 +852,8 @@ static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char
   int* cnt_dev = a.arr<int>(64 * nm + MAXLV);
 
   Batch<KMapJob> kmaps;
-  Batch<RowJob> fills, rows;                        // fills (-1) run before the scatters
+  Batch<RowJob> fills, rows, prefills;              // fills (-1) run before the scatters; prefills: the tables of the strided maps, before k_plan_strided_maps
+  Batch<SMapJob> smaps;
   Batch<SortJob> sorts;
   Batch<PairJob> pairs;
   struct Child { const int* pnbr; int64_t n_parent; int* nbr; } children[MAXLV];
@@ -847,8 +887,15 @@ static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char
       } else {
         const int ks = r.K == 27 ? 3 : 2;
         const int nbx = (int)fc_cdiv(r.n_out, 256);
-        kmaps.add({SC(r.out), (const unsigned long long*)din[S_KEYS], (const int*)din[S_VALS], (unsigned long long)(din[S_CAP] - 1), nbr,
-                   r.n_out, r.K, ks, (int)din[S_STRIDE], nbx}, (int64_t)r.K * nbx);
+        const int64_t* dout = sets + SETW * r.out;
+        if (r.in != r.out && dout[S_STRIDE] == 2 * din[S_STRIDE]) {      // stride s -> 2 s: from the input side (k_plan_strided_maps)
+          smaps.add({SC(r.in), (const unsigned long long*)dout[S_KEYS], (const int*)dout[S_VALS], (unsigned long long)(dout[S_CAP] - 1), nbr,
+                     r.n_in, r.n_out, ks, (int)din[S_STRIDE], (int)fc_cdiv(8 * r.n_in, 256)}, fc_cdiv(8 * r.n_in, 256));
+          prefills.add({nullptr, nbr, r.n_out, r.n_out, r.K, 3, nbx}, fc_cdiv((int64_t)r.K * r.n_out, 1024));
+        } else {
+          kmaps.add({SC(r.out), (const unsigned long long*)din[S_KEYS], (const int*)din[S_VALS], (unsigned long long)(din[S_CAP] - 1), nbr,
+                     r.n_out, r.K, ks, (int)din[S_STRIDE], nbx}, (int64_t)r.K * nbx);
+        }
       }
       if (conv && backward) {
         nbr_t = a.arr<int>((int64_t)r.K * r.n_in);
@@ -856,7 +903,7 @@ static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char
         if (r.self) {
           rows.add({nbr, nbr_t, r.n_in, r.n_in, r.K, 0, nbx}, (int64_t)r.K * nbx);
         } else {
-          fills.add({nullptr, nbr_t, r.n_in, r.n_in, r.K, 1, nbx}, (int64_t)r.K * nbx);
+          fills.add({nullptr, nbr_t, r.n_in, r.n_in, r.K, 3, nbx}, fc_cdiv((int64_t)r.K * r.n_in, 1024));
           const int nbo = (int)fc_cdiv(r.n_out, 256);
           rows.add({nbr, nbr_t, r.n_out, r.n_in, r.K, 2, nbo}, (int64_t)r.K * nbo);
         }
@@ -946,13 +993,20 @@ static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char
   // ---- launches, in dependency order ----
   FC_HIP(hipMemsetAsync(cnt_dev, 0, sizeof(int) * (64 * nm + MAXLV), stream));
   int rc;
-  auto rows_bytes = [](const Batch<RowJob>& b) { double t = 0; for (int i = 0; i < b.count; ++i) t += (double)b.j[i].K * b.j[i].n * (b.j[i].mode == 1 ? 4.0 : 8.0); return t; };
+  auto rows_bytes = [](const Batch<RowJob>& b) { double t = 0; for (int i = 0; i < b.count; ++i) t += (double)b.j[i].K * b.j[i].n * ((b.j[i].mode == 1 || b.j[i].mode == 3) ? 4.0 : 8.0); return t; };
   double by = 0;
   for (int i = 0; i < gen.count; ++i) by += 16.0 * gen.j[i].n;
   { Bracket br(probe, PK_GEN, by, stream); if ((rc = launch_batch(gen, 256, stream, k_plan_gen_coords))) return rc; }
   by = 0;
   for (int i = 0; i < kmaps.count; ++i) by += (double)kmaps.j[i].n_out * (16.0 + kmaps.j[i].K * (4.0 + 12.0));      // coords, table entry written, slot probed
-  { Bracket br(probe, PK_KMAPS, by, stream); if ((rc = launch_batch(kmaps, 256, stream, k_plan_kernel_maps))) return rc; }
+  for (int i = 0; i < smaps.count; ++i)             // strided maps: input coords, <= 8 probes of 12 B per input row, the table filled and hit
+    by += (double)smaps.j[i].n_in * (16.0 + 3.4 * 12.0 + 3.4 * 4.0) + (double)smaps.j[i].n_out * smaps.j[i].ks * smaps.j[i].ks * smaps.j[i].ks * 4.0;
+  {
+    Bracket br(probe, PK_KMAPS, by, stream);
+    if ((rc = launch_batch(prefills, 256, stream, k_plan_rows))) return rc;
+    if ((rc = launch_batch(smaps, 256, stream, k_plan_strided_maps))) return rc;
+    if ((rc = launch_batch(kmaps, 256, stream, k_plan_kernel_maps))) return rc;
+  }
   by = 0;
   for (int c = 0; c < nchildren; ++c) by += 27.0 * 4.0 * (children[c].n_parent + 8.0 * children[c].n_parent);
   {
