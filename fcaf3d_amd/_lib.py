@@ -7,6 +7,7 @@ is missing the product path raises.
 import ctypes
 import os
 import re
+import threading
 import time
 
 import torch
@@ -138,11 +139,13 @@ class _PinnedRing:
 
     def __init__(self, n=16):
         self.bufs, self.evts, self.i = [None] * n, [None] * n, 0
+        self.lock = threading.Lock()             # the main thread and the lookahead plan thread both upload: one slot each
 
     def upload(self, arr, device):
         """arr: numpy array (any shape, a dtype torch knows) -> device tensor, copied asynchronously on the current stream"""
-        i = self.i
-        self.i = (i + 1) % len(self.bufs)
+        with self.lock:
+            i = self.i
+            self.i = (i + 1) % len(self.bufs)
         if self.evts[i] is not None and not self.evts[i].query():
             t0 = time.perf_counter()
             self.evts[i].synchronize()

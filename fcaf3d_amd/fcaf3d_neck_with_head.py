@@ -668,13 +668,34 @@ class Fcaf3DAssigner:
         boxes = pts.new_zeros((B, M, 7))
         labels = torch.zeros((B, M), dtype=torch.int64, device=dev)
         if sum(lens):
-            allb = torch.cat([g.tensor.to(dev) for g in gt_bboxes if len(g)])
-            alll = torch.cat([l.to(dev) for g, l in zip(gt_bboxes, gt_labels) if len(g)])
-            slot = L.upload(np.concatenate([i * M + np.arange(n) for i, n in enumerate(lens) if n]), dev)
-            packed = allb.clone()
-            packed[:, 2] += allb[:, 5] * 0.5                     # gravity centre (DepthInstance3DBoxes.gravity_center)
-            boxes.view(B * M, 7)[slot] = packed                  # (.,7): DepthInstance3DBoxes pads yaw-less boxes with a zero yaw
-            labels.view(B * M)[slot] = alll.to(torch.int64)
+            host_boxes = all(not g.tensor.is_cuda for g in gt_bboxes)
+            host_labels = all(not l.is_cuda for l in gt_labels)
+            if host_boxes:
+                # annotations as a data loader hands them over (host tensors): packed on the host, ONE pinned upload (r6: eight
+                # blocking per-scene copies + a dozen tiny launches per step on the coordinate stream)
+                hb = np.zeros((B, M, 7), dtype=np.float32)
+                for i, g in enumerate(gt_bboxes):
+                    if lens[i]:
+                        t = g.tensor.detach().numpy().astype(np.float32)
+                        hb[i, :lens[i], :t.shape[1]] = t
+                        hb[i, :lens[i], 2] = t[:, 2] + t[:, 5] * np.float32(0.5)      # gravity centre (DepthInstance3DBoxes.gravity_center)
+                boxes = L.upload(hb, dev)
+            if host_labels:
+                hl = np.zeros((B, M), dtype=np.int64)
+                for i, l in enumerate(gt_labels):
+                    if lens[i]:
+                        hl[i, :lens[i]] = l.detach().numpy().astype(np.int64)
+                labels = L.upload(hl, dev)
+            if not (host_boxes and host_labels):
+                slot = L.upload(np.concatenate([i * M + np.arange(n) for i, n in enumerate(lens) if n]), dev)
+            if not host_boxes:
+                allb = torch.cat([g.tensor.to(dev) for g in gt_bboxes if len(g)])
+                packed = allb.clone()
+                packed[:, 2] += allb[:, 5] * 0.5                 # gravity centre (DepthInstance3DBoxes.gravity_center)
+                boxes.view(B * M, 7)[slot] = packed              # (.,7): DepthInstance3DBoxes pads yaw-less boxes with a zero yaw
+            if not host_labels:
+                alll = torch.cat([l.to(dev) for g, l in zip(gt_bboxes, gt_labels) if len(g)])
+                labels.view(B * M)[slot] = alll.to(torch.int64)
         # pinned + non_blocking: a pageable host->device copy would block the host until the whole forward has drained
         box_count = L.upload(np.asarray(lens, dtype=np.int32), dev)
         if pre is not None:
