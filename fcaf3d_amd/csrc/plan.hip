@@ -352,14 +352,25 @@ __global__ void k_plan_rows(Batch<RowJob> bt) {
     else for (int64_t q = e; q < tot; ++q) j.dst[q] = -1;
     return;
   }
-  const int k = (int)(lb / j.nbx);
-  const int64_t i = (lb % j.nbx) * 256 + threadIdx.x;
-  if (i >= j.n) return;
-  if (j.mode == 0) j.dst[(int64_t)k * j.n + i] = j.src[(int64_t)(j.K - 1 - k) * j.n + i];
-  else if (j.mode == 1) j.dst[(int64_t)k * j.n + i] = -1;
-  else {
-    const int v = j.src[(int64_t)k * j.n + i];
-    if (v >= 0) j.dst[(int64_t)k * j.n2 + v] = (int)i;
+  // four entries per thread, 256 apart (coalesced), their loads in flight together: at 4 bytes per thread a full chip holds ~2 MB in
+  // flight — 1 TB/s at 2 us of latency (r6: the fills went 28 -> 10 us as 16-byte stores; the same for the copies and the scatters).
+  // job blocks = K * ceil(nbx / 4)
+  const int per = (j.nbx + 3) >> 2;
+  const int k = (int)(lb / per);
+  const int64_t i0 = (lb % per) * 1024 + threadIdx.x;
+  int v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = i0 + 256 * u;
+    v[u] = -1;
+    if (i < j.n && j.mode != 1) v[u] = j.src[(int64_t)(j.mode == 0 ? j.K - 1 - k : k) * j.n + i];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = i0 + 256 * u;
+    if (i >= j.n) continue;
+    if (j.mode == 2) { if (v[u] >= 0) j.dst[(int64_t)k * j.n2 + v[u]] = (int)i; }
+    else j.dst[(int64_t)k * j.n + i] = v[u];
   }
 }
 
@@ -440,7 +451,7 @@ __global__ void k_plan_permute(Batch<SortJob> bt) {
   const int k = (int)(lb / j.nbx);
   const int64_t t = (lb % j.nbx) * 256 + threadIdx.x;
   if (t >= j.n) return;
-  j.sorted[(int64_t)k * j.n + t] = j.tab[(int64_t)k * j.n + j.order[t]];
+  j.sorted[(int64_t)k * j.n + t] = j.tab[(int64_t)k * j.n + j.order[t]];      // (four rows per thread: no faster — a gather of 4-byte entries)
 }
 
 // ---- LSD radix argsort of 27-bit keys (the occupancy masks), stable: 3 passes of 9 bits; all sort jobs of a plan per launch -------
@@ -901,11 +912,11 @@ static int stage2(const int64_t* cfg, int64_t* out, const int* counts_host, char
         nbr_t = a.arr<int>((int64_t)r.K * r.n_in);
         const int nbx = (int)fc_cdiv(r.n_in, 256);
         if (r.self) {
-          rows.add({nbr, nbr_t, r.n_in, r.n_in, r.K, 0, nbx}, (int64_t)r.K * nbx);
+          rows.add({nbr, nbr_t, r.n_in, r.n_in, r.K, 0, nbx}, (int64_t)r.K * ((nbx + 3) / 4));
         } else {
           fills.add({nullptr, nbr_t, r.n_in, r.n_in, r.K, 3, nbx}, fc_cdiv((int64_t)r.K * r.n_in, 1024));
           const int nbo = (int)fc_cdiv(r.n_out, 256);
-          rows.add({nbr, nbr_t, r.n_out, r.n_in, r.K, 2, nbo}, (int64_t)r.K * nbo);
+          rows.add({nbr, nbr_t, r.n_out, r.n_in, r.K, 2, nbo}, (int64_t)r.K * ((nbo + 3) / 4));
         }
       }
     }
